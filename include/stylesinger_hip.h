@@ -1,0 +1,303 @@
+/*
+ * libstylesinger_hip — C-ABI boundary of the MI355X-native StyleSinger inference hot path.
+ *
+ * The reference (AaronZ345/StyleSinger) has no FFI: its operator surface is the Python classes
+ * `modules/StyleSinger/stylesinger.py::StyleSinger` and the vocoder plugin
+ * `tasks/tts/vocoder_infer/hifigan_nsf.py::HifiGAN`.  This header is what a
+ * ctypes binding for that path binds instead of the stock torch ops; every entry point cites the
+ * reference code it replaces.  `stylesinger_amd/lib.py` is that binding.
+ *
+ * Conventions
+ *   - plain C, raw device pointers + sizes, no torch types; the caller (PyTorch) owns every buffer;
+ *   - every launch goes to the `hipStream_t` passed in (as `void*`), nothing synchronises, nothing
+ *     allocates, so every call is hipGraph-capturable;
+ *   - return 0 on success, <0 on error; `ss_last_error()` gives the message (thread-local);
+ *   - activations are fp32, channels-last: `[B][T_pad][C]` with `lens[b]` valid rows per item
+ *     (rows >= lens[b] behave as the zero padding a B=1 reference run would see);
+ *   - weights are packed once (ss_pack_*) into the K-contiguous `[N][taps*Kp]` layout the MFMA
+ *     kernel streams.
+ */
+#ifndef STYLESINGER_HIP_H
+#define STYLESINGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+#define SS_MAX_TAPS 16
+#define SS_MAX_LAYERS 32
+
+const char* ss_last_error(void);
+int ss_abi_version(void);
+/* number of compute units / name of device `dev` (sanity: must be gfx950) */
+int ss_device_info(int dev, int* n_cu, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic fp32-MFMA implicit-GEMM 1-D convolution / linear layer.
+ *   out[b][t][n] = epilogue( sum_{j<ntaps} sum_{ci<Cin} A'[b][t+tap_off[j]][ci] * W[n][j][ci] )
+ *   A' = lrelu((A + a_bias) * a_scale) for rows inside [0, lens[b]), 0 outside (zero padding).
+ * Replaces torch conv1d / conv_transpose1d (polyphase) / linear / addmm at every call site of
+ * the hot path, e.g. modules/diff/net.py:61-64, modules/hifigan/hifigan_nsf.py:33-47,
+ * modules/commons/common_layers.py:548-582.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  SS_EPI_STORE = 0,   /* v=(acc+bias)*pre_scale; act; +R; *post_scale; (+=C); row mask          */
+  SS_EPI_GATE = 1,    /* paired 32-col blocks: gate_mode 0: sigmoid(v0)*tanh(v1) (net.py:72-73);   *
+                       *                       gate_mode 1: tanh(v0)*sigmoid(v1) (wavenet.py:6-11) */
+  SS_EPI_RESSKIP = 2, /* n<Nh: C=(R+v)*post_scale ; n>=Nh: C2 (+)= v  (net.py:75-77)              */
+  SS_EPI_DDPM = 3     /* v = predicted noise -> fused DDPM posterior step on C (shallow_diffusion_tts.py:130-162) */
+};
+enum { SS_ACT_NONE_ = 0, SS_ACT_RELU_ = 1, SS_ACT_GELU_ = 2, SS_ACT_MISH_ = 3, SS_ACT_TANH_ = 4, SS_ACT_LRELU_ = 5 };
+
+enum { SS_TILE_AUTO = 0, SS_TILE_128x128 = 1, SS_TILE_64x128 = 2, SS_TILE_64x64 = 3, SS_TILE_128x64 = 4, SS_TILE_128x32 = 5 };
+
+typedef struct ss_conv_gemm_args {
+  /* A operand */
+  const float* A;
+  int64_t a_batch_stride; /* floats */
+  int32_t lda;            /* floats, multiple of 4 */
+  int32_t Cin;            /* multiple of 4 */
+  int32_t ntaps;
+  int32_t tap_off[SS_MAX_TAPS];
+  const int32_t* lens; /* [B] or NULL (= T) */
+  int32_t B, T;
+  const float* a_bias; /* [Cin] or NULL */
+  float a_scale;       /* 1.0 = none */
+  float a_lrelu;       /* slope, 1.0 = none */
+  /* B operand (packed by ss_pack_conv_weight) */
+  const float* W;
+  int32_t N;  /* logical columns written */
+  int32_t Np; /* packed rows, multiple of 32 */
+  int32_t Kp; /* packed channels per tap, multiple of 32 */
+  /* epilogue */
+  int32_t epi;
+  const float* bias; /* [Np] packed order or NULL */
+  float pre_scale;
+  int32_t act;
+  float act_slope;
+  const float* E; /* GATE: pre-activation addend [B][T][lde] in packed column order, or NULL */
+  int32_t lde;
+  int64_t e_batch_stride;
+  int32_t gate_mode;
+  const float* R; /* STORE/RESSKIP: residual [B][T][ldr] */
+  int32_t ldr;
+  int64_t r_batch_stride;
+  float post_scale;
+  int32_t accumulate; /* STORE: C += ; RESSKIP: C2 += */
+  int32_t mask_rows;  /* write 0 to rows >= lens[b] */
+  float* C;
+  int32_t ldc;
+  int64_t c_batch_stride;
+  float* C2; /* RESSKIP second half */
+  int32_t ldc2;
+  int64_t c2_batch_stride;
+  int32_t Nh; /* RESSKIP split point */
+  /* DDPM epilogue (C is x_t in/out, [B][T][N]) */
+  float ddpm_recip, ddpm_recipm1, ddpm_c1, ddpm_c2, ddpm_sigma;
+  const float* noise; /* [B][T][N] or NULL -> Philox(seed, step) */
+  uint64_t seed;
+  uint32_t step;
+  /* tiling: 0 = auto, else one of SS_TILE_* (BMxBN) */
+  int32_t tile;
+} ss_conv_gemm_args;
+
+int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
+
+/* Weight packing (device -> device).  src is the torch parameter layout [Cout][Cin][k] (conv1d,
+ * k=1 for nn.Linear [out][in]).  dst is [Np][k*Kp] with zero fill.  If scale0 != NULL (from
+ * ss_weight_norm_scale) the weight-norm reparametrisation w = g * v / ||v|| (torch.nn.utils.weight_norm,
+ * dim=0; hifigan_nsf.py:171-178, wavenet.py:37-52) is folded: row o is multiplied by scale0[o].  interleave_half > 0 reorders rows for SS_EPI_GATE: packed 32-row
+ * block 2p holds rows [p*32, p*32+32) of the first half, block 2p+1 those of the second half
+ * (half = interleave_half rows; rows beyond the half are zero).  row_scale multiplies every row. */
+int ss_pack_conv_weight(const float* src, const float* scale0, float* dst, int Cout, int Cin, int k, int Np, int Kp,
+                        int interleave_half, float row_scale, void* stream);
+/* scale[r] = g[r] / ||v[r,:]||_2 : the weight-norm factor along dim 0 (rows x cols view of v) */
+int ss_weight_norm_scale(const float* v, const float* g, float* scale, int rows, int cols, void* stream);
+/* ConvTranspose1d weight [Cin][Cout][k] (stride u, padding (k-u)/2, k == 2u) -> two polyphase groups,
+ * each a 2-tap conv with N = nph*Cout columns (hifigan_nsf.py:121-123).  group 0: phases [0,u-pad) taps (t, t-1);
+ * group 1: phases [u-pad,u) taps (t+1, t).  dst = [Np][2*Kp]. */
+int ss_pack_convtr_weight(const float* src, const float* scale0, float* dst, int Cin, int Cout, int k, int u, int group,
+                          int Np, int Kp, void* stream);
+/* bias [n] -> packed order [Np] (same interleave rule), optional second bias added (b + b2) */
+int ss_pack_bias(const float* src, const float* src2, float* dst, int n, int Np, int interleave_half, int repeat,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-wise / elementwise pieces
+ * ------------------------------------------------------------------------------------------ */
+/* LayerNorm over the last dim C (eps inside sqrt, torch.nn.LayerNorm; common_layers.py:75-82,
+ * tts_modules.py:37-56).  y may alias x.  mask_rows: rows >= lens[b] are written as 0. */
+int ss_layernorm(const float* x, float* y, const float* gamma, const float* beta, int B, int T, int C, int ldx, int ldy,
+                 int64_t x_batch_stride, int64_t y_batch_stride, float eps, const int32_t* lens, int mask_rows,
+                 void* stream);
+
+/* Multi-head attention core, flash-style, fp32 MFMA: O = softmax(Q K^T * scale + key_mask) V.
+ * Q [B][Tq][ldq] (head h at column h*D), K/V [B][Tk][ldk|ldv]; key j valid iff j < klens[b].
+ * Replaces the bmm/softmax/bmm inside F.multi_head_attention_forward (common_layers.py:277-286)
+ * and nn.MultiheadAttention (lse.py:19,41).  D must be 128. */
+int ss_attention(const float* Q, const float* K, const float* V, float* O, int B, int H, int D, int Tq, int Tk, int ldq,
+                 int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                 const int32_t* qlens, const int32_t* klens, float scale, void* stream);
+
+/* out[b][t][:] = scale * table[idx[b][t]][:]  (+ out if accumulate).  idx int64 (torch LongTensor).
+ * nn.Embedding lookups: tts_modules.py:339-346, stylesinger.py:31-36,246 */
+int ss_embedding(const int64_t* idx, const float* table, float* out, int rows, int C, int n_table, float scale,
+                 int accumulate, void* stream);
+/* fairseq make_positions (utils/tts_utils.py:6-18) + sinusoidal table lookup
+ * (common_layers.py:129-148): pos = cumsum(nz)*nz where nz = (probe != 0) ; out (+)= alpha*alpha_dev[0]*table[pos].
+ * probe is either int64 tokens (probe_i64) or the first channel of a float tensor (probe_f32, row stride ldp). */
+int ss_make_positions(const int64_t* probe_i64, const float* probe_f32, int ldp, int64_t probe_batch_stride,
+                      int32_t* pos, int B, int T, void* stream);
+int ss_table_add(const int32_t* pos, const float* table, int table_rows, float* out, int ldo, int64_t out_batch_stride,
+                 int B, int T, int C, const float* alpha_dev, float alpha, int accumulate, void* stream);
+/* y = (a + b_row_broadcast...) helpers: out[b][t][c] = (x[b][t][c] + v1[b][c] + v2[b][c] (+ y[b][t][c])) * (t < lens[b]) */
+int ss_add_bcast_mask(const float* x, const float* v1, const float* v2, const float* y, float* out, int B, int T, int C,
+                      const int32_t* lens, void* stream);
+/* gather rows: out[b][t][:] = (idx[b][t] > 0) ? src[b][idx[b][t]-1][:] : 0  (expand_states, fs2.py:258-262) */
+int ss_gather_expand(const float* src, const int64_t* mel2ph, float* out, int B, int Tsrc, int T, int C, void* stream);
+int ss_gather_expand_i64(const int64_t* src, const int64_t* mel2ph, int64_t* out, int B, int Tsrc, int T, void* stream);
+/* NoteEncoder dur_ln: out[r][c] += dur[r]*w[c] + b[c]  (stylesinger.py:33-35) */
+int ss_note_dur_add(const float* dur, const float* w, const float* b, float* out, int rows, int C, void* stream);
+/* DurationPredictor.out2dur + LengthRegulator (tts_modules.py:122-130,158-188):
+ * dur = max(round(exp(x)-1),0)*(tok!=0); mel2ph[b][t] = phoneme index (1-based) or 0; lens[b] = frames.
+ * Call with Tmax = 0 first (durations + lens only), read lens, then with Tmax = max(lens) to fill mel2ph. */
+int ss_length_regulate(const float* logdur, const int64_t* tokens, int64_t* dur_out, int64_t* mel2ph, int32_t* lens, int B,
+                       int Tp, int Tmax, void* stream);
+/* lens[b] = number of t with mel2ph[b][t] > 0 */
+int ss_count_nonzero_i64(const int64_t* x, int32_t* lens, int B, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Residual Style Adaptor pieces
+ * ------------------------------------------------------------------------------------------ */
+/* RQ codebook lookup (modules/StyleSinger/RQ.py:30-55,117-128,226-270): depth residual nearest-code
+ * search (first-min tie-break), out = x + (sum_q - x); codes int64 [rows][depth]. codebooks [depth][n_embed+1][C] */
+int ss_rq_lookup(const float* x, const float* codebooks, float* out, int64_t* codes, int rows, int C, int n_embed,
+                 int depth, void* stream);
+/* x[b][t][c] += f0[b][t] on valid rows (lse.py:119-122) */
+int ss_add_rowscalar(float* x, const float* s, int B, int T, int C, const int32_t* lens, void* stream);
+/* lens[b] = 1 + last t with ref_mels[b][t][0] != 0  (padding mask of the reference mel, lse.py:109) */
+int ss_ref_lens(const float* ref_mels, int B, int T, int C, int32_t* lens, void* stream);
+/* x[r][:] = 0 where ref[r*ldref] == 0  (per-frame padding mask inside the valid range, lse.py:109,193) */
+int ss_mask_rows_by_ref(float* x, const float* ref, int ldref, int rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Diffusion samplers.  A `ss_wavenet` describes one denoiser (DiffNet / DDiffNet, net.py:58-130,215-266)
+ * with packed weights.  All pointers are device pointers owned by the caller.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ss_wavenet {
+  int32_t C;        /* residual channels */
+  int32_t L;        /* residual layers */
+  int32_t cond_dim; /* encoder hidden */
+  int32_t dil_cycle;
+  int32_t in_dim;  /* 80 (mel) / 1 (f0) */
+  int32_t out_dim; /* 80 / 3 */
+  int32_t steps;
+  const float* w_in; /* mel: packed [C][Kp(in_dim)] ; f0: raw input_projection weight [C/2] */
+  const float* b_in; /* [C] (mel) / [C/2] (f0) */
+  const float* uv_embed; /* f0 only: [2][C/2] */
+  const float* dstep;    /* [steps][L][C]: diffusion_projection_l(mlp(sinemb(step))) */
+  const float* w_dil[SS_MAX_LAYERS]; /* packed gate-interleaved [2C][3*C] */
+  const float* w_out[SS_MAX_LAYERS]; /* packed [2C][C] */
+  const float* b_out[SS_MAX_LAYERS]; /* [2C] */
+  const float* w_cond;               /* packed [L*2C][cond_dim], per-layer gate interleave */
+  const float* b_cond;               /* [L*2C] = conditioner bias + dilated conv bias, packed order */
+  const float* w_skip;               /* packed [C][C] */
+  const float* b_skip;
+  const float* w_final; /* packed [Np(out_dim)][C] */
+  const float* b_final;
+  /* schedule tables: HOST pointers, fp32 [steps] each (the loop driver reads them on the host and passes
+   * per-step scalars by value; shallow_diffusion_tts.py:99-119, gaussian_multinomial_diffusion.py:237-284) */
+  const float* sqrt_recip_ac;
+  const float* sqrt_recipm1_ac;
+  const float* post_c1;
+  const float* post_c2;
+  const float* post_logvar;
+  const float* log_alpha;         /* f0 only */
+  const float* log_1m_alpha;      /* f0 only */
+  const float* log_cumprod_alpha; /* f0 only */
+  const float* log_1m_cumprod_alpha;
+} ss_wavenet;
+
+/* bytes of scratch the samplers need for (B, T) */
+int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int T);
+
+/* Shallow mel diffusion, whole reverse loop (DiffusionDecoder.forward infer branch,
+ * shallow_diffusion_tts.py:296-306 + p_sample :155-162).
+ *   x      [B][T][80] in: x_K (already q_sampled) ; out: x_0 (normalised)
+ *   cond   [B][T][cond_dim]
+ *   noise  [steps][B][T][80] tape (index s = loop step t) or NULL -> Philox(seed)
+ *   step_lo/step_hi: run t = step_hi-1 ... step_lo (full loop: 0, steps) */
+int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
+                      const float* noise, uint64_t seed, int step_lo, int step_hi, int precompute_cond, void* ws,
+                      int64_t ws_bytes, void* stream);
+/* q_sample + norm_spec: x = sqrt_ac*((mel-min)/(max-min)*2-1) + sqrt_1mac*z  (shallow_diffusion_tts.py:199-204,271-272) */
+int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac, float sqrt_1mac,
+                   const float* noise, uint64_t seed, float* x, int B, int T, int M, void* stream);
+/* denorm_spec (+ optional row mask): mel = (x+1)/2*(max-min)+min (shallow_diffusion_tts.py:274-275) */
+int ss_mel_denorm(const float* x, const float* spec_min, const float* spec_max, float* mel, int B, int T, int M,
+                  const int32_t* lens, void* stream);
+
+/* Joint Gaussian(f0)/multinomial(uv) reverse loop (GaussianMultinomialDiffusion.sample,
+ * gaussian_multinomial_diffusion.py:922-942 with gaussian_p_sample :326-333, p_sample :410-413).
+ *   f0     [B][T] in: z_f0 ~ N(0,1); out: final normalised f0
+ *   uv     [B][T] int32 in: initial class (0); out: final class
+ *   lo/hi  [B][T] per-frame clamp bounds (dyn_clip, stylesinger.py:275-283)
+ *   noise  [steps][B][T] gaussian tape or NULL ; gumbel_u [steps][B][2][T] uniform tape or NULL */
+int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, const float* cond, const float* lo, const float* hi,
+                     const int32_t* lens, int B, int T, const float* noise, const float* gumbel_u, uint64_t seed,
+                     int step_lo, int step_hi, int precompute_cond, void* ws, int64_t ws_bytes, void* stream);
+
+/* f0 post-processing of the two predictors (stylesinger.py:216-311, utils/pitch_utils.py:22-31,65-78):
+ * midi -> clamp bounds ; merge ; denorm ; coarse. */
+int ss_f0_bounds(const int64_t* midi, float* lo, float* hi, int n, void* stream);
+int ss_pitch_post(const float* f0_a, const int32_t* uv_a, const float* f0_b, const int32_t* uv_b, const int64_t* midi,
+                  const int64_t* mel2ph, float* pitch_pred /*[n][2]*/, float* f0_denorm, int64_t* pitch_coarse, int n,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HiFi-GAN-NSF vocoder (modules/hifigan/hifigan_nsf.py:105-169, modules/parallel_wavegan/models/source.py:311-531)
+ * ------------------------------------------------------------------------------------------ */
+#define SS_HG_MAX_UPS 6
+#define SS_HG_MAX_KERNELS 4
+typedef struct ss_hifigan {
+  int32_t n_ups, n_kernels, c0, sr, harmonics; /* harmonics = 8 -> 9 sine channels */
+  int32_t up_rate[SS_HG_MAX_UPS], up_k[SS_HG_MAX_UPS];
+  int32_t rb_k[SS_HG_MAX_KERNELS], rb_d[SS_HG_MAX_KERNELS][3];
+  const float* w_pre; /* packed [c0][7*Kp(80)] */
+  const float* b_pre;
+  const float* w_up[SS_HG_MAX_UPS][2]; /* two polyphase groups */
+  const float* b_up[SS_HG_MAX_UPS];    /* [u*Cout] repeated per phase */
+  const float* w_noise[SS_HG_MAX_UPS]; /* raw [c][1][k] */
+  const float* b_noise[SS_HG_MAX_UPS];
+  const float* w_rb1[SS_HG_MAX_UPS][SS_HG_MAX_KERNELS][3]; /* convs1 packed */
+  const float* b_rb1[SS_HG_MAX_UPS][SS_HG_MAX_KERNELS][3];
+  const float* w_rb2[SS_HG_MAX_UPS][SS_HG_MAX_KERNELS][3]; /* convs2 packed */
+  const float* b_rb2[SS_HG_MAX_UPS][SS_HG_MAX_KERNELS][3];
+  const float* w_post; /* raw [1][c_last][7] */
+  const float* b_post;
+  const float* src_w; /* SourceModuleHnNSF.l_linear.weight [9] */
+  const float* src_b; /* [1] */
+} ss_hifigan;
+
+int64_t ss_hifigan_workspace_bytes(const ss_hifigan* hg, int B, int T);
+/* mel [B][T][80] (already clipped), f0 [B][T] Hz -> wav [B][T*hop].  Noise tapes (or NULL -> Philox):
+ *   rand_ini [B][9] uniform ; sine_noise [B][L][9] normal.  lens = valid frames per item. */
+int ss_hifigan_forward(const ss_hifigan* hg, const float* mel, const float* f0, const int32_t* lens, int B, int T,
+                       const float* rand_ini, const float* sine_noise, uint64_t seed, float* wav, float* har_source_out,
+                       void* ws, int64_t ws_bytes, void* stream);
+
+/* NSF harmonic source only (SineGen + l_linear + tanh): f0 [B][T] Hz -> har [B][T*hop] */
+int ss_hifigan_source(const ss_hifigan* hg, const float* f0, int B, int T, const float* rand_ini, const float* sine_noise,
+                      uint64_t seed, float* har, void* ws, int64_t ws_bytes, void* stream);
+
+/* utility: y = clip(x, lo, hi) ; fill ; philox normal fill (for tests/bench inputs on device) */
+int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, void* stream);
+int ss_fill_normal(float* x, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STYLESINGER_HIP_H */

@@ -1,0 +1,31 @@
+// Error reporting + device sanity for libstylesinger_hip.
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void ss_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ss_last_error(void) { return g_err; }
+extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+extern "C" int ss_device_info(int dev, int* n_cu, char* arch, int arch_len) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) {
+    ss_set_error("ss_device_info: %s", hipGetErrorString(e));
+    return SS_ERR_HIP;
+  }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (arch && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return SS_OK;
+}

@@ -1,0 +1,103 @@
+// Shared device/host helpers for libstylesinger_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#define SS_OK 0
+#define SS_ERR_ARG (-1)
+#define SS_ERR_HIP (-2)
+#define SS_ERR_UNSUPPORTED (-3)
+
+void ss_set_error(const char* fmt, ...);
+
+#define SS_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      ss_set_error(__VA_ARGS__);           \
+      return SS_ERR_ARG;                   \
+    }                                      \
+  } while (0)
+
+#define SS_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      ss_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return SS_ERR_HIP;                                                        \
+    }                                                                           \
+  } while (0)
+
+#define SS_PROPAGATE(expr)        \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != SS_OK) return rc__; \
+  } while (0)
+
+static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ----------------------------------------------------------------------------------------------
+// Device math. Activations follow the torch CPU definitions the reference relies on.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ss_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// nn.GELU() default = erf form (modules/commons/common_layers.py:574, modules/StyleSinger/lse.py:183)
+__device__ __forceinline__ float ss_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// F.softplus(beta=1, threshold=20) then tanh (modules/diff/diffusion.py:64-66)
+__device__ __forceinline__ float ss_mish(float x) {
+  float sp = (x > 20.0f) ? x : log1pf(expf(x));
+  return x * tanhf(sp);
+}
+__device__ __forceinline__ float ss_lrelu(float x, float slope) { return x >= 0.0f ? x : x * slope; }
+
+enum SsAct { SS_ACT_NONE = 0, SS_ACT_RELU = 1, SS_ACT_GELU = 2, SS_ACT_MISH = 3, SS_ACT_TANH = 4, SS_ACT_LRELU = 5 };
+
+__device__ __forceinline__ float ss_apply_act(float v, int act, float slope) {
+  switch (act) {
+    case SS_ACT_RELU: return fmaxf(v, 0.0f);
+    case SS_ACT_GELU: return ss_gelu(v);
+    case SS_ACT_MISH: return ss_mish(v);
+    case SS_ACT_TANH: return tanhf(v);
+    case SS_ACT_LRELU: return ss_lrelu(v, slope);
+    default: return v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (production noise; parity tests inject a tape instead).
+// ----------------------------------------------------------------------------------------------
+struct SsPhilox {
+  uint32_t k0, k1;
+  __device__ __forceinline__ SsPhilox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+  __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t ka, uint32_t kb) const {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ ka, n1 = lo1, n2 = hi0 ^ c[3] ^ kb, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  // 4 x 32 random bits for counter (c0,c1,c2,c3)
+  __device__ __forceinline__ void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) const {
+    uint32_t c[4] = {c0, c1, c2, c3};
+    uint32_t ka = k0, kb = k1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      round(c, ka, kb);
+      ka += 0x9E3779B9u;
+      kb += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+  }
+};
+// uniform in (0,1]
+__device__ __forceinline__ float ss_u01(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+// two standard normals from two 32-bit words (Box-Muller)
+__device__ __forceinline__ void ss_boxmuller(uint32_t a, uint32_t b, float& z0, float& z1) {
+  float u1 = ss_u01(a), u2 = ss_u01(b);
+  float r = sqrtf(-2.0f * logf(u1));
+  float s, c;
+  sincosf(6.28318530717958647692f * u2, &s, &c);
+  z0 = r * c;
+  z1 = r * s;
+}

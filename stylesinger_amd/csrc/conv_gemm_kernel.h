@@ -1,0 +1,335 @@
+// Generic fp32-MFMA implicit-GEMM 1-D convolution for gfx950 (CDNA4).
+//
+//   out[b][t][n] = epi( sum_j sum_ci A'[b][t + tap_off[j]][ci] * W[n][j][ci] )
+//
+// Design (MI355X-first):
+//   * v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA at the 157 TF/s fp32 rate. One wave owns a
+//     (32*TM)x(32*TN) output sub-tile in AGPR/VGPRs (16 regs per 32x32 block).
+//   * activations are channels-last so a conv tap is a row shift of the same [rows][C] panel:
+//     no im2col is ever materialised; out-of-range rows are zero-filled in the global->LDS stage.
+//   * both operands are staged K-contiguous ([row][32+4] floats, 144-B row stride) so every lane
+//     fetches its 4 consecutive K values with ONE conflict-free ds_read_b128; the K order inside a
+//     32-chunk is permuted (k = 8q + 4h + s) identically for A and B, which the sum does not care about.
+//   * double-buffered LDS, one barrier per K-chunk, register-staged prefetch of chunk c+1 issued
+//     before the MFMAs of chunk c.
+//   * block -> tile map keeps all N-tiles of one M-tile on one XCD (ids congruent mod 8) so the
+//     activation panel is fetched once per XCD L2.
+//   * epilogues are fused: bias / activation / residual / gate / residual+skip / DDPM posterior step.
+#pragma once
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;  // floats; 144-byte rows keep 16-B alignment and are b128 conflict-free
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles,
+                                                        int n_tiles) {
+  constexpr int WTM = BM / WAVES_M;  // rows per wave
+  constexpr int WTN = BN / WAVES_N;  // cols per wave
+  constexpr int TM = WTM / 32;
+  constexpr int TN = WTN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(TM >= 1 && TN >= 1, "tile too small");
+  constexpr int A_F4 = BM * (BK / 4) / 256;  // float4 per thread per chunk
+  constexpr int B_F4 = BN * (BK / 4) / 256;
+  static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                        // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;      // [2][BN][LDS_LD]
+
+  // ---- block -> (m tile, n tile): all n tiles of an m tile share (blockIdx % 8) -> same XCD ----
+  const int id = blockIdx.x;
+  const int grp = id / (8 * n_tiles);
+  const int rem = id % (8 * n_tiles);
+  const int mt = grp * 8 + (rem & 7);
+  const int nt = rem >> 3;
+  if (mt >= m_tiles) return;
+  const int b = mt / m_tiles_per_item;
+  const int t0 = (mt % m_tiles_per_item) * BM;
+  const int n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  const int len = a.lens ? a.lens[b] : a.T;
+  const float* Ab = a.A + (int64_t)b * a.a_batch_stride;
+
+  const int kchunks_per_tap = a.Kp / BK;
+  const int nchunks = a.ntaps * kchunks_per_tap;
+  const int ldw = a.ntaps * a.Kp;
+
+  // staging coordinates
+  const int st_c4 = tid & 7;        // float4 column inside the 32-wide chunk
+  const int st_row = tid >> 3;      // 0..31
+  const bool has_pro = (a.a_bias != nullptr) || (a.a_scale != 1.0f) || (a.a_lrelu != 1.0f);
+
+  float4 ra[A_F4], rb[B_F4];
+
+  auto load_chunk = [&](int c) {
+    const int tap = c / kchunks_per_tap;
+    const int ci0 = (c - tap * kchunks_per_tap) * BK;
+    const int off = a.tap_off[tap];
+    const int ci = ci0 + st_c4 * 4;
+    const bool ci_ok = ci < a.Cin;
+    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_pro && a.a_bias && ci_ok) pb = *reinterpret_cast<const float4*>(a.a_bias + ci);
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int r = t0 + st_row + i * 32 + off;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ci_ok && r >= 0 && r < len) {
+        v = *reinterpret_cast<const float4*>(Ab + (int64_t)r * a.lda + ci);
+        if (has_pro) {
+          v.x = (v.x + pb.x) * a.a_scale; v.y = (v.y + pb.y) * a.a_scale;
+          v.z = (v.z + pb.z) * a.a_scale; v.w = (v.w + pb.w) * a.a_scale;
+          if (a.a_lrelu != 1.0f) {
+            v.x = ss_lrelu(v.x, a.a_lrelu); v.y = ss_lrelu(v.y, a.a_lrelu);
+            v.z = ss_lrelu(v.z, a.a_lrelu); v.w = ss_lrelu(v.w, a.a_lrelu);
+          }
+        }
+      }
+      ra[i] = v;
+    }
+    const int kcol = tap * a.Kp + ci0 + st_c4 * 4;
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int n = n0 + st_row + i * 32;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < a.Np) v = *reinterpret_cast<const float4*>(a.W + (int64_t)n * ldw + kcol);
+      rb[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* Ad = As + buf * BM * LDS_LD;
+    float* Bd = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i)
+      *reinterpret_cast<float4*>(Ad + (st_row + i * 32) * LDS_LD + st_c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i)
+      *reinterpret_cast<float4*>(Bd + (st_row + i * 32) * LDS_LD + st_c4 * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* Ac = As + cur * BM * LDS_LD + (wm * WTM + l31) * LDS_LD + 4 * lh;
+    const float* Bc = Bs + cur * BN * LDS_LD + (wn * WTN + l31) * LDS_LD + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) af[m] = *reinterpret_cast<const float4*>(Ac + m * 32 * LDS_LD + q * 8);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) bf[n] = *reinterpret_cast<const float4*>(Bc + n * 32 * LDS_LD + q * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+          const float av = (s == 0) ? af[m].x : (s == 1) ? af[m].y : (s == 2) ? af[m].z : af[m].w;
+#pragma unroll
+          for (int n = 0; n < TN; ++n) {
+            const float bv = (s == 0) ? bf[n].x : (s == 1) ? bf[n].y : (s == 2) ? bf[n].z : bf[n].w;
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (c + 1 < nchunks) {
+      store_chunk(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // ------------------------------------------------------------------------------------------
+  const int row_base = t0 + wm * WTM;
+  const int col_base = n0 + wn * WTN;
+
+  if constexpr (EPI == SS_EPI_STORE) {
+    float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+    const float* Rb = a.R ? a.R + (int64_t)b * a.r_batch_stride : nullptr;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = col_base + n * 32 + l31;
+      if (col >= a.N) continue;
+      const float bs = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row >= a.T) continue;
+          float v = (acc[m][n][r] + bs) * a.pre_scale;
+          v = ss_apply_act(v, a.act, a.act_slope);
+          if (Rb) v += Rb[(int64_t)row * a.ldr + col];
+          v *= a.post_scale;
+          float* p = Cb + (int64_t)row * a.ldc + col;
+          if (a.accumulate) v += *p;
+          if (a.mask_rows && row >= len) v = 0.f;
+          *p = v;
+        }
+      }
+    }
+  } else if constexpr (EPI == SS_EPI_GATE) {
+    if constexpr (TN % 2 == 0) {
+      float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+      const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+#pragma unroll
+      for (int n = 0; n < TN; n += 2) {
+        const int pc0 = col_base + n * 32 + l31;  // packed column of first member
+        const int pc1 = pc0 + 32;
+        const int oc = (pc0 >> 6) * 32 + l31;  // output channel
+        if (oc >= a.N) continue;
+        const float b0 = a.bias ? a.bias[pc0] : 0.f;
+        const float b1 = a.bias ? a.bias[pc1] : 0.f;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= a.T) continue;
+            float v0 = acc[m][n][r] + b0;
+            float v1 = acc[m][n + 1][r] + b1;
+            if (Eb) {
+              v0 += Eb[(int64_t)row * a.lde + pc0];
+              v1 += Eb[(int64_t)row * a.lde + pc1];
+            }
+            float g = (a.gate_mode == 0) ? ss_sigmoid(v0) * tanhf(v1) : tanhf(v0) * ss_sigmoid(v1);
+            if (a.mask_rows && row >= len) g = 0.f;
+            Cb[(int64_t)row * a.ldc + oc] = g;
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == SS_EPI_RESSKIP) {
+    float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+    float* C2b = a.C2 + (int64_t)b * a.c2_batch_stride;
+    const float* Rb = a.R + (int64_t)b * a.r_batch_stride;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = col_base + n * 32 + l31;
+      if (col >= a.N) continue;
+      const float bs = a.bias ? a.bias[col] : 0.f;
+      const bool first = col < a.Nh;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row >= a.T) continue;
+          float v = acc[m][n][r] + bs;
+          const bool dead = a.mask_rows && row >= len;
+          if (first) {
+            float x = (Rb[(int64_t)row * a.ldr + col] + v) * a.post_scale;
+            Cb[(int64_t)row * a.ldc + col] = dead ? 0.f : x;
+          } else {
+            float* p = C2b + (int64_t)row * a.ldc2 + (col - a.Nh);
+            if (a.accumulate) v += *p;
+            *p = dead ? 0.f : v;
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == SS_EPI_DDPM) {
+    // v = eps_theta. x0 = clamp(recip*x - recipm1*eps, -1, 1); mean = c1*x0 + c2*x; x <- mean + sigma*z
+    float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+    const SsPhilox rng(a.seed);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = col_base + n * 32 + l31;
+      if (col >= a.N) continue;
+      const float bs = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row >= a.T) continue;
+          const float eps = acc[m][n][r] + bs;
+          float* p = Cb + (int64_t)row * a.ldc + col;
+          const float x = *p;
+          float x0 = a.ddpm_recip * x - a.ddpm_recipm1 * eps;
+          x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+          float mean = a.ddpm_c1 * x0 + a.ddpm_c2 * x;
+          float z = 0.f;
+          if (a.ddpm_sigma != 0.f) {
+            const int64_t idx = ((int64_t)b * a.T + row) * a.N + col;
+            if (a.noise) {
+              z = a.noise[idx];
+            } else {
+              uint32_t o[4];
+              rng.gen((uint32_t)idx, (uint32_t)(idx >> 32), a.step, 0x4d454c44u, o);
+              float z1;
+              ss_boxmuller(o[0], o[1], z, z1);
+            }
+          }
+          float xn = mean + a.ddpm_sigma * z;
+          if (a.mask_rows && row >= len) xn = 0.f;
+          *p = xn;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+int launch(const ss_conv_gemm_args& a, hipStream_t stream) {
+  const int m_tiles_per_item = ss_cdiv(a.T, BM);
+  const int m_tiles = m_tiles_per_item * a.B;
+  const int n_cols = (EPI == SS_EPI_GATE) ? a.Np : a.N;
+  const int n_tiles = ss_cdiv(n_cols, BN);
+  const int m_tiles_pad = ss_cdiv(m_tiles, 8) * 8;
+  const int grid = m_tiles_pad * n_tiles;
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>), dim3(grid), dim3(256), lds, stream, a,
+                     m_tiles_per_item, m_tiles, n_tiles);
+  SS_CHECK_LAUNCH("ss_conv_gemm");
+  return SS_OK;
+}
+
+
+template <int EPI>
+int launch_tile(int tile, const ss_conv_gemm_args& a, hipStream_t stream) {
+  switch (tile) {
+    case SS_TILE_128x128: return launch<128, 128, 2, 2, EPI>(a, stream);
+    case SS_TILE_64x128: return launch<64, 128, 2, 2, EPI>(a, stream);
+    case SS_TILE_128x64: return launch<128, 64, 4, 1, EPI>(a, stream);
+    case SS_TILE_64x64:
+      if constexpr (EPI != SS_EPI_GATE) return launch<64, 64, 2, 2, EPI>(a, stream);
+    case SS_TILE_128x32:
+      if constexpr (EPI != SS_EPI_GATE) return launch<128, 32, 4, 1, EPI>(a, stream);
+    default: ss_set_error("ss_conv_gemm: bad tile %d for epilogue %d", tile, EPI); return SS_ERR_ARG;
+  }
+}
+}  // namespace
