@@ -1,0 +1,121 @@
+"""Generate tests/golden/*.pt by running the REAL reference (AaronZ345/StyleSinger at /root/reference).
+
+TEST INFRASTRUCTURE ONLY; runs in the build container (the reference does not exist on the GPU box).
+    python -m oracle.gen_golden            # regenerate every fixture
+The reference modules are imported unmodified (oracle/refimport.py); weights come from
+stylesinger_amd.synth (loaded through the reference's own load_state_dict(strict=True)); every
+torch.rand*/randn* draw is served from a seeded NoiseTape so the HIP path and the CPU restatement can
+consume the identical noise.  One reference instance per step-count (the schedule buffers are sized at
+construction, modules/StyleSinger/stylesinger.py:69-73,101-113).
+"""
+import contextlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refimport  # noqa: E402
+from stylesinger_amd import config, synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@contextlib.contextmanager
+def tape_rng(tape):
+    """Route the reference's global-RNG draws through the tape (order-preserving)."""
+    o = (torch.randn, torch.rand, torch.randn_like, torch.rand_like)
+
+    def _shape(args):
+        return tuple(args[0]) if len(args) == 1 and isinstance(args[0], (tuple, list, torch.Size)) else tuple(args)
+
+    torch.randn = lambda *a, **k: tape.randn(*_shape(a))
+    torch.rand = lambda *a, **k: tape.rand(*_shape(a))
+    torch.randn_like = lambda x, **k: tape.randn(*x.shape)
+    torch.rand_like = lambda x, **k: tape.rand(*x.shape)
+    try:
+        yield
+    finally:
+        torch.randn, torch.rand, torch.randn_like, torch.rand_like = o
+
+
+def build_reference(steps_mel, steps_f0, seed=1234):
+    R = refimport.load(dict(timesteps=steps_mel, K_step=steps_mel, f0_timesteps=steps_f0))
+    hp = config.make_hparams(dict(timesteps=steps_mel, K_step=steps_mel, f0_timesteps=steps_f0))
+    model = R["StyleSinger"](refimport.FakeDict(hp["vocab_size"]))
+    sd = synth.synth_acoustic_state_dict(hp, seed)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    return model, hp, sd
+
+
+def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True, seed=1234, keep_stages=True):
+    model, hp, sd = build_reference(steps_mel, steps_f0, seed)
+    batch = synth.synth_batch(B, T, Tp, Tr, hp, seed)
+    tape = synth.NoiseTape(seed + 1)
+    stages = {}
+    hooks = []
+    if keep_stages:
+        def grab(key, fn=lambda o: o):
+            def h(mod, inp, out):
+                stages[key] = fn(out).detach().clone()
+            return h
+        hooks.append(model.encoder.register_forward_hook(grab("encoder_out")))
+        hooks.append(model.style_extractor.encoder.register_forward_hook(grab("style_pre_rq")))
+        hooks.append(model.style_extractor.register_forward_hook(grab("style_rq", lambda o: o[0])))
+        hooks.append(model.ln_proj.register_forward_hook(grab("diff_cond")))
+        hooks.append(model.decoder.register_forward_hook(grab("decoder_out")))
+    with torch.no_grad(), tape_rng(tape):
+        ret = model(batch["txt_tokens"], mel2ph=batch["mel2ph"] if give_mel2ph else None, spk_embed=batch["spk_embed"],
+                    emo_embed=batch["emo_embed"], ref_mels=batch["ref_mels"], ref_f0=batch["ref_f0"], global_steps=320000,
+                    infer=True, note=batch["note"], note_dur=batch["note_dur"], note_type=batch["note_type"])
+    for h in hooks:
+        h.remove()
+    keys = ["mel2ph", "style", "pitch_pred", "f0_denorm", "decoder_inp", "mel_out", "dur"]
+    out = {k: ret[k].detach().clone() for k in keys if k in ret and torch.is_tensor(ret[k])}
+    if "dur_choice" in ret:
+        out["dur_choice"] = ret["dur_choice"].clone()
+    out.update(stages)
+    meta = dict(B=B, T=T, Tp=Tp, Tr=Tr, steps_mel=steps_mel, steps_f0=steps_f0, give_mel2ph=give_mel2ph, seed=seed,
+                tape_seed=seed + 1, tape_log=tape.log)
+    torch.save(dict(meta=meta, out=out), os.path.join(GOLD, name + ".pt"))
+    print(f"[gen_golden] {name}: T_out={out['mel_out'].shape[1]} draws={len(tape.log)} keys={sorted(out)}")
+
+
+def run_vocoder_case(name, B, T, seed=1234):
+    R = refimport.load()
+    cfg = config.make_vocoder_config()
+    gen = R["HifiGanGenerator"](cfg)
+    vsd = synth.synth_vocoder_state_dict(cfg, seed)
+    gen.load_state_dict(vsd, strict=True)
+    gen.remove_weight_norm()
+    gen.eval()
+    g = torch.Generator().manual_seed(seed + 7)
+    mel = (torch.randn(B, T, 80, generator=g) * 0.8 - 3.0).clamp(-6, 1.5)
+    f0 = 220.0 + 80.0 * torch.sin(torch.arange(T)[None, :] / 5.0 + torch.arange(B)[:, None])
+    f0[:, T // 3: T // 3 + max(T // 6, 1)] = 0.0  # an unvoiced run
+    tape = synth.NoiseTape(seed + 2)
+    grabbed = {}
+    hook = gen.m_source.register_forward_hook(lambda m, i, o: grabbed.__setitem__("har", o[0].detach().clone()))
+    with torch.no_grad(), tape_rng(tape):
+        wav = gen(mel.transpose(1, 2), f0)
+    hook.remove()
+    torch.save(dict(meta=dict(B=B, T=T, seed=seed, tape_seed=seed + 2, tape_log=tape.log),
+                    inp=dict(mel=mel, f0=f0), out=dict(wav=wav[:, 0].clone(), har=grabbed["har"][:, :, 0].clone())),
+               os.path.join(GOLD, name + ".pt"))
+    print(f"[gen_golden] {name}: wav {tuple(wav.shape)} draws={len(tape.log)}")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    run_acoustic_case("acoustic_tiny_s4", B=1, T=48, Tp=6, Tr=40, steps_mel=4, steps_f0=4)
+    run_acoustic_case("acoustic_b2_s3", B=2, T=40, Tp=5, Tr=36, steps_mel=3, steps_f0=3)
+    run_acoustic_case("acoustic_dur_s2", B=1, T=0, Tp=7, Tr=32, steps_mel=2, steps_f0=2, give_mel2ph=False)
+    run_acoustic_case("acoustic_t64_s100", B=1, T=64, Tp=8, Tr=48, steps_mel=100, steps_f0=100, keep_stages=False)
+    run_vocoder_case("vocoder_t12", B=1, T=12)
+    run_vocoder_case("vocoder_b2_t9", B=2, T=9)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""Hyper-parameters of the accelerated path.
+
+These are the *resolved* values of the reference's yaml chain for this path
+(egs/stylesinger.yaml <- egs/egs_bases/tts/fs2.yaml <- base.yaml <- config_base.yaml, plus
+egs/datasets/audio/emotion/base_text2mel.yaml); `tests/test_config.py` pins them against a dump of the
+reference's own `set_hparams()` result (tests/golden/hparams.json).  The host side accepts the
+reference's global `hparams` dict as an override (`make_hparams(ref_hparams)`), so the entrypoint
+keeps working with the reference's config loader unchanged.
+"""
+import copy
+
+SPEC_MIN = [-6.0] * 80
+SPEC_MAX = [
+    0.03640973940491676, 0.039425432682037354, 0.29524752497673035, 0.45784831047058105, 0.48333120346069336,
+    0.5335848927497864, 0.6071611046791077, 0.5474293828010559, 0.6076506972312927, 0.5390501022338867,
+    0.5743886232376099, 0.485751211643219, 0.4248744249343872, 0.4843744933605194, 0.43331536650657654,
+    0.5356124639511108, 0.4875929355621338, 0.48614853620529175, 0.44228559732437134, 0.5027499198913574,
+    0.6554337739944458, 0.3469322919845581, 0.33981558680534363, 0.37933868169784546, 0.34751009941101074,
+    0.22094282507896423, 0.252963662147522, 0.18274202942848206, 0.1976650059223175, 0.1770155429840088,
+    0.18206502497196198, 0.1002601608633995, 0.18640224635601044, 0.27240633964538574, 0.04153885692358017,
+    -0.010289354249835014, -0.012929759919643402, 0.035185474902391434, 0.18124309182167053, -0.14512233436107635,
+    -0.1778590828180313, -0.20491982996463776, -0.30119436979293823, -0.1735714226961136, -0.1039585992693901,
+    -0.177497997879982, -0.28803232312202454, -0.24049188196659088, -0.4682924747467041, -0.5791841745376587,
+    -0.5170156955718994, -0.6380605697631836, -0.7147259712219238, -0.6607836484909058, -0.7288452982902527,
+    -0.6338580250740051, -0.7092624306678772, -0.8101216554641724, -0.7633087038993835, -0.8251329660415649,
+    -0.6936700940132141, -0.5180960297584534, -0.7972619533538818, -0.807314932346344, -0.7151175737380981,
+    -0.7785399556159973, -0.8709449768066406, -0.8360402584075928, -0.8253681659698486, -0.9778416156768799,
+    -1.12929368019104, -1.3274869918823242, -1.3071579933166504, -1.5234452486038208, -1.6191706657409668,
+    -1.708594799041748, -1.8246771097183228, -1.9193823337554932, -2.1361801624298096, -2.3829283714294434,
+]
+
+DEFAULT_HPARAMS = dict(
+    hidden_size=256, enc_layers=4, dec_layers=4, num_heads=2, enc_ffn_kernel_size=9, dec_ffn_kernel_size=9,
+    ffn_padding="SAME", ffn_act="gelu", use_pos_embed=True, dur_predictor_layers=2, dur_predictor_kernel=3,
+    predictor_hidden=-1, predictor_layers=5, predictor_kernel=5, dur_loss="mse", audio_num_mel_bins=80, keep_bins=80,
+    residual_layers=20, residual_channels=256, dilation_cycle_length=4,
+    f0_residual_layers=10, f0_residual_channels=192, f0_dilation_cycle_length=4,
+    timesteps=100, K_step=100, f0_timesteps=100, max_beta=0.06, f0_max_beta=0.06, schedule_type="linear",
+    nRQ=128, rq_depth=4, emo=True, emo_size=256, style=True, umln=True, use_spk_embed=True, use_spk_id=False,
+    f0_gen="gmdiff", decoder="diffsinger", diff_decoder_type="wavenet", use_txt_cond=True,
+    pitch_type="frame", use_uv=True, pitch_norm="log", use_pitch_embed=True, use_energy_embed=False,
+    predictor_grad=1.0, forcing=20000, rq_start=20500, diff_start=100000,
+    spec_min=SPEC_MIN, spec_max=SPEC_MAX, mel_vmin=-6.0, mel_vmax=1.5,
+    audio_sample_rate=48000, hop_size=256, vocoder="HifiGAN_NSF", use_nsf=True, seed=1234,
+    vocab_size=61,  # ZH_checkpoint_phone_set.json (58) + <pad>,<EOS>,<UNK> (utils/text/text_encoder.py:11)
+)
+
+# The released HiFi-GAN config ships only inside the un-vendored checkpoint
+# (tasks/tts/vocoder_infer/hifigan_nsf.py:49-55); SURVEY.md §8(d) fixes this V1-style assumption.
+DEFAULT_VOCODER = dict(
+    resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
+    resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    use_pitch_embed=True, audio_sample_rate=48000, harmonic_num=8,
+)
+
+
+def make_hparams(overrides=None):
+    hp = copy.deepcopy(DEFAULT_HPARAMS)
+    if overrides:
+        for k in hp:
+            if k in overrides:
+                hp[k] = overrides[k]
+        for k in ("vocab_size",):
+            if k in overrides:
+                hp[k] = overrides[k]
+    return hp
+
+
+def make_vocoder_config(overrides=None):
+    cfg = copy.deepcopy(DEFAULT_VOCODER)
+    if overrides:
+        cfg.update({k: v for k, v in overrides.items() if k in cfg})
+    return cfg
