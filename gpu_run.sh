@@ -1,0 +1,10 @@
+#!/bin/bash
+# helper run on the GPU box by gpurun: args = what to run
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+case "$1" in
+  tests) python -m pytest tests -x -q -m gpu -s 2>&1 | tail -60 | tee gpurun_out/tests.log ;;
+  kernels) python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -40 | tee gpurun_out/kernels.log ;;
+  parity) python -m pytest tests/test_gpu_parity.py -x -q -m gpu -s 2>&1 | tail -60 | tee gpurun_out/parity.log ;;
+  *) shift 0; "$@" ;;
+esac

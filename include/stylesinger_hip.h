@@ -34,6 +34,8 @@ const char* ss_last_error(void);
 int ss_abi_version(void);
 /* number of compute units / name of device `dev` (sanity: must be gfx950) */
 int ss_device_info(int dev, int* n_cu, char* arch, int arch_len);
+/* out[0..2] = sizeof(ss_conv_gemm_args), sizeof(ss_wavenet), sizeof(ss_hifigan): lets a binding verify its mirror */
+int ss_struct_sizes(int64_t* out, int n);
 
 /* ------------------------------------------------------------------------------------------
  * Generic fp32-MFMA implicit-GEMM 1-D convolution / linear layer.
@@ -153,9 +155,10 @@ int ss_make_positions(const int64_t* probe_i64, const float* probe_f32, int ldp,
                       int32_t* pos, int B, int T, void* stream);
 int ss_table_add(const int32_t* pos, const float* table, int table_rows, float* out, int ldo, int64_t out_batch_stride,
                  int B, int T, int C, const float* alpha_dev, float alpha, int accumulate, void* stream);
-/* y = (a + b_row_broadcast...) helpers: out[b][t][c] = (x[b][t][c] + v1[b][c] + v2[b][c] (+ y[b][t][c])) * (t < lens[b]) */
-int ss_add_bcast_mask(const float* x, const float* v1, const float* v2, const float* y, float* out, int B, int T, int C,
-                      const int32_t* lens, void* stream);
+/* out[b][t][c] = ((((x + v1[b][c]) + y1) + v2[b][c]) + y2) * (t < lens[b]); v1/y1/v2/y2 optional.
+ * The fixed order reproduces the reference's in-place adds (stylesinger.py:139-142,158-177). */
+int ss_add_bcast_mask(const float* x, const float* v1, const float* y1, const float* v2, const float* y2, float* out,
+                      int B, int T, int C, const int32_t* lens, void* stream);
 /* gather rows: out[b][t][:] = (idx[b][t] > 0) ? src[b][idx[b][t]-1][:] : 0  (expand_states, fs2.py:258-262) */
 int ss_gather_expand(const float* src, const int64_t* mel2ph, float* out, int B, int Tsrc, int T, int C, void* stream);
 int ss_gather_expand_i64(const int64_t* src, const int64_t* mel2ph, int64_t* out, int B, int Tsrc, int T, void* stream);

@@ -29,3 +29,15 @@ extern "C" int ss_device_info(int dev, int* n_cu, char* arch, int arch_len) {
   }
   return SS_OK;
 }
+
+// sizes of the public structs, so the ctypes mirror in stylesinger_amd/lib.py can be verified at load time
+extern "C" int ss_struct_sizes(int64_t* out, int n) {
+  if (!out || n < 3) {
+    ss_set_error("ss_struct_sizes: need room for 3 entries");
+    return SS_ERR_ARG;
+  }
+  out[0] = (int64_t)sizeof(ss_conv_gemm_args);
+  out[1] = (int64_t)sizeof(ss_wavenet);
+  out[2] = (int64_t)sizeof(ss_hifigan);
+  return SS_OK;
+}

@@ -117,10 +117,11 @@ __global__ void table_add_kernel(const int32_t* __restrict__ pos, const float* _
   }
 }
 
-// out = (x + v1[b] + v2[b] + y) * (t < lens[b])
+// out = ((((x + v1[b]) + y1) + v2[b]) + y2) * (t < lens[b])   (every addend optional; order as in stylesinger.py:139-166)
 __global__ void add_bcast_mask_kernel(const float* __restrict__ x, const float* __restrict__ v1,
-                                      const float* __restrict__ v2, const float* __restrict__ y, float* __restrict__ out,
-                                      int B, int T, int C, const int32_t* __restrict__ lens) {
+                                      const float* __restrict__ y1, const float* __restrict__ v2,
+                                      const float* __restrict__ y2, float* __restrict__ out, int B, int T, int C,
+                                      const int32_t* __restrict__ lens) {
   const int64_t total = (int64_t)B * T * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -128,8 +129,9 @@ __global__ void add_bcast_mask_kernel(const float* __restrict__ x, const float* 
     const int b = (int)(r / T), t = (int)(r % T);
     float v = x[i];
     if (v1) v += v1[(int64_t)b * C + c];
-    if (y) v += y[i];
+    if (y1) v += y1[i];
     if (v2) v += v2[(int64_t)b * C + c];
+    if (y2) v += y2[i];
     if (lens && t >= lens[b]) v = 0.f;
     out[i] = v;
   }
@@ -318,11 +320,11 @@ extern "C" int ss_table_add(const int32_t* pos, const float* table, int table_ro
   return SS_OK;
 }
 
-extern "C" int ss_add_bcast_mask(const float* x, const float* v1, const float* v2, const float* y, float* out, int B,
-                                 int T, int C, const int32_t* lens, void* stream) {
+extern "C" int ss_add_bcast_mask(const float* x, const float* v1, const float* y1, const float* v2, const float* y2,
+                                 float* out, int B, int T, int C, const int32_t* lens, void* stream) {
   SS_CHECK_ARG(x && out, "ss_add_bcast_mask: null pointer");
   hipLaunchKernelGGL(add_bcast_mask_kernel, dim3(grid_for((int64_t)B * T * C)), dim3(256), 0, (hipStream_t)stream, x, v1,
-                     v2, y, out, B, T, C, lens);
+                     y1, v2, y2, out, B, T, C, lens);
   SS_CHECK_LAUNCH("ss_add_bcast_mask");
   return SS_OK;
 }

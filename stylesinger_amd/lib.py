@@ -1,0 +1,251 @@
+"""ctypes binding of libstylesinger_hip.so (the C-ABI in include/stylesinger_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol cannot be resolved this
+module raises, and every op raises `StyleSingerHipError` on a non-zero status.  PyTorch is used only
+for device memory (`tensor.data_ptr()`) and streams.
+"""
+import ctypes as C
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstylesinger_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "stylesinger_hip.h")
+
+SS_MAX_TAPS = 16
+SS_MAX_LAYERS = 32
+SS_HG_MAX_UPS = 6
+SS_HG_MAX_KERNELS = 4
+
+EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class StyleSingerHipError(RuntimeError):
+    pass
+
+
+class ConvGemmArgs(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("a_batch_stride", C.c_int64), ("lda", C.c_int32), ("Cin", C.c_int32), ("ntaps", C.c_int32),
+        ("tap_off", C.c_int32 * SS_MAX_TAPS), ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("a_bias", _vp),
+        ("a_scale", C.c_float), ("a_lrelu", C.c_float),
+        ("W", _vp), ("N", C.c_int32), ("Np", C.c_int32), ("Kp", C.c_int32),
+        ("epi", C.c_int32), ("bias", _vp), ("pre_scale", C.c_float), ("act", C.c_int32), ("act_slope", C.c_float),
+        ("E", _vp), ("lde", C.c_int32), ("e_batch_stride", C.c_int64), ("gate_mode", C.c_int32),
+        ("R", _vp), ("ldr", C.c_int32), ("r_batch_stride", C.c_int64), ("post_scale", C.c_float),
+        ("accumulate", C.c_int32), ("mask_rows", C.c_int32),
+        ("C", _vp), ("ldc", C.c_int32), ("c_batch_stride", C.c_int64),
+        ("C2", _vp), ("ldc2", C.c_int32), ("c2_batch_stride", C.c_int64), ("Nh", C.c_int32),
+        ("ddpm_recip", C.c_float), ("ddpm_recipm1", C.c_float), ("ddpm_c1", C.c_float), ("ddpm_c2", C.c_float),
+        ("ddpm_sigma", C.c_float), ("noise", _vp), ("seed", C.c_uint64), ("step", C.c_uint32), ("tile", C.c_int32),
+    ]
+
+
+class WaveNet(C.Structure):
+    _fields_ = [
+        ("C", C.c_int32), ("L", C.c_int32), ("cond_dim", C.c_int32), ("dil_cycle", C.c_int32), ("in_dim", C.c_int32),
+        ("out_dim", C.c_int32), ("steps", C.c_int32),
+        ("w_in", _vp), ("b_in", _vp), ("uv_embed", _vp), ("dstep", _vp),
+        ("w_dil", _vp * SS_MAX_LAYERS), ("w_out", _vp * SS_MAX_LAYERS), ("b_out", _vp * SS_MAX_LAYERS),
+        ("w_cond", _vp), ("b_cond", _vp), ("w_skip", _vp), ("b_skip", _vp), ("w_final", _vp), ("b_final", _vp),
+        ("sqrt_recip_ac", _vp), ("sqrt_recipm1_ac", _vp), ("post_c1", _vp), ("post_c2", _vp), ("post_logvar", _vp),
+        ("log_alpha", _vp), ("log_1m_alpha", _vp), ("log_cumprod_alpha", _vp), ("log_1m_cumprod_alpha", _vp),
+    ]
+
+
+class HifiGan(C.Structure):
+    _fields_ = [
+        ("n_ups", C.c_int32), ("n_kernels", C.c_int32), ("c0", C.c_int32), ("sr", C.c_int32), ("harmonics", C.c_int32),
+        ("up_rate", C.c_int32 * SS_HG_MAX_UPS), ("up_k", C.c_int32 * SS_HG_MAX_UPS),
+        ("rb_k", C.c_int32 * SS_HG_MAX_KERNELS), ("rb_d", (C.c_int32 * 3) * SS_HG_MAX_KERNELS),
+        ("w_pre", _vp), ("b_pre", _vp),
+        ("w_up", (_vp * 2) * SS_HG_MAX_UPS), ("b_up", _vp * SS_HG_MAX_UPS),
+        ("w_noise", _vp * SS_HG_MAX_UPS), ("b_noise", _vp * SS_HG_MAX_UPS),
+        ("w_rb1", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS), ("b_rb1", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS),
+        ("w_rb2", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS), ("b_rb2", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS),
+        ("w_post", _vp), ("b_post", _vp), ("src_w", _vp), ("src_b", _vp),
+    ]
+
+
+_CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "uint32_t": C.c_uint32,
+          "float": C.c_float, "void": None}
+
+
+def declarations():
+    """{name: (restype, [argtypes])} parsed from the public header, so the binding cannot drift from it."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+    out = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(ss_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", txt, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        restype = C.c_char_p if "char" in ret else _CTYPE[ret]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(C.c_void_p)
+                else:
+                    base = [t for t in a.replace("const", " ").split() if t in _CTYPE]
+                    assert base, f"cannot parse parameter '{a}' of {name}"
+                    argtypes.append(_CTYPE[base[0]])
+        out[name] = (restype, argtypes)
+    return out
+
+
+def declared_symbols():
+    """Every `ss_*` function the public header declares."""
+    return sorted(declarations())
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). Raises if it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StyleSingerHipError(
+            f"{LIB_PATH} not found: build it with `python -m stylesinger_amd.build` (hipcc, gfx950). "
+            "The StyleSinger HIP path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in declarations().items():
+        if not hasattr(lib, name):
+            raise StyleSingerHipError(f"libstylesinger_hip.so does not export {name}")
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    sizes = (C.c_int64 * 3)()
+    if lib.ss_struct_sizes(sizes, 3) != 0:
+        raise StyleSingerHipError("ss_struct_sizes failed")
+    mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan))
+    if tuple(sizes) != mine:
+        raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
+    if lib.ss_abi_version() != 1:
+        raise StyleSingerHipError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ss_last_error().decode(errors="replace")
+        raise StyleSingerHipError(f"{what} failed ({rc}): {msg}")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None) as a plain int."""
+    if t is None:
+        return None
+    assert t.is_cuda, "HIP path needs device tensors"
+    return t.data_ptr()
+
+
+def hptr(a):
+    """Host pointer of a contiguous numpy array."""
+    return a.ctypes.data
+
+
+def _f(x):
+    return float(x)
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------
+# thin op wrappers (argument marshalling only)
+# ---------------------------------------------------------------------------------------------
+def conv_gemm(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,), lens=None, a_bias=None, a_scale=1.0,
+              a_lrelu=1.0, epi=EPI_STORE, bias=None, pre_scale=1.0, act=ACT_NONE, act_slope=0.0, E=None, lde=0, e_bs=0,
+              gate_mode=0, R=None, ldr=0, r_bs=None, post_scale=1.0, accumulate=False, mask_rows=True, ldc=None, c_bs=None,
+              C2=None, ldc2=0, c2_bs=0, Nh=0, tile=0):
+    a = ConvGemmArgs()
+    a.A = ptr(A); a.lda = lda if lda is not None else Cin
+    a.a_batch_stride = a_bs if a_bs is not None else T * a.lda
+    a.Cin = Cin; a.ntaps = len(taps)
+    for i, o in enumerate(taps):
+        a.tap_off[i] = int(o)
+    a.lens = ptr(lens); a.B = B; a.T = T; a.a_bias = ptr(a_bias); a.a_scale = a_scale; a.a_lrelu = a_lrelu
+    a.W = ptr(W); a.N = N; a.Np = Np; a.Kp = Kp
+    a.epi = epi; a.bias = ptr(bias); a.pre_scale = pre_scale; a.act = act; a.act_slope = act_slope
+    a.E = ptr(E); a.lde = lde; a.e_batch_stride = e_bs; a.gate_mode = gate_mode
+    a.R = ptr(R); a.ldr = ldr; a.r_batch_stride = r_bs if r_bs is not None else T * ldr
+    a.post_scale = post_scale; a.accumulate = int(accumulate); a.mask_rows = int(mask_rows)
+    a.C = ptr(out); a.ldc = ldc if ldc is not None else N
+    a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
+    a.C2 = ptr(C2); a.ldc2 = ldc2; a.c2_batch_stride = c2_bs; a.Nh = Nh; a.tile = tile
+    check(load().ss_conv_gemm(C.byref(a), stream_ptr()), "ss_conv_gemm")
+
+
+def pack_conv_weight(w, *, scale0=None, interleave_half=0, row_scale=1.0):
+    """torch conv/linear weight [Cout, Cin(, k)] (device) -> packed [Np][k*Kp] device tensor."""
+    if w.dim() == 2:
+        w = w[:, :, None]
+    w = w.contiguous().float()
+    Cout, Cin, k = w.shape
+    Kp = round_up(Cin, 32)
+    Np = 2 * round_up(interleave_half, 32) if interleave_half else round_up(Cout, 32)
+    dst = torch.empty(Np, k * Kp, device=w.device, dtype=torch.float32)
+    check(load().ss_pack_conv_weight(ptr(w), ptr(scale0), ptr(dst), Cout, Cin, k, Np, Kp, interleave_half, _f(row_scale),
+                                     stream_ptr()), "ss_pack_conv_weight")
+    return dst
+
+
+def weight_norm_scale(v, g):
+    v = v.contiguous().float()
+    g = g.contiguous().float().reshape(-1)
+    rows = v.shape[0]
+    out = torch.empty(rows, device=v.device, dtype=torch.float32)
+    check(load().ss_weight_norm_scale(ptr(v), ptr(g), ptr(out), rows, v.numel() // rows, stream_ptr()), "ss_weight_norm_scale")
+    return out
+
+
+def pack_convtr_weight(w, scale0, u, group):
+    w = w.contiguous().float()
+    Cin, Cout, k = w.shape
+    pad = (k - u) // 2
+    nph = (u - pad) if group == 0 else pad
+    Np = round_up(nph * Cout, 32)
+    Kp = round_up(Cin, 32)
+    dst = torch.empty(Np, 2 * Kp, device=w.device, dtype=torch.float32)
+    check(load().ss_pack_convtr_weight(ptr(w), ptr(scale0), ptr(dst), Cin, Cout, k, u, group, Np, Kp, stream_ptr()),
+          "ss_pack_convtr_weight")
+    return dst
+
+
+def pack_bias(b, *, b2=None, Np=None, interleave_half=0, repeat=1):
+    b = b.contiguous().float()
+    n = b.numel()
+    if Np is None:
+        Np = 2 * round_up(interleave_half, 32) if interleave_half else round_up(n * repeat, 32)
+    dst = torch.empty(Np, device=b.device, dtype=torch.float32)
+    check(load().ss_pack_bias(ptr(b), ptr(b2), ptr(dst), n, Np, interleave_half, repeat, stream_ptr()), "ss_pack_bias")
+    return dst
+
+
+def layernorm(x, gamma, beta, *, B, T, C_, out=None, lens=None, mask_rows=False, eps=1e-5):
+    out = x if out is None else out
+    check(load().ss_layernorm(ptr(x), ptr(out), ptr(gamma), ptr(beta), B, T, C_, C_, C_, T * C_,
+                              T * C_, _f(eps), ptr(lens), int(mask_rows), stream_ptr()), "ss_layernorm")
+    return out
+
+
+def attention(Q, K, V, O, *, B, H, D, Tq, Tk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, qlens=None, klens=None, scale):
+    check(load().ss_attention(ptr(Q), ptr(K), ptr(V), ptr(O), B, H, D, Tq, Tk, ldq, ldk, ldv, ldo, q_bs,
+                              k_bs, v_bs, o_bs, ptr(qlens), ptr(klens), _f(scale),
+                              stream_ptr()), "ss_attention")

@@ -1,0 +1,545 @@
+"""`StyleSingerHIP` — host-side mirror of `modules/StyleSinger/stylesinger.py::StyleSinger` for inference.
+
+Same constructor (`StyleSingerHIP(dictionary, out_dims=None)`), same `forward(...) -> dict` keys, and it
+loads the reference `state_dict` unchanged (names + shapes are the weight contract), so
+`inference/StyleSinger.py::build_model` / `tasks/StyleSinger/stylesinger.py::build_tts_model` can swap
+the class and keep `load_ckpt(model, ..., 'model', strict=False)`.
+
+All arithmetic runs in libstylesinger_hip.so (hand-written gfx950 kernels) through `lib.py`; torch is
+used for device buffers, views/concats (data movement only) and the stream.  There is no CPU path.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import spec as _spec
+from .config import make_hparams
+
+_lib = L.load
+
+
+class _Packed:
+    """A conv/linear weight in the MFMA kernel's layout + its metadata."""
+    __slots__ = ("W", "bias", "Cout", "Cin", "k", "Np", "Kp", "half")
+
+    def __init__(self, W, bias, Cout, Cin, k, half=0):
+        self.W, self.bias, self.Cout, self.Cin, self.k, self.half = W, bias, Cout, Cin, k, half
+        self.Np, self.Kp = W.shape[0], W.shape[1] // k
+
+
+def _sin_table(n, dim):
+    """SinusoidalPositionalEmbedding.get_embedding (common_layers.py:107-124), host fp32, padding row 0 zeroed."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+    e = torch.arange(n, dtype=torch.float).unsqueeze(1) * e.unsqueeze(0)
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1).view(n, -1)
+    e[0, :] = 0
+    return e
+
+
+def _step_emb_table(steps, dim):
+    """SinusoidalPosEmb(t) for t = 0..steps-1 (modules/diff/net.py:32-44)."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half) * -e)
+    e = torch.arange(steps)[:, None].float() * e[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1).contiguous()
+
+
+class StyleSingerHIP(torch.nn.Module):
+    def __init__(self, dictionary=None, out_dims=None, hparams=None):
+        super().__init__()
+        hp = make_hparams(hparams)
+        if dictionary is not None:
+            hp["vocab_size"] = len(dictionary)
+        self.hp = hp
+        self.hidden_size = hp["hidden_size"]
+        self.out_dims = out_dims or hp["audio_num_mel_bins"]
+        self._names = []
+        for name, shape in _spec.acoustic_spec(hp):
+            self._names.append(name)
+            self.register_buffer(self._mangle(name), torch.zeros(*shape), persistent=True)
+        self._packed_version = -1
+        self._weights_version = 0
+        self._pk = None
+        self._pos_table = None
+        self.training = False
+
+    # ---- state_dict contract ------------------------------------------------------------------
+    @staticmethod
+    def _mangle(name):
+        return "p__" + name.replace(".", "__")
+
+    def state_dict(self, *args, **kwargs):
+        return {n: getattr(self, self._mangle(n)) for n in self._names}
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [n for n in self._names if n not in state_dict]
+        unexpected = [k for k in state_dict if k not in set(self._names)]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"StyleSingerHIP.load_state_dict: missing={missing[:5]} unexpected={unexpected[:5]}")
+        with torch.no_grad():
+            for n in self._names:
+                if n in state_dict:
+                    dst = getattr(self, self._mangle(n))
+                    src = state_dict[n]
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise RuntimeError(f"size mismatch for {n}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+                    dst.copy_(src)
+        self._weights_version += 1
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def p(self, name):
+        return getattr(self, self._mangle(name))
+
+    def train(self, mode=True):
+        if mode:
+            raise RuntimeError("StyleSingerHIP is an inference-only drop-in (training is out of scope, SURVEY.md §8)")
+        return super().train(False)
+
+    # ---- weight packing ---------------------------------------------------------------------
+    def _pack_conv(self, wname, bname=None, *, half=0, scale0=None, row_scale=1.0, bias2=None):
+        w = self.p(wname)
+        if w.dim() == 2:
+            Cout, Cin, k = w.shape[0], w.shape[1], 1
+        else:
+            Cout, Cin, k = w.shape
+        W = L.pack_conv_weight(w, scale0=scale0, interleave_half=half, row_scale=row_scale)
+        bias = None
+        if bname is not None:
+            bias = L.pack_bias(self.p(bname), b2=bias2, interleave_half=half)
+        return _Packed(W, bias, Cout, Cin, k, half)
+
+    def _pack_wn_conv(self, prefix, *, half=0):
+        v, g = self.p(prefix + ".weight_v"), self.p(prefix + ".weight_g")
+        s0 = L.weight_norm_scale(v, g)
+        Cout, Cin, k = v.shape
+        W = L.pack_conv_weight(v, scale0=s0, interleave_half=half)
+        bias = L.pack_bias(self.p(prefix + ".bias"), interleave_half=half)
+        return _Packed(W, bias, Cout, Cin, k, half)
+
+    def _pack_wavenet(self, prefix, gen, C, Lyr, cycle, steps, in_dim, out_dim, f0):
+        hp = self.hp
+        H = hp["hidden_size"]
+        dev = self.p(prefix + ".mlp.0.weight").device
+        keep = []
+        net = L.WaveNet()
+        net.C, net.L, net.cond_dim, net.dil_cycle, net.in_dim, net.out_dim, net.steps = C, Lyr, H, cycle, in_dim, out_dim, steps
+        if f0:
+            w_in = self.p(prefix + ".input_projection.weight").reshape(-1).contiguous()
+            b_in = self.p(prefix + ".input_projection.bias").contiguous()
+            uve = self.p(prefix + ".uv_embed.weight").contiguous()
+            keep += [w_in, b_in, uve]
+            net.w_in, net.b_in, net.uv_embed = w_in.data_ptr(), b_in.data_ptr(), uve.data_ptr()
+        else:
+            pin = self._pack_conv(prefix + ".input_projection.weight", prefix + ".input_projection.bias")
+            keep.append(pin)
+            net.w_in, net.b_in = pin.W.data_ptr(), pin.bias.data_ptr()
+        # dstep[s][l][:] = diffusion_projection_l(mlp(SinusoidalPosEmb(s)))  (net.py:66,118-119) — weights-only table
+        emb = _step_emb_table(steps, C).to(dev)
+        m0 = self._pack_conv(prefix + ".mlp.0.weight", prefix + ".mlp.0.bias")
+        m2 = self._pack_conv(prefix + ".mlp.2.weight", prefix + ".mlp.2.bias")
+        h1 = torch.empty(steps, 4 * C, device=dev)
+        h2 = torch.empty(steps, C, device=dev)
+        L.conv_gemm(emb, m0.W, h1, B=1, T=steps, Cin=C, N=4 * C, Np=m0.Np, Kp=m0.Kp, bias=m0.bias, act=L.ACT_MISH, mask_rows=False)
+        L.conv_gemm(h1, m2.W, h2, B=1, T=steps, Cin=4 * C, N=C, Np=m2.Np, Kp=m2.Kp, bias=m2.bias, mask_rows=False)
+        dstep = torch.empty(steps, Lyr, C, device=dev)
+        wc_rows, bc_rows = [], []
+        for l in range(Lyr):
+            p = f"{prefix}.residual_layers.{l}"
+            dp = self._pack_conv(p + ".diffusion_projection.weight", p + ".diffusion_projection.bias")
+            L.conv_gemm(h2, dp.W, dstep[:, l], B=1, T=steps, Cin=C, N=C, Np=dp.Np, Kp=dp.Kp, bias=dp.bias, ldc=Lyr * C,
+                        mask_rows=False)
+            dil = self._pack_conv(p + ".dilated_conv.weight", None, half=C)
+            out = self._pack_conv(p + ".output_projection.weight", p + ".output_projection.bias")
+            cnd = self._pack_conv(p + ".conditioner_projection.weight", p + ".conditioner_projection.bias", half=C,
+                                  bias2=self.p(p + ".dilated_conv.bias"))
+            keep += [dil, out, cnd]
+            net.w_dil[l], net.w_out[l], net.b_out[l] = dil.W.data_ptr(), out.W.data_ptr(), out.bias.data_ptr()
+            wc_rows.append(cnd.W)
+            bc_rows.append(cnd.bias)
+        w_cond = torch.cat(wc_rows, 0).contiguous()
+        b_cond = torch.cat(bc_rows, 0).contiguous()
+        skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
+        fin = self._pack_conv(prefix + ".output_projection.weight", prefix + ".output_projection.bias")
+        keep += [dstep, w_cond, b_cond, skip, fin]
+        net.dstep, net.w_cond, net.b_cond = dstep.data_ptr(), w_cond.data_ptr(), b_cond.data_ptr()
+        net.w_skip, net.b_skip, net.w_final, net.b_final = skip.W.data_ptr(), skip.bias.data_ptr(), fin.W.data_ptr(), fin.bias.data_ptr()
+        # schedule tables live on the host (the loop driver passes per-step scalars by value)
+        def host(name):
+            a = np.ascontiguousarray(self.p(f"{gen}.{name}").detach().cpu().numpy().astype(np.float32))
+            keep.append(a)
+            return a.ctypes.data
+        net.sqrt_recip_ac, net.sqrt_recipm1_ac = host("sqrt_recip_alphas_cumprod"), host("sqrt_recipm1_alphas_cumprod")
+        net.post_c1, net.post_c2 = host("posterior_mean_coef1"), host("posterior_mean_coef2")
+        net.post_logvar = host("posterior_log_variance_clipped")
+        if f0:
+            net.log_alpha, net.log_1m_alpha = host("log_alpha"), host("log_1_min_alpha")
+            net.log_cumprod_alpha, net.log_1m_cumprod_alpha = host("log_cumprod_alpha"), host("log_1_min_cumprod_alpha")
+        sched = {k: self.p(f"{gen}.{k}").detach().cpu() for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod")}
+        return dict(net=net, keep=keep, sched=sched)
+
+    def _pack_fft(self, prefix, n_layers):
+        layers = []
+        for i in range(n_layers):
+            p = f"{prefix}.layers.{i}.op"
+            layers.append(dict(
+                ln1=(self.p(p + ".layer_norm1.weight"), self.p(p + ".layer_norm1.bias")),
+                qkv=self._pack_conv(p + ".self_attn.in_proj_weight"),
+                out=self._pack_conv(p + ".self_attn.out_proj.weight"),
+                ln2=(self.p(p + ".layer_norm2.weight"), self.p(p + ".layer_norm2.bias")),
+                ffn1=self._pack_conv(p + ".ffn.ffn_1.weight", p + ".ffn.ffn_1.bias"),
+                ffn2=self._pack_conv(p + ".ffn.ffn_2.weight", p + ".ffn.ffn_2.bias")))
+        return dict(layers=layers, ln=(self.p(prefix + ".layer_norm.weight"), self.p(prefix + ".layer_norm.bias")))
+
+    def pack(self):
+        """(Re)build every packed weight on the current device; called lazily by forward."""
+        hp = self.hp
+        dev = self.p("mel_out.weight").device
+        if not dev.type == "cuda":
+            raise L.StyleSingerHipError("StyleSingerHIP needs its weights on a GPU (model.to('cuda')): there is no CPU path")
+        pk = {}
+        pk["enc"] = self._pack_fft("encoder", hp["enc_layers"])
+        pk["dec"] = self._pack_fft("decoder", hp["dec_layers"])
+        pk["mel_out"] = self._pack_conv("mel_out.weight", "mel_out.bias")
+        pk["spk"] = self._pack_conv("spk_embed_proj.weight", "spk_embed_proj.bias")
+        pk["emo"] = self._pack_conv("emo_embed_proj.weight", "emo_embed_proj.bias")
+        pk["dur"] = [dict(conv=self._pack_conv(f"dur_predictor.conv.{i}.1.weight", f"dur_predictor.conv.{i}.1.bias"),
+                          ln=(self.p(f"dur_predictor.conv.{i}.3.weight"), self.p(f"dur_predictor.conv.{i}.3.bias")))
+                     for i in range(hp["dur_predictor_layers"])]
+        pk["dur_lin"] = self._pack_conv("dur_predictor.linear.weight", "dur_predictor.linear.bias")
+        # RSA
+        wn = []
+        for i in range(4):
+            inl = self._pack_wn_conv(f"style_extractor.wavenet.in_layers.{i}", half=80)
+            v, g = self.p(f"style_extractor.wavenet.res_skip_layers.{i}.weight_v"), self.p(f"style_extractor.wavenet.res_skip_layers.{i}.weight_g")
+            s0 = L.weight_norm_scale(v, g)
+            b = self.p(f"style_extractor.wavenet.res_skip_layers.{i}.bias")
+            if i < 3:
+                res = _Packed(L.pack_conv_weight(v[:80], scale0=s0[:80].contiguous()), L.pack_bias(b[:80]), 80, 80, 1)
+                skp = _Packed(L.pack_conv_weight(v[80:], scale0=s0[80:].contiguous()), L.pack_bias(b[80:]), 80, 80, 1)
+            else:
+                res = None
+                skp = _Packed(L.pack_conv_weight(v, scale0=s0), L.pack_bias(b), 80, 80, 1)
+            wn.append(dict(inl=inl, res=res, skip=skp))
+        pk["wn"] = wn
+        cb = []
+        for rb in range(5):
+            for blk in range(2):
+                p = f"style_extractor.encoder.res_blocks.{rb}.blocks.{blk}"
+                cb.append(dict(ln=(self.p(p + ".0.weight"), self.p(p + ".0.bias")), c1=self._pack_conv(p + ".1.weight", p + ".1.bias"),
+                               c2=self._pack_conv(p + ".4.weight", p + ".4.bias")))
+        pk["cb"] = cb
+        pk["cb_ln"] = (self.p("style_extractor.encoder.last_norm.weight"), self.p("style_extractor.encoder.last_norm.bias"))
+        pk["cb_post"] = self._pack_conv("style_extractor.encoder.post_net1.weight", "style_extractor.encoder.post_net1.bias")
+        pk["codebooks"] = torch.stack([self.p(f"style_extractor.rqvae.codebooks.{d}.weight") for d in range(hp["rq_depth"])]).contiguous()
+        pk["l1"] = self._pack_conv("l1.weight", "l1.bias")
+        al = []
+        H = hp["hidden_size"]
+        for i in range(2):
+            p = f"align.layers.{i}"
+            w, b = self.p(p + ".multihead_attn.in_proj_weight"), self.p(p + ".multihead_attn.in_proj_bias")
+            al.append(dict(
+                q=_Packed(L.pack_conv_weight(w[:H]), L.pack_bias(b[:H]), H, H, 1),
+                kv=_Packed(L.pack_conv_weight(w[H:]), L.pack_bias(b[H:]), 2 * H, H, 1),
+                out=self._pack_conv(p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias"),
+                n1=(self.p(p + ".norm1.weight"), self.p(p + ".norm1.bias")), n2=(self.p(p + ".norm2.weight"), self.p(p + ".norm2.bias")),
+                l1=self._pack_conv(p + ".linear1.weight", p + ".linear1.bias"), l2=self._pack_conv(p + ".linear2.weight", p + ".linear2.bias")))
+        pk["align"] = al
+        pk["f0_a"] = self._pack_wavenet("gm_diffnet", "f0_gen", hp["f0_residual_channels"], hp["f0_residual_layers"],
+                                        hp["f0_dilation_cycle_length"], hp["f0_timesteps"], 1, 3, True)
+        pk["f0_b"] = self._pack_wavenet("gm_diffnet_inpainte", "f0_gen_inpainte", hp["f0_residual_channels"], hp["f0_residual_layers"],
+                                        hp["f0_dilation_cycle_length"], hp["f0_timesteps"], 1, 3, True)
+        pk["mel"] = self._pack_wavenet("postdiff.denoise_fn", "postdiff", hp["residual_channels"], hp["residual_layers"],
+                                       hp["dilation_cycle_length"], hp["timesteps"], hp["audio_num_mel_bins"], hp["audio_num_mel_bins"], False)
+        pk["ln_proj"] = self._pack_conv("ln_proj.weight", "ln_proj.bias")
+        pk["spec_min"] = self.p("postdiff.spec_min").reshape(-1).contiguous()
+        pk["spec_max"] = self.p("postdiff.spec_max").reshape(-1).contiguous()
+        self._pk = pk
+        self._packed_version = self._weights_version
+        self._pack_device = dev
+        self._pos_table = None
+        torch.cuda.synchronize()
+
+    def _ensure_packed(self):
+        dev = self.p("mel_out.weight").device
+        if self._pk is None or self._packed_version != self._weights_version or self._pack_device != dev:
+            self.pack()
+
+    def _pos(self, n, dev):
+        if self._pos_table is None or self._pos_table.shape[0] < n:
+            self._pos_table = _sin_table(max(n, 2048), self.hp["hidden_size"]).to(dev)
+        return self._pos_table
+
+    # ---- op helpers -----------------------------------------------------------------------------
+    def _gemm(self, x, pk, out, B, T, *, taps=None, lens=None, act=L.ACT_NONE, pre_scale=1.0, R=None, mask_rows=True,
+              N=None, **kw):
+        if taps is None:
+            taps = [(j - (pk.k - 1) // 2) for j in range(pk.k)]
+        N = pk.Cout if N is None else N
+        L.conv_gemm(x, pk.W, out, B=B, T=T, Cin=pk.Cin, N=N, Np=pk.Np, Kp=pk.Kp, taps=taps, lens=lens, bias=pk.bias,
+                    act=act, pre_scale=pre_scale, R=R, ldr=(N if R is not None else 0), mask_rows=mask_rows, **kw)
+        return out
+
+    def _fft_blocks(self, pkb, x, B, T, lens):
+        """4 x EncSALayer + final LN (tts_modules.py:281-306, common_layers.py:649-673), in place on x [B,T,H]."""
+        H = self.hp["hidden_size"]
+        nh = self.hp["num_heads"]
+        D = H // nh
+        dev = x.device
+        h = torch.empty(B, T, H, device=dev)
+        qkv = torch.empty(B, T, 3 * H, device=dev)
+        att = torch.zeros(B, T, H, device=dev)
+        ff = torch.empty(B, T, 4 * H, device=dev)
+        for ly in pkb["layers"]:
+            L.layernorm(x, *ly["ln1"], B=B, T=T, C_=H, out=h)
+            self._gemm(h, ly["qkv"], qkv, B, T, lens=lens, mask_rows=False)
+            L.attention(qkv, qkv[:, :, H:], qkv[:, :, 2 * H:], att, B=B, H=nh, D=D, Tq=T, Tk=T, ldq=3 * H, ldk=3 * H, ldv=3 * H,
+                        ldo=H, q_bs=T * 3 * H, k_bs=T * 3 * H, v_bs=T * 3 * H, o_bs=T * H, qlens=lens, klens=lens, scale=D ** -0.5)
+            self._gemm(att, ly["out"], x, B, T, lens=lens, R=x)
+            L.layernorm(x, *ly["ln2"], B=B, T=T, C_=H, out=h)
+            k = ly["ffn1"].k
+            self._gemm(h, ly["ffn1"], ff, B, T, lens=lens, act=L.ACT_GELU, pre_scale=k ** -0.5, mask_rows=False)
+            self._gemm(ff, ly["ffn2"], x, B, T, lens=lens, R=x)
+        L.layernorm(x, *pkb["ln"], B=B, T=T, C_=H, out=x, lens=lens, mask_rows=True)
+        return x
+
+    # ---- forward ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, txt_tokens, mel2ph=None, spk_embed=None, emo_embed=None, ref_mels=None, ref_f0=None, f0=None, uv=None,
+                skip_decoder=False, global_steps=0, infer=False, note=None, note_dur=None, note_type=None, **kwargs):
+        """Mirror of StyleSinger.forward (modules/StyleSinger/stylesinger.py:119-187), inference branch only.
+
+        Extra keyword arguments: `noise` (dict from synth.draw_acoustic_noise: a recorded noise tape for
+        parity tests; default = on-device Philox), `seed` (Philox seed)."""
+        if not infer or f0 is not None or uv is not None:
+            raise NotImplementedError("StyleSingerHIP implements the inference path only (infer=True, f0/uv predicted)")
+        self._ensure_packed()
+        lib, hp, pk = _lib(), self.hp, self._pk
+        st = L.stream_ptr
+        dev = txt_tokens.device
+        H = hp["hidden_size"]
+        noise = kwargs.get("noise")
+        seed = int(kwargs.get("seed", hp["seed"]))
+        ret = {}
+        B, Tp = txt_tokens.shape
+        txt_tokens = txt_tokens.contiguous()
+        f32 = dict(device=dev, dtype=torch.float32)
+        lens_p = torch.empty(B, device=dev, dtype=torch.int32)
+        L.check(lib.ss_count_nonzero_i64(L.ptr(txt_tokens), L.ptr(lens_p), B, Tp, st()), "count_nonzero")
+
+        # ---- phoneme encoder (a1) + note encoder (a2) ----
+        x = torch.empty(B, Tp, H, **f32)
+        pos_p = torch.empty(B, Tp, device=dev, dtype=torch.int32)
+        tab = self._pos(max(Tp, 8) + 2, dev)
+        L.check(lib.ss_embedding(L.ptr(txt_tokens), L.ptr(self.p("encoder.embed_tokens.weight")), L.ptr(x), B * Tp, H,
+                                 hp["vocab_size"], math.sqrt(H), 0, st()), "embedding")
+        L.check(lib.ss_make_positions(L.ptr(txt_tokens), None, 0, 0, L.ptr(pos_p), B, Tp, st()), "make_positions")
+        L.check(lib.ss_table_add(L.ptr(pos_p), L.ptr(tab), tab.shape[0], L.ptr(x), H, Tp * H, B, Tp, H, None, 1.0, 1, st()), "table_add")
+        L.check(lib.ss_add_bcast_mask(L.ptr(x), None, None, None, None, L.ptr(x), B, Tp, H, L.ptr(lens_p), st()), "mask")
+        enc = self._fft_blocks(pk["enc"], x, B, Tp, lens_p)
+        ret["encoder_out_text"] = enc.clone()
+        note_out = torch.empty(B, Tp, H, **f32)
+        note, note_type, note_dur = note.contiguous(), note_type.contiguous(), note_dur.contiguous().float()
+        L.check(lib.ss_embedding(L.ptr(note), L.ptr(self.p("note_encoder.emb.weight")), L.ptr(note_out), B * Tp, H, 100, math.sqrt(H), 0, st()), "note emb")
+        L.check(lib.ss_note_dur_add(L.ptr(note_dur), L.ptr(self.p("note_encoder.dur_ln.weight").reshape(-1).contiguous()),
+                                    L.ptr(self.p("note_encoder.dur_ln.bias")), L.ptr(note_out), B * Tp, H, st()), "note dur")
+        L.check(lib.ss_embedding(L.ptr(note_type), L.ptr(self.p("note_encoder.type_emb.weight")), L.ptr(note_out), B * Tp, H, 5, math.sqrt(H), 1, st()), "type emb")
+        L.check(lib.ss_add_bcast_mask(L.ptr(enc), None, L.ptr(note_out), None, None, L.ptr(enc), B, Tp, H, None, st()), "enc+note")
+
+        # ---- speaker / emotion projections ----
+        spk = torch.empty(B, H, **f32)
+        emo = torch.empty(B, H, **f32)
+        self._gemm(spk_embed.contiguous().float(), pk["spk"], spk, 1, B, mask_rows=False)
+        self._gemm(emo_embed.contiguous().float(), pk["emo"], emo, 1, B, mask_rows=False)
+        ret["spk_embed"], ret["emo_embed"] = spk[:, None, :], emo[:, None, :]
+
+        # ---- duration predictor + length regulator (a3) ----
+        dur_inp = torch.empty(B, Tp, H, **f32)
+        L.check(lib.ss_add_bcast_mask(L.ptr(enc), L.ptr(spk), None, L.ptr(emo), None, L.ptr(dur_inp), B, Tp, H, L.ptr(lens_p), st()), "dur_inp")
+        hbuf = torch.empty(B, Tp, H, **f32)
+        cur = dur_inp
+        for lyr in pk["dur"]:
+            self._gemm(cur, lyr["conv"], hbuf, B, Tp, lens=lens_p, act=L.ACT_RELU, mask_rows=False)
+            cur = L.layernorm(hbuf, *lyr["ln"], B=B, T=Tp, C_=H, out=torch.empty_like(hbuf), lens=lens_p, mask_rows=True)
+        logdur = torch.empty(B, Tp, 4, **f32)
+        L.conv_gemm(cur, pk["dur_lin"].W, logdur, B=B, T=Tp, Cin=H, N=1, Np=pk["dur_lin"].Np, Kp=pk["dur_lin"].Kp, lens=lens_p,
+                    bias=pk["dur_lin"].bias, ldc=4, mask_rows=True)
+        logdur = logdur[:, :, 0].contiguous()
+        lens_t = torch.empty(B, device=dev, dtype=torch.int32)
+        if mel2ph is None:
+            dur = torch.empty(B, Tp, device=dev, dtype=torch.int64)
+            L.check(lib.ss_length_regulate(L.ptr(logdur), L.ptr(txt_tokens), L.ptr(dur), None, L.ptr(lens_t), B, Tp, 0, st()), "dur")
+            T = int(lens_t.max().item())  # host sync: the frame count is data dependent
+            if T <= 0:
+                raise L.StyleSingerHipError("predicted durations are all zero")
+            mel2ph = torch.empty(B, T, device=dev, dtype=torch.int64)
+            L.check(lib.ss_length_regulate(L.ptr(logdur), L.ptr(txt_tokens), L.ptr(dur), L.ptr(mel2ph), L.ptr(lens_t), B, Tp, T, st()), "lr")
+            ret["dur"], ret["dur_choice"] = logdur[:, :, None], dur
+        else:
+            mel2ph = mel2ph.contiguous()
+            T = mel2ph.shape[1]
+            L.check(lib.ss_count_nonzero_i64(L.ptr(mel2ph), L.ptr(lens_t), B, T, st()), "lens_t")
+            ret["dur"] = logdur
+        ret["mel2ph"] = mel2ph
+        dec = torch.empty(B, T, H, **f32)
+        L.check(lib.ss_gather_expand(L.ptr(enc), L.ptr(mel2ph), L.ptr(dec), B, Tp, T, H, st()), "expand")
+        # UMLN (a4): DistributionUncertainty returns x unchanged when not training (umln.py:48-50)
+
+        # ---- Residual Style Adaptor (a5,a6) + style-to-content attention (a7) ----
+        ref_mels = ref_mels.contiguous().float()
+        Tr = ref_mels.shape[1]
+        if ref_f0.dim() == 1:
+            ref_f0 = ref_f0[None]
+        ref_f0 = ref_f0.contiguous().float()
+        ret["ref_f0"] = ref_f0
+        lens_r = torch.empty(B, device=dev, dtype=torch.int32)
+        L.check(lib.ss_ref_lens(L.ptr(ref_mels), B, Tr, 80, L.ptr(lens_r), st()), "ref_lens")
+        xr = ref_mels.clone()
+        acts = torch.empty(B, Tr, 80, **f32)
+        wn_out = torch.zeros(B, Tr, 80, **f32)
+        for i, w in enumerate(pk["wn"]):
+            inl = w["inl"]
+            L.conv_gemm(xr, inl.W, acts, B=B, T=Tr, Cin=80, N=80, Np=inl.Np, Kp=inl.Kp, taps=(-1, 0, 1), lens=lens_r,
+                        epi=L.EPI_GATE, gate_mode=1, bias=inl.bias, ldc=80, mask_rows=False)
+            if w["res"] is not None:
+                self._gemm(acts, w["res"], xr, B, Tr, lens=lens_r, R=xr)
+            self._gemm(acts, w["skip"], wn_out, B, Tr, lens=lens_r, accumulate=True)
+        L.check(lib.ss_add_rowscalar(L.ptr(wn_out), L.ptr(ref_f0), B, Tr, 80, L.ptr(lens_r), st()), "add f0")
+        h80 = torch.empty(B, Tr, 80, **f32)
+        h160 = torch.empty(B, Tr, 160, **f32)
+        for blk in pk["cb"]:
+            L.layernorm(wn_out, *blk["ln"], B=B, T=Tr, C_=80, out=h80)
+            self._gemm(h80, blk["c1"], h160, B, Tr, lens=lens_r, act=L.ACT_GELU, pre_scale=blk["c1"].k ** -0.5, mask_rows=False)
+            self._gemm(h160, blk["c2"], wn_out, B, Tr, lens=lens_r, R=wn_out)
+        L.layernorm(wn_out, *pk["cb_ln"], B=B, T=Tr, C_=80, out=h80, lens=lens_r, mask_rows=True)
+        pre_rq = torch.empty(B, Tr, H, **f32)
+        self._gemm(h80, pk["cb_post"], pre_rq, B, Tr, lens=lens_r)
+        ret["style_pre_rq"] = pre_rq
+        zq = torch.empty(B, Tr, H, **f32)
+        codes = torch.empty(B, Tr, hp["rq_depth"], device=dev, dtype=torch.int64)
+        L.check(lib.ss_rq_lookup(L.ptr(pre_rq), L.ptr(pk["codebooks"]), L.ptr(zq), L.ptr(codes), B * Tr, H, hp["nRQ"], hp["rq_depth"], st()), "rq")
+        ret["rq_codes"], ret["style_rq"], ret["rq_loss"] = codes, zq, 0.0
+        cat = torch.empty(B, Tr, 2 * H, **f32)
+        cat[:, :, :H].copy_(zq)
+        pos_r = torch.empty(B, Tr, device=dev, dtype=torch.int32)
+        tabr = self._pos(Tr + 2, dev)
+        L.check(lib.ss_make_positions(None, L.ptr(zq), H, Tr * H, L.ptr(pos_r), B, Tr, st()), "pos style")
+        L.check(lib.ss_table_add(L.ptr(pos_r), L.ptr(tabr), tabr.shape[0], L.ptr(cat) + 4 * H, 2 * H, Tr * 2 * H, B, Tr, H, None, 1.0, 0, st()), "pos add")
+        sty = torch.empty(B, Tr, H, **f32)
+        self._gemm(cat, pk["l1"], sty, B, Tr, mask_rows=False)
+        xs = dec.clone()
+        q = torch.empty(B, T, H, **f32)
+        kv = torch.empty(B, Tr, 2 * H, **f32)
+        att = torch.zeros(B, T, H, **f32)
+        ffh = torch.empty(B, T, 2048, **f32)
+        for al in pk["align"]:
+            self._gemm(xs, al["q"], q, B, T, mask_rows=False)
+            self._gemm(sty, al["kv"], kv, B, Tr, mask_rows=False)
+            L.attention(q, kv, kv[:, :, H:], att, B=B, H=2, D=H // 2, Tq=T, Tk=Tr, ldq=H, ldk=2 * H, ldv=2 * H, ldo=H,
+                        q_bs=T * H, k_bs=Tr * 2 * H, v_bs=Tr * 2 * H, o_bs=T * H, qlens=None, klens=lens_r, scale=(H // 2) ** -0.5)
+            self._gemm(att, al["out"], xs, B, T, R=xs, mask_rows=False)
+            L.layernorm(xs, *al["n1"], B=B, T=T, C_=H)
+            self._gemm(xs, al["l1"], ffh, B, T, act=L.ACT_RELU, mask_rows=False)
+            self._gemm(ffh, al["l2"], xs, B, T, R=xs, mask_rows=False)
+            L.layernorm(xs, *al["n2"], B=B, T=T, C_=H)
+        ret["style"] = style = xs
+        ret["gloss"] = 0.0
+
+        # ---- pitch: two joint Gaussian/multinomial diffusions (a8) + post-processing (a9) ----
+        midi = torch.empty(B, T, device=dev, dtype=torch.int64)
+        L.check(lib.ss_gather_expand_i64(L.ptr(note), L.ptr(mel2ph), L.ptr(midi), B, Tp, T, st()), "midi")
+        lo = torch.empty(B, T, **f32)
+        hi = torch.empty(B, T, **f32)
+        L.check(lib.ss_f0_bounds(L.ptr(midi), L.ptr(lo), L.ptr(hi), B * T, st()), "bounds")
+        cond_b = torch.empty(B, T, H, **f32)
+        L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), None, L.ptr(emo), L.ptr(style), L.ptr(cond_b), B, T, H, L.ptr(lens_t), st()), "cond_b")
+        res = {}
+        ws_bytes = max(lib.ss_wavenet_workspace_bytes(C_byref(pk["f0_a"]["net"]), B, T),
+                       lib.ss_wavenet_workspace_bytes(C_byref(pk["mel"]["net"]), B, T))
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        for key, cond in (("f0_a", dec), ("f0_b", cond_b)):
+            net = pk[key]["net"]
+            S = net.steps
+            nz = noise[key] if noise is not None else None
+            if nz is not None:
+                f0v = nz["z0"].to(dev).reshape(B, T).contiguous().float()
+                zs = nz["z_steps"].to(dev).reshape(S, B, T).contiguous().float()
+                us = nz["u_steps"].to(dev).reshape(S, B, 2, T).contiguous().float()
+            else:
+                f0v = torch.empty(B, T, **f32)
+                L.check(lib.ss_fill_normal(L.ptr(f0v), B * T, seed + (11 if key == "f0_a" else 13), 0, st()), "z0")
+                zs = us = None
+            uvv = torch.zeros(B, T, device=dev, dtype=torch.int32)
+            L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(f0v), L.ptr(uvv), L.ptr(cond), L.ptr(lo), L.ptr(hi), L.ptr(lens_t), B, T,
+                                         L.ptr(zs), L.ptr(us), seed + (17 if key == "f0_a" else 19), 0, S, 1, L.ptr(ws), ws_bytes, st()), key)
+            res[key] = (f0v, uvv)
+        ret["gdiff1"] = ret["mdiff1"] = ret["gdiff2"] = ret["mdiff2"] = 0.0
+        pitch_pred = torch.empty(B, T, 2, **f32)
+        f0_denorm = torch.empty(B, T, **f32)
+        coarse = torch.empty(B, T, device=dev, dtype=torch.int64)
+        L.check(lib.ss_pitch_post(L.ptr(res["f0_a"][0]), L.ptr(res["f0_a"][1]), L.ptr(res["f0_b"][0]), L.ptr(res["f0_b"][1]),
+                                  L.ptr(midi), L.ptr(mel2ph), L.ptr(pitch_pred), L.ptr(f0_denorm), L.ptr(coarse), B * T, st()), "pitch_post")
+        ret["pitch_pred"], ret["f0_denorm"], ret["f0_denorm_pred"] = pitch_pred, f0_denorm, f0_denorm
+        ret["f0_a"], ret["uv_a"], ret["f0_b"], ret["uv_b"] = res["f0_a"][0], res["f0_a"][1], res["f0_b"][0], res["f0_b"][1]
+        pitch_emb = torch.empty(B, T, H, **f32)
+        L.check(lib.ss_embedding(L.ptr(coarse), L.ptr(self.p("pitch_embed.weight")), L.ptr(pitch_emb), B * T, H, 300, 1.0, 0, st()), "pitch emb")
+        dec_inp = torch.empty(B, T, H, **f32)
+        L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), L.ptr(pitch_emb), L.ptr(emo), L.ptr(style), L.ptr(dec_inp), B, T, H, L.ptr(lens_t), st()), "dec_inp")
+        ret["decoder_inp"] = dec_inp
+        if skip_decoder:
+            return ret
+
+        # ---- FFT decoder -> coarse mel (a10) ----
+        xd = dec_inp.clone()
+        pos_t = torch.empty(B, T, device=dev, dtype=torch.int32)
+        tabt = self._pos(T + 2, dev)
+        L.check(lib.ss_make_positions(None, L.ptr(dec_inp), H, T * H, L.ptr(pos_t), B, T, st()), "pos dec")
+        L.check(lib.ss_table_add(L.ptr(pos_t), L.ptr(tabt), tabt.shape[0], L.ptr(xd), H, T * H, B, T, H,
+                                 L.ptr(self.p("decoder.pos_embed_alpha")), 1.0, 1, st()), "pos add dec")
+        xd = self._fft_blocks(pk["dec"], xd, B, T, lens_t)
+        ret["decoder_out"] = xd
+        M = hp["audio_num_mel_bins"]
+        coarse_mel = torch.empty(B, T, M, **f32)
+        self._gemm(xd, pk["mel_out"], coarse_mel, B, T, lens=lens_t)
+        ret["fs2_mel"] = coarse_mel
+        ret["x_mask"] = (mel2ph > 0).float()[:, :, None]
+        if not (global_steps > hp["diff_start"]):
+            ret["mel_out"] = coarse_mel
+            return ret
+
+        # ---- condition projection (a11) + shallow mel diffusion (a12) ----
+        gcat = torch.cat([coarse_mel, dec_inp, spk[:, None, :].expand(-1, T, -1), emo[:, None, :].expand(-1, T, -1), style], -1).contiguous()
+        cond = torch.empty(B, T, H, **f32)
+        self._gemm(gcat, pk["ln_proj"], cond, B, T, mask_rows=False)
+        ret["diff_cond"] = cond
+        net = pk["mel"]["net"]
+        K = hp["K_step"]
+        sa = float(pk["mel"]["sched"]["sqrt_alphas_cumprod"][K - 1])
+        s1 = float(pk["mel"]["sched"]["sqrt_one_minus_alphas_cumprod"][K - 1])
+        xm = torch.empty(B, T, M, **f32)
+        nz = noise["mel"] if noise is not None else None
+        zq_n = zs_n = None
+        if nz is not None:
+            zq_n = nz["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
+            zs_n = nz["z_steps"].to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()
+        L.check(lib.ss_mel_qsample(L.ptr(coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), seed + 23,
+                                   L.ptr(xm), B, T, M, st()), "qsample")
+        L.check(lib.ss_meldiff_sample(C_byref(net), L.ptr(xm), L.ptr(cond), L.ptr(lens_t), B, T, L.ptr(zs_n), seed + 29, 0, K, 1,
+                                      L.ptr(ws), ws_bytes, st()), "meldiff")
+        mel_out = torch.empty(B, T, M, **f32)
+        # the reference does not mask padded frames here (shallow_diffusion_tts.py:305-306); with per-item
+        # lengths the frames past lens[b] are not part of the utterance, so they are written as 0.
+        L.check(lib.ss_mel_denorm(L.ptr(xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(lens_t), st()), "denorm")
+        ret["mel_out"] = mel_out
+        ret["diff"] = 0.0
+        ret["lens"] = lens_t
+        return ret
+
+
+def C_byref(struct):
+    import ctypes
+    return ctypes.addressof(struct)

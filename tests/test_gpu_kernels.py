@@ -1,0 +1,236 @@
+"""GPU unit parity: each HIP kernel against a plain fp32 torch CPU statement of the same op, through the C-ABI."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from stylesinger_amd import lib as L  # noqa: E402
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _ref_conv(x, w, b, dil, lens):
+    """channels-last same conv with per-item zero padding beyond lens."""
+    B, T, C = x.shape
+    out = torch.zeros(B, T, w.shape[0])
+    k = w.shape[-1]
+    for i in range(B):
+        n = int(lens[i])
+        xi = x[i:i + 1, :n].transpose(1, 2)
+        out[i, :n] = F.conv1d(xi, w, b, padding=(k - 1) // 2 * dil, dilation=dil).transpose(1, 2)[0]
+    return out
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k,dil,tile", [
+    (2, 70, 256, 256, 3, 2, 0), (1, 130, 80, 160, 5, 1, 0), (3, 33, 256, 1024, 9, 1, 0), (2, 200, 192, 96, 1, 1, 0),
+    (1, 300, 32, 32, 11, 5, 5), (1, 300, 64, 64, 7, 3, 4), (2, 129, 128, 128, 3, 1, 1), (2, 129, 128, 128, 3, 1, 2),
+    (2, 129, 128, 128, 3, 1, 3), (1, 40, 1104, 256, 1, 1, 0), (1, 64, 256, 3, 1, 1, 0),
+])
+def test_conv_gemm_store(B, T, Cin, Cout, k, dil, tile):
+    d = dev()
+    x = _rand(B, T, Cin, seed=1)
+    w = _rand(Cout, Cin, k, seed=2, scale=1 / math.sqrt(Cin * k))
+    b = _rand(Cout, seed=3, scale=0.1)
+    r = _rand(B, T, Cout, seed=4)
+    lens = torch.tensor([T - 3 * i for i in range(B)], dtype=torch.int32)
+    ref = F.gelu(_ref_conv(x, w, b, dil, lens) * 0.5)
+    ref = ref + r
+    for i in range(B):
+        ref[i, int(lens[i]):] = 0
+    W = L.pack_conv_weight(w.to(d))
+    bias = L.pack_bias(b.to(d))
+    out = torch.full((B, T, Cout), 7.0, device=d)
+    L.conv_gemm(x.to(d), W, out, B=B, T=T, Cin=Cin, N=Cout, Np=W.shape[0], Kp=W.shape[1] // k,
+                taps=[(j - (k - 1) // 2) * dil for j in range(k)], lens=lens.to(d), bias=bias, pre_scale=0.5, act=L.ACT_GELU,
+                R=r.to(d), ldr=Cout, tile=tile)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_conv_gemm_prologue_bias_lrelu_scale_accumulate():
+    d = dev()
+    B, T, C = 2, 90, 64
+    x = _rand(B, T, C, seed=5)
+    ab = _rand(C, seed=6)
+    w = _rand(C, C, 3, seed=7, scale=0.1)
+    b = _rand(C, seed=8, scale=0.1)
+    lens = torch.tensor([90, 61], dtype=torch.int32)
+    xa = F.leaky_relu((x + ab) * 0.7, 0.1)
+    prev = _rand(B, T, C, seed=9)
+    ref = prev + _ref_conv(xa, w, b, 1, lens) * (1 / 3)
+    for i in range(B):
+        ref[i, int(lens[i]):] = 0
+    W = L.pack_conv_weight(w.to(d))
+    out = prev.to(d).clone()
+    L.conv_gemm(x.to(d), W, out, B=B, T=T, Cin=C, N=C, Np=W.shape[0], Kp=W.shape[1] // 3, taps=(-1, 0, 1), lens=lens.to(d),
+                a_bias=ab.to(d), a_scale=0.7, a_lrelu=0.1, bias=L.pack_bias(b.to(d)), post_scale=1 / 3, accumulate=True)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("C,mode", [(256, 0), (192, 0), (80, 1)])
+def test_conv_gemm_gate_and_resskip(C, mode):
+    d = dev()
+    B, T = 2, 100
+    x = _rand(B, T, C, seed=11)
+    w = _rand(2 * C, C, 3, seed=12, scale=1 / math.sqrt(3 * C))
+    b = _rand(2 * C, seed=13, scale=0.1)
+    e = _rand(B, T, 2 * C, seed=14)
+    lens = torch.tensor([T, T - 17], dtype=torch.int32)
+    y = _ref_conv(x, w, b, 2, lens) + e
+    g_ref = torch.sigmoid(y[..., :C]) * torch.tanh(y[..., C:]) if mode == 0 else torch.tanh(y[..., :C]) * torch.sigmoid(y[..., C:])
+    W = L.pack_conv_weight(w.to(d), interleave_half=C)
+    bias = L.pack_bias(b.to(d), interleave_half=C)
+    Np = W.shape[0]
+    # E must be in packed column order
+    ep = torch.zeros(B, T, Np)
+    Cp = Np // 2
+    for p in range(Cp // 32):
+        n = min(32, C - p * 32)
+        if n <= 0:
+            break
+        ep[..., (2 * p) * 32:(2 * p) * 32 + n] = e[..., p * 32:p * 32 + n]
+        ep[..., (2 * p + 1) * 32:(2 * p + 1) * 32 + n] = e[..., C + p * 32:C + p * 32 + n]
+    g = torch.empty(B, T, C, device=d)
+    L.conv_gemm(x.to(d), W, g, B=B, T=T, Cin=C, N=C, Np=Np, Kp=W.shape[1] // 3, taps=(-2, 0, 2), lens=lens.to(d), epi=L.EPI_GATE,
+                gate_mode=mode, bias=bias, E=ep.to(d), lde=Np, e_bs=T * Np, ldc=C, mask_rows=False)
+    for i in range(B):
+        n = int(lens[i])
+        assert (g[i, :n].cpu() - g_ref[i, :n]).abs().max().item() < 2e-5
+    if C % 32 == 0:
+        wo = _rand(2 * C, C, 1, seed=15, scale=1 / math.sqrt(C))
+        bo = _rand(2 * C, seed=16, scale=0.1)
+        xs = _rand(B, T, C, seed=17)
+        sk = _rand(B, T, C, seed=18)
+        gv = g_ref.clone()
+        for i in range(B):
+            gv[i, int(lens[i]):] = 0
+        yo = F.conv1d(gv.transpose(1, 2), wo, bo).transpose(1, 2)
+        x_ref = (xs + yo[..., :C]) / math.sqrt(2.0)
+        s_ref = sk + yo[..., C:]
+        Wo = L.pack_conv_weight(wo.to(d))
+        xd, sd_ = xs.to(d).clone(), sk.to(d).clone()
+        L.conv_gemm(gv.to(d), Wo, xd, B=B, T=T, Cin=C, N=2 * C, Np=Wo.shape[0], Kp=Wo.shape[1], lens=lens.to(d), epi=L.EPI_RESSKIP,
+                    bias=L.pack_bias(bo.to(d)), Nh=C, R=xd, ldr=C, ldc=C, post_scale=1 / math.sqrt(2.0), C2=sd_, ldc2=C, c2_bs=T * C,
+                    accumulate=True, mask_rows=False)
+        assert (xd.cpu() - x_ref).abs().max().item() < 2e-5
+        assert (sd_.cpu() - s_ref).abs().max().item() < 2e-5
+
+
+def test_convtranspose_polyphase():
+    d = dev()
+    for (Cin, Cout, u) in [(64, 32, 8), (32, 16, 2)]:
+        k = 2 * u
+        B, T = 2, 37
+        x = _rand(B, T, Cin, seed=21)
+        v = _rand(Cin, Cout, k, seed=22, scale=0.1)
+        g = torch.rand(Cin, 1, 1) + 0.5
+        b = _rand(Cout, seed=23, scale=0.1)
+        w = v * (g / v.reshape(Cin, -1).norm(dim=1).reshape(Cin, 1, 1))
+        ref = F.conv_transpose1d(F.leaky_relu(x, 0.1).transpose(1, 2), w, b, stride=u, padding=(k - u) // 2).transpose(1, 2)
+        s0 = L.weight_norm_scale(v.to(d), g.to(d))
+        out = torch.zeros(B, T * u, Cout, device=d)
+        pad = (k - u) // 2
+        nph0 = u - pad
+        bias = L.pack_bias(b.to(d), repeat=u)
+        for grp in range(2):
+            W = L.pack_convtr_weight(v.to(d), s0, u, grp)
+            nph = nph0 if grp == 0 else u - nph0
+            o = out.view(B, T, u * Cout)[:, :, (0 if grp == 0 else nph0 * Cout):]
+            L.conv_gemm(x.to(d), W, o, B=B, T=T, Cin=Cin, N=nph * Cout, Np=W.shape[0], Kp=W.shape[1] // 2,
+                        taps=(0, -1) if grp == 0 else (1, 0), a_lrelu=0.1, bias=bias, ldc=u * Cout, c_bs=T * u * Cout)
+        assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+def test_layernorm_and_masks():
+    d = dev()
+    for C in (80, 256):
+        B, T = 2, 50
+        x = _rand(B, T, C, seed=31) * 3 + 1
+        g, b = _rand(C, seed=32) + 1, _rand(C, seed=33)
+        lens = torch.tensor([50, 20], dtype=torch.int32)
+        ref = F.layer_norm(x, (C,), g, b, 1e-5)
+        ref[1, 20:] = 0
+        y = L.layernorm(x.to(d), g.to(d), b.to(d), B=B, T=T, C_=C, out=torch.empty(B, T, C, device=d), lens=lens.to(d), mask_rows=True)
+        assert (y.cpu() - ref).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("Tq,Tk,B", [(70, 70, 2), (33, 200, 1), (257, 129, 2)])
+def test_attention(Tq, Tk, B):
+    d = dev()
+    H, D = 2, 128
+    q, k, v = _rand(B, Tq, H * D, seed=41), _rand(B, Tk, H * D, seed=42), _rand(B, Tk, H * D, seed=43)
+    klens = torch.tensor([Tk - 5 * i for i in range(B)], dtype=torch.int32)
+    scale = D ** -0.5
+    ref = torch.zeros(B, Tq, H * D)
+    for b in range(B):
+        n = int(klens[b])
+        for h in range(H):
+            s = (q[b, :, h * D:(h + 1) * D] * scale) @ k[b, :n, h * D:(h + 1) * D].t()
+            ref[b, :, h * D:(h + 1) * D] = torch.softmax(s, -1) @ v[b, :n, h * D:(h + 1) * D]
+    o = torch.zeros(B, Tq, H * D, device=d)
+    L.attention(q.to(d), k.to(d), v.to(d), o, B=B, H=H, D=D, Tq=Tq, Tk=Tk, ldq=H * D, ldk=H * D, ldv=H * D, ldo=H * D, q_bs=Tq * H * D,
+                k_bs=Tk * H * D, v_bs=Tk * H * D, o_bs=Tq * H * D, klens=klens.to(d), scale=scale)
+    assert (o.cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_rq_lookup_exact_codes():
+    d = dev()
+    lib = L.load()
+    rows, C, n, depth = 203, 256, 128, 4
+    x = _rand(rows, C, seed=51)
+    cb = torch.stack([_rand(n + 1, C, seed=60 + i) * (0.8 * 0.6 ** i) for i in range(depth)])
+    r, agg, codes = x.clone(), torch.zeros_like(x), []
+    for i in range(depth):
+        c = cb[i, :-1]
+        dist = torch.addmm(r.pow(2).sum(1, keepdim=True) + c.t().pow(2).sum(0, keepdim=True), r, c.t(), alpha=-2.0)
+        kk = dist.argmin(-1)
+        r = r - c[kk]
+        agg = agg + c[kk]
+        codes.append(kk)
+    ref = x + (agg - x)
+    out = torch.empty(rows, C, device=d)
+    cod = torch.empty(rows, depth, device=d, dtype=torch.int64)
+    xd, cbd = x.to(d), cb.to(d).contiguous()  # keep alive: L.ptr() of a temporary would dangle
+    L.check(lib.ss_rq_lookup(L.ptr(xd), L.ptr(cbd), L.ptr(out), L.ptr(cod), rows, C, n, depth, L.stream_ptr()))
+    assert torch.equal(cod.cpu(), torch.stack(codes, -1))  # integer work: bit-exact
+    assert (out.cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_positions_embedding_lengthreg():
+    d = dev()
+    lib = L.load()
+    B, Tp = 2, 9
+    tok = torch.tensor([[5, 3, 0, 7, 9, 0, 0, 2, 1], [4, 4, 4, 0, 0, 0, 0, 0, 0]])
+    pos = torch.empty(B, Tp, dtype=torch.int32, device=d)
+    tokd = tok.to(d)
+    L.check(lib.ss_make_positions(L.ptr(tokd), None, 0, 0, L.ptr(pos), B, Tp, L.stream_ptr()))
+    m = (tok != 0).int()
+    assert torch.equal(pos.cpu().long(), (torch.cumsum(m, 1) * m).long())
+    logdur = torch.tensor([[1.2, 0.1, 3.0, 1.7, -2.0, 0.5, 0.5, 1.0986123, 2.2], [0.9, 1.5, 1.1, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]])
+    dur = torch.clamp(torch.round(logdur.exp() - 1), min=0).long() * (tok != 0).long()
+    T = int(dur.sum(-1).max())
+    dur_o = torch.empty(B, Tp, dtype=torch.int64, device=d)
+    lens = torch.empty(B, dtype=torch.int32, device=d)
+    m2p = torch.empty(B, T, dtype=torch.int64, device=d)
+    ldd = logdur.to(d)
+    L.check(lib.ss_length_regulate(L.ptr(ldd), L.ptr(tokd), L.ptr(dur_o), None, L.ptr(lens), B, Tp, 0, L.stream_ptr()))
+    assert torch.equal(dur_o.cpu(), dur) and lens.cpu().tolist() == dur.sum(-1).tolist()
+    L.check(lib.ss_length_regulate(L.ptr(ldd), L.ptr(tokd), L.ptr(dur_o), L.ptr(m2p), L.ptr(lens), B, Tp, T, L.stream_ptr()))
+    ref = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        p = 0
+        for i in range(Tp):
+            ref[b, p:p + int(dur[b, i])] = i + 1
+            p += int(dur[b, i])
+    assert torch.equal(m2p.cpu(), ref)

@@ -1,0 +1,144 @@
+"""GPU parity of the whole hot path: HIP (through the C-ABI) vs the golden outputs of the REAL reference and
+vs the CPU restatement, with a shared noise tape.  Tolerances are stated next to each check."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import harness  # noqa: E402
+from oracle import restatement as R  # noqa: E402
+from stylesinger_amd import config, synth  # noqa: E402
+from stylesinger_amd.model import StyleSingerHIP  # noqa: E402
+from stylesinger_amd.vocoder import HifiGAN  # noqa: E402
+
+MEL_L1_TOL = 1e-4      # north_star: mel L1 <= 1e-4 vs the reference (fp32)
+STAGE_TOL = 2e-4       # max-abs on intermediate activations (O(1) magnitudes)
+
+
+def _run_hip(meta):
+    hp, sd, batch = harness.case_setup(meta)
+    dev = torch.device("cuda:0")
+    model = StyleSingerHIP(None, hparams=hp)
+    model.load_state_dict(sd, strict=True)
+    model.eval().to(dev)
+    tape = synth.NoiseTape(meta["tape_seed"])
+    T = meta["T"]
+    gold_T = None
+    noise = None
+    if meta["give_mel2ph"]:
+        noise = synth.draw_acoustic_noise(tape, meta["B"], T, meta["steps_f0"], meta["steps_mel"])
+    b = {k: v.to(dev) for k, v in batch.items()}
+    kw = dict(spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"], ref_f0=b["ref_f0"], global_steps=320000,
+              infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"])
+    if meta["give_mel2ph"]:
+        ret = model(b["txt_tokens"], mel2ph=b["mel2ph"], noise=noise, **kw)
+    else:
+        # durations are predicted: T is only known after the duration stage, so draw the tape for that T
+        pre = model(b["txt_tokens"], mel2ph=None, skip_decoder=True, **kw)
+        T = pre["mel2ph"].shape[1]
+        noise = synth.draw_acoustic_noise(tape, meta["B"], T, meta["steps_f0"], meta["steps_mel"])
+        ret = model(b["txt_tokens"], mel2ph=None, noise=noise, **kw)
+    torch.cuda.synchronize()
+    return ret, tape
+
+
+@pytest.mark.parametrize("name", ["acoustic_tiny_s4", "acoustic_b2_s3", "acoustic_dur_s2", "acoustic_t64_s100"])
+def test_acoustic_hip_matches_reference_golden(name):
+    case = harness.load_case(name)
+    meta, gold = case["meta"], case["out"]
+    ret, tape = _run_hip(meta)
+    assert tape.log == meta["tape_log"]
+    assert torch.equal(ret["mel2ph"].cpu(), gold["mel2ph"])           # integer: bit-exact
+    if "dur_choice" in gold:
+        assert torch.equal(ret["dur_choice"].cpu(), gold["dur_choice"])
+    for k_hip, k_gold in [("encoder_out_text", "encoder_out"), ("style_pre_rq", "style_pre_rq"), ("style_rq", "style_rq"),
+                          ("style", "style"), ("decoder_inp", "decoder_inp"), ("decoder_out", "decoder_out"),
+                          ("diff_cond", "diff_cond"), ("pitch_pred", "pitch_pred")]:
+        if k_gold in gold:
+            err = (ret[k_hip].cpu() - gold[k_gold]).abs().max().item()
+            assert err <= STAGE_TOL, f"{name}:{k_hip} max abs err {err:.3e}"
+    uv_flip = ((ret["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).float().mean().item()
+    assert uv_flip == 0.0, f"voicing flips {uv_flip}"
+    assert torch.allclose(ret["f0_denorm"].cpu(), gold["f0_denorm"], rtol=2e-4, atol=1e-2)
+    l1 = (ret["mel_out"].cpu() - gold["mel_out"]).abs().mean().item()
+    mx = (ret["mel_out"].cpu() - gold["mel_out"]).abs().max().item()
+    print(f"{name}: mel L1 {l1:.3e} max {mx:.3e}")
+    assert l1 <= MEL_L1_TOL, f"{name}: mel L1 {l1:.3e}"
+
+
+@pytest.mark.parametrize("name", ["vocoder_t12", "vocoder_b2_t9"])
+def test_vocoder_hip_matches_reference_golden(name):
+    case = harness.load_case(name)
+    meta = case["meta"]
+    cfg, vsd = harness.vocoder_case_setup(meta)
+    voc = HifiGAN(cfg, vsd, device="cuda:0")
+    tape = synth.NoiseTape(meta["tape_seed"])
+    B, T = meta["B"], meta["T"]
+    noise = synth.draw_vocoder_noise(tape, B, T * 256)
+    assert tape.log == meta["tape_log"]
+    wav, har = voc.model(case["inp"]["mel"].cuda(), case["inp"]["f0"].cuda(), noise=noise, return_source=True)
+    e_h = (har.cpu() - case["out"]["har"]).abs().max().item()
+    e_w = (wav.cpu() - case["out"]["wav"]).abs().max().item()
+    print(f"{name}: har max err {e_h:.3e} wav max err {e_w:.3e}")
+    assert e_h <= 2e-4     # fp32 sin of a ~1e3-rad phase: 1 ulp of the argument is ~6e-5
+    assert e_w <= 5e-4     # waveform in [-1,1] after 4 upsampling stages
+    if B == 1:
+        w1 = voc.spec2wav(case["inp"]["mel"][0].numpy(), f0=case["inp"]["f0"][0].numpy(), noise=noise)
+        assert abs(w1 - case["out"]["wav"][0].numpy()).max() <= 5e-4
+
+
+def test_ragged_batch_equals_per_item_runs():
+    """Per-item lengths: a padded batch must reproduce each item run alone (the reference is B=1 only)."""
+    hp = config.make_hparams(dict(timesteps=3, K_step=3, f0_timesteps=3))
+    sd = synth.synth_acoustic_state_dict(hp, 5)
+    dev = torch.device("cuda:0")
+    model = StyleSingerHIP(None, hparams=hp)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    items = [synth.synth_utterance(0, 70, 7, 50, hp, 5), synth.synth_utterance(1, 45, 5, 38, hp, 5)]
+    T, Tp, Tr = 70, 7, 50
+    def pad(t, n):
+        out = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype)
+        out[:t.shape[0]] = t
+        return out
+    batch = {k: torch.stack([pad(it[k], {"txt_tokens": Tp, "note": Tp, "note_type": Tp, "note_dur": Tp, "mel2ph": T,
+                                         "ref_mels": Tr, "ref_f0": Tr}.get(k, it[k].shape[0])) for it in items]) for k in items[0]}
+    tape = synth.NoiseTape(9)
+    noise = synth.draw_acoustic_noise(tape, 2, T, 3, 3)
+    def run(b, nz):
+        b = {k: v.to(dev) for k, v in b.items()}
+        return model(b["txt_tokens"], mel2ph=b["mel2ph"], spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
+                     ref_f0=b["ref_f0"], global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"], noise=nz)
+    full = run(batch, noise)
+    for i, (Ti, it) in enumerate(zip((70, 45), items)):
+        nz = {k: {kk: (vv[:, i:i + 1, ..., :Ti] if kk in ("z_steps", "u_steps") else vv[i:i + 1, ..., :Ti]) for kk, vv in v.items()} for k, v in noise.items()}
+        one = run({k: v[None] for k, v in it.items()}, nz)
+        d = (full["mel_out"][i, :Ti] - one["mel_out"][0]).abs().max().item()
+        assert d <= 1e-5, (i, d)
+        assert torch.equal(full["uv_a"][i, :Ti], one["uv_a"][0])
+    assert full["mel_out"][1, 45:].abs().max().item() == 0.0
+
+
+def test_oracle_vs_hip_medium_size():
+    """Beyond the committed fixtures: a mid-size case checked against the CPU restatement run on this box."""
+    hp = config.make_hparams(dict(timesteps=8, K_step=8, f0_timesteps=8))
+    sd = synth.synth_acoustic_state_dict(hp, 21)
+    B, T, Tp, Tr = 2, 300, 10, 260
+    batch = synth.synth_batch(B, T, Tp, Tr, hp, 21)
+    tape = synth.NoiseTape(22)
+    with torch.no_grad():
+        ref = R.acoustic_forward(sd, hp, batch, tape, mel2ph=batch["mel2ph"])
+    dev = torch.device("cuda:0")
+    model = StyleSingerHIP(None, hparams=hp)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(22), B, T, 8, 8)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    ret = model(b["txt_tokens"], mel2ph=b["mel2ph"], spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
+                ref_f0=b["ref_f0"], global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"], noise=noise)
+    assert torch.equal(ret["rq_codes"].cpu(), ref["rq_codes"])
+    flips = (ret["uv_a"].cpu().long() != ref["uv_a"]).float().mean().item() + (ret["uv_b"].cpu().long() != ref["uv_b"]).float().mean().item()
+    assert flips == 0.0
+    l1 = (ret["mel_out"].cpu() - ref["mel_out"]).abs().mean().item()
+    print(f"medium: mel L1 {l1:.3e}")
+    assert l1 <= MEL_L1_TOL

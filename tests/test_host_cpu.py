@@ -1,0 +1,93 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the ctypes mirror
+matches the C structs, the parameter/hparams contract matches the reference dump, synthetic data is
+deterministic, and the product refuses to run without a GPU instead of falling back."""
+import json
+import os
+
+import pytest
+import torch
+
+from stylesinger_amd import config, lib, spec, synth
+
+
+def test_library_loads_and_exports_header_symbols():
+    l = lib.load()
+    names = lib.declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(l, n), n
+    assert l.ss_abi_version() == 1
+    assert l.ss_last_error() is not None
+
+
+def test_ctypes_struct_mirror_matches_c():
+    import ctypes
+    l = lib.load()
+    sizes = (ctypes.c_int64 * 3)()
+    assert l.ss_struct_sizes(sizes, 3) == 0
+    assert tuple(sizes) == (ctypes.sizeof(lib.ConvGemmArgs), ctypes.sizeof(lib.WaveNet), ctypes.sizeof(lib.HifiGan))
+
+
+def test_argument_errors_are_reported_not_crashed():
+    l = lib.load()
+    assert l.ss_conv_gemm(None, None) != 0
+    assert b"null args" in l.ss_last_error()
+    assert l.ss_layernorm(None, None, None, None, 1, 1, 8, 8, 8, 8, 8, 1e-5, None, 0, None) != 0
+
+
+def test_param_spec_matches_reference_dump(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "param_spec.json")))
+    mine = spec.acoustic_spec(config.make_hparams())
+    assert [[k, list(s)] for k, s in mine] == ref["acoustic"]
+    minev = spec.vocoder_spec(config.make_vocoder_config())
+    assert [[k, list(s)] for k, s in minev] == ref["vocoder"]
+
+
+def test_hparams_match_reference_dump(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "hparams.json")))
+    hp = config.make_hparams()
+    for k, v in ref.items():
+        assert hp[k] == v, k
+
+
+def test_synthetic_weights_and_inputs_are_deterministic():
+    hp = config.make_hparams(dict(timesteps=4, K_step=4, f0_timesteps=4))
+    a = synth.synth_acoustic_state_dict(hp, 7)
+    b = synth.synth_acoustic_state_dict(hp, 7)
+    assert set(a) == {n for n, _ in spec.acoustic_spec(hp)}
+    for k in ("mel_out.weight", "postdiff.denoise_fn.residual_layers.3.dilated_conv.weight", "postdiff.betas"):
+        assert torch.equal(a[k], b[k])
+    assert a["gm_diffnet.mlp.0.weight"] is a["f0_gen._denoise_fn.mlp.0.weight"]
+    x = synth.synth_batch(2, 20, 4, 16, hp, 3)
+    y = synth.synth_batch(2, 20, 4, 16, hp, 3)
+    assert all(torch.equal(x[k], y[k]) for k in x)
+    assert (x["mel2ph"] > 0).all() and x["mel2ph"].max() == 4
+
+
+def test_model_state_dict_contract_and_no_cpu_fallback():
+    from stylesinger_amd.model import StyleSingerHIP
+    hp = config.make_hparams(dict(timesteps=2, K_step=2, f0_timesteps=2))
+    m = StyleSingerHIP(None, hparams=hp)
+    sd = synth.synth_acoustic_state_dict(hp, 1)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    m.load_state_dict(sd, strict=True)
+    assert torch.equal(m.state_dict()["ln_proj.weight"], sd["ln_proj.weight"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"bogus": torch.zeros(1)}, strict=True)
+    m.eval()
+    with pytest.raises(RuntimeError):
+        m.train()
+    if not torch.cuda.is_available():
+        b = synth.synth_batch(1, 8, 2, 8, hp, 1)
+        with pytest.raises(lib.StyleSingerHipError):
+            m(b["txt_tokens"], mel2ph=b["mel2ph"], spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
+              ref_f0=b["ref_f0"], infer=True, global_steps=320000, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"])
+
+
+def test_vocoder_registry_surface():
+    from stylesinger_amd import vocoder
+    assert vocoder.get_vocoder_cls({"vocoder": "HifiGAN_NSF"}) is vocoder.HifiGAN
+    g = vocoder.HifiGanGeneratorHIP()
+    vsd = synth.synth_vocoder_state_dict()
+    g.load_state_dict(vsd, strict=True)
+    assert g.hop == 256
