@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Benchmark of the StyleSinger inference hot path on MI355X (contract: see the task statement).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole hot path (phoneme encoder -> RSA -> two f0 diffusions -> FFT decoder ->
+100-step shallow mel diffusion -> [RCCL all_gather of mels when N>1] -> HiFi-GAN-NSF) over one batch of
+synthetic utterances per GPU, inputs resident in HBM, device Philox noise.  Workload = BASELINE.json
+configs[1]: batch 8 x 8 s (T=1500 frames, 48 kHz / hop 256), 100 diffusion steps, fp32; N>1 is
+configs[2] (8 utterances per GPU, weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MEL_FLOP_PER_FRAME_STEP = 26.43e6   # SURVEY.md §8(d), algorithmic (cond-proj counted)
+F0_FLOP_PER_FRAME_STEP = 7.94e6     # per network
+VOC_FLOP_PER_FRAME = 614.6e6
+REST_FLOP_PER_FRAME = 45e6
+PEAK_FP32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1500, help="mel frames per utterance (1500 = 8 s)")
+    ap.add_argument("--diff-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=750)
+    return ap.parse_args()
+
+
+def kernel_roofline(infer, B, T, iters=20):
+    """Dominant kernel = dilated-conv+gate GEMM of the mel denoiser (2000 launches per step).
+    Timed live with events on the launch stream; algorithmic flops = 2*frames*(3*256)*512 per launch."""
+    from stylesinger_amd import lib as L
+    net = infer.model._pk["mel"]
+    C, Lyr = 256, 20
+    dev = infer.device
+    X = torch.randn(B, T, C, device=dev)
+    E = torch.randn(B, T, Lyr * 2 * C, device=dev)
+    G = torch.empty(B, T, C, device=dev)
+    lens = torch.full((B,), T, device=dev, dtype=torch.int32)
+    dil_w = [k for k in net["keep"] if hasattr(k, "half") and k.half == C and k.k == 3]
+    dstep = [k for k in net["keep"] if torch.is_tensor(k) and k.dim() == 3 and k.shape[1] == Lyr][0]
+
+    def launch(l):
+        d = 1 << (l % 4)
+        w = dil_w[l]
+        L.conv_gemm(X, w.W, G, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, taps=(-d, 0, d), lens=lens, a_bias=dstep[0, l],
+                    epi=L.EPI_GATE, E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
+    for l in range(4):
+        launch(l)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        launch(i % Lyr)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 2.0 * B * T * (3 * C) * (2 * C)
+    return dict(bound="mfma", kernel="conv_gemm_kernel<GATE> (mel dilated conv k=3, 256->512, + gate)", achieved=flops / sec / 1e12,
+                peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s", frac=flops / sec / PEAK_FP32_MFMA, traffic=None,
+                us_per_launch=sec * 1e6, flops_per_launch=flops)
+
+
+def cpu_baseline(hp, frames):
+    """The oracle (CPU restatement of the reference) timed on this box's host cores: a reported baseline only."""
+    from oracle import restatement as R
+    from stylesinger_amd import config, synth
+    torch.manual_seed(0)
+    sd = synth.synth_acoustic_state_dict(hp, 1234)
+    cfg = config.make_vocoder_config()
+    vsd = synth.synth_vocoder_state_dict(cfg, 1234)
+    Tp = max(2, frames * 28 // 1500)
+    batch = synth.synth_batch(1, frames, Tp, frames, hp, 1234)
+    tape = synth.NoiseTape(1)
+    with torch.no_grad():
+        t0 = time.time()
+        ret = R.acoustic_forward(sd, hp, batch, tape, mel2ph=batch["mel2ph"])
+        mel = ret["mel_out"].clamp(hp["mel_vmin"], hp["mel_vmax"])
+        R.hifigan_forward(vsd, cfg, mel, ret["f0_denorm"], tape)
+        dt = time.time() - t0
+    return dict(value=frames / dt, unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"B=1, T={frames} frames, {hp['K_step']}+2x{hp['f0_timesteps']} diffusion steps + HiFi-GAN-NSF, fp32, "
+                       f"oracle/restatement.py (torch CPU, {torch.get_num_threads()} threads), {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from stylesinger_amd import config, dist as ssd, synth
+    from stylesinger_amd.infer import StyleSingerInfer
+    hp = config.make_hparams(dict(timesteps=args.diff_steps, K_step=args.diff_steps, f0_timesteps=args.diff_steps))
+    B, T = args.batch, args.frames
+    Tp, Tr = max(2, T * 28 // 1500), T
+    sd = synth.synth_acoustic_state_dict(hp, 1234)
+    vsd = synth.synth_vocoder_state_dict(None, 1234)
+    infer = StyleSingerInfer(hp, device=dev, model_state=sd, vocoder_state=vsd)
+    batch = synth.synth_batch(B, T, Tp, Tr, hp, 1234, first_index=rank * B)
+    batch = {k: v.to(dev) for k, v in batch.items()}
+
+    def step(i):
+        res = infer.infer_batch(batch, seed=1234 + 7919 * i + rank, vocode=False)
+        mel, f0, lens = ssd.gather_mels(res["mel"], res["f0"], res["lens"])
+        own = slice(rank * B, (rank + 1) * B) if world > 1 else slice(None)
+        wav = infer.vocode(mel[own], f0[own], lens[own], seed=4321 + i)
+        return wav, lens
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    sync()
+    t0 = time.perf_counter()
+    frames_local = 0
+    for i in range(args.steps):
+        wav, lens = step(i)
+        frames_local += B * T
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert torch.isfinite(wav).all(), "non-finite waveform"
+    total_frames = frames_local * world
+    value = total_frames / dt
+    flop_per_frame = (MEL_FLOP_PER_FRAME_STEP + 2 * F0_FLOP_PER_FRAME_STEP) * args.diff_steps + VOC_FLOP_PER_FRAME + REST_FLOP_PER_FRAME
+
+    if rank == 0:
+        out = {
+            "metric": "mel-frames/sec (end-to-end infer incl. vocoder)", "value": value, "unit": "mel-frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random weights + inputs; no checkpoint ships)",
+            "config": {"workload": f"batch={B}x{T / 187.5:.1f}s utterances per GPU (T={T} frames, Tp={Tp}, Tr={Tr}), "
+                                   f"{args.diff_steps} mel + 2x{args.diff_steps} f0 diffusion steps + HiFi-GAN-NSF, fp32",
+                       "global_batch": B * world, "frames_per_utterance": T, "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_frame": flop_per_frame / 1e9,
+                       "e2e_fraction_of_fp32_mfma_peak": value / world * flop_per_frame / PEAK_FP32_MFMA},
+        }
+        out["roofline"] = kernel_roofline(infer, B, T)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hp, args.cpu_frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

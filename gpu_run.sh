@@ -6,5 +6,7 @@ case "$1" in
   tests) python -m pytest tests -x -q -m gpu -s 2>&1 | tail -60 | tee gpurun_out/tests.log ;;
   kernels) python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -40 | tee gpurun_out/kernels.log ;;
   parity) python -m pytest tests/test_gpu_parity.py -x -q -m gpu -s 2>&1 | tail -60 | tee gpurun_out/parity.log ;;
-  *) shift 0; "$@" ;;
+  smoke) python __graft_entry__.py smoke 2>&1 | tail -5 | tee gpurun_out/smoke.log ;;
+  bench) shift; python bench.py "$@" 2>&1 | tail -5 | tee gpurun_out/bench.log ;;
+  *) "$@" ;;
 esac

@@ -1,0 +1,83 @@
+"""Inference entrypoint of the HIP path: mirror of `inference/StyleSinger.py::StyleSingerInfer`.
+
+`StyleSingerInfer(hparams).forward_model(inp)` keeps the reference's single-utterance contract
+(inference/StyleSinger.py:41-63: run the model, drop all-zero frames, clip the mel to
+[mel_vmin, mel_vmax], vocode with the predicted f0).  `infer_batch` is the batched, device-resident
+form the benchmark and the data-parallel driver use.  The feature extractors of `preprocess_input`
+(resemblyzer / emotion LSTM / parselmouth / librosa, :94-137) are outside the hot path:
+`inp` must already carry `mel`, `f0`, `spk_embed`, `emo_embed`.
+"""
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import make_hparams, make_vocoder_config
+from .model import StyleSingerHIP
+from .vocoder import get_vocoder_cls
+
+
+class StyleSingerInfer:
+    def __init__(self, hparams=None, device=None, model_state=None, vocoder_state=None, vocoder_config=None, dictionary=None):
+        self.hparams = make_hparams(hparams)
+        if device is None:
+            if not torch.cuda.is_available():
+                raise L.StyleSingerHipError("StyleSingerInfer (HIP) needs a GPU: there is no CPU path")
+            device = "cuda"
+        self.device = torch.device(device)
+        self.model = self.build_model(dictionary, model_state)
+        self.model.eval()
+        self.model.to(self.device)
+        self.vocoder = get_vocoder_cls(self.hparams)(config=make_vocoder_config(vocoder_config), state_dict=vocoder_state,
+                                                     device=self.device, hparams=self.hparams)
+
+    def build_model(self, dictionary=None, state=None):
+        model = StyleSingerHIP(dictionary, hparams=self.hparams)
+        if state is not None:
+            model.load_state_dict(state, strict=False)
+        return model
+
+    # ---- batched, device resident -------------------------------------------------------------
+    @torch.no_grad()
+    def infer_batch(self, batch, noise=None, vocoder_noise=None, seed=None, vocode=True):
+        """batch: dict of device tensors (txt_tokens, note, note_dur, note_type, spk_embed, emo_embed, ref_mels,
+        ref_f0, optional mel2ph).  Returns dict(mel [B,T,80], f0 [B,T], lens int32 [B], wav [B,T*hop])."""
+        hp = self.hparams
+        seed = hp["seed"] if seed is None else seed
+        out = self.model(batch["txt_tokens"], mel2ph=batch.get("mel2ph"), spk_embed=batch["spk_embed"], emo_embed=batch["emo_embed"],
+                         ref_mels=batch["ref_mels"], ref_f0=batch["ref_f0"], global_steps=320000, infer=True, note=batch["note"],
+                         note_dur=batch["note_dur"], note_type=batch["note_type"], noise=noise, seed=seed)
+        res = dict(mel=out["mel_out"], f0=out["f0_denorm"], lens=out["lens"], model_out=out)
+        if vocode:
+            res["wav"] = self.vocode(out["mel_out"], out["f0_denorm"], out["lens"], noise=vocoder_noise, seed=seed + 101)
+        return res
+
+    @torch.no_grad()
+    def vocode(self, mel, f0, lens, noise=None, seed=1234):
+        hp = self.hparams
+        mel_c = torch.empty_like(mel)
+        L.check(L.load().ss_clip(L.ptr(mel), L.ptr(mel_c), mel.numel(), float(hp["mel_vmin"]), float(hp["mel_vmax"]), L.stream_ptr()), "ss_clip")
+        return self.vocoder.spec2wav_batch(mel_c, f0, lens=lens, noise=noise, seed=seed)
+
+    # ---- the reference's single-utterance surface ---------------------------------------------
+    def input_to_batch(self, item):
+        """inference/StyleSinger.py:139-172 (f0 must already be the normalised/interpolated log2 contour)."""
+        d = self.device
+        t = lambda x, dt: torch.as_tensor(np.asarray(x), dtype=dt)[None].to(d)
+        return dict(txt_tokens=t(item["ph_token"], torch.long), ref_mels=t(item["mel"], torch.float32),
+                    spk_embed=t(item["spk_embed"], torch.float32), emo_embed=t(item["emo_embed"], torch.float32),
+                    note=t(item["note"], torch.long), note_dur=t(item["note_dur"], torch.float32),
+                    note_type=t(item["note_type"], torch.long), ref_f0=t(item["f0"], torch.float32),
+                    **({"mel2ph": t(item["mel2ph"], torch.long)} if "mel2ph" in item else {}))
+
+    def forward_model(self, inp, noise=None, vocoder_noise=None):
+        sample = self.input_to_batch(inp)
+        res = self.infer_batch(sample, noise=noise, vocoder_noise=None, vocode=False)
+        mel_pred = res["mel"].cpu().numpy()
+        f0_pred = res["f0"].cpu().numpy()
+        mask = np.abs(mel_pred).sum(-1) > 0
+        mel_pred = np.clip(mel_pred[mask], self.hparams["mel_vmin"], self.hparams["mel_vmax"])
+        f0_pred = f0_pred[mask]
+        return self.vocoder.spec2wav(mel_pred, f0=f0_pred, noise=vocoder_noise)
+
+    def infer_once(self, inp):
+        return self.forward_model(inp)

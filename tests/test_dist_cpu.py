@@ -1,0 +1,69 @@
+"""world_size-2 gloo test of the data-parallel driver (sharding rule + the single all_gather), on CPU with fake
+compute functions — the GPU kernels are covered by the -m gpu tests."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stylesinger_amd import dist as ssd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    items = list(range(6))  # 6 utterances, item i has length 10+i
+
+    def infer_fn(mine):
+        T = 16
+        mel = torch.zeros(len(mine), T, 80)
+        f0 = torch.zeros(len(mine), T)
+        lens = torch.tensor([10 + i for i in mine], dtype=torch.int32)
+        for j, i in enumerate(mine):
+            mel[j, :10 + i] = float(i + 1)
+            f0[j, :10 + i] = 100.0 + i
+        return mel, f0, lens
+
+    def vocode_fn(mel, f0, lens):
+        return mel.mean(-1).repeat_interleave(4, dim=1)
+
+    out = ssd.run_sharded(infer_fn, vocode_fn, items, rank, world, pad_T=16)
+    q.put((rank, out["mel_all"][:, 0, 0].tolist(), out["lens_all"].tolist(), out["local_indices"], tuple(out["wav_local"].shape)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_gather():
+    assert ssd.shard_indices(7, 1, 3) == [1, 4]
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, first_vals, lens_all, local, wshape in res:
+        # gathered order = rank-major: rank0's items (0,2,4) then rank1's (1,3,5)
+        assert first_vals == [1.0, 3.0, 5.0, 2.0, 4.0, 6.0]
+        assert lens_all == [10, 12, 14, 11, 13, 15]
+        assert local == list(range(rank, 6, 2))
+        assert wshape == (3, 64)
+
+
+def test_single_process_is_identity():
+    mel, f0, lens = torch.randn(2, 5, 80), torch.randn(2, 5), torch.tensor([5, 3], dtype=torch.int32)
+    a, b, c = ssd.gather_mels(mel, f0, lens)
+    assert a is mel and b is f0 and c is lens
