@@ -8,5 +8,6 @@ case "$1" in
   parity) python -m pytest tests/test_gpu_parity.py -x -q -m gpu -s 2>&1 | tail -60 | tee gpurun_out/parity.log ;;
   smoke) python __graft_entry__.py smoke 2>&1 | tail -5 | tee gpurun_out/smoke.log ;;
   bench) shift; python bench.py "$@" 2>&1 | tail -5 | tee gpurun_out/bench.log ;;
+  prof) shift; cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py "$@" 2>&1 | tail -3; cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof | head -20 ;;
   *) "$@" ;;
 esac

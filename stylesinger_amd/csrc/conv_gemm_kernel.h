@@ -72,51 +72,66 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
   const int st_row = tid >> 3;      // 0..31
   const bool has_pro = (a.a_bias != nullptr) || (a.a_scale != 1.0f) || (a.a_lrelu != 1.0f);
 
-  float4 ra[A_F4], rb[B_F4];
+  float4 ra[A_F4], rb[B_F4], rpb;
+  unsigned a_valid = 0;  // bit i: ra[i] is inside [0,len) x [0,Cin)
+  unsigned b_valid = 0;  // bit i: packed weight row exists
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i)
+    if (n0 + st_row + i * 32 < a.Np) b_valid |= 1u << i;
+  const int len_m1 = len > 0 ? len - 1 : 0;
 
+  // Issue the global loads of chunk c. NOTHING here depends on the loaded values (addresses are clamped
+  // instead of predicated), so hipcc places no s_waitcnt before the MFMAs of the current chunk: the
+  // L2/HBM latency of chunk c+1 hides under the 2048 MFMA cycles of chunk c.
   auto load_chunk = [&](int c) {
     const int tap = c / kchunks_per_tap;
     const int ci0 = (c - tap * kchunks_per_tap) * BK;
     const int off = a.tap_off[tap];
     const int ci = ci0 + st_c4 * 4;
     const bool ci_ok = ci < a.Cin;
-    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has_pro && a.a_bias && ci_ok) pb = *reinterpret_cast<const float4*>(a.a_bias + ci);
+    const int ci_c = ci_ok ? ci : 0;
+    if (a.a_bias) rpb = *reinterpret_cast<const float4*>(a.a_bias + ci_c);
+    a_valid = 0;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int r = t0 + st_row + i * 32 + off;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ci_ok && r >= 0 && r < len) {
-        v = *reinterpret_cast<const float4*>(Ab + (int64_t)r * a.lda + ci);
-        if (has_pro) {
-          v.x = (v.x + pb.x) * a.a_scale; v.y = (v.y + pb.y) * a.a_scale;
-          v.z = (v.z + pb.z) * a.a_scale; v.w = (v.w + pb.w) * a.a_scale;
-          if (a.a_lrelu != 1.0f) {
-            v.x = ss_lrelu(v.x, a.a_lrelu); v.y = ss_lrelu(v.y, a.a_lrelu);
-            v.z = ss_lrelu(v.z, a.a_lrelu); v.w = ss_lrelu(v.w, a.a_lrelu);
-          }
-        }
-      }
-      ra[i] = v;
+      const bool ok = ci_ok && r >= 0 && r < len;
+      const int rc = r < 0 ? 0 : (r > len_m1 ? len_m1 : r);
+      ra[i] = *reinterpret_cast<const float4*>(Ab + (int64_t)rc * a.lda + ci_c);
+      a_valid |= (ok ? 1u : 0u) << i;
     }
     const int kcol = tap * a.Kp + ci0 + st_c4 * 4;
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-      const int n = n0 + st_row + i * 32;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < a.Np) v = *reinterpret_cast<const float4*>(a.W + (int64_t)n * ldw + kcol);
-      rb[i] = v;
+      int n = n0 + st_row + i * 32;
+      n = n < a.Np ? n : a.Np - 1;
+      rb[i] = *reinterpret_cast<const float4*>(a.W + (int64_t)n * ldw + kcol);
     }
   };
+  // Apply the A prologue (bias/scale/leaky-relu, zero padding) and write the staged registers to LDS.
   auto store_chunk = [&](int buf) {
     float* Ad = As + buf * BM * LDS_LD;
     float* Bd = Bs + buf * BN * LDS_LD;
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i)
-      *reinterpret_cast<float4*>(Ad + (st_row + i * 32) * LDS_LD + st_c4 * 4) = ra[i];
+    for (int i = 0; i < A_F4; ++i) {
+      float4 v = ra[i];
+      if (has_pro) {
+        if (a.a_bias) { v.x += rpb.x; v.y += rpb.y; v.z += rpb.z; v.w += rpb.w; }
+        v.x *= a.a_scale; v.y *= a.a_scale; v.z *= a.a_scale; v.w *= a.a_scale;
+        if (a.a_lrelu != 1.0f) {
+          v.x = ss_lrelu(v.x, a.a_lrelu); v.y = ss_lrelu(v.y, a.a_lrelu);
+          v.z = ss_lrelu(v.z, a.a_lrelu); v.w = ss_lrelu(v.w, a.a_lrelu);
+        }
+      }
+      if (!((a_valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(Ad + (st_row + i * 32) * LDS_LD + st_c4 * 4) = v;
+    }
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i)
-      *reinterpret_cast<float4*>(Bd + (st_row + i * 32) * LDS_LD + st_c4 * 4) = rb[i];
+    for (int i = 0; i < B_F4; ++i) {
+      float4 v = rb[i];
+      if (!((b_valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(Bd + (st_row + i * 32) * LDS_LD + st_c4 * 4) = v;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -170,28 +185,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
   const int row_base = t0 + wm * WTM;
   const int col_base = n0 + wn * WTN;
 
+  // Every epilogue is two-phase: (1) issue ALL the global reads it needs into registers, (2) compute + store.
+  // The output may alias the inputs (in-place residual updates), so the compiler cannot hoist a load above a
+  // store by itself; without the split every element pays a full load round trip.
+  auto row_of = [&](int m, int r) { return row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh; };
+
   if constexpr (EPI == SS_EPI_STORE) {
     float* Cb = a.C + (int64_t)b * a.c_batch_stride;
     const float* Rb = a.R ? a.R + (int64_t)b * a.r_batch_stride : nullptr;
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = col_base + n * 32 + l31;
-      if (col >= a.N) continue;
-      const float bs = a.bias ? a.bias[col] : 0.f;
+      const bool col_ok = col < a.N;
+      const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
+        float rv[16], pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row >= a.T) continue;
+          const int row = row_of(m, r);
+          const bool ok = col_ok && row < a.T;
+          rv[r] = (Rb && ok) ? Rb[(int64_t)row * a.ldr + col] : 0.f;
+          pv[r] = (a.accumulate && ok) ? Cb[(int64_t)row * a.ldc + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_of(m, r);
+          if (!col_ok || row >= a.T) continue;
           float v = (acc[m][n][r] + bs) * a.pre_scale;
           v = ss_apply_act(v, a.act, a.act_slope);
-          if (Rb) v += Rb[(int64_t)row * a.ldr + col];
-          v *= a.post_scale;
-          float* p = Cb + (int64_t)row * a.ldc + col;
-          if (a.accumulate) v += *p;
+          v = (v + rv[r]) * a.post_scale + pv[r];
           if (a.mask_rows && row >= len) v = 0.f;
-          *p = v;
+          Cb[(int64_t)row * a.ldc + col] = v;
         }
       }
     }
@@ -201,24 +226,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
       const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
 #pragma unroll
       for (int n = 0; n < TN; n += 2) {
-        const int pc0 = col_base + n * 32 + l31;  // packed column of first member
+        const int pc0 = col_base + n * 32 + l31;  // packed column of the first member of the pair
         const int pc1 = pc0 + 32;
         const int oc = (pc0 >> 6) * 32 + l31;  // output channel
-        if (oc >= a.N) continue;
-        const float b0 = a.bias ? a.bias[pc0] : 0.f;
-        const float b1 = a.bias ? a.bias[pc1] : 0.f;
+        const bool col_ok = oc < a.N;
+        const float b0 = (a.bias && col_ok) ? a.bias[pc0] : 0.f;
+        const float b1 = (a.bias && col_ok) ? a.bias[pc1] : 0.f;
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
+          float e0[16], e1[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row >= a.T) continue;
-            float v0 = acc[m][n][r] + b0;
-            float v1 = acc[m][n + 1][r] + b1;
-            if (Eb) {
-              v0 += Eb[(int64_t)row * a.lde + pc0];
-              v1 += Eb[(int64_t)row * a.lde + pc1];
-            }
+            const int row = row_of(m, r);
+            const bool ok = Eb && col_ok && row < a.T;
+            e0[r] = ok ? Eb[(int64_t)row * a.lde + pc0] : 0.f;
+            e1[r] = ok ? Eb[(int64_t)row * a.lde + pc1] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row_of(m, r);
+            if (!col_ok || row >= a.T) continue;
+            const float v0 = acc[m][n][r] + b0 + e0[r];
+            const float v1 = acc[m][n + 1][r] + b1 + e1[r];
             float g = (a.gate_mode == 0) ? ss_sigmoid(v0) * tanhf(v1) : tanhf(v0) * ss_sigmoid(v1);
             if (a.mask_rows && row >= len) g = 0.f;
             Cb[(int64_t)row * a.ldc + oc] = g;
@@ -233,25 +262,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = col_base + n * 32 + l31;
-      if (col >= a.N) continue;
-      const float bs = a.bias ? a.bias[col] : 0.f;
-      const bool first = col < a.Nh;
+      const bool col_ok = col < a.N;
+      const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
+      const bool first = col < a.Nh;  // uniform per 32-column block
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
+        float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row >= a.T) continue;
-          float v = acc[m][n][r] + bs;
+          const int row = row_of(m, r);
+          const bool ok = col_ok && row < a.T;
+          if (first) pv[r] = ok ? Rb[(int64_t)row * a.ldr + col] : 0.f;
+          else pv[r] = (ok && a.accumulate) ? C2b[(int64_t)row * a.ldc2 + (col - a.Nh)] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_of(m, r);
+          if (!col_ok || row >= a.T) continue;
+          const float v = acc[m][n][r] + bs;
           const bool dead = a.mask_rows && row >= len;
-          if (first) {
-            float x = (Rb[(int64_t)row * a.ldr + col] + v) * a.post_scale;
-            Cb[(int64_t)row * a.ldc + col] = dead ? 0.f : x;
-          } else {
-            float* p = C2b + (int64_t)row * a.ldc2 + (col - a.Nh);
-            if (a.accumulate) v += *p;
-            *p = dead ? 0.f : v;
-          }
+          if (first) Cb[(int64_t)row * a.ldc + col] = dead ? 0.f : (pv[r] + v) * a.post_scale;
+          else C2b[(int64_t)row * a.ldc2 + (col - a.Nh)] = dead ? 0.f : v + pv[r];
         }
       }
     }
@@ -262,35 +293,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = col_base + n * 32 + l31;
-      if (col >= a.N) continue;
-      const float bs = a.bias ? a.bias[col] : 0.f;
+      const bool col_ok = col < a.N;
+      const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
+        float xv[16], zv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row >= a.T) continue;
+          const int row = row_of(m, r);
+          const bool ok = col_ok && row < a.T;
+          xv[r] = ok ? Cb[(int64_t)row * a.ldc + col] : 0.f;
+          zv[r] = (ok && a.noise && a.ddpm_sigma != 0.f) ? a.noise[((int64_t)b * a.T + row) * a.N + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_of(m, r);
+          if (!col_ok || row >= a.T) continue;
           const float eps = acc[m][n][r] + bs;
-          float* p = Cb + (int64_t)row * a.ldc + col;
-          const float x = *p;
+          const float x = xv[r];
           float x0 = a.ddpm_recip * x - a.ddpm_recipm1 * eps;
           x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-          float mean = a.ddpm_c1 * x0 + a.ddpm_c2 * x;
-          float z = 0.f;
-          if (a.ddpm_sigma != 0.f) {
+          const float mean = a.ddpm_c1 * x0 + a.ddpm_c2 * x;
+          float z = zv[r];
+          if (a.ddpm_sigma != 0.f && !a.noise) {
             const int64_t idx = ((int64_t)b * a.T + row) * a.N + col;
-            if (a.noise) {
-              z = a.noise[idx];
-            } else {
-              uint32_t o[4];
-              rng.gen((uint32_t)idx, (uint32_t)(idx >> 32), a.step, 0x4d454c44u, o);
-              float z1;
-              ss_boxmuller(o[0], o[1], z, z1);
-            }
+            uint32_t o[4];
+            rng.gen((uint32_t)idx, (uint32_t)(idx >> 32), a.step, 0x4d454c44u, o);
+            float z1;
+            ss_boxmuller(o[0], o[1], z, z1);
           }
           float xn = mean + a.ddpm_sigma * z;
           if (a.mask_rows && row >= len) xn = 0.f;
-          *p = xn;
+          Cb[(int64_t)row * a.ldc + col] = xn;
         }
       }
     }
