@@ -1,0 +1,82 @@
+"""Micro-benchmark of the hot conv_gemm launches (mel/f0 gate + res/skip, vocoder convs) with HIP events.
+    python tools/kbench.py [--tile N] [--iters K] [--which gate|resskip|voc|all]
+"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stylesinger_amd import lib as L  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--which", default="all")
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--T", type=int, default=1500)
+    a = ap.parse_args()
+    d = torch.device("cuda:0")
+    B, T = a.B, a.T
+    lens = torch.full((B,), T, device=d, dtype=torch.int32)
+    res = []
+    for (name, C, Lyr) in (("mel", 256, 20), ("f0", 192, 10)):
+        X = torch.randn(B, T, C, device=d)
+        G = torch.randn(B, T, C, device=d)
+        S = torch.zeros(B, T, C, device=d)
+        E = torch.randn(B, T, Lyr * 2 * C, device=d)
+        w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
+        wo = torch.randn(2 * C, C, 1, device=d) / math.sqrt(C)
+        bo = torch.randn(2 * C, device=d) * 0.1
+        ab = torch.randn(C, device=d)
+        W = L.pack_conv_weight(w, interleave_half=C)
+        Wo = L.pack_conv_weight(wo)
+        bop = L.pack_bias(bo)
+        if a.which in ("gate", "all"):
+            f = lambda: L.conv_gemm(X, W, G, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, taps=(-2, 0, 2), lens=lens, a_bias=ab,
+                                    epi=L.EPI_GATE, E=E, lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, tile=a.tile)
+            s = timeit(f, a.iters)
+            fl = 2.0 * B * T * 3 * C * 2 * C
+            res.append((f"{name} gate  K={3 * C} N={2 * C}", s, fl))
+        if a.which in ("resskip", "all"):
+            f = lambda: L.conv_gemm(G, Wo, X, B=B, T=T, Cin=C, N=2 * C, Np=2 * C, Kp=C, lens=lens, epi=L.EPI_RESSKIP, bias=bop, Nh=C,
+                                    R=X, ldr=C, ldc=C, post_scale=0.7071, C2=S, ldc2=C, c2_bs=T * C, accumulate=True, tile=a.tile)
+            s = timeit(f, a.iters)
+            fl = 2.0 * B * T * C * 2 * C
+            res.append((f"{name} resskip K={C} N={2 * C}", s, fl))
+    if a.which in ("voc", "all"):
+        for (C, R, k) in ((256, 8, 7), (128, 64, 7), (64, 128, 11), (32, 256, 11), (32, 256, 3)):
+            rows = T * R
+            X = torch.randn(B, rows, C, device=d)
+            Y = torch.empty(B, rows, C, device=d)
+            w = torch.randn(C, C, k, device=d) / math.sqrt(k * C)
+            W = L.pack_conv_weight(w)
+            bias = L.pack_bias(torch.randn(C, device=d))
+            ln = torch.full((B,), rows, device=d, dtype=torch.int32)
+            f = lambda: L.conv_gemm(X, W, Y, B=B, T=rows, Cin=C, N=C, Np=W.shape[0], Kp=W.shape[1] // k,
+                                    taps=[(j - k // 2) * 3 for j in range(k)], lens=ln, a_lrelu=0.1, bias=bias, R=X, ldr=C, tile=a.tile)
+            s = timeit(f, max(3, a.iters // 5))
+            res.append((f"voc C={C} rows={rows} k={k}", s, 2.0 * B * rows * C * C * k))
+    for name, s, fl in res:
+        print(f"{name:34s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.2f} TF/s  ({fl / s / 157.3e12 * 100:5.1f}% of fp32 MFMA peak)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# usage: tools/pmc.sh <outname> <counters...> -- <command...>   (run on the GPU box; separate pass per call)
+out=$1; shift
+ctrs=()
+while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+shift
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$out -o $out -- "$@" > /tmp/pmc_$out.log 2>&1
+tail -2 /tmp/pmc_$out.log
+cd $GRAFT_REPO_ROOT
+python - <<PY
+import csv, glob, collections
+f = glob.glob("gpurun_out/pmc_$out/**/*counter_collection.csv", recursive=True)
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for fn in f:
+    for r in csv.DictReader(open(fn)):
+        k = r["Kernel_Name"][:70]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+        cnt[(k, r["Counter_Name"])] += 1
+for k, d in agg.items():
+    if "conv_gemm" in k or "attention" in k:
+        print(k)
+        for c, v in d.items(): print(f"    {c:32s} avg/dispatch = {v / cnt[(k, c)]:.4g}   (n={cnt[(k,c)]})")
+PY
