@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--diff-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=750)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads for the CPU oracle; 16 is the fastest setting on the 2x64-core EPYC GPU-box host "
+                         "(tools/cpu_threads.py: 8:0.38s 16:0.35s 32:0.78s 64:2.0s 128:5.0s per 10 steps)")
     return ap.parse_args()
 
 
@@ -76,11 +79,12 @@ def kernel_roofline(infer, B, T, iters=20):
                 us_per_launch=sec * 1e6, flops_per_launch=flops)
 
 
-def cpu_baseline(hp, frames):
+def cpu_baseline(hp, frames, threads):
     """The oracle (CPU restatement of the reference) timed on this box's host cores: a reported baseline only."""
     from oracle import restatement as R
     from stylesinger_amd import config, synth
     torch.manual_seed(0)
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or threads)))
     sd = synth.synth_acoustic_state_dict(hp, 1234)
     cfg = config.make_vocoder_config()
     vsd = synth.synth_vocoder_state_dict(cfg, 1234)
@@ -167,7 +171,7 @@ def main():
         }
         out["roofline"] = kernel_roofline(infer, B, T)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(hp, args.cpu_frames)
+            out["cpu_baseline"] = cpu_baseline(hp, args.cpu_frames, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,6 +8,6 @@ case "$1" in
   parity) python -m pytest tests/test_gpu_parity.py -x -q -m gpu -s 2>&1 | tail -60 | tee gpurun_out/parity.log ;;
   smoke) python __graft_entry__.py smoke 2>&1 | tail -5 | tee gpurun_out/smoke.log ;;
   bench) shift; python bench.py "$@" 2>&1 | tail -5 | tee gpurun_out/bench.log ;;
-  prof) shift; cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py "$@" 2>&1 | tail -3; cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof | head -20 ;;
+  prof) shift; cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py "$@" 2>&1 | grep -E "^\{" | tee $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json | cut -c1-300; cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); head -25 "$f" | cut -c1-220 ;;
   *) "$@" ;;
 esac
