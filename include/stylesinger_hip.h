@@ -54,7 +54,8 @@ enum {
 };
 enum { SS_ACT_NONE_ = 0, SS_ACT_RELU_ = 1, SS_ACT_GELU_ = 2, SS_ACT_MISH_ = 3, SS_ACT_TANH_ = 4, SS_ACT_LRELU_ = 5 };
 
-enum { SS_TILE_AUTO = 0, SS_TILE_128x128 = 1, SS_TILE_64x128 = 2, SS_TILE_64x64 = 3, SS_TILE_128x64 = 4, SS_TILE_128x32 = 5 };
+enum { SS_TILE_AUTO = 0, SS_TILE_128x128 = 1, SS_TILE_64x128 = 2, SS_TILE_64x64 = 3, SS_TILE_128x64 = 4, SS_TILE_128x32 = 5,
+       SS_TILE_96x256 = 6, SS_TILE_96x128 = 7, SS_TILE_64x256 = 8, SS_TILE_256x32 = 9, SS_TILE_256x64 = 10 };
 
 typedef struct ss_conv_gemm_args {
   /* A operand */

@@ -17,6 +17,7 @@
 //   * epilogues are fused: bias / activation / residual / gate / residual+skip / DDPM posterior step.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/stylesinger_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,17 +35,18 @@ constexpr int LDS_LD = BK;  // floats; no padding: the 16-B slots of a row are X
 __device__ __forceinline__ int lds_slot(int row, int slot) { return row * LDS_LD + ((slot ^ ((row >> 1) & 7)) << 2); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles,
-                                                        int n_tiles) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles,
+                                                        int n_tiles, int dbg) {
   constexpr int WTM = BM / WAVES_M;  // rows per wave
   constexpr int WTN = BN / WAVES_N;  // cols per wave
   constexpr int TM = WTM / 32;
   constexpr int TN = WTN / 32;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  static_assert(TM >= 1 && TN >= 1, "tile too small");
-  constexpr int A_F4 = BM * (BK / 4) / 256;  // float4 per thread per chunk
-  constexpr int B_F4 = BN * (BK / 4) / 256;
-  static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
+  constexpr int NT = 64 * WAVES_M * WAVES_N;  // threads per block
+  constexpr int RP = NT / 8;                   // tile rows staged per pass (8 threads x float4 cover the 32-wide chunk)
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int A_F4 = BM / RP;  // float4 per thread per chunk
+  constexpr int B_F4 = BN / RP;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                        // [2][BM][LDS_LD]
@@ -68,77 +70,91 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
   const int wn = wave % WAVES_N;
 
   const int len = a.lens ? a.lens[b] : a.T;
-  const float* Ab = a.A + (int64_t)b * a.a_batch_stride;
 
   const int kchunks_per_tap = a.Kp / BK;
   const int nchunks = a.ntaps * kchunks_per_tap;
   const int ldw = a.ntaps * a.Kp;
 
-  // staging coordinates
-  const int st_c4 = tid & 7;        // float4 column inside the 32-wide chunk
-  const int st_row = tid >> 3;      // 0..31
-  const bool has_pro = (a.a_bias != nullptr) || (a.a_scale != 1.0f) || (a.a_lrelu != 1.0f);
+  // ---- operand fetch through buffer resources: the hardware range check IS the zero padding ----
+  // A: records = len*lda*4 bytes of this item -> rows >= len read 0; a negative row gives a negative byte offset,
+  //    i.e. >= 2^31 as unsigned, also out of range -> 0. No clamps, no validity masks, 32-bit address math.
+  // W: records = Np*ldw*4 -> packed rows beyond Np read 0.
+  // (descriptor inputs go through readfirstlane so that hipcc can PROVE them wave-uniform; otherwise every
+  //  buffer op is wrapped in a waterfall loop - cdna_hip_programming.md T20)
+  auto uniform_ptr = [](const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.W), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 4), 0x00020000);
+  // A-prologue bias through a descriptor as well (a plain pointer select would become a FLAT load, which also
+  // counts on lgkmcnt and would stall the LDS fragment reads); no bias -> 0 records -> reads 0.
+  const __amdgpu_buffer_rsrc_t rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.a_bias ? a.a_bias : a.W), 0, __builtin_amdgcn_readfirstlane(a.a_bias ? a.Cin * 4 : 0), 0x00020000);
 
-  float4 ra[A_F4], rb[B_F4], rpb;
-  unsigned a_valid = 0;  // bit i: ra[i] is inside [0,len) x [0,Cin)
-  unsigned b_valid = 0;  // bit i: packed weight row exists
+  // staging coordinates: 8 threads x float4 cover one 32-wide K chunk of a row; RP rows per pass
+  const int st_c4 = tid & 7;
+  const int st_row = tid >> 3;
+  const int a_off0 = ((t0 + st_row) * a.lda + st_c4 * 4) * 4;  // byte offset of (row, col) of pass 0, tap offset 0
+  const int a_pass = RP * a.lda * 4;
+  const int w_off0 = ((n0 + st_row) * ldw + st_c4 * 4) * 4;
+  const int w_pass = RP * ldw * 4;
+  const float pro_scale = a.a_scale, pro_slope = a.a_lrelu;
+
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ra[A_F4], rb[B_F4];
+  float4 rpb;
+
+  // K-chunk cursor (uniform): chunk c = (tap, ci0); advanced incrementally, no division in the loop
+  struct Cursor { int tap, ci0; };
+  auto advance = [&](Cursor& k) {
+    k.ci0 += BK;
+    if (k.ci0 >= a.Kp) { k.ci0 = 0; ++k.tap; }
+  };
+
+  // Issue the fetches of a chunk. Nothing here depends on loaded data, so no s_waitcnt is placed before the
+  // MFMAs that follow in program order: the L2/HBM latency hides under them.
+  auto load_a = [&](const Cursor& k) {
+    const int ci = k.ci0 + st_c4 * 4;
+    const bool ci_ok = ci < a.Cin;  // only false in the zero-padded tail of a Cin that is not a multiple of 32
+    const int chunk_off = (a.tap_off[k.tap] * a.lda + k.ci0) * 4;
+    const int oob = ci_ok ? 0 : (int)0x80000000;  // OR-ed into the offset: one branch-free load either way
+    rpb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, ci * 4, 0, 0));
 #pragma unroll
-  for (int i = 0; i < B_F4; ++i)
-    if (n0 + st_row + i * 32 < a.Np) b_valid |= 1u << i;
-  const int len_m1 = len > 0 ? len - 1 : 0;
-
-  // Issue the global loads of chunk c. NOTHING here depends on the loaded values (addresses are clamped
-  // instead of predicated), so hipcc places no s_waitcnt before the MFMAs of the current chunk: the
-  // L2/HBM latency of chunk c+1 hides under the 2048 MFMA cycles of chunk c.
-  auto load_chunk = [&](int c) {
-    const int tap = c / kchunks_per_tap;
-    const int ci0 = (c - tap * kchunks_per_tap) * BK;
-    const int off = a.tap_off[tap];
-    const int ci = ci0 + st_c4 * 4;
-    const bool ci_ok = ci < a.Cin;
-    const int ci_c = ci_ok ? ci : 0;
-    if (a.a_bias) rpb = *reinterpret_cast<const float4*>(a.a_bias + ci_c);
-    a_valid = 0;
+    for (int i = 0; i < A_F4; ++i)
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_off0 + i * a_pass + chunk_off) | oob, 0, 0);
+  };
+  auto load_b = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off0 + i * w_pass + c * (BK * 4), 0, 0);
+  };
+  // A prologue: lrelu((x + bias) * scale) on real elements, exact 0 on padding; branch-free
+  // (lrelu(x,s) = max(x,0) + s*min(x,0), identity for s = 1), then the swizzled LDS write.
+  auto store_a = [&](int buf, const Cursor& k) {
+    float* Ad = As + buf * BM * LDS_LD;
+    const int r0 = t0 + st_row + a.tap_off[k.tap];
+    const bool c_ok = k.ci0 + st_c4 * 4 < a.Cin;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const int r = t0 + st_row + i * 32 + off;
-      const bool ok = ci_ok && r >= 0 && r < len;
-      const int rc = r < 0 ? 0 : (r > len_m1 ? len_m1 : r);
-      ra[i] = *reinterpret_cast<const float4*>(Ab + (int64_t)rc * a.lda + ci_c);
-      a_valid |= (ok ? 1u : 0u) << i;
-    }
-    const int kcol = tap * a.Kp + ci0 + st_c4 * 4;
-#pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-      int n = n0 + st_row + i * 32;
-      n = n < a.Np ? n : a.Np - 1;
-      rb[i] = *reinterpret_cast<const float4*>(a.W + (int64_t)n * ldw + kcol);
+      float4 v = __builtin_bit_cast(float4, ra[i]);
+      const bool ok = c_ok && (unsigned)(r0 + i * RP) < (unsigned)len;
+      v.x = (v.x + rpb.x) * pro_scale; v.y = (v.y + rpb.y) * pro_scale;
+      v.z = (v.z + rpb.z) * pro_scale; v.w = (v.w + rpb.w) * pro_scale;
+      v.x = fmaxf(v.x, 0.f) + pro_slope * fminf(v.x, 0.f); v.y = fmaxf(v.y, 0.f) + pro_slope * fminf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f) + pro_slope * fminf(v.z, 0.f); v.w = fmaxf(v.w, 0.f) + pro_slope * fminf(v.w, 0.f);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(Ad + lds_slot(st_row + i * RP, st_c4)) = v;
     }
   };
-  // Apply the A prologue (bias/scale/leaky-relu, zero padding) and write the staged registers to LDS.
-  auto store_chunk = [&](int buf) {
-    float* Ad = As + buf * BM * LDS_LD;
+  auto store_b = [&](int buf) {
     float* Bd = Bs + buf * BN * LDS_LD;
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-      float4 v = ra[i];
-      if (has_pro) {
-        if (a.a_bias) { v.x += rpb.x; v.y += rpb.y; v.z += rpb.z; v.w += rpb.w; }
-        v.x *= a.a_scale; v.y *= a.a_scale; v.z *= a.a_scale; v.w *= a.a_scale;
-        if (a.a_lrelu != 1.0f) {
-          v.x = ss_lrelu(v.x, a.a_lrelu); v.y = ss_lrelu(v.y, a.a_lrelu);
-          v.z = ss_lrelu(v.z, a.a_lrelu); v.w = ss_lrelu(v.w, a.a_lrelu);
-        }
-      }
-      if (!((a_valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(Ad + lds_slot(st_row + i * 32, st_c4)) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-      float4 v = rb[i];
-      if (!((b_valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(Bd + lds_slot(st_row + i * 32, st_c4)) = v;
-    }
+    for (int i = 0; i < B_F4; ++i)
+      *reinterpret_cast<float4*>(Bd + lds_slot(st_row + i * RP, st_c4)) = __builtin_bit_cast(float4, rb[i]);
   };
 
   f32x16 acc[TM][TN];
@@ -149,8 +165,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
+  Cursor kc{0, 0};
+  load_a(kc);
+  load_b(0);
+  store_a(0, kc);
+  store_b(0);
   __syncthreads();
 
   const int l31 = lane & 31;
@@ -181,12 +200,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
       }
     }
   };
-  for (int c = 0; c < nchunks; ++c) {
+  // Main loop. The MFMA stream of a chunk (4 groups of 4*TM*TN matrix ops, 64 cycles each) is the clock; every
+  // other instruction of the chunk is placed BETWEEN groups so that it issues in the shadow of in-flight MFMAs
+  // (one wave per SIMD cannot rely on other waves to fill the pipe):
+  //   [frags q0,q1] [A fetch c+1] G0 [frags q2] [W fetch c+1] G1 [frags q3] G2 [prologue + LDS write c+1] G3 | barrier
+  // The last chunk is peeled so the steady-state body is one straight-line block.
+  for (int c = 0; c + 1 < nchunks; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
     const float* Ac = As + cur * BM * LDS_LD;
     const float* Bc = Bs + cur * BN * LDS_LD;
-    // software-pipelined fragment reads: group q+1 is in flight while group q feeds the matrix pipe
+    float4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    read_frags(Ac, Bc, 0, af0, bf0);
+    read_frags(Ac, Bc, 1, af1, bf1);
+    advance(kc);
+    load_a(kc);
+    __builtin_amdgcn_sched_barrier(0);  // pin: fetches are ISSUED here, two MFMA groups before their first use
+    mfma_group(af0, bf0);
+    read_frags(Ac, Bc, 2, af0, bf0);
+    load_b(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(af1, bf1);
+    read_frags(Ac, Bc, 3, af1, bf1);
+    mfma_group(af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);  // pin: the LDS writes of chunk c+1 go in the shadow of the last group
+    store_a(cur ^ 1, kc);
+    store_b(cur ^ 1);
+    mfma_group(af1, bf1);
+    __syncthreads();
+  }
+  {
+    const int cur = (nchunks - 1) & 1;
+    const float* Ac = As + cur * BM * LDS_LD;
+    const float* Bc = Bs + cur * BN * LDS_LD;
     float4 af0[TM], bf0[TN], af1[TM], bf1[TN];
     read_frags(Ac, Bc, 0, af0, bf0);
     read_frags(Ac, Bc, 1, af1, bf1);
@@ -196,10 +241,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
     read_frags(Ac, Bc, 3, af1, bf1);
     mfma_group(af0, bf0);
     mfma_group(af1, bf1);
-    if (c + 1 < nchunks) {
-      store_chunk(cur ^ 1);
-      __syncthreads();
-    }
   }
 
   // ------------------------------------------------------------------------------------------
@@ -354,6 +395,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ss_conv_gemm_args 
   }
 }
 
+inline int dbg_flags() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SS_DBG");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 int launch(const ss_conv_gemm_args& a, hipStream_t stream) {
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
@@ -369,8 +419,8 @@ int launch(const ss_conv_gemm_args& a, hipStream_t stream) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>), dim3(grid), dim3(256), lds, stream, a,
-                     m_tiles_per_item, m_tiles, n_tiles);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, stream, a,
+                     m_tiles_per_item, m_tiles, n_tiles, dbg_flags());
   SS_CHECK_LAUNCH("ss_conv_gemm");
   return SS_OK;
 }
@@ -378,15 +428,27 @@ int launch(const ss_conv_gemm_args& a, hipStream_t stream) {
 
 template <int EPI>
 int launch_tile(int tile, const ss_conv_gemm_args& a, hipStream_t stream) {
+  constexpr bool G = EPI == SS_EPI_GATE;  // GATE needs an even number of 32-col blocks per wave
   switch (tile) {
     case SS_TILE_128x128: return launch<128, 128, 2, 2, EPI>(a, stream);
     case SS_TILE_64x128: return launch<64, 128, 2, 2, EPI>(a, stream);
     case SS_TILE_128x64: return launch<128, 64, 4, 1, EPI>(a, stream);
+    case SS_TILE_96x256: return launch<96, 256, 1, 4, EPI>(a, stream);
+    case SS_TILE_96x128: return launch<96, 128, 1, 2, EPI>(a, stream);
+    case SS_TILE_64x256: return launch<64, 256, 1, 4, EPI>(a, stream);
+    case SS_TILE_256x64: return launch<256, 64, 4, 1, EPI>(a, stream);
     case SS_TILE_64x64:
-      if constexpr (EPI != SS_EPI_GATE) return launch<64, 64, 2, 2, EPI>(a, stream);
+      if constexpr (!G) return launch<64, 64, 2, 2, EPI>(a, stream);
+      break;
     case SS_TILE_128x32:
-      if constexpr (EPI != SS_EPI_GATE) return launch<128, 32, 4, 1, EPI>(a, stream);
-    default: ss_set_error("ss_conv_gemm: bad tile %d for epilogue %d", tile, EPI); return SS_ERR_ARG;
+      if constexpr (!G) return launch<128, 32, 4, 1, EPI>(a, stream);
+      break;
+    case SS_TILE_256x32:
+      if constexpr (!G) return launch<256, 32, 4, 1, EPI>(a, stream);
+      break;
+    default: break;
   }
+  ss_set_error("ss_conv_gemm: bad tile %d for epilogue %d", tile, EPI);
+  return SS_ERR_ARG;
 }
 }  // namespace

@@ -28,11 +28,19 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--sweep", default="", help="comma separated tile ids to sweep (overrides --tile)")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--which", default="all")
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--T", type=int, default=1500)
     a = ap.parse_args()
+    if a.sweep:
+        import subprocess
+        for t in a.sweep.split(","):
+            print(f"--- tile {t}")
+            sys.stdout.flush()
+            subprocess.run([sys.executable, __file__, "--tile", t, "--which", a.which, "--iters", str(a.iters), "--B", str(a.B), "--T", str(a.T)])
+        return
     d = torch.device("cuda:0")
     B, T = a.B, a.T
     lens = torch.full((B,), T, device=d, dtype=torch.int32)
