@@ -44,8 +44,9 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ float ss_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Gate nonlinearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error
 // <= ~3e-7 on outputs in [-1,1], far inside the 1e-4 mel budget, and ~10x fewer VALU ops than ocml tanhf/expf.
-__device__ __forceinline__ float ss_sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ss_tanh_fast(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// (v_rcp_f32 directly: __frcp_rn expands to the 10-instruction correctly-rounded division sequence)
+__device__ __forceinline__ float ss_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ss_tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 // nn.GELU() default = erf form (modules/commons/common_layers.py:574, modules/StyleSinger/lse.py:183)
 __device__ __forceinline__ float ss_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // F.softplus(beta=1, threshold=20) then tanh (modules/diff/diffusion.py:64-66)

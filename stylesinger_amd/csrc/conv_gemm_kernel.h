@@ -18,6 +18,7 @@
 #pragma once
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/stylesinger_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   const int t0 = (mt % m_tiles_per_item) * BM;
   const int n0 = nt * BN;
 
+  const unsigned long long ts0 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // (one wave per SIMD cannot rely on other waves to fill the pipe):
   //   [frags q0,q1] [A fetch c+1] G0 [frags q2] [W fetch c+1] G1 [frags q3] G2 [prologue + LDS write c+1] G3 | barrier
   // The last chunk is peeled so the steady-state body is one straight-line block.
+  const unsigned long long ts1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
   for (int c = 0; c + 1 < nchunks; ++c) {
     const int cur = c & 1;
     const float* Ac = As + cur * BM * LDS_LD;
@@ -228,6 +231,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     mfma_group(af1, bf1);
     __syncthreads();
   }
+  // Epilogue operands that live in HBM (GATE: the hoisted conditioner slab E, 40 KB row stride; RESSKIP: x and the
+  // skip accumulator) are fetched BEFORE the last chunk's MFMAs when they fit in registers, so their miss latency
+  // (~2 us) hides under >= 2048 MFMA cycles instead of stalling the epilogue.
+  const int row_base = t0 + wm * WTM;
+  const int col_base = n0 + wn * WTN;
+  auto row_of = [&](int m, int r) { return row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh; };
+  constexpr bool PREFETCH = (EPI == SS_EPI_GATE || EPI == SS_EPI_RESSKIP) && (TM * TN <= 2);
+  float pre[PREFETCH ? TM : 1][PREFETCH ? TN : 1][16];
+  if constexpr (PREFETCH && EPI == SS_EPI_GATE) {
+    const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int pc = col_base + n * 32 + l31;
+      const bool col_ok = ((pc >> 6) * 32 + l31) < a.N;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_of(m, r);
+          pre[m][n][r] = (Eb && col_ok && row < a.T) ? Eb[(int64_t)row * a.lde + pc] : 0.f;
+        }
+    }
+  }
+  if constexpr (PREFETCH && EPI == SS_EPI_RESSKIP) {
+    const float* Rb = a.R + (int64_t)b * a.r_batch_stride;
+    const float* C2b = a.C2 + (int64_t)b * a.c2_batch_stride;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = col_base + n * 32 + l31;
+      const bool col_ok = col < a.N;
+      const bool first = col < a.Nh;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_of(m, r);
+          const bool ok = col_ok && row < a.T;
+          if (first) pre[m][n][r] = ok ? Rb[(int64_t)row * a.ldr + col] : 0.f;
+          else pre[m][n][r] = (ok && a.accumulate) ? C2b[(int64_t)row * a.ldc2 + (col - a.Nh)] : 0.f;
+        }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   {
     const int cur = (nchunks - 1) & 1;
     const float* Ac = As + cur * BM * LDS_LD;
@@ -246,14 +292,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // ------------------------------------------------------------------------------------------
   // Epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // ------------------------------------------------------------------------------------------
-  const int row_base = t0 + wm * WTM;
-  const int col_base = n0 + wn * WTN;
-
+  const unsigned long long ts2 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
   // Every epilogue is two-phase: (1) issue ALL the global reads it needs into registers, (2) compute + store.
   // The output may alias the inputs (in-place residual updates), so the compiler cannot hoist a load above a
   // store by itself; without the split every element pays a full load round trip.
-  auto row_of = [&](int m, int r) { return row_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh; };
-
   if constexpr (EPI == SS_EPI_STORE) {
     float* Cb = a.C + (int64_t)b * a.c_batch_stride;
     const float* Rb = a.R ? a.R + (int64_t)b * a.r_batch_stride : nullptr;
@@ -288,68 +330,102 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     if constexpr (TN % 2 == 0) {
       float* Cb = a.C + (int64_t)b * a.c_batch_stride;
       const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+      // interior wave tiles (all rows < min(T, len), all channels < N) skip every per-element predicate
+      const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+      const bool interior = (row_base + WTM <= row_lim) && (((col_base + WTN) >> 1) <= a.N);
+      auto gate_tile = [&](auto checked_tag) {
+        constexpr bool CHECK = decltype(checked_tag)::value;
 #pragma unroll
-      for (int n = 0; n < TN; n += 2) {
-        const int pc0 = col_base + n * 32 + l31;  // packed column of the first member of the pair
-        const int pc1 = pc0 + 32;
-        const int oc = (pc0 >> 6) * 32 + l31;  // output channel
-        const bool col_ok = oc < a.N;
-        const float b0 = (a.bias && col_ok) ? a.bias[pc0] : 0.f;
-        const float b1 = (a.bias && col_ok) ? a.bias[pc1] : 0.f;
+        for (int n = 0; n < TN; n += 2) {
+          const int pc0 = col_base + n * 32 + l31;  // packed column of the first member of the pair
+          const int pc1 = pc0 + 32;
+          const int oc = (pc0 >> 6) * 32 + l31;  // output channel
+          const bool col_ok = !CHECK || oc < a.N;
+          const float b0 = (a.bias && col_ok) ? a.bias[pc0] : 0.f;
+          const float b1 = (a.bias && col_ok) ? a.bias[pc1] : 0.f;
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
-          float e0[16], e1[16];
+          for (int m = 0; m < TM; ++m) {
+            float e0[16], e1[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = row_of(m, r);
-            const bool ok = Eb && col_ok && row < a.T;
-            e0[r] = ok ? Eb[(int64_t)row * a.lde + pc0] : 0.f;
-            e1[r] = ok ? Eb[(int64_t)row * a.lde + pc1] : 0.f;
-          }
+            for (int r = 0; r < 16; ++r) {
+              if constexpr (PREFETCH) {
+                e0[r] = pre[m][n][r];
+                e1[r] = pre[m][n + 1][r];
+              } else {
+                const int row = row_of(m, r);
+                const bool ok = Eb && col_ok && (!CHECK || row < a.T);
+                e0[r] = ok ? Eb[(int64_t)row * a.lde + pc0] : 0.f;
+                e1[r] = ok ? Eb[(int64_t)row * a.lde + pc1] : 0.f;
+              }
+            }
+            float* cp = Cb + (int64_t)(row_base + m * 32 + 4 * lh) * a.ldc + oc;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = row_of(m, r);
-            if (!col_ok || row >= a.T) continue;
-            const float v0 = acc[m][n][r] + b0 + e0[r];
-            const float v1 = acc[m][n + 1][r] + b1 + e1[r];
-            float g = (a.gate_mode == 0) ? ss_sigmoid_fast(v0) * ss_tanh_fast(v1) : ss_tanh_fast(v0) * ss_sigmoid_fast(v1);
-            if (a.mask_rows && row >= len) g = 0.f;
-            Cb[(int64_t)row * a.ldc + oc] = g;
+            for (int r = 0; r < 16; ++r) {
+              const int rr = (r & 3) + 8 * (r >> 2);
+              const float v0 = acc[m][n][r] + b0 + e0[r];
+              const float v1 = acc[m][n + 1][r] + b1 + e1[r];
+              float g = (a.gate_mode == 0) ? ss_sigmoid_fast(v0) * ss_tanh_fast(v1) : ss_tanh_fast(v0) * ss_sigmoid_fast(v1);
+              if constexpr (CHECK) {
+                const int row = row_base + m * 32 + 4 * lh + rr;
+                if (!col_ok || row >= a.T) continue;
+                if (a.mask_rows && row >= len) g = 0.f;
+              }
+              cp[(int64_t)rr * a.ldc] = g;
+            }
           }
         }
-      }
+      };
+      if (interior) gate_tile(std::false_type{});
+      else gate_tile(std::true_type{});
     }
   } else if constexpr (EPI == SS_EPI_RESSKIP) {
     float* Cb = a.C + (int64_t)b * a.c_batch_stride;
     float* C2b = a.C2 + (int64_t)b * a.c2_batch_stride;
     const float* Rb = a.R + (int64_t)b * a.r_batch_stride;
+    const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+    const bool interior = (row_base + WTM <= row_lim) && (col_base + WTN <= a.N);
+    auto rs_tile = [&](auto checked_tag) {
+      constexpr bool CHECK = decltype(checked_tag)::value;
 #pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      const int col = col_base + n * 32 + l31;
-      const bool col_ok = col < a.N;
-      const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
-      const bool first = col < a.Nh;  // uniform per 32-column block
+      for (int n = 0; n < TN; ++n) {
+        const int col = col_base + n * 32 + l31;
+        const bool col_ok = !CHECK || col < a.N;
+        const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
+        const bool first = col < a.Nh;  // uniform per 32-column block
 #pragma unroll
-      for (int m = 0; m < TM; ++m) {
-        float pv[16];
+        for (int m = 0; m < TM; ++m) {
+          float pv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_of(m, r);
-          const bool ok = col_ok && row < a.T;
-          if (first) pv[r] = ok ? Rb[(int64_t)row * a.ldr + col] : 0.f;
-          else pv[r] = (ok && a.accumulate) ? C2b[(int64_t)row * a.ldc2 + (col - a.Nh)] : 0.f;
-        }
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (PREFETCH) {
+              pv[r] = pre[m][n][r];
+            } else {
+              const int row = row_of(m, r);
+              const bool ok = col_ok && (!CHECK || row < a.T);
+              if (first) pv[r] = ok ? Rb[(int64_t)row * a.ldr + col] : 0.f;
+              else pv[r] = (ok && a.accumulate) ? C2b[(int64_t)row * a.ldc2 + (col - a.Nh)] : 0.f;
+            }
+          }
+          float* cp = first ? Cb + (int64_t)(row_base + m * 32 + 4 * lh) * a.ldc + col
+                            : C2b + (int64_t)(row_base + m * 32 + 4 * lh) * a.ldc2 + (col - a.Nh);
+          const int64_t ld = first ? a.ldc : a.ldc2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_of(m, r);
-          if (!col_ok || row >= a.T) continue;
-          const float v = acc[m][n][r] + bs;
-          const bool dead = a.mask_rows && row >= len;
-          if (first) Cb[(int64_t)row * a.ldc + col] = dead ? 0.f : (pv[r] + v) * a.post_scale;
-          else C2b[(int64_t)row * a.ldc2 + (col - a.Nh)] = dead ? 0.f : v + pv[r];
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const float v = acc[m][n][r] + bs;
+            float o = first ? (pv[r] + v) * a.post_scale : v + pv[r];
+            if constexpr (CHECK) {
+              const int row = row_base + m * 32 + 4 * lh + rr;
+              if (!col_ok || row >= a.T) continue;
+              if (a.mask_rows && row >= len) o = 0.f;
+            }
+            cp[rr * ld] = o;
+          }
         }
       }
-    }
+    };
+    if (interior) rs_tile(std::false_type{});
+    else rs_tile(std::true_type{});
   } else if constexpr (EPI == SS_EPI_DDPM) {
     // v = eps_theta. x0 = clamp(recip*x - recipm1*eps, -1, 1); mean = c1*x0 + c2*x; x <- mean + sigma*z
     float* Cb = a.C + (int64_t)b * a.c_batch_stride;
@@ -392,6 +468,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
         }
       }
     }
+  }
+  if ((dbg & 16) && EPI == SS_EPI_GATE && a.C2 && lane == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(a.C2) + ((size_t)blockIdx.x * (NT / 64) + wave) * 8;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_readcyclecounter();
+    o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    o[6] = blockIdx.x;
   }
 }
 

@@ -67,6 +67,8 @@ class StyleSingerHIP(torch.nn.Module):
         self._pk = None
         self._pos_table = None
         self.training = False
+        import os
+        self.n_streams = int(os.environ.get("SS_STREAMS", "2"))  # 1 = everything on the caller's stream
 
     # ---- state_dict contract ------------------------------------------------------------------
     @staticmethod
@@ -269,6 +271,13 @@ class StyleSingerHIP(torch.nn.Module):
         if self._pk is None or self._packed_version != self._weights_version or self._pack_device != dev:
             self.pack()
 
+    def _streams(self, n):
+        """Side HIP streams: independent launch sequences (the two f0 samplers, batch halves of the mel sampler) run
+        concurrently so that one sequence's kernel tails/launch gaps are filled by the other's blocks."""
+        if not hasattr(self, "_side_streams") or len(self._side_streams) < n:
+            self._side_streams = [torch.cuda.Stream() for _ in range(n)]
+        return self._side_streams[:n]
+
     def _pos(self, n, dev):
         if self._pos_table is None or self._pos_table.shape[0] < n:
             self._pos_table = _sin_table(max(n, 2048), self.hp["hidden_size"]).to(dev)
@@ -458,9 +467,8 @@ class StyleSingerHIP(torch.nn.Module):
         cond_b = torch.empty(B, T, H, **f32)
         L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), None, L.ptr(emo), L.ptr(style), L.ptr(cond_b), B, T, H, L.ptr(lens_t), st()), "cond_b")
         res = {}
-        ws_bytes = max(lib.ss_wavenet_workspace_bytes(C_byref(pk["f0_a"]["net"]), B, T),
-                       lib.ss_wavenet_workspace_bytes(C_byref(pk["mel"]["net"]), B, T))
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        ws_f0_bytes = lib.ss_wavenet_workspace_bytes(C_byref(pk["f0_a"]["net"]), B, T)
+        jobs = []
         for key, cond in (("f0_a", dec), ("f0_b", cond_b)):
             net = pk[key]["net"]
             S = net.steps
@@ -474,9 +482,19 @@ class StyleSingerHIP(torch.nn.Module):
                 L.check(lib.ss_fill_normal(L.ptr(f0v), B * T, seed + (11 if key == "f0_a" else 13), 0, st()), "z0")
                 zs = us = None
             uvv = torch.zeros(B, T, device=dev, dtype=torch.int32)
-            L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(f0v), L.ptr(uvv), L.ptr(cond), L.ptr(lo), L.ptr(hi), L.ptr(lens_t), B, T,
-                                         L.ptr(zs), L.ptr(us), seed + (17 if key == "f0_a" else 19), 0, S, 1, L.ptr(ws), ws_bytes, st()), key)
+            wsk = torch.empty(ws_f0_bytes, device=dev, dtype=torch.uint8)
+            jobs.append((key, net, S, cond, f0v, uvv, zs, us, wsk))
             res[key] = (f0v, uvv)
+        main = torch.cuda.current_stream()
+        side = self._streams(2) if self.n_streams >= 2 else [main, main]
+        for sd_ in set(side) - {main}:
+            sd_.wait_stream(main)
+        for (key, net, S, cond, f0v, uvv, zs, us, wsk), strm in zip(jobs, side):
+            with torch.cuda.stream(strm):
+                L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(f0v), L.ptr(uvv), L.ptr(cond), L.ptr(lo), L.ptr(hi), L.ptr(lens_t), B, T,
+                                             L.ptr(zs), L.ptr(us), seed + (17 if key == "f0_a" else 19), 0, S, 1, L.ptr(wsk), ws_f0_bytes, st()), key)
+        for sd_ in set(side) - {main}:
+            main.wait_stream(sd_)
         ret["gdiff1"] = ret["mdiff1"] = ret["gdiff2"] = ret["mdiff2"] = 0.0
         pitch_pred = torch.empty(B, T, 2, **f32)
         f0_denorm = torch.empty(B, T, **f32)
@@ -528,8 +546,25 @@ class StyleSingerHIP(torch.nn.Module):
             zs_n = nz["z_steps"].to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()
         L.check(lib.ss_mel_qsample(L.ptr(coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), seed + 23,
                                    L.ptr(xm), B, T, M, st()), "qsample")
-        L.check(lib.ss_meldiff_sample(C_byref(net), L.ptr(xm), L.ptr(cond), L.ptr(lens_t), B, T, L.ptr(zs_n), seed + 29, 0, K, 1,
-                                      L.ptr(ws), ws_bytes, st()), "meldiff")
+        nsplit = 2 if (self.n_streams >= 2 and B >= 2) else 1
+        bounds = [B * i // nsplit for i in range(nsplit + 1)]
+        main = torch.cuda.current_stream()
+        side = self._streams(nsplit) if nsplit > 1 else [main]
+        parts = []
+        for i in range(nsplit):
+            b0, b1 = bounds[i], bounds[i + 1]
+            nb = b1 - b0
+            wsb = lib.ss_wavenet_workspace_bytes(C_byref(net), nb, T)
+            zpart = zs_n[:, b0:b1].contiguous() if (zs_n is not None and nsplit > 1) else zs_n
+            parts.append((b0, nb, wsb, torch.empty(wsb, device=dev, dtype=torch.uint8), zpart))
+        for sd_ in set(side) - {main}:
+            sd_.wait_stream(main)
+        for (b0, nb, wsb, wsp, zpart), strm in zip(parts, side):
+            with torch.cuda.stream(strm):
+                L.check(lib.ss_meldiff_sample(C_byref(net), L.ptr(xm[b0:]), L.ptr(cond[b0:]), L.ptr(lens_t[b0:]), nb, T, L.ptr(zpart),
+                                              seed + 29 + 7919 * b0, 0, K, 1, L.ptr(wsp), wsb, st()), "meldiff")
+        for sd_ in set(side) - {main}:
+            main.wait_stream(sd_)
         mel_out = torch.empty(B, T, M, **f32)
         # the reference does not mask padded frames here (shallow_diffusion_tts.py:305-306); with per-item
         # lengths the frames past lens[b] are not part of the utterance, so they are written as 0.
