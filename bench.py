@@ -74,9 +74,13 @@ def kernel_roofline(infer, B, T, iters=20):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * B * T * (3 * C) * (2 * C)
-    return dict(bound="mfma", kernel="conv_gemm_kernel<GATE> (mel dilated conv k=3, 256->512, + gate)", achieved=flops / sec / 1e12,
-                peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s", frac=flops / sec / PEAK_FP32_MFMA, traffic=None,
-                us_per_launch=sec * 1e6, flops_per_launch=flops)
+    # traffic: FETCH_SIZE + WRITE_SIZE of this launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_mel_gate.md):
+    # 27.9 MB fetched (uncorrected; wide reads are tallied at 1/2 on gfx950) + 12.3 MB written; algorithmic bytes 50.7 MB.
+    traffic = 40.2e6 if (B * T == 12000) else None
+    return dict(bound="mfma", kernel="conv_gemm_kernel<64,128,2,2,GATE> (mel dilated conv k=3, 256->512, + gate)",
+                achieved=flops / sec / 1e12, peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s", frac=flops / sec / PEAK_FP32_MFMA,
+                traffic=traffic, us_per_launch=sec * 1e6, flops_per_launch=flops, launches_per_step=2000,
+                algorithmic_bytes_per_launch=50.7e6)
 
 
 def cpu_baseline(hp, frames, threads):

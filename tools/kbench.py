@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--sweep", default="", help="comma separated tile ids to sweep (overrides --tile)")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--which", default="all")
+    ap.add_argument("--net", default="both", help="mel|f0|both")
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--T", type=int, default=1500)
     a = ap.parse_args()
@@ -46,10 +47,13 @@ def main():
     lens = torch.full((B,), T, device=d, dtype=torch.int32)
     res = []
     for (name, C, Lyr) in (("mel", 256, 20), ("f0", 192, 10)):
+        if a.net not in ("both", name):
+            continue
         X = torch.randn(B, T, C, device=d)
         G = torch.randn(B, T, C, device=d)
         S = torch.zeros(B, T, C, device=d)
         E = torch.randn(B, T, Lyr * 2 * C, device=d)
+        layer = [0]
         w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
         wo = torch.randn(2 * C, C, 1, device=d) / math.sqrt(C)
         bo = torch.randn(2 * C, device=d) * 0.1
@@ -58,8 +62,10 @@ def main():
         Wo = L.pack_conv_weight(wo)
         bop = L.pack_bias(bo)
         if a.which in ("gate", "all"):
-            f = lambda: L.conv_gemm(X, W, G, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, taps=(-2, 0, 2), lens=lens, a_bias=ab,
-                                    epi=L.EPI_GATE, E=E, lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, tile=a.tile)
+            def f():
+                layer[0] = (layer[0] + 1) % Lyr  # walk the conditioner slab like the real loop (E is 491 MB: HBM, not L2)
+                L.conv_gemm(X, W, G, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, taps=(-2, 0, 2), lens=lens, a_bias=ab,
+                            epi=L.EPI_GATE, E=E[:, :, layer[0] * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, tile=a.tile)
             s = timeit(f, a.iters)
             fl = 2.0 * B * T * 3 * C * 2 * C
             res.append((f"{name} gate  K={3 * C} N={2 * C}", s, fl))
