@@ -114,8 +114,12 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SS_BENCH_ONE_DEVICE"):  # orchestration smoke test on a 1-GPU box: all ranks on cuda:0 over gloo
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -102,6 +102,7 @@ typedef struct ss_conv_gemm_args {
   float ddpm_recip, ddpm_recipm1, ddpm_c1, ddpm_c2, ddpm_sigma;
   const float* noise; /* [B][T][N] or NULL -> Philox(seed, step) */
   uint64_t seed;
+  const uint64_t* seed_dev; /* optional device word added to `seed` at run time (keeps hipGraph replays fresh) */
   uint32_t step;
   /* tiling: 0 = auto, else one of SS_TILE_* (BMxBN) */
   int32_t tile;
@@ -232,14 +233,16 @@ int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int T);
  * shallow_diffusion_tts.py:296-306 + p_sample :155-162).
  *   x      [B][T][80] in: x_K (already q_sampled) ; out: x_0 (normalised)
  *   cond   [B][T][cond_dim]
- *   noise  [steps][B][T][80] tape (index s = loop step t) or NULL -> Philox(seed)
+ *   noise  [steps][B][T][80] tape (index s = loop step t) or NULL -> Philox(seed + *seed_dev)
+ *   seed_dev: optional device word added to the seed when the kernels run, so a captured hipGraph of this call
+ *             draws fresh noise on every replay (NULL = use `seed` alone)
  *   step_lo/step_hi: run t = step_hi-1 ... step_lo (full loop: 0, steps) */
 int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
-                      const float* noise, uint64_t seed, int step_lo, int step_hi, int precompute_cond, void* ws,
-                      int64_t ws_bytes, void* stream);
+                      const float* noise, uint64_t seed, const uint64_t* seed_dev, int step_lo, int step_hi,
+                      int precompute_cond, void* ws, int64_t ws_bytes, void* stream);
 /* q_sample + norm_spec: x = sqrt_ac*((mel-min)/(max-min)*2-1) + sqrt_1mac*z  (shallow_diffusion_tts.py:199-204,271-272) */
 int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac, float sqrt_1mac,
-                   const float* noise, uint64_t seed, float* x, int B, int T, int M, void* stream);
+                   const float* noise, uint64_t seed, const uint64_t* seed_dev, float* x, int B, int T, int M, void* stream);
 /* denorm_spec (+ optional row mask): mel = (x+1)/2*(max-min)+min (shallow_diffusion_tts.py:274-275) */
 int ss_mel_denorm(const float* x, const float* spec_min, const float* spec_max, float* mel, int B, int T, int M,
                   const int32_t* lens, void* stream);
@@ -252,7 +255,8 @@ int ss_mel_denorm(const float* x, const float* spec_min, const float* spec_max, 
  *   noise  [steps][B][T] gaussian tape or NULL ; gumbel_u [steps][B][2][T] uniform tape or NULL */
 int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, const float* cond, const float* lo, const float* hi,
                      const int32_t* lens, int B, int T, const float* noise, const float* gumbel_u, uint64_t seed,
-                     int step_lo, int step_hi, int precompute_cond, void* ws, int64_t ws_bytes, void* stream);
+                     const uint64_t* seed_dev, int step_lo, int step_hi, int precompute_cond, void* ws, int64_t ws_bytes,
+                     void* stream);
 
 /* f0 post-processing of the two predictors (stylesinger.py:216-311, utils/pitch_utils.py:22-31,65-78):
  * midi -> clamp bounds ; merge ; denorm ; coarse. */
@@ -299,7 +303,7 @@ int ss_hifigan_source(const ss_hifigan* hg, const float* f0, int B, int T, const
 
 /* utility: y = clip(x, lo, hi) ; fill ; philox normal fill (for tests/bench inputs on device) */
 int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, void* stream);
-int ss_fill_normal(float* x, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+int ss_fill_normal(float* x, int64_t n, uint64_t seed, const uint64_t* seed_dev, uint64_t offset, void* stream);
 
 #ifdef __cplusplus
 }

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   } else if constexpr (EPI == SS_EPI_DDPM) {
     // v = eps_theta. x0 = clamp(recip*x - recipm1*eps, -1, 1); mean = c1*x0 + c2*x; x <- mean + sigma*z
     float* Cb = a.C + (int64_t)b * a.c_batch_stride;
-    const SsPhilox rng(a.seed);
+    const SsPhilox rng(a.seed + (a.seed_dev ? a.seed_dev[0] : 0ull));
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = col_base + n * 32 + l31;

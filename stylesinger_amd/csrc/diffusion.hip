@@ -193,10 +193,10 @@ __device__ __forceinline__ float log_add_exp(float a, float b) {
 __global__ void f0_update_kernel(const float* __restrict__ O, float* __restrict__ f0, int32_t* __restrict__ uv,
                                  const float* __restrict__ lo, const float* __restrict__ hi,
                                  const float* __restrict__ noise, const float* __restrict__ gumbel_u, uint64_t seed,
-                                 int step, int B, int T, float recip, float recipm1, float c1, float c2, float sigma,
+                                 const uint64_t* __restrict__ seed_dev, int step, int B, int T, float recip, float recipm1, float c1, float c2, float sigma,
                                  float log_alpha_t, float log_1m_alpha_t, float log_cp_tm1, float log_1m_cp_tm1) {
   const int64_t n = (int64_t)B * T;
-  const SsPhilox rng(seed);
+  const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
   const float LOG2 = 0.69314718055994530942f;
   const float LOG_TINY = -69.07755278982137f;  // log(1e-30) as torch computes log(clamp(onehot, 1e-30))
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -257,8 +257,9 @@ __global__ void f0_update_kernel(const float* __restrict__ O, float* __restrict_
 // q_sample of the normalised coarse mel
 __global__ void mel_qsample_kernel(const float* __restrict__ mel, const float* __restrict__ smin,
                                    const float* __restrict__ smax, float sa, float s1, const float* __restrict__ noise,
-                                   uint64_t seed, float* __restrict__ x, int64_t rows, int M) {
-  const SsPhilox rng(seed);
+                                   uint64_t seed, const uint64_t* __restrict__ seed_dev, float* __restrict__ x, int64_t rows,
+                                   int M) {
+  const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
   const int64_t n = rows * M;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % M);
@@ -349,8 +350,8 @@ extern "C" int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int 
 }
 
 extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
-                                 const float* noise, uint64_t seed, int step_lo, int step_hi, int do_precompute, void* ws,
-                                 int64_t ws_bytes, void* stream_) {
+                                 const float* noise, uint64_t seed, const uint64_t* seed_dev, int step_lo, int step_hi,
+                                 int do_precompute, void* ws, int64_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SS_CHECK_ARG(net && x && cond && ws, "ss_meldiff_sample: null pointer");
   SS_CHECK_ARG(net->L > 0 && net->L <= SS_MAX_LAYERS && (net->C % 32) == 0, "ss_meldiff_sample: bad net C=%d L=%d", net->C, net->L);
@@ -400,6 +401,7 @@ extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* c
     f.ddpm_sigma = t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f;
     f.noise = noise ? noise + (int64_t)t * B * T * M : nullptr;
     f.seed = seed;
+    f.seed_dev = seed_dev;
     f.step = (uint32_t)t;
     SS_PROPAGATE(ss_conv_gemm(&f, stream));
   }
@@ -408,8 +410,8 @@ extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* c
 
 extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, const float* cond, const float* lo,
                                 const float* hi, const int32_t* lens, int B, int T, const float* noise,
-                                const float* gumbel_u, uint64_t seed, int step_lo, int step_hi, int do_precompute, void* ws,
-                                int64_t ws_bytes, void* stream_) {
+                                const float* gumbel_u, uint64_t seed, const uint64_t* seed_dev, int step_lo, int step_hi,
+                                int do_precompute, void* ws, int64_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SS_CHECK_ARG(net && f0 && uv && cond && lo && hi && ws, "ss_f0diff_sample: null pointer");
   SS_CHECK_ARG(net->L > 0 && net->L <= SS_MAX_LAYERS && (net->C % 64) == 0, "ss_f0diff_sample: bad net C=%d L=%d", net->C, net->L);
@@ -443,7 +445,7 @@ extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, c
     const int tm1 = t > 0 ? t - 1 : 0;
     hipLaunchKernelGGL(f0_update_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w.O, f0, uv, lo, hi,
                        noise ? noise + (int64_t)t * n : nullptr, gumbel_u ? gumbel_u + (int64_t)t * n * 2 : nullptr, seed,
-                       t, B, T, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
+                       seed_dev, t, B, T, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
                        t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f, net->log_alpha[t], net->log_1m_alpha[t],
                        net->log_cumprod_alpha[tm1], net->log_1m_cumprod_alpha[tm1]);
     SS_CHECK_LAUNCH("f0_update_kernel");
@@ -452,11 +454,11 @@ extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, c
 }
 
 extern "C" int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac,
-                              float sqrt_1mac, const float* noise, uint64_t seed, float* x, int B, int T, int M,
-                              void* stream) {
+                              float sqrt_1mac, const float* noise, uint64_t seed, const uint64_t* seed_dev, float* x, int B,
+                              int T, int M, void* stream) {
   SS_CHECK_ARG(coarse_mel && spec_min && spec_max && x, "ss_mel_qsample: null pointer");
   hipLaunchKernelGGL(mel_qsample_kernel, dim3(grid_for((int64_t)B * T * M)), dim3(256), 0, (hipStream_t)stream, coarse_mel,
-                     spec_min, spec_max, sqrt_ac, sqrt_1mac, noise, seed, x, (int64_t)B * T, M);
+                     spec_min, spec_max, sqrt_ac, sqrt_1mac, noise, seed, seed_dev, x, (int64_t)B * T, M);
   SS_CHECK_LAUNCH("ss_mel_qsample");
   return SS_OK;
 }

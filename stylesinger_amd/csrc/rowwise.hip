@@ -249,8 +249,9 @@ __global__ void clip_kernel(const float* __restrict__ x, float* __restrict__ y, 
     y[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
-__global__ void fill_normal_kernel(float* __restrict__ x, int64_t n, uint64_t seed, uint64_t offset) {
-  const SsPhilox rng(seed);
+__global__ void fill_normal_kernel(float* __restrict__ x, int64_t n, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                   uint64_t offset) {
+  const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i * 4 < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t o[4];
     const uint64_t ctr = offset + (uint64_t)i;
@@ -402,10 +403,10 @@ extern "C" int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, 
   return SS_OK;
 }
 
-extern "C" int ss_fill_normal(float* x, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+extern "C" int ss_fill_normal(float* x, int64_t n, uint64_t seed, const uint64_t* seed_dev, uint64_t offset, void* stream) {
   SS_CHECK_ARG(x && n > 0, "ss_fill_normal: bad args");
   hipLaunchKernelGGL(fill_normal_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, seed,
-                     offset);
+                     seed_dev, offset);
   SS_CHECK_LAUNCH("ss_fill_normal");
   return SS_OK;
 }

@@ -43,7 +43,7 @@ class ConvGemmArgs(C.Structure):
         ("C", _vp), ("ldc", C.c_int32), ("c_batch_stride", C.c_int64),
         ("C2", _vp), ("ldc2", C.c_int32), ("c2_batch_stride", C.c_int64), ("Nh", C.c_int32),
         ("ddpm_recip", C.c_float), ("ddpm_recipm1", C.c_float), ("ddpm_c1", C.c_float), ("ddpm_c2", C.c_float),
-        ("ddpm_sigma", C.c_float), ("noise", _vp), ("seed", C.c_uint64), ("step", C.c_uint32), ("tile", C.c_int32),
+        ("ddpm_sigma", C.c_float), ("noise", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("step", C.c_uint32), ("tile", C.c_int32),
     ]
 
 

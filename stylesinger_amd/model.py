@@ -49,6 +49,58 @@ def _step_emb_table(steps, dim):
     return torch.cat((e.sin(), e.cos()), dim=-1).contiguous()
 
 
+
+class _DiffPlan:
+    """Static device buffers (+ optional captured hipGraphs) of the three diffusion loops for one (B, T).
+
+    The loops are ~13 000 launches per pass; for small batches they are launch-bound, so the launch sequence is
+    captured once per shape with `torch.cuda.CUDAGraph` (the raw HIP launches go to the capture stream) and replayed.
+    Noise stays fresh across replays through the device seed word (`seed_dev` of the C-ABI)."""
+
+    def __init__(self, model, B, T, dev):
+        hp, pk, lib = model.hp, model._pk, _lib()
+        H, M = hp["hidden_size"], hp["audio_num_mel_bins"]
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.B, self.T = B, T
+        self.seed = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.lens = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.cond_a = torch.empty(B, T, H, **f32)
+        self.cond_b = torch.empty(B, T, H, **f32)
+        self.lo = torch.empty(B, T, **f32)
+        self.hi = torch.empty(B, T, **f32)
+        self.f0 = [torch.empty(B, T, **f32) for _ in range(2)]
+        self.uv = [torch.zeros(B, T, device=dev, dtype=torch.int32) for _ in range(2)]
+        self.ws_f0_bytes = lib.ss_wavenet_workspace_bytes(C_byref(pk["f0_a"]["net"]), B, T)
+        self.ws_f0 = [torch.empty(self.ws_f0_bytes, device=dev, dtype=torch.uint8) for _ in range(2)]
+        self.coarse_mel = torch.empty(B, T, M, **f32)
+        self.cond_mel = torch.empty(B, T, H, **f32)
+        self.xm = torch.empty(B, T, M, **f32)
+        nsplit = 2 if (model.n_streams >= 2 and B >= 2) else 1
+        self.bounds = [B * i // nsplit for i in range(nsplit + 1)]
+        self.ws_mel = []
+        for i in range(nsplit):
+            nb = self.bounds[i + 1] - self.bounds[i]
+            wsb = lib.ss_wavenet_workspace_bytes(C_byref(pk["mel"]["net"]), nb, T)
+            self.ws_mel.append((wsb, torch.empty(wsb, device=dev, dtype=torch.uint8)))
+        self.g_f0 = None
+        self.g_mel = None
+
+
+def _capture(fn):
+    """Warm up `fn` on a side stream, then capture it into a CUDAGraph (hipGraph)."""
+    cur = torch.cuda.current_stream()
+    s = torch.cuda.Stream()
+    s.wait_stream(cur)
+    with torch.cuda.stream(s):
+        fn()
+    cur.wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
 class StyleSingerHIP(torch.nn.Module):
     def __init__(self, dictionary=None, out_dims=None, hparams=None):
         super().__init__()
@@ -69,6 +121,9 @@ class StyleSingerHIP(torch.nn.Module):
         self.training = False
         import os
         self.n_streams = int(os.environ.get("SS_STREAMS", "2"))  # 1 = everything on the caller's stream
+        # hipGraph capture of the diffusion loops: "auto" = only where launch overhead matters (small B*T)
+        self.use_graphs = os.environ.get("SS_GRAPHS", "auto")
+        self._plans = {}
 
     # ---- state_dict contract ------------------------------------------------------------------
     @staticmethod
@@ -316,6 +371,75 @@ class StyleSingerHIP(torch.nn.Module):
         L.layernorm(x, *pkb["ln"], B=B, T=T, C_=H, out=x, lens=lens, mask_rows=True)
         return x
 
+    # ---- diffusion loops on a plan -------------------------------------------------------------------
+    def _plan(self, B, T, dev):
+        key = (B, T, dev.index)
+        if key not in self._plans:
+            if len(self._plans) >= 8:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = _DiffPlan(self, B, T, dev)
+        return self._plans[key]
+
+    def _want_graphs(self, B, T):
+        if self.use_graphs in ("1", "on", "true", True):
+            return True
+        if self.use_graphs in ("0", "off", "false", False):
+            return False
+        return B * T <= 3000  # kernels of <= ~25 us: launch-bound without a graph
+
+    def _run_f0_pair(self, pl, seed, tape=None):
+        """Both joint f0/uv samplers (independent given their conditions) on two streams."""
+        lib, pk = _lib(), self._pk
+        B, T = pl.B, pl.T
+        sdp = L.ptr(pl.seed)
+        main = torch.cuda.current_stream()
+        side = self._streams(2) if self.n_streams >= 2 else [main, main]
+        jobs = []
+        for i, (key, cond) in enumerate((("f0_a", pl.cond_a), ("f0_b", pl.cond_b))):
+            zs = us = None
+            if tape is not None:
+                zs, us = tape[key]
+            else:
+                L.check(lib.ss_fill_normal(L.ptr(pl.f0[i]), B * T, seed + (11 if i == 0 else 13), sdp, 0, L.stream_ptr()), "z0")
+            jobs.append((key, cond, i, zs, us))
+        for sd_ in set(side) - {main}:
+            sd_.wait_stream(main)
+        for (key, cond, i, zs, us), strm in zip(jobs, side):
+            net = pk[key]["net"]
+            with torch.cuda.stream(strm):
+                L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(pl.f0[i]), L.ptr(pl.uv[i]), L.ptr(cond), L.ptr(pl.lo), L.ptr(pl.hi),
+                                             L.ptr(pl.lens), B, T, L.ptr(zs), L.ptr(us), seed + (17 if i == 0 else 19), sdp, 0, net.steps, 1,
+                                             L.ptr(pl.ws_f0[i]), pl.ws_f0_bytes, L.stream_ptr()), key)
+        for sd_ in set(side) - {main}:
+            main.wait_stream(sd_)
+
+    def _run_mel(self, pl, seed, tape=None):
+        """q_sample + the shallow reverse loop (batch halves on two streams)."""
+        lib, pk, hp = _lib(), self._pk, self.hp
+        B, T, M = pl.B, pl.T, hp["audio_num_mel_bins"]
+        net = pk["mel"]["net"]
+        K = hp["K_step"]
+        sa = float(pk["mel"]["sched"]["sqrt_alphas_cumprod"][K - 1])
+        s1 = float(pk["mel"]["sched"]["sqrt_one_minus_alphas_cumprod"][K - 1])
+        sdp = L.ptr(pl.seed)
+        zq_n, zs_n = tape if tape is not None else (None, None)
+        L.check(lib.ss_mel_qsample(L.ptr(pl.coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), seed + 23, sdp,
+                                   L.ptr(pl.xm), B, T, M, L.stream_ptr()), "qsample")
+        nsplit = len(pl.ws_mel)
+        main = torch.cuda.current_stream()
+        side = self._streams(nsplit) if nsplit > 1 else [main]
+        zparts = [zs_n[:, pl.bounds[i]:pl.bounds[i + 1]].contiguous() if (zs_n is not None and nsplit > 1) else zs_n for i in range(nsplit)]
+        for sd_ in set(side) - {main}:
+            sd_.wait_stream(main)
+        for i, strm in enumerate(side):
+            b0, nb = pl.bounds[i], pl.bounds[i + 1] - pl.bounds[i]
+            wsb, wsp = pl.ws_mel[i]
+            with torch.cuda.stream(strm):
+                L.check(lib.ss_meldiff_sample(C_byref(net), L.ptr(pl.xm[b0:]), L.ptr(pl.cond_mel[b0:]), L.ptr(pl.lens[b0:]), nb, T,
+                                              L.ptr(zparts[i]), seed + 29 + 7919 * b0, sdp, 0, K, 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff")
+        for sd_ in set(side) - {main}:
+            main.wait_stream(sd_)
+
     # ---- forward ----------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, emo_embed=None, ref_mels=None, ref_f0=None, f0=None, uv=None,
@@ -461,40 +585,32 @@ class StyleSingerHIP(torch.nn.Module):
         # ---- pitch: two joint Gaussian/multinomial diffusions (a8) + post-processing (a9) ----
         midi = torch.empty(B, T, device=dev, dtype=torch.int64)
         L.check(lib.ss_gather_expand_i64(L.ptr(note), L.ptr(mel2ph), L.ptr(midi), B, Tp, T, st()), "midi")
-        lo = torch.empty(B, T, **f32)
-        hi = torch.empty(B, T, **f32)
-        L.check(lib.ss_f0_bounds(L.ptr(midi), L.ptr(lo), L.ptr(hi), B * T, st()), "bounds")
-        cond_b = torch.empty(B, T, H, **f32)
-        L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), None, L.ptr(emo), L.ptr(style), L.ptr(cond_b), B, T, H, L.ptr(lens_t), st()), "cond_b")
-        res = {}
-        ws_f0_bytes = lib.ss_wavenet_workspace_bytes(C_byref(pk["f0_a"]["net"]), B, T)
-        jobs = []
-        for key, cond in (("f0_a", dec), ("f0_b", cond_b)):
-            net = pk[key]["net"]
-            S = net.steps
-            nz = noise[key] if noise is not None else None
-            if nz is not None:
-                f0v = nz["z0"].to(dev).reshape(B, T).contiguous().float()
-                zs = nz["z_steps"].to(dev).reshape(S, B, T).contiguous().float()
-                us = nz["u_steps"].to(dev).reshape(S, B, 2, T).contiguous().float()
-            else:
-                f0v = torch.empty(B, T, **f32)
-                L.check(lib.ss_fill_normal(L.ptr(f0v), B * T, seed + (11 if key == "f0_a" else 13), 0, st()), "z0")
-                zs = us = None
-            uvv = torch.zeros(B, T, device=dev, dtype=torch.int32)
-            wsk = torch.empty(ws_f0_bytes, device=dev, dtype=torch.uint8)
-            jobs.append((key, net, S, cond, f0v, uvv, zs, us, wsk))
-            res[key] = (f0v, uvv)
-        main = torch.cuda.current_stream()
-        side = self._streams(2) if self.n_streams >= 2 else [main, main]
-        for sd_ in set(side) - {main}:
-            sd_.wait_stream(main)
-        for (key, net, S, cond, f0v, uvv, zs, us, wsk), strm in zip(jobs, side):
-            with torch.cuda.stream(strm):
-                L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(f0v), L.ptr(uvv), L.ptr(cond), L.ptr(lo), L.ptr(hi), L.ptr(lens_t), B, T,
-                                             L.ptr(zs), L.ptr(us), seed + (17 if key == "f0_a" else 19), 0, S, 1, L.ptr(wsk), ws_f0_bytes, st()), key)
-        for sd_ in set(side) - {main}:
-            main.wait_stream(sd_)
+        pl = self._plan(B, T, dev)
+        pl.lens.copy_(lens_t)
+        pl.seed.fill_(seed)
+        L.check(lib.ss_f0_bounds(L.ptr(midi), L.ptr(pl.lo), L.ptr(pl.hi), B * T, st()), "bounds")
+        pl.cond_a.copy_(dec)  # = decoder_inp * tgt_nonpadding (the gather already wrote 0 on padding)
+        L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), None, L.ptr(emo), L.ptr(style), L.ptr(pl.cond_b), B, T, H, L.ptr(lens_t), st()), "cond_b")
+        for u in pl.uv:
+            u.zero_()
+        graphs = noise is None and self._want_graphs(B, T)
+        if noise is not None:
+            tape = {}
+            for i, key in enumerate(("f0_a", "f0_b")):
+                nz, S = noise[key], pk[key]["net"].steps
+                pl.f0[i].copy_(nz["z0"].to(dev).reshape(B, T).float())
+                tape[key] = (nz["z_steps"].to(dev).reshape(S, B, T).contiguous().float(),
+                             nz["u_steps"].to(dev).reshape(S, B, 2, T).contiguous().float())
+            self._run_f0_pair(pl, seed, tape)
+        elif graphs:
+            if pl.g_f0 is None:
+                pl.g_f0 = _capture(lambda: self._run_f0_pair(pl, seed))
+                for u in pl.uv:
+                    u.zero_()
+            pl.g_f0.replay()
+        else:
+            self._run_f0_pair(pl, seed)
+        res = {"f0_a": (pl.f0[0].clone(), pl.uv[0].clone()), "f0_b": (pl.f0[1].clone(), pl.uv[1].clone())}
         ret["gdiff1"] = ret["mdiff1"] = ret["gdiff2"] = ret["mdiff2"] = 0.0
         pitch_pred = torch.empty(B, T, 2, **f32)
         f0_denorm = torch.empty(B, T, **f32)
@@ -531,40 +647,23 @@ class StyleSingerHIP(torch.nn.Module):
 
         # ---- condition projection (a11) + shallow mel diffusion (a12) ----
         gcat = torch.cat([coarse_mel, dec_inp, spk[:, None, :].expand(-1, T, -1), emo[:, None, :].expand(-1, T, -1), style], -1).contiguous()
-        cond = torch.empty(B, T, H, **f32)
+        cond = pl.cond_mel
         self._gemm(gcat, pk["ln_proj"], cond, B, T, mask_rows=False)
-        ret["diff_cond"] = cond
-        net = pk["mel"]["net"]
+        ret["diff_cond"] = cond.clone()
+        pl.coarse_mel.copy_(coarse_mel)
         K = hp["K_step"]
-        sa = float(pk["mel"]["sched"]["sqrt_alphas_cumprod"][K - 1])
-        s1 = float(pk["mel"]["sched"]["sqrt_one_minus_alphas_cumprod"][K - 1])
-        xm = torch.empty(B, T, M, **f32)
-        nz = noise["mel"] if noise is not None else None
-        zq_n = zs_n = None
-        if nz is not None:
+        if noise is not None:
+            nz = noise["mel"]
             zq_n = nz["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
             zs_n = nz["z_steps"].to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()
-        L.check(lib.ss_mel_qsample(L.ptr(coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), seed + 23,
-                                   L.ptr(xm), B, T, M, st()), "qsample")
-        nsplit = 2 if (self.n_streams >= 2 and B >= 2) else 1
-        bounds = [B * i // nsplit for i in range(nsplit + 1)]
-        main = torch.cuda.current_stream()
-        side = self._streams(nsplit) if nsplit > 1 else [main]
-        parts = []
-        for i in range(nsplit):
-            b0, b1 = bounds[i], bounds[i + 1]
-            nb = b1 - b0
-            wsb = lib.ss_wavenet_workspace_bytes(C_byref(net), nb, T)
-            zpart = zs_n[:, b0:b1].contiguous() if (zs_n is not None and nsplit > 1) else zs_n
-            parts.append((b0, nb, wsb, torch.empty(wsb, device=dev, dtype=torch.uint8), zpart))
-        for sd_ in set(side) - {main}:
-            sd_.wait_stream(main)
-        for (b0, nb, wsb, wsp, zpart), strm in zip(parts, side):
-            with torch.cuda.stream(strm):
-                L.check(lib.ss_meldiff_sample(C_byref(net), L.ptr(xm[b0:]), L.ptr(cond[b0:]), L.ptr(lens_t[b0:]), nb, T, L.ptr(zpart),
-                                              seed + 29 + 7919 * b0, 0, K, 1, L.ptr(wsp), wsb, st()), "meldiff")
-        for sd_ in set(side) - {main}:
-            main.wait_stream(sd_)
+            self._run_mel(pl, seed, (zq_n, zs_n))
+        elif graphs:
+            if pl.g_mel is None:
+                pl.g_mel = _capture(lambda: self._run_mel(pl, seed))
+            pl.g_mel.replay()
+        else:
+            self._run_mel(pl, seed)
+        xm = pl.xm
         mel_out = torch.empty(B, T, M, **f32)
         # the reference does not mask padded frames here (shallow_diffusion_tts.py:305-306); with per-item
         # lengths the frames past lens[b] are not part of the utterance, so they are written as 0.
