@@ -55,13 +55,12 @@ def kernel_roofline(infer, B, T, iters=20):
     E = torch.randn(B, T, Lyr * 2 * C, device=dev)
     G = torch.empty(B, T, C, device=dev)
     lens = torch.full((B,), T, device=dev, dtype=torch.int32)
-    dil_w = [k for k in net["keep"] if hasattr(k, "half") and k.half == C and k.k == 3]
-    dstep = [k for k in net["keep"] if torch.is_tensor(k) and k.dim() == 3 and k.shape[1] == Lyr][0]
+    packs = net["packs"][0]
+    dstep = packs["dstep"]
 
     def launch(l):
         d = 1 << (l % 4)
-        w = dil_w[l]
-        L.conv_gemm(X, w.W, G, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, taps=(-d, 0, d), lens=lens, a_bias=dstep[0, l],
+        L.conv_gemm(X, packs[f"w_dil.{l}"], G, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, taps=(-d, 0, d), lens=lens, a_bias=dstep[0, l],
                     epi=L.EPI_GATE, E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
     for l in range(4):
         launch(l)

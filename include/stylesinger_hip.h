@@ -55,7 +55,8 @@ enum {
 enum { SS_ACT_NONE_ = 0, SS_ACT_RELU_ = 1, SS_ACT_GELU_ = 2, SS_ACT_MISH_ = 3, SS_ACT_TANH_ = 4, SS_ACT_LRELU_ = 5 };
 
 enum { SS_TILE_AUTO = 0, SS_TILE_128x128 = 1, SS_TILE_64x128 = 2, SS_TILE_64x64 = 3, SS_TILE_128x64 = 4, SS_TILE_128x32 = 5,
-       SS_TILE_96x256 = 6, SS_TILE_96x128 = 7, SS_TILE_64x256 = 8, SS_TILE_256x32 = 9, SS_TILE_256x64 = 10 };
+       SS_TILE_96x256 = 6, SS_TILE_96x128 = 7, SS_TILE_64x256 = 8, SS_TILE_256x32 = 9, SS_TILE_256x64 = 10,
+       SS_TILE_64x64_2W = 11 /* 2 waves of 32x64 */, SS_TILE_128x128_8W = 12 /* 8 waves of 32x64 */ };
 
 typedef struct ss_conv_gemm_args {
   /* A operand */
@@ -106,6 +107,10 @@ typedef struct ss_conv_gemm_args {
   uint32_t step;
   /* tiling: 0 = auto, else one of SS_TILE_* (BMxBN) */
   int32_t tile;
+  /* grouped launch: batch item b uses weight set g = b / group_size (0 = one set). Strides in floats. Lets the two
+   * independent f0 denoisers (same shapes, different weights) share every launch: 2x the blocks per kernel. */
+  int32_t group_size;
+  int64_t w_group_stride, bias_group_stride, a_bias_group_stride;
 } ss_conv_gemm_args;
 
 int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
@@ -224,6 +229,11 @@ typedef struct ss_wavenet {
   const float* log_1m_alpha;      /* f0 only */
   const float* log_cumprod_alpha; /* f0 only */
   const float* log_1m_cumprod_alpha;
+  /* paired nets (n_groups = 2): every weight pointer above is net 0's; net g's tensor lives gs_* floats further.
+   * Both nets must share shapes and schedules (the two DDiffNets of stylesinger.py:69-73 do). */
+  int32_t n_groups;
+  int64_t gs_w_in, gs_b_in, gs_uv_embed, gs_dstep, gs_w_dil, gs_w_out, gs_b_out, gs_w_cond, gs_b_cond, gs_w_skip, gs_b_skip,
+      gs_w_final, gs_b_final;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */
@@ -249,6 +259,8 @@ int ss_mel_denorm(const float* x, const float* spec_min, const float* spec_max, 
 
 /* Joint Gaussian(f0)/multinomial(uv) reverse loop (GaussianMultinomialDiffusion.sample,
  * gaussian_multinomial_diffusion.py:922-942 with gaussian_p_sample :326-333, p_sample :410-413).
+ *   With net->n_groups == 2 the call runs BOTH samplers at once: every per-item array below is [2B] long, items
+ *   [0,B) belong to net 0 (agnostic) and [B,2B) to net 1 (specific); pass B = 2*B_utterances.
  *   f0     [B][T] in: z_f0 ~ N(0,1); out: final normalised f0
  *   uv     [B][T] int32 in: initial class (0); out: final class
  *   lo/hi  [B][T] per-frame clamp bounds (dyn_clip, stylesinger.py:275-283)

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   const int wn = wave % WAVES_N;
 
   const int len = a.lens ? a.lens[b] : a.T;
+  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;  // weight set of this batch item (grouped launch)
+  const float* Wg = a.W + (int64_t)grp_w * a.w_group_stride;
+  const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
+  const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;
 
   const int kchunks_per_tap = a.Kp / BK;
   const int nchunks = a.ntaps * kchunks_per_tap;
@@ -92,11 +96,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w =
-      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.W), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Wg), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 4), 0x00020000);
   // A-prologue bias through a descriptor as well (a plain pointer select would become a FLAT load, which also
   // counts on lgkmcnt and would stall the LDS fragment reads); no bias -> 0 records -> reads 0.
   const __amdgpu_buffer_rsrc_t rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(a.a_bias ? a.a_bias : a.W), 0, __builtin_amdgcn_readfirstlane(a.a_bias ? a.Cin * 4 : 0), 0x00020000);
+      uniform_ptr(abiasg ? abiasg : Wg), 0, __builtin_amdgcn_readfirstlane(abiasg ? a.Cin * 4 : 0), 0x00020000);
 
   // staging coordinates: 8 threads x float4 cover one 32-wide K chunk of a row; RP rows per pass
   const int st_c4 = tid & 7;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     for (int n = 0; n < TN; ++n) {
       const int col = col_base + n * 32 + l31;
       const bool col_ok = col < a.N;
-      const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
+      const float bs = (biasg && col_ok) ? biasg[col] : 0.f;
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
         float rv[16], pv[16];
@@ -341,8 +345,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
           const int pc1 = pc0 + 32;
           const int oc = (pc0 >> 6) * 32 + l31;  // output channel
           const bool col_ok = !CHECK || oc < a.N;
-          const float b0 = (a.bias && col_ok) ? a.bias[pc0] : 0.f;
-          const float b1 = (a.bias && col_ok) ? a.bias[pc1] : 0.f;
+          const float b0 = (biasg && col_ok) ? biasg[pc0] : 0.f;
+          const float b1 = (biasg && col_ok) ? biasg[pc1] : 0.f;
 #pragma unroll
           for (int m = 0; m < TM; ++m) {
             float e0[16], e1[16];
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       for (int n = 0; n < TN; ++n) {
         const int col = col_base + n * 32 + l31;
         const bool col_ok = !CHECK || col < a.N;
-        const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
+        const float bs = (biasg && col_ok) ? biasg[col] : 0.f;
         const bool first = col < a.Nh;  // uniform per 32-column block
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     for (int n = 0; n < TN; ++n) {
       const int col = col_base + n * 32 + l31;
       const bool col_ok = col < a.N;
-      const float bs = (a.bias && col_ok) ? a.bias[col] : 0.f;
+      const float bs = (biasg && col_ok) ? biasg[col] : 0.f;
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
         float xv[16], zv[16];
@@ -520,6 +524,8 @@ int launch_tile(int tile, const ss_conv_gemm_args& a, hipStream_t stream) {
     case SS_TILE_96x128: return launch<96, 128, 1, 2, EPI>(a, stream);
     case SS_TILE_64x256: return launch<64, 256, 1, 4, EPI>(a, stream);
     case SS_TILE_256x64: return launch<256, 64, 4, 1, EPI>(a, stream);
+    case SS_TILE_64x64_2W: return launch<64, 64, 2, 1, EPI>(a, stream);
+    case SS_TILE_128x128_8W: return launch<128, 128, 4, 2, EPI>(a, stream);
     case SS_TILE_64x64:
       if constexpr (!G) return launch<64, 64, 2, 2, EPI>(a, stream);
       break;

@@ -82,6 +82,11 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
   a.ldc = NE;
   a.c_batch_stride = (int64_t)T * NE;
   a.mask_rows = 0;
+  if (net->n_groups > 1) {
+    a.group_size = B / net->n_groups;
+    a.w_group_stride = net->gs_w_cond;
+    a.bias_group_stride = net->gs_b_cond;
+  }
   return ss_conv_gemm(&a, stream);
 }
 
@@ -115,6 +120,11 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     a.C = w.G;
     a.ldc = C;
     a.c_batch_stride = (int64_t)T * C;
+    if (net->n_groups > 1) {
+      a.group_size = B / net->n_groups;
+      a.w_group_stride = net->gs_w_dil;
+      a.a_bias_group_stride = net->gs_dstep;
+    }
     SS_PROPAGATE(ss_conv_gemm(&a, stream));
     // y = output_projection(g) ; x = (x + y[:C]) / sqrt(2) ; skip += y[C:]   (net.py:75-77)
     ss_conv_gemm_args o = base_args(B, T, lens);
@@ -140,6 +150,11 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     o.ldc2 = C;
     o.c2_batch_stride = (int64_t)T * C;
     o.accumulate = l > 0;
+    if (net->n_groups > 1) {
+      o.group_size = B / net->n_groups;
+      o.w_group_stride = net->gs_w_out;
+      o.bias_group_stride = net->gs_b_out;
+    }
     SS_PROPAGATE(ss_conv_gemm(&o, stream));
   }
   // x = relu(skip_projection(sum(skip) / sqrt(L)))   (net.py:124-127)
@@ -159,6 +174,11 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
   s.C = w.G;
   s.ldc = C;
   s.c_batch_stride = (int64_t)T * C;
+  if (net->n_groups > 1) {
+    s.group_size = B / net->n_groups;
+    s.w_group_stride = net->gs_w_skip;
+    s.bias_group_stride = net->gs_b_skip;
+  }
   return ss_conv_gemm(&s, stream);
 }
 
@@ -168,16 +188,17 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
 __global__ void f0_input_kernel(const float* __restrict__ f0, const int32_t* __restrict__ uv,
                                 const float* __restrict__ w_in, const float* __restrict__ b_in,
                                 const float* __restrict__ uv_embed, float* __restrict__ X, int B, int T, int C,
-                                const int32_t* __restrict__ lens) {
+                                const int32_t* __restrict__ lens, int group_size, int64_t gs_w, int64_t gs_b, int64_t gs_e) {
   const int half = C / 2;
   const int64_t total = (int64_t)B * T * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const int64_t r = i / C;
     const int b = (int)(r / T), t = (int)(r % T);
+    const int g = group_size > 0 ? b / group_size : 0;
     float v;
-    if (c < half) v = w_in[c] * f0[r] + b_in[c];
-    else v = uv_embed[(uv[r] != 0 ? 1 : 0) * half + (c - half)];
+    if (c < half) v = w_in[g * gs_w + c] * f0[r] + b_in[g * gs_b + c];
+    else v = uv_embed[g * gs_e + (uv[r] != 0 ? 1 : 0) * half + (c - half)];
     if (lens && t >= lens[b]) v = 0.f;
     X[i] = v;
   }
@@ -356,6 +377,7 @@ extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* c
   SS_CHECK_ARG(net && x && cond && ws, "ss_meldiff_sample: null pointer");
   SS_CHECK_ARG(net->L > 0 && net->L <= SS_MAX_LAYERS && (net->C % 32) == 0, "ss_meldiff_sample: bad net C=%d L=%d", net->C, net->L);
   SS_CHECK_ARG(0 <= step_lo && step_lo <= step_hi && step_hi <= net->steps, "ss_meldiff_sample: bad step range");
+  SS_CHECK_ARG(net->n_groups <= 1, "ss_meldiff_sample: grouped nets are only supported by the f0 sampler");
   const WsLayout w = ws_layout(net, B, T, ws);
   SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_meldiff_sample: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
   const int C = net->C, M = net->in_dim;
@@ -417,6 +439,7 @@ extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, c
   SS_CHECK_ARG(net->L > 0 && net->L <= SS_MAX_LAYERS && (net->C % 64) == 0, "ss_f0diff_sample: bad net C=%d L=%d", net->C, net->L);
   SS_CHECK_ARG(0 <= step_lo && step_lo <= step_hi && step_hi <= net->steps, "ss_f0diff_sample: bad step range");
   SS_CHECK_ARG(net->out_dim == 3 && net->in_dim == 1, "ss_f0diff_sample: net must be the 1->3 DDiffNet");
+  SS_CHECK_ARG(net->n_groups <= 1 || (net->n_groups == 2 && B % 2 == 0), "ss_f0diff_sample: paired nets need an even item count");
   const WsLayout w = ws_layout(net, B, T, ws);
   SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_f0diff_sample: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
   const int C = net->C;
@@ -424,7 +447,8 @@ extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, c
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
   for (int t = step_hi - 1; t >= step_lo; --t) {
     hipLaunchKernelGGL(f0_input_kernel, dim3(grid_for(n * C)), dim3(256), 0, stream, f0, uv, net->w_in, net->b_in,
-                       net->uv_embed, w.X, B, T, C, lens);
+                       net->uv_embed, w.X, B, T, C, lens, net->n_groups > 1 ? B / net->n_groups : 0, net->gs_w_in, net->gs_b_in,
+                       net->gs_uv_embed);
     SS_CHECK_LAUNCH("f0_input_kernel");
     SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream));
     ss_conv_gemm_args f = base_args(B, T, lens);
@@ -441,6 +465,11 @@ extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, c
     f.C = w.O;
     f.ldc = 4;
     f.c_batch_stride = (int64_t)T * 4;
+    if (net->n_groups > 1) {
+      f.group_size = B / net->n_groups;
+      f.w_group_stride = net->gs_w_final;
+      f.bias_group_stride = net->gs_b_final;
+    }
     SS_PROPAGATE(ss_conv_gemm(&f, stream));
     const int tm1 = t > 0 ? t - 1 : 0;
     hipLaunchKernelGGL(f0_update_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w.O, f0, uv, lo, hi,

@@ -44,6 +44,7 @@ class ConvGemmArgs(C.Structure):
         ("C2", _vp), ("ldc2", C.c_int32), ("c2_batch_stride", C.c_int64), ("Nh", C.c_int32),
         ("ddpm_recip", C.c_float), ("ddpm_recipm1", C.c_float), ("ddpm_c1", C.c_float), ("ddpm_c2", C.c_float),
         ("ddpm_sigma", C.c_float), ("noise", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("step", C.c_uint32), ("tile", C.c_int32),
+        ("group_size", C.c_int32), ("w_group_stride", C.c_int64), ("bias_group_stride", C.c_int64), ("a_bias_group_stride", C.c_int64),
     ]
 
 
@@ -56,7 +57,9 @@ class WaveNet(C.Structure):
         ("w_cond", _vp), ("b_cond", _vp), ("w_skip", _vp), ("b_skip", _vp), ("w_final", _vp), ("b_final", _vp),
         ("sqrt_recip_ac", _vp), ("sqrt_recipm1_ac", _vp), ("post_c1", _vp), ("post_c2", _vp), ("post_logvar", _vp),
         ("log_alpha", _vp), ("log_1m_alpha", _vp), ("log_cumprod_alpha", _vp), ("log_1m_cumprod_alpha", _vp),
-    ]
+        ("n_groups", C.c_int32),
+    ] + [(n, C.c_int64) for n in ("gs_w_in", "gs_b_in", "gs_uv_embed", "gs_dstep", "gs_w_dil", "gs_w_out", "gs_b_out", "gs_w_cond",
+                                  "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")]
 
 
 class HifiGan(C.Structure):

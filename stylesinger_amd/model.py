@@ -63,15 +63,19 @@ class _DiffPlan:
         f32 = dict(device=dev, dtype=torch.float32)
         self.B, self.T = B, T
         self.seed = torch.zeros(1, device=dev, dtype=torch.int64)
-        self.lens = torch.zeros(B, device=dev, dtype=torch.int32)
-        self.cond_a = torch.empty(B, T, H, **f32)
-        self.cond_b = torch.empty(B, T, H, **f32)
-        self.lo = torch.empty(B, T, **f32)
-        self.hi = torch.empty(B, T, **f32)
-        self.f0 = [torch.empty(B, T, **f32) for _ in range(2)]
-        self.uv = [torch.zeros(B, T, device=dev, dtype=torch.int32) for _ in range(2)]
-        self.ws_f0_bytes = lib.ss_wavenet_workspace_bytes(C_byref(pk["f0_a"]["net"]), B, T)
-        self.ws_f0 = [torch.empty(self.ws_f0_bytes, device=dev, dtype=torch.uint8) for _ in range(2)]
+        # f0 pair: items [0,B) = agnostic net, [B,2B) = specific net (grouped launches)
+        self.lens2 = torch.zeros(2 * B, device=dev, dtype=torch.int32)
+        self.lens = self.lens2[:B]
+        self.cond2 = torch.empty(2 * B, T, H, **f32)
+        self.cond_a, self.cond_b = self.cond2[:B], self.cond2[B:]
+        self.lo2 = torch.empty(2 * B, T, **f32)
+        self.hi2 = torch.empty(2 * B, T, **f32)
+        self.f02 = torch.empty(2 * B, T, **f32)
+        self.uv2 = torch.zeros(2 * B, T, device=dev, dtype=torch.int32)
+        self.f0 = [self.f02[:B], self.f02[B:]]
+        self.uv = [self.uv2[:B], self.uv2[B:]]
+        self.ws_f0_bytes = lib.ss_wavenet_workspace_bytes(C_byref(pk["f0_pair"]["net"]), 2 * B, T)
+        self.ws_f0 = torch.empty(self.ws_f0_bytes, device=dev, dtype=torch.uint8)
         self.coarse_mel = torch.empty(B, T, M, **f32)
         self.cond_mel = torch.empty(B, T, H, **f32)
         self.xm = torch.empty(B, T, M, **f32)
@@ -120,7 +124,7 @@ class StyleSingerHIP(torch.nn.Module):
         self._pos_table = None
         self.training = False
         import os
-        self.n_streams = int(os.environ.get("SS_STREAMS", "2"))  # 1 = everything on the caller's stream
+        self.n_streams = int(os.environ.get("SS_STREAMS", "1"))  # 2 = split the mel batch over two streams (slower at C2: half-size launches balance worse)
         # hipGraph capture of the diffusion loops: "auto" = only where launch overhead matters (small B*T)
         self.use_graphs = os.environ.get("SS_GRAPHS", "auto")
         self._plans = {}
@@ -178,23 +182,17 @@ class StyleSingerHIP(torch.nn.Module):
         bias = L.pack_bias(self.p(prefix + ".bias"), interleave_half=half)
         return _Packed(W, bias, Cout, Cin, k, half)
 
-    def _pack_wavenet(self, prefix, gen, C, Lyr, cycle, steps, in_dim, out_dim, f0):
-        hp = self.hp
-        H = hp["hidden_size"]
+    def _pack_wavenet_tensors(self, prefix, C, Lyr, steps, f0):
+        """Packed device tensors of one denoiser (DiffNet / DDiffNet), keyed like the ss_wavenet fields."""
         dev = self.p(prefix + ".mlp.0.weight").device
-        keep = []
-        net = L.WaveNet()
-        net.C, net.L, net.cond_dim, net.dil_cycle, net.in_dim, net.out_dim, net.steps = C, Lyr, H, cycle, in_dim, out_dim, steps
+        t = {}
         if f0:
-            w_in = self.p(prefix + ".input_projection.weight").reshape(-1).contiguous()
-            b_in = self.p(prefix + ".input_projection.bias").contiguous()
-            uve = self.p(prefix + ".uv_embed.weight").contiguous()
-            keep += [w_in, b_in, uve]
-            net.w_in, net.b_in, net.uv_embed = w_in.data_ptr(), b_in.data_ptr(), uve.data_ptr()
+            t["w_in"] = self.p(prefix + ".input_projection.weight").reshape(-1).contiguous()
+            t["b_in"] = self.p(prefix + ".input_projection.bias").contiguous()
+            t["uv_embed"] = self.p(prefix + ".uv_embed.weight").contiguous()
         else:
             pin = self._pack_conv(prefix + ".input_projection.weight", prefix + ".input_projection.bias")
-            keep.append(pin)
-            net.w_in, net.b_in = pin.W.data_ptr(), pin.bias.data_ptr()
+            t["w_in"], t["b_in"] = pin.W, pin.bias
         # dstep[s][l][:] = diffusion_projection_l(mlp(SinusoidalPosEmb(s)))  (net.py:66,118-119) — weights-only table
         emb = _step_emb_table(steps, C).to(dev)
         m0 = self._pack_conv(prefix + ".mlp.0.weight", prefix + ".mlp.0.bias")
@@ -214,22 +212,52 @@ class StyleSingerHIP(torch.nn.Module):
             out = self._pack_conv(p + ".output_projection.weight", p + ".output_projection.bias")
             cnd = self._pack_conv(p + ".conditioner_projection.weight", p + ".conditioner_projection.bias", half=C,
                                   bias2=self.p(p + ".dilated_conv.bias"))
-            keep += [dil, out, cnd]
-            net.w_dil[l], net.w_out[l], net.b_out[l] = dil.W.data_ptr(), out.W.data_ptr(), out.bias.data_ptr()
+            t[f"w_dil.{l}"], t[f"w_out.{l}"], t[f"b_out.{l}"] = dil.W, out.W, out.bias
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
-        w_cond = torch.cat(wc_rows, 0).contiguous()
-        b_cond = torch.cat(bc_rows, 0).contiguous()
+        t["dstep"] = dstep
+        t["w_cond"] = torch.cat(wc_rows, 0).contiguous()
+        t["b_cond"] = torch.cat(bc_rows, 0).contiguous()
         skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
         fin = self._pack_conv(prefix + ".output_projection.weight", prefix + ".output_projection.bias")
-        keep += [dstep, w_cond, b_cond, skip, fin]
-        net.dstep, net.w_cond, net.b_cond = dstep.data_ptr(), w_cond.data_ptr(), b_cond.data_ptr()
-        net.w_skip, net.b_skip, net.w_final, net.b_final = skip.W.data_ptr(), skip.bias.data_ptr(), fin.W.data_ptr(), fin.bias.data_ptr()
+        t["w_skip"], t["b_skip"], t["w_final"], t["b_final"] = skip.W, skip.bias, fin.W, fin.bias
+        torch.cuda.synchronize()
+        return t
+
+    def _pack_wavenet(self, prefixes, gen, C, Lyr, cycle, steps, in_dim, out_dim, f0):
+        """Build the ss_wavenet descriptor of one net, or of a PAIR of same-shaped nets (grouped launches: every
+        weight tensor is stacked [2][...] so that net g sits gs_* floats after net 0)."""
+        hp = self.hp
+        packs = [self._pack_wavenet_tensors(pf, C, Lyr, steps, f0) for pf in prefixes]
+        keep = []
+        net = L.WaveNet()
+        net.C, net.L, net.cond_dim, net.dil_cycle, net.in_dim, net.out_dim, net.steps = C, Lyr, hp["hidden_size"], cycle, in_dim, out_dim, steps
+        net.n_groups = len(packs)
+
+        def place(key):
+            if len(packs) == 1:
+                tt = packs[0][key].contiguous()
+                gs = 0
+            else:
+                tt = torch.stack([pk_[key] for pk_ in packs]).contiguous()
+                gs = packs[0][key].numel()
+            keep.append(tt)
+            return tt.data_ptr(), gs
+
+        for key in ("w_in", "b_in", "dstep", "w_cond", "b_cond", "w_skip", "b_skip", "w_final", "b_final") + (("uv_embed",) if f0 else ()):
+            ptr_, gs = place(key)
+            setattr(net, key, ptr_)
+            setattr(net, "gs_" + key, gs)
+        for l in range(Lyr):
+            for key, arr in (("w_dil", net.w_dil), ("w_out", net.w_out), ("b_out", net.b_out)):
+                ptr_, gs = place(f"{key}.{l}")
+                arr[l] = ptr_
+                setattr(net, "gs_" + key, gs)
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):
-            a = np.ascontiguousarray(self.p(f"{gen}.{name}").detach().cpu().numpy().astype(np.float32))
-            keep.append(a)
-            return a.ctypes.data
+            arr = np.ascontiguousarray(self.p(f"{gen}.{name}").detach().cpu().numpy().astype(np.float32))
+            keep.append(arr)
+            return arr.ctypes.data
         net.sqrt_recip_ac, net.sqrt_recipm1_ac = host("sqrt_recip_alphas_cumprod"), host("sqrt_recipm1_alphas_cumprod")
         net.post_c1, net.post_c2 = host("posterior_mean_coef1"), host("posterior_mean_coef2")
         net.post_logvar = host("posterior_log_variance_clipped")
@@ -237,7 +265,7 @@ class StyleSingerHIP(torch.nn.Module):
             net.log_alpha, net.log_1m_alpha = host("log_alpha"), host("log_1_min_alpha")
             net.log_cumprod_alpha, net.log_1m_cumprod_alpha = host("log_cumprod_alpha"), host("log_1_min_cumprod_alpha")
         sched = {k: self.p(f"{gen}.{k}").detach().cpu() for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod")}
-        return dict(net=net, keep=keep, sched=sched)
+        return dict(net=net, keep=keep, sched=sched, packs=packs)
 
     def _pack_fft(self, prefix, n_layers):
         layers = []
@@ -306,11 +334,11 @@ class StyleSingerHIP(torch.nn.Module):
                 n1=(self.p(p + ".norm1.weight"), self.p(p + ".norm1.bias")), n2=(self.p(p + ".norm2.weight"), self.p(p + ".norm2.bias")),
                 l1=self._pack_conv(p + ".linear1.weight", p + ".linear1.bias"), l2=self._pack_conv(p + ".linear2.weight", p + ".linear2.bias")))
         pk["align"] = al
-        pk["f0_a"] = self._pack_wavenet("gm_diffnet", "f0_gen", hp["f0_residual_channels"], hp["f0_residual_layers"],
-                                        hp["f0_dilation_cycle_length"], hp["f0_timesteps"], 1, 3, True)
-        pk["f0_b"] = self._pack_wavenet("gm_diffnet_inpainte", "f0_gen_inpainte", hp["f0_residual_channels"], hp["f0_residual_layers"],
-                                        hp["f0_dilation_cycle_length"], hp["f0_timesteps"], 1, 3, True)
-        pk["mel"] = self._pack_wavenet("postdiff.denoise_fn", "postdiff", hp["residual_channels"], hp["residual_layers"],
+        f0_args = (hp["f0_residual_channels"], hp["f0_residual_layers"], hp["f0_dilation_cycle_length"], hp["f0_timesteps"], 1, 3, True)
+        # the two f0 denoisers have identical shapes and schedules -> one grouped descriptor (items [0,B): agnostic
+        # net, [B,2B): specific net): every launch of the f0 loops carries 2x the blocks.
+        pk["f0_pair"] = self._pack_wavenet(["gm_diffnet", "gm_diffnet_inpainte"], "f0_gen", *f0_args)
+        pk["mel"] = self._pack_wavenet(["postdiff.denoise_fn"], "postdiff", hp["residual_channels"], hp["residual_layers"],
                                        hp["dilation_cycle_length"], hp["timesteps"], hp["audio_num_mel_bins"], hp["audio_num_mel_bins"], False)
         pk["ln_proj"] = self._pack_conv("ln_proj.weight", "ln_proj.bias")
         pk["spec_min"] = self.p("postdiff.spec_min").reshape(-1).contiguous()
@@ -388,30 +416,19 @@ class StyleSingerHIP(torch.nn.Module):
         return B * T <= 3000  # kernels of <= ~25 us: launch-bound without a graph
 
     def _run_f0_pair(self, pl, seed, tape=None):
-        """Both joint f0/uv samplers (independent given their conditions) on two streams."""
+        """Both joint f0/uv samplers in ONE grouped loop (they are independent given their conditions)."""
         lib, pk = _lib(), self._pk
         B, T = pl.B, pl.T
         sdp = L.ptr(pl.seed)
-        main = torch.cuda.current_stream()
-        side = self._streams(2) if self.n_streams >= 2 else [main, main]
-        jobs = []
-        for i, (key, cond) in enumerate((("f0_a", pl.cond_a), ("f0_b", pl.cond_b))):
-            zs = us = None
-            if tape is not None:
-                zs, us = tape[key]
-            else:
-                L.check(lib.ss_fill_normal(L.ptr(pl.f0[i]), B * T, seed + (11 if i == 0 else 13), sdp, 0, L.stream_ptr()), "z0")
-            jobs.append((key, cond, i, zs, us))
-        for sd_ in set(side) - {main}:
-            sd_.wait_stream(main)
-        for (key, cond, i, zs, us), strm in zip(jobs, side):
-            net = pk[key]["net"]
-            with torch.cuda.stream(strm):
-                L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(pl.f0[i]), L.ptr(pl.uv[i]), L.ptr(cond), L.ptr(pl.lo), L.ptr(pl.hi),
-                                             L.ptr(pl.lens), B, T, L.ptr(zs), L.ptr(us), seed + (17 if i == 0 else 19), sdp, 0, net.steps, 1,
-                                             L.ptr(pl.ws_f0[i]), pl.ws_f0_bytes, L.stream_ptr()), key)
-        for sd_ in set(side) - {main}:
-            main.wait_stream(sd_)
+        net = pk["f0_pair"]["net"]
+        zs = us = None
+        if tape is not None:
+            zs, us = tape  # [S][2B][T], [S][2B][2][T]
+        else:
+            L.check(lib.ss_fill_normal(L.ptr(pl.f02), 2 * B * T, seed + 11, sdp, 0, L.stream_ptr()), "z0")
+        L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(pl.f02), L.ptr(pl.uv2), L.ptr(pl.cond2), L.ptr(pl.lo2), L.ptr(pl.hi2),
+                                     L.ptr(pl.lens2), 2 * B, T, L.ptr(zs), L.ptr(us), seed + 17, sdp, 0, net.steps, 1,
+                                     L.ptr(pl.ws_f0), pl.ws_f0_bytes, L.stream_ptr()), "f0 pair")
 
     def _run_mel(self, pl, seed, tape=None):
         """q_sample + the shallow reverse loop (batch halves on two streams)."""
@@ -586,27 +603,28 @@ class StyleSingerHIP(torch.nn.Module):
         midi = torch.empty(B, T, device=dev, dtype=torch.int64)
         L.check(lib.ss_gather_expand_i64(L.ptr(note), L.ptr(mel2ph), L.ptr(midi), B, Tp, T, st()), "midi")
         pl = self._plan(B, T, dev)
-        pl.lens.copy_(lens_t)
+        pl.lens2[:B].copy_(lens_t)
+        pl.lens2[B:].copy_(lens_t)
         pl.seed.fill_(seed)
-        L.check(lib.ss_f0_bounds(L.ptr(midi), L.ptr(pl.lo), L.ptr(pl.hi), B * T, st()), "bounds")
+        L.check(lib.ss_f0_bounds(L.ptr(midi), L.ptr(pl.lo2), L.ptr(pl.hi2), B * T, st()), "bounds")
+        pl.lo2[B:].copy_(pl.lo2[:B])
+        pl.hi2[B:].copy_(pl.hi2[:B])
         pl.cond_a.copy_(dec)  # = decoder_inp * tgt_nonpadding (the gather already wrote 0 on padding)
         L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), None, L.ptr(emo), L.ptr(style), L.ptr(pl.cond_b), B, T, H, L.ptr(lens_t), st()), "cond_b")
-        for u in pl.uv:
-            u.zero_()
+        pl.uv2.zero_()
         graphs = noise is None and self._want_graphs(B, T)
         if noise is not None:
-            tape = {}
-            for i, key in enumerate(("f0_a", "f0_b")):
-                nz, S = noise[key], pk[key]["net"].steps
-                pl.f0[i].copy_(nz["z0"].to(dev).reshape(B, T).float())
-                tape[key] = (nz["z_steps"].to(dev).reshape(S, B, T).contiguous().float(),
-                             nz["u_steps"].to(dev).reshape(S, B, 2, T).contiguous().float())
-            self._run_f0_pair(pl, seed, tape)
+            S = pk["f0_pair"]["net"].steps
+            na, nb_ = noise["f0_a"], noise["f0_b"]
+            pl.f0[0].copy_(na["z0"].to(dev).reshape(B, T).float())
+            pl.f0[1].copy_(nb_["z0"].to(dev).reshape(B, T).float())
+            zs = torch.cat([na["z_steps"].to(dev).reshape(S, B, T), nb_["z_steps"].to(dev).reshape(S, B, T)], 1).contiguous().float()
+            us = torch.cat([na["u_steps"].to(dev).reshape(S, B, 2, T), nb_["u_steps"].to(dev).reshape(S, B, 2, T)], 1).contiguous().float()
+            self._run_f0_pair(pl, seed, (zs, us))
         elif graphs:
             if pl.g_f0 is None:
                 pl.g_f0 = _capture(lambda: self._run_f0_pair(pl, seed))
-                for u in pl.uv:
-                    u.zero_()
+                pl.uv2.zero_()
             pl.g_f0.replay()
         else:
             self._run_f0_pair(pl, seed)
