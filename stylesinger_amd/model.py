@@ -636,6 +636,7 @@ class StyleSingerHIP(torch.nn.Module):
         L.check(lib.ss_pitch_post(L.ptr(res["f0_a"][0]), L.ptr(res["f0_a"][1]), L.ptr(res["f0_b"][0]), L.ptr(res["f0_b"][1]),
                                   L.ptr(midi), L.ptr(mel2ph), L.ptr(pitch_pred), L.ptr(f0_denorm), L.ptr(coarse), B * T, st()), "pitch_post")
         ret["pitch_pred"], ret["f0_denorm"], ret["f0_denorm_pred"] = pitch_pred, f0_denorm, f0_denorm
+        ret["pitch_coarse"] = coarse
         ret["f0_a"], ret["uv_a"], ret["f0_b"], ret["uv_b"] = res["f0_a"][0], res["f0_a"][1], res["f0_b"][0], res["f0_b"][1]
         pitch_emb = torch.empty(B, T, H, **f32)
         L.check(lib.ss_embedding(L.ptr(coarse), L.ptr(self.p("pitch_embed.weight")), L.ptr(pitch_emb), B * T, H, 300, 1.0, 0, st()), "pitch emb")
