@@ -58,10 +58,16 @@ def kernel_roofline(infer, B, T, iters=20):
     packs = net["packs"][0]
     dstep = packs["dstep"]
 
+    wino = infer.model.use_wino
+
     def launch(l):
         d = 1 << (l % 4)
-        L.conv_gemm(X, packs[f"w_dil.{l}"], G, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, taps=(-d, 0, d), lens=lens, a_bias=dstep[0, l],
-                    epi=L.EPI_GATE, E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
+        kw = dict(B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=dstep[0, l], epi=L.EPI_GATE, E=E[:, :, l * 2 * C:],
+                  lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
+        if wino:  # what the loop driver launches: Winograd F(2,3) form of the same layer
+            L.wino_gate(X, packs[f"w_dil_wino.{l}"], G, dilation=d, **kw)
+        else:
+            L.conv_gemm(X, packs[f"w_dil.{l}"], G, taps=(-d, 0, d), **kw)
     for l in range(4):
         launch(l)
     torch.cuda.synchronize()
@@ -76,7 +82,8 @@ def kernel_roofline(infer, B, T, iters=20):
     # traffic: FETCH_SIZE + WRITE_SIZE of this launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_mel_gate.md):
     # 27.9 MB fetched (uncorrected; wide reads are tallied at 1/2 on gfx950) + 12.3 MB written; algorithmic bytes 50.7 MB.
     traffic = 40.2e6 if (B * T == 12000) else None
-    return dict(bound="mfma", kernel="conv_gemm_kernel<64,128,2,2,GATE> (mel dilated conv k=3, 256->512, + gate)",
+    name = "wino_gate_kernel (Winograd F(2,3)" if wino else "conv_gemm_kernel<64,128,2,2,GATE> (direct"
+    return dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)",
                 achieved=flops / sec / 1e12, peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s", frac=flops / sec / PEAK_FP32_MFMA,
                 traffic=traffic, us_per_launch=sec * 1e6, flops_per_launch=flops, launches_per_step=2000,
                 algorithmic_bytes_per_launch=50.7e6)

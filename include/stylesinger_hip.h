@@ -115,6 +115,15 @@ typedef struct ss_conv_gemm_args {
 
 int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
 
+/* Winograd F(2,3) form of the 3-tap dilated conv + SS_EPI_GATE epilogue (net.py:66-73): same arguments as the
+ * direct call except that W is the TRANSFORMED weight packed as a 4-"tap" tensor (ss_wino_weight_transform then
+ * ss_pack_conv_weight(k=4, interleave_half=C)) and the dilation is passed explicitly (power of two). 1.5x fewer
+ * matrix ops; results equal the direct form to fp32 rounding. Uses A, lda, Cin, lens, B, T, a_bias, W, N, Np, Kp, E,
+ * lde, gate_mode, bias, mask_rows, C, ldc, batch strides and the group fields of ss_conv_gemm_args. */
+int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* stream);
+/* src [Cout][Cin][3] -> dst [Cout][Cin][4]: g0=w0, g1=(w0+w1+w2)/2, g2=(w0-w1+w2)/2, g3=w2 */
+int ss_wino_weight_transform(const float* src, float* dst, int Cout, int Cin, void* stream);
+
 /* Weight packing (device -> device).  src is the torch parameter layout [Cout][Cin][k] (conv1d,
  * k=1 for nn.Linear [out][in]).  dst is [Np][k*Kp] with zero fill.  If scale0 != NULL (from
  * ss_weight_norm_scale) the weight-norm reparametrisation w = g * v / ||v|| (torch.nn.utils.weight_norm,
@@ -232,6 +241,9 @@ typedef struct ss_wavenet {
   /* paired nets (n_groups = 2): every weight pointer above is net 0's; net g's tensor lives gs_* floats further.
    * Both nets must share shapes and schedules (the two DDiffNets of stylesinger.py:69-73 do). */
   int32_t n_groups;
+  /* optional Winograd-transformed dilated-conv weights (packed [2C][4*Kp], gate-interleaved); NULL -> direct conv */
+  const float* w_dil_wino[SS_MAX_LAYERS];
+  int64_t gs_w_dil_wino;
   int64_t gs_w_in, gs_b_in, gs_uv_embed, gs_dstep, gs_w_dil, gs_w_out, gs_b_out, gs_w_cond, gs_b_cond, gs_w_skip, gs_b_skip,
       gs_w_final, gs_b_final;
 } ss_wavenet;

@@ -125,7 +125,13 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       a.w_group_stride = net->gs_w_dil;
       a.a_bias_group_stride = net->gs_dstep;
     }
-    SS_PROPAGATE(ss_conv_gemm(&a, stream));
+    if (net->w_dil_wino[l]) {  // Winograd F(2,3): pairs of frames (t, t+d) from 4 products instead of 6
+      a.W = net->w_dil_wino[l];
+      a.w_group_stride = net->gs_w_dil_wino;
+      SS_PROPAGATE(ss_wino_gate(&a, d, stream));
+    } else {
+      SS_PROPAGATE(ss_conv_gemm(&a, stream));
+    }
     // y = output_projection(g) ; x = (x + y[:C]) / sqrt(2) ; skip += y[C:]   (net.py:75-77)
     ss_conv_gemm_args o = base_args(B, T, lens);
     o.A = w.G;

@@ -1,0 +1,380 @@
+// Winograd F(2,3) version of the denoisers' hot layer: 3-tap dilated conv + conditioner addend + gate
+// (modules/diff/net.py:66-73), exact-fp32 MFMA, 1.5x fewer matrix ops than the direct form.
+//
+//   y[t] = x[t] + dstep   (0 outside [0,len))          z[t] = w0.y[t-d] + w1.y[t] + w2.y[t+d] + E[t]
+//   g[t] = sigmoid(z[t][:C]) * tanh(z[t][C:])
+//
+// Frames t and t+d share three of their four inputs, so the pair (t, t+d) is computed from 4 products instead of 6:
+//   m0 = (y[t-d]-y[t+d]).w0     m1 = (y[t]+y[t+d]).(w0+w1+w2)/2     m2 = (y[t+d]-y[t]).(w0-w1+w2)/2     m3 = (y[t]-y[t+2d]).w2
+//   z[t] = m0+m1+m2             z[t+d] = m1-m2-m3
+// Pairs are formed inside groups of 2d frames (t = g*2d + s, s < d), which works for any power-of-two dilation.
+// GEMM view: rows = pairs, 4 "components" each a [pairs x C] x [C x 2C] product with its own accumulator; the input
+// transform is fused into the global->LDS stage (two row fetches + one add per element), the output transform into
+// the epilogue.  Tile = 64 pairs x 64 packed columns, 4 waves of 32x32 (x4 components = 64 accumulator registers);
+// the two N-waves of a tile hold the sigmoid half and the tanh half of the same 32 channels and swap activations
+// through LDS.  Main-loop skeleton (LDS swizzle, buffer-resource fetch, MFMA-shadow scheduling) = conv_gemm_kernel.h.
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LD = BK;
+constexpr int BP = 64;  // pairs per tile (= 128 output frames)
+
+__device__ __forceinline__ int lds_slot(int row, int slot) { return row * LD + ((slot ^ ((row >> 1) & 7)) << 2); }
+
+// TN = 32-column blocks per wave. TN=1: tile 64 pairs x 64 cols (fine-grained: best balance for the f0 pair), the two
+// N-waves swap activations through LDS. TN=2: tile 64 x 128, each wave owns both gate operands (twice the MFMAs per
+// barrier: best for the mel net where 384 tiles still fill the chip).
+template <int TN>
+__global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args a, int p_tiles_per_item, int p_tiles,
+                                                        int n_tiles, int log2d) {
+  constexpr int BN = 64 * TN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][BP][LD]
+  float* Bs = smem + 2 * BP * LD;    // [2][BN][LD]
+
+  const int id = blockIdx.x;
+  const int grp = id / (8 * n_tiles);
+  const int rem = id % (8 * n_tiles);
+  const int pt = grp * 8 + (rem & 7);
+  const int nt = rem >> 3;
+  if (pt >= p_tiles) return;
+  const int b = pt / p_tiles_per_item;
+  const int p0 = (pt % p_tiles_per_item) * BP;
+  const int n0 = nt * BN;
+  const int d = 1 << log2d;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+  const float* Wg = a.W + (int64_t)grp_w * a.w_group_stride;
+  const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;
+  const int kchunks = a.Kp / BK;
+  const int ldw = 4 * a.Kp;
+
+  auto uniform_ptr = [](const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Wg), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(abiasg ? abiasg : Wg), 0, __builtin_amdgcn_readfirstlane(abiasg ? a.Cin * 4 : 0), 0x00020000);
+
+  const int st_c4 = tid & 7;
+  const int st_row = tid >> 3;  // 0..31; two passes cover the 64 pair rows / 64 weight rows
+  // frame of pair p: t = (p >> log2d) * 2d + (p & (d-1))
+  int t_of[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = p0 + st_row + i * 32;
+    t_of[i] = ((p >> log2d) << (log2d + 1)) + (p & (d - 1));
+  }
+  const int w_off0 = ((n0 + st_row) * ldw + st_c4 * 4) * 4;
+  const int w_pass = 32 * ldw * 4;
+  const int col_b = st_c4 * 4 * 4;
+
+  // component j -> (row offset of operand A, of operand B, sign of B) in units of d
+  //   j0: y[t-d] - y[t+d]   j1: y[t] + y[t+d]   j2: y[t+d] - y[t]   j3: y[t] - y[t+2d]
+  u32x4 ra[2][2], rb[2 * TN];
+  float4 rpb;
+  // description of the chunk being fetched / written (all wave-uniform scalars; selected, never branched on)
+  struct Stage { int oa, ob, ci0; float sgn; };
+  auto stage_of = [&](int j, int ci0) {
+    Stage st;
+    st.oa = (j == 0) ? -d : (j == 2) ? d : 0;
+    st.ob = (j == 3) ? 2 * d : (j == 2) ? 0 : d;
+    st.sgn = (j == 1) ? 1.0f : -1.0f;
+    st.ci0 = ci0;
+    return st;
+  };
+  auto load_a = [&](const Stage& k) {
+    const int ci = k.ci0 + st_c4 * 4;
+    const int oob = ci < a.Cin ? 0 : (int)0x80000000;
+    rpb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, ci * 4, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (((t_of[i] + k.oa) * a.lda + k.ci0) * 4 + col_b) | oob, 0, 0);
+      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (((t_of[i] + k.ob) * a.lda + k.ci0) * 4 + col_b) | oob, 0, 0);
+    }
+  };
+  auto load_b = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off0 + i * w_pass + c * (BK * 4), 0, 0);
+  };
+  auto store_a = [&](int buf, const Stage& k) {
+    float* Ad = As + buf * BP * LD;
+    const bool c_ok = k.ci0 + st_c4 * 4 < a.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 va = __builtin_bit_cast(float4, ra[i][0]);
+      float4 vb = __builtin_bit_cast(float4, ra[i][1]);
+      const bool oka = c_ok && (unsigned)(t_of[i] + k.oa) < (unsigned)len;
+      const bool okb = c_ok && (unsigned)(t_of[i] + k.ob) < (unsigned)len;
+      // y = x + dstep on real frames, exact 0 on padding (the fetch already returned 0 there)
+      const float ma = oka ? 1.0f : 0.0f, mb = okb ? k.sgn : 0.0f;
+      float4 v;
+      v.x = (va.x + ma * rpb.x) + (k.sgn * vb.x + mb * rpb.x);
+      v.y = (va.y + ma * rpb.y) + (k.sgn * vb.y + mb * rpb.y);
+      v.z = (va.z + ma * rpb.z) + (k.sgn * vb.z + mb * rpb.z);
+      v.w = (va.w + ma * rpb.w) + (k.sgn * vb.w + mb * rpb.w);
+      *reinterpret_cast<float4*>(Ad + lds_slot(st_row + i * 32, st_c4)) = v;
+    }
+  };
+  auto store_b = [&](int buf) {
+    float* Bd = Bs + buf * BN * LD;
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i)
+      *reinterpret_cast<float4*>(Bd + lds_slot(st_row + i * 32, st_c4)) = __builtin_bit_cast(float4, rb[i]);
+  };
+
+  f32x16 acc[4][TN];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+  {
+    const Stage s0 = stage_of(0, 0);
+    load_a(s0);
+    load_b(0);
+    store_a(0, s0);
+    store_b(0);
+  }
+  __syncthreads();
+
+  const int swz = (l31 >> 1) & 7;
+  const int a_row = (wm * 32 + l31) * LD;
+  const int b_row = (wn * 32 * TN + l31) * LD;
+  struct BF { float4 v[TN]; };
+  auto read_frags = [&](const float* Ac, const float* Bc, int q, float4& af, BF& bf) {
+    const int so = ((2 * q + lh) ^ swz) << 2;
+    af = *reinterpret_cast<const float4*>(Ac + a_row + so);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) bf.v[n] = *reinterpret_cast<const float4*>(Bc + b_row + n * 32 * LD + so);
+  };
+  auto mfma4 = [&](f32x16 (&c)[TN], const float4& af, const BF& bf) {
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.v[n].x, c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.v[n].y, c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.v[n].z, c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.v[n].w, c[n], 0, 0, 0);
+  };
+
+  // One K chunk of component J accumulated into its own accumulator; the next chunk (same component, or the first
+  // chunk of component J+1 at the wrap) is fetched / transformed / written in the shadow of the MFMAs.
+  int c = 0;
+  auto chunk = [&](auto jtag, f32x16 (&cacc)[TN], int k) {
+    constexpr int J = decltype(jtag)::value;
+    const bool wrap = (k + 1 >= kchunks);
+    const Stage cur_s = stage_of(J, 0), nxt_s = stage_of(J + 1, 0);
+    Stage nx;
+    nx.oa = wrap ? nxt_s.oa : cur_s.oa;
+    nx.ob = wrap ? nxt_s.ob : cur_s.ob;
+    nx.sgn = wrap ? nxt_s.sgn : cur_s.sgn;
+    nx.ci0 = wrap ? 0 : (k + 1) * BK;
+    const int cur = c & 1;
+    const float* Ac = As + cur * BP * LD;
+    const float* Bc = Bs + cur * BN * LD;
+    float4 af0, af1;
+    BF bf0, bf1;
+    read_frags(Ac, Bc, 0, af0, bf0);
+    read_frags(Ac, Bc, 1, af1, bf1);
+    load_a(nx);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cacc, af0, bf0);
+    read_frags(Ac, Bc, 2, af0, bf0);
+    load_b(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cacc, af1, bf1);
+    read_frags(Ac, Bc, 3, af1, bf1);
+    mfma4(cacc, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(cur ^ 1, nx);
+    store_b(cur ^ 1);
+    mfma4(cacc, af1, bf1);
+    __syncthreads();
+    ++c;
+  };
+  for (int k = 0; k < kchunks; ++k) chunk(std::integral_constant<int, 0>{}, acc[0], k);
+  for (int k = 0; k < kchunks; ++k) chunk(std::integral_constant<int, 1>{}, acc[1], k);
+  for (int k = 0; k < kchunks; ++k) chunk(std::integral_constant<int, 2>{}, acc[2], k);
+  for (int k = 0; k + 1 < kchunks; ++k) chunk(std::integral_constant<int, 3>{}, acc[3], k);
+  {  // last chunk: nothing left to fetch
+    const int cur = c & 1;
+    const float* Ac = As + cur * BP * LD;
+    const float* Bc = Bs + cur * BN * LD;
+    float4 af0, af1;
+    BF bf0, bf1;
+    read_frags(Ac, Bc, 0, af0, bf0);
+    read_frags(Ac, Bc, 1, af1, bf1);
+    mfma4(acc[3], af0, bf0);
+    read_frags(Ac, Bc, 2, af0, bf0);
+    mfma4(acc[3], af1, bf1);
+    read_frags(Ac, Bc, 3, af1, bf1);
+    mfma4(acc[3], af0, bf0);
+    mfma4(acc[3], af1, bf1);
+  }
+
+  // ---- epilogue: output transform z[t] = m0+m1+m2, z[t+d] = m1-m2-m3, conditioner addend, gate ----
+  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+  float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+  const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+  auto frame_of = [&](int pl) {
+    const int p = p0 + wm * 32 + pl;
+    return ((p >> log2d) << (log2d + 1)) + (p & (d - 1));
+  };
+  if constexpr (TN == 2) {
+    // the wave owns both gate operands of channels [oc0, oc0+32): columns pc0 (first operand) and pc0+32 (second)
+    const int pc0 = n0 + wn * 64 + l31;
+    const int oc = (pc0 >> 6) * 32 + l31;
+    if (oc >= a.N) return;
+    const float b0 = a.bias ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc0] : 0.f;
+    const float b1 = a.bias ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc0 + 32] : 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // half 0: frame t, half 1: frame t+d
+      float e0[16], e1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = frame_of((r & 3) + 8 * (r >> 2) + 4 * lh) + half * d;
+        const bool ok = Eb && t < a.T;
+        e0[r] = ok ? Eb[(int64_t)t * a.lde + pc0] : 0.f;
+        e1[r] = ok ? Eb[(int64_t)t * a.lde + pc0 + 32] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = frame_of((r & 3) + 8 * (r >> 2) + 4 * lh) + half * d;
+        if (t >= a.T) continue;
+        const float z0 = half == 0 ? acc[0][0][r] + acc[1][0][r] + acc[2][0][r] : acc[1][0][r] - acc[2][0][r] - acc[3][0][r];
+        const float z1 = half == 0 ? acc[0][1][r] + acc[1][1][r] + acc[2][1][r] : acc[1][1][r] - acc[2][1][r] - acc[3][1][r];
+        const float v0 = z0 + b0 + e0[r], v1 = z1 + b1 + e1[r];
+        float g = (a.gate_mode == 0) ? ss_sigmoid_fast(v0) * ss_tanh_fast(v1) : ss_tanh_fast(v0) * ss_sigmoid_fast(v1);
+        if (t >= row_lim) g = 0.f;
+        Cb[(int64_t)t * a.ldc + oc] = g;
+      }
+    }
+  } else {
+    // wave wn=0 holds the first gate operand of channels [oc0, oc0+32), wave wn=1 the second; wn=0 finishes frame t,
+    // wn=1 frame t+d, and the partners' activations travel through LDS.
+    __syncthreads();  // every wave is done with the operand tiles: reuse LDS as the exchange buffer
+    float* X0 = smem;                // [2 wm][32 pairs][33]: second-operand activation of frame t   (written by wn=1)
+    float* X1 = smem + 2 * 32 * 33;  // [2 wm][32 pairs][33]: first-operand activation of frame t+d  (written by wn=0)
+    const int pc = n0 + wn * 32 + l31;  // packed column
+    const int oc = (n0 >> 1) + l31;     // output channel
+    const bool col_ok = oc < a.N;
+    const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc] : 0.f;
+    const bool use_sig = (wn == 0) == (a.gate_mode == 0);
+    float mine[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int t = frame_of(pl);
+      const float z0 = acc[0][0][r] + acc[1][0][r] + acc[2][0][r];
+      const float z1 = acc[1][0][r] - acc[2][0][r] - acc[3][0][r];
+      float e0 = bs, e1 = bs;
+      if (Eb && col_ok) {
+        if (t < a.T) e0 += Eb[(int64_t)t * a.lde + pc];
+        if (t + d < a.T) e1 += Eb[(int64_t)(t + d) * a.lde + pc];
+      }
+      const float u0 = use_sig ? ss_sigmoid_fast(z0 + e0) : ss_tanh_fast(z0 + e0);
+      const float u1 = use_sig ? ss_sigmoid_fast(z1 + e1) : ss_tanh_fast(z1 + e1);
+      if (wn == 0) {
+        mine[r] = u0;
+        X1[(wm * 32 + pl) * 33 + l31] = u1;
+      } else {
+        mine[r] = u1;
+        X0[(wm * 32 + pl) * 33 + l31] = u0;
+      }
+    }
+    __syncthreads();
+    if (!col_ok) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int t = frame_of(pl) + (wn == 0 ? 0 : d);
+      if (t >= a.T) continue;
+      const float other = (wn == 0) ? X0[(wm * 32 + pl) * 33 + l31] : X1[(wm * 32 + pl) * 33 + l31];
+      float g = mine[r] * other;
+      if (t >= row_lim) g = 0.f;
+      Cb[(int64_t)t * a.ldc + oc] = g;
+    }
+  }
+}
+
+// g0 = w0, g1 = (w0+w1+w2)/2, g2 = (w0-w1+w2)/2, g3 = w2   (src [rows][3] -> dst [rows][4], rows = Cout*Cin)
+__global__ void wino_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+    const float w0 = src[i * 3 + 0], w1 = src[i * 3 + 1], w2 = src[i * 3 + 2];
+    dst[i * 4 + 0] = w0;
+    dst[i * 4 + 1] = (w0 + w1 + w2) * 0.5f;
+    dst[i * 4 + 2] = (w0 - w1 + w2) * 0.5f;
+    dst[i * 4 + 3] = w2;
+  }
+}
+
+}  // namespace
+
+extern "C" int ss_wino_weight_transform(const float* src, float* dst, int Cout, int Cin, void* stream) {
+  SS_CHECK_ARG(src && dst && Cout > 0 && Cin > 0, "ss_wino_weight_transform: bad args");
+  const int64_t rows = (int64_t)Cout * Cin;
+  const int grid = (int)((rows + 255) / 256 < 4096 ? (rows + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, rows);
+  SS_CHECK_LAUNCH("ss_wino_weight_transform");
+  return SS_OK;
+}
+
+extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* stream) {
+  SS_CHECK_ARG(args != nullptr, "ss_wino_gate: null args");
+  const ss_conv_gemm_args& a = *args;
+  SS_CHECK_ARG(a.A && a.W && a.C, "ss_wino_gate: null A/W/C");
+  SS_CHECK_ARG(dilation >= 1 && (dilation & (dilation - 1)) == 0 && dilation <= 64, "ss_wino_gate: dilation %d must be a power of two", dilation);
+  SS_CHECK_ARG((a.Kp % BK) == 0 && a.Kp >= a.Cin && (a.Cin & 3) == 0 && (a.lda & 3) == 0, "ss_wino_gate: bad K dims");
+  SS_CHECK_ARG((a.Np % 64) == 0 && 2 * a.N <= a.Np, "ss_wino_gate: Np=%d must be a multiple of 64 and >= 2*N", a.Np);
+  SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31), "ss_wino_gate: item too large for 32-bit offsets");
+  int log2d = 0;
+  while ((1 << log2d) < dilation) ++log2d;
+  const int pairs_per_item = ss_cdiv(a.T, 2 * dilation) * dilation;
+  const int p_tiles_per_item = ss_cdiv(pairs_per_item, BP);
+  const int p_tiles = p_tiles_per_item * a.B;
+  // tile choice: 64x128 (TN=2) has twice the MFMAs per barrier; use it when its (coarser) tiles still balance:
+  // blocks/CU close below an integer is good, e.g. mel C2: 384 blocks on 256 CUs = 1.5 -> makespan 2 units of a
+  // 2x faster-per-flop tile; f0 pair: 564 -> 3 units: worse than the fine 1128-block grid.
+  int tn = a.tile == SS_TILE_64x128 ? 2 : a.tile == SS_TILE_64x64 ? 1 : 0;
+  if (tn == 0) {
+    const long b2 = (long)p_tiles * ss_cdiv(a.Np, 128), b1 = (long)p_tiles * (a.Np / 64);
+    const double t2 = (double)ss_cdiv(b2, 256) * 2.0 / 0.92, t1 = (double)ss_cdiv(b1, 256) * 1.0 / 0.75;
+    tn = ((a.Np % 128) == 0 && t2 <= t1) ? 2 : 1;
+  }
+  if (tn == 2) {
+    SS_CHECK_ARG((a.Np % 128) == 0, "ss_wino_gate: TN=2 needs Np multiple of 128");
+    const int n_tiles = a.Np / 128;
+    const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
+    const size_t lds = (size_t)2 * (BP + 128) * LD * sizeof(float);
+    hipLaunchKernelGGL(wino_gate_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d);
+  } else {
+    const int n_tiles = a.Np / 64;
+    const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
+    const size_t lds = (size_t)2 * (BP + 64) * LD * sizeof(float);
+    hipLaunchKernelGGL(wino_gate_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d);
+  }
+  SS_CHECK_LAUNCH("ss_wino_gate");
+  return SS_OK;
+}

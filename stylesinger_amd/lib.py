@@ -57,7 +57,7 @@ class WaveNet(C.Structure):
         ("w_cond", _vp), ("b_cond", _vp), ("w_skip", _vp), ("b_skip", _vp), ("w_final", _vp), ("b_final", _vp),
         ("sqrt_recip_ac", _vp), ("sqrt_recipm1_ac", _vp), ("post_c1", _vp), ("post_c2", _vp), ("post_logvar", _vp),
         ("log_alpha", _vp), ("log_1m_alpha", _vp), ("log_cumprod_alpha", _vp), ("log_1m_cumprod_alpha", _vp),
-        ("n_groups", C.c_int32),
+        ("n_groups", C.c_int32), ("w_dil_wino", _vp * SS_MAX_LAYERS), ("gs_w_dil_wino", C.c_int64),
     ] + [(n, C.c_int64) for n in ("gs_w_in", "gs_b_in", "gs_uv_embed", "gs_dstep", "gs_w_dil", "gs_w_out", "gs_b_out", "gs_w_cond",
                                   "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")]
 
@@ -173,10 +173,15 @@ def round_up(x, m):
 # ---------------------------------------------------------------------------------------------
 # thin op wrappers (argument marshalling only)
 # ---------------------------------------------------------------------------------------------
-def conv_gemm(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,), lens=None, a_bias=None, a_scale=1.0,
-              a_lrelu=1.0, epi=EPI_STORE, bias=None, pre_scale=1.0, act=ACT_NONE, act_slope=0.0, E=None, lde=0, e_bs=0,
-              gate_mode=0, R=None, ldr=0, r_bs=None, post_scale=1.0, accumulate=False, mask_rows=True, ldc=None, c_bs=None,
-              C2=None, ldc2=0, c2_bs=0, Nh=0, tile=0):
+def conv_gemm(A, W, out, **kw):
+    a = _fill_args(A, W, out, **kw)
+    check(load().ss_conv_gemm(C.byref(a), stream_ptr()), "ss_conv_gemm")
+
+
+def _fill_args(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,), lens=None, a_bias=None, a_scale=1.0,
+               a_lrelu=1.0, epi=EPI_STORE, bias=None, pre_scale=1.0, act=ACT_NONE, act_slope=0.0, E=None, lde=0, e_bs=0,
+               gate_mode=0, R=None, ldr=0, r_bs=None, post_scale=1.0, accumulate=False, mask_rows=True, ldc=None, c_bs=None,
+               C2=None, ldc2=0, c2_bs=0, Nh=0, tile=0, group_size=0, w_gs=0, bias_gs=0, a_bias_gs=0):
     a = ConvGemmArgs()
     a.A = ptr(A); a.lda = lda if lda is not None else Cin
     a.a_batch_stride = a_bs if a_bs is not None else T * a.lda
@@ -192,7 +197,23 @@ def conv_gemm(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,)
     a.C = ptr(out); a.ldc = ldc if ldc is not None else N
     a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
     a.C2 = ptr(C2); a.ldc2 = ldc2; a.c2_batch_stride = c2_bs; a.Nh = Nh; a.tile = tile
-    check(load().ss_conv_gemm(C.byref(a), stream_ptr()), "ss_conv_gemm")
+    a.group_size = group_size; a.w_group_stride = w_gs; a.bias_group_stride = bias_gs; a.a_bias_group_stride = a_bias_gs
+    return a
+
+
+def wino_gate(A, Wt, out, *, dilation, **kw):
+    """Winograd F(2,3) dilated conv + gate (ss_wino_gate); Wt = packed transformed weights (4 'taps')."""
+    kw.setdefault("epi", EPI_GATE)
+    a = _fill_args(A, Wt, out, **kw)
+    check(load().ss_wino_gate(C.byref(a), int(dilation), stream_ptr()), "ss_wino_gate")
+
+
+def wino_weight(w):
+    """conv weight [Cout][Cin][3] (device) -> transformed [Cout][Cin][4]."""
+    w = w.contiguous().float()
+    out = torch.empty(w.shape[0], w.shape[1], 4, device=w.device, dtype=torch.float32)
+    check(load().ss_wino_weight_transform(ptr(w), ptr(out), w.shape[0], w.shape[1], stream_ptr()), "ss_wino_weight_transform")
+    return out
 
 
 def pack_conv_weight(w, *, scale0=None, interleave_half=0, row_scale=1.0):

@@ -127,6 +127,8 @@ class StyleSingerHIP(torch.nn.Module):
         self.n_streams = int(os.environ.get("SS_STREAMS", "1"))  # 2 = split the mel batch over two streams (slower at C2: half-size launches balance worse)
         # hipGraph capture of the diffusion loops: "auto" = only where launch overhead matters (small B*T)
         self.use_graphs = os.environ.get("SS_GRAPHS", "auto")
+        # Winograd F(2,3) for the denoisers' 3-tap dilated convs (1.5x fewer matrix ops, fp32-rounding-equal results)
+        self.use_wino = os.environ.get("SS_WINO", "1") not in ("0", "off", "false")
         self._plans = {}
 
     # ---- state_dict contract ------------------------------------------------------------------
@@ -213,6 +215,11 @@ class StyleSingerHIP(torch.nn.Module):
             cnd = self._pack_conv(p + ".conditioner_projection.weight", p + ".conditioner_projection.bias", half=C,
                                   bias2=self.p(p + ".dilated_conv.bias"))
             t[f"w_dil.{l}"], t[f"w_out.{l}"], t[f"b_out.{l}"] = dil.W, out.W, out.bias
+            if self.use_wino:
+                wsrc = self.p(p + ".dilated_conv.weight").contiguous()
+                wt = torch.empty(2 * C, C, 4, device=dev)
+                L.check(L.load().ss_wino_weight_transform(L.ptr(wsrc), L.ptr(wt), 2 * C, C, L.stream_ptr()), "wino transform")
+                t[f"w_dil_wino.{l}"] = L.pack_conv_weight(wt, interleave_half=C)
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
         t["dstep"] = dstep
@@ -253,6 +260,10 @@ class StyleSingerHIP(torch.nn.Module):
                 ptr_, gs = place(f"{key}.{l}")
                 arr[l] = ptr_
                 setattr(net, "gs_" + key, gs)
+            if self.use_wino:
+                ptr_, gs = place(f"w_dil_wino.{l}")
+                net.w_dil_wino[l] = ptr_
+                net.gs_w_dil_wino = gs
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):
             arr = np.ascontiguousarray(self.p(f"{gen}.{name}").detach().cpu().numpy().astype(np.float32))

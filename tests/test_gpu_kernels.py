@@ -234,3 +234,52 @@ def test_positions_embedding_lengthreg():
             ref[b, p:p + int(dur[b, i])] = i + 1
             p += int(dur[b, i])
     assert torch.equal(m2p.cpu(), ref)
+
+
+@pytest.mark.parametrize("tile", [2, 3])
+@pytest.mark.parametrize("C,d,T,B", [(256, 1, 150, 2), (256, 2, 203, 1), (256, 8, 97, 2), (192, 4, 260, 2)])
+def test_winograd_gate_equals_direct_conv(C, d, T, B, tile):
+    """ss_wino_gate (Winograd F(2,3)) vs a plain torch statement of conv(x + bias) + E -> sigmoid*tanh, with ragged lens,
+    odd T (partial last group) and every dilation of the cycle."""
+    dv = dev()
+    x = _rand(B, T, C, seed=71)
+    ab = _rand(C, seed=72)
+    w = _rand(2 * C, C, 3, seed=73, scale=1 / math.sqrt(3 * C))
+    Lyr = 3
+    e = _rand(B, T, Lyr * 2 * C, seed=74)
+    lens = torch.tensor([T - 11 * i for i in range(B)], dtype=torch.int32)
+    ref = torch.zeros(B, T, C)
+    for i in range(B):
+        n = int(lens[i])
+        y = (x[i:i + 1, :n] + ab).transpose(1, 2)
+        z = F.conv1d(y, w, None, padding=d, dilation=d).transpose(1, 2)[0] + e[i, :n, 2 * C:4 * C]
+        ref[i, :n] = torch.sigmoid(z[:, :C]) * torch.tanh(z[:, C:])
+    Wt = L.pack_conv_weight(L.wino_weight(w.to(dv)), interleave_half=C)
+    Np = Wt.shape[0]
+    # E in packed column order (layer slab 1 of 3)
+    ep = torch.zeros(B, T, Lyr * Np)
+    for p in range(C // 32):
+        ep[..., Np + (2 * p) * 32:Np + (2 * p) * 32 + 32] = e[..., 2 * C + p * 32:2 * C + p * 32 + 32]
+        ep[..., Np + (2 * p + 1) * 32:Np + (2 * p + 1) * 32 + 32] = e[..., 3 * C + p * 32:3 * C + p * 32 + 32]
+    epd = ep.to(dv)
+    g = torch.full((B, T, C), 5.0, device=dv)
+    L.wino_gate(x.to(dv), Wt, g, dilation=d, B=B, T=T, Cin=C, N=C, Np=Np, Kp=C, lens=lens.to(dv), a_bias=ab.to(dv),
+                E=epd[:, :, Np:], lde=Lyr * Np, e_bs=T * Lyr * Np, ldc=C, mask_rows=True, tile=tile)  # 2: 64x128, 3: 64x64
+    err = (g.cpu() - ref).abs().max().item()
+    assert err < 5e-6, err
+
+
+def test_grouped_launch_uses_per_item_weight_sets():
+    dv = dev()
+    B, T, C = 4, 70, 64
+    x = _rand(B, T, C, seed=81)
+    ws = [_rand(C, C, 3, seed=82 + g_, scale=0.1) for g_ in range(2)]
+    bs = [_rand(C, seed=84 + g_, scale=0.1) for g_ in range(2)]
+    lens = torch.full((B,), T, dtype=torch.int32)
+    ref = torch.stack([_ref_conv(x[i:i + 1], ws[i // 2], bs[i // 2], 1, lens[i:i + 1])[0] for i in range(B)])
+    Wp = torch.stack([L.pack_conv_weight(w_.to(dv)) for w_ in ws]).contiguous()
+    bp = torch.stack([L.pack_bias(b_.to(dv)) for b_ in bs]).contiguous()
+    out = torch.empty(B, T, C, device=dv)
+    L.conv_gemm(x.to(dv), Wp, out, B=B, T=T, Cin=C, N=C, Np=Wp.shape[1], Kp=Wp.shape[2] // 3, taps=(-1, 0, 1), lens=lens.to(dv),
+                bias=bp, group_size=2, w_gs=Wp[0].numel(), bias_gs=bp[0].numel())
+    assert (out.cpu() - ref).abs().max().item() < 2e-5

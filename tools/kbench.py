@@ -69,6 +69,15 @@ def main():
             s = timeit(f, a.iters)
             fl = 2.0 * B * T * 3 * C * 2 * C
             res.append((f"{name} gate  K={3 * C} N={2 * C}", s, fl))
+        if a.which in ("wino", "all"):
+            Wt = L.pack_conv_weight(L.wino_weight(w), interleave_half=C)
+            def fw():
+                layer[0] = (layer[0] + 1) % Lyr
+                L.wino_gate(X, Wt, G, dilation=2, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=ab,
+                            E=E[:, :, layer[0] * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, tile=a.tile)
+            s = timeit(fw, a.iters)
+            fl = 2.0 * B * T * 3 * C * 2 * C
+            res.append((f"{name} WINO gate K={3 * C} N={2 * C} (algorithmic flops)", s, fl))
         if a.which in ("resskip", "all"):
             f = lambda: L.conv_gemm(G, Wo, X, B=B, T=T, Cin=C, N=2 * C, Np=2 * C, Kp=C, lens=lens, epi=L.EPI_RESSKIP, bias=bop, Nh=C,
                                     R=X, ldr=C, ldc=C, post_scale=0.7071, C2=S, ldc2=C, c2_bs=T * C, accumulate=True, tile=a.tile)
