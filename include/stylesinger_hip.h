@@ -262,6 +262,12 @@ int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int T);
 int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
                       const float* noise, uint64_t seed, const uint64_t* seed_dev, int step_lo, int step_hi,
                       int precompute_cond, void* ws, int64_t ws_bytes, void* stream);
+/* Strided deterministic (DDIM, eta=0) sampler over the same denoiser: network times ts[0] > ts[1] > ... (HOST array),
+ * alphas_cumprod = HOST schedule table [steps]. BASELINE config 5; the reference has no such sampler (its strided
+ * option is PLMS, shallow_diffusion_tts.py:165-197), so parity is against the oracle's restatement only. */
+int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
+                           const int32_t* ts, int n_ts, const float* alphas_cumprod, int precompute_cond, void* ws,
+                           int64_t ws_bytes, void* stream);
 /* q_sample + norm_spec: x = sqrt_ac*((mel-min)/(max-min)*2-1) + sqrt_1mac*z  (shallow_diffusion_tts.py:199-204,271-272) */
 int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac, float sqrt_1mac,
                    const float* noise, uint64_t seed, const uint64_t* seed_dev, float* x, int B, int T, int M, void* stream);

@@ -411,6 +411,28 @@ def mel_diffusion(sd, hp, coarse_mel, cond, tape, trace=None):
     return (x + 1) / 2 * (smax - smin) + smin
 
 
+def mel_ddim(sd, hp, coarse_mel, cond, tape, ts):
+    """Deterministic strided sampler (DDIM, eta=0; Song et al. 2021 eq. 12) over the reference's DiffNet and schedule.
+    NOT in the reference (BASELINE config 5 is "new; no reference sampler"): this restatement is the only oracle."""
+    g = lambda k: sd[f"postdiff.{k}"]
+    smin, smax = g("spec_min")[0], g("spec_max")[0]
+    K = hp["K_step"]
+    B, T, M = coarse_mel.shape
+    x = (coarse_mel - smin) / (smax - smin) * 2 - 1
+    zq = tape.randn(B, 1, M, T)[:, 0].transpose(1, 2)
+    x = g("sqrt_alphas_cumprod")[K - 1] * x + g("sqrt_one_minus_alphas_cumprod")[K - 1] * zq
+    ac = g("alphas_cumprod")
+    for i, t_ in enumerate(ts):
+        t = torch.full((B,), int(t_), dtype=torch.long)
+        eps = diffnet(sd, hp, x, t, cond)
+        x0 = (g("sqrt_recip_alphas_cumprod")[t_] * x - g("sqrt_recipm1_alphas_cumprod")[t_] * eps).clamp(-1.0, 1.0)
+        ac_t = ac[t_]
+        ac_p = ac[ts[i + 1]] if i + 1 < len(ts) else torch.tensor(1.0)
+        eps2 = (x - ac_t.sqrt() * x0) / (1 - ac_t).sqrt()
+        x = ac_p.sqrt() * x0 + (1 - ac_p).sqrt() * eps2
+    return (x + 1) / 2 * (smax - smin) + smin
+
+
 # ------------------------------------------------------------------------------------------------
 # top level: StyleSinger.forward(infer=True)  (modules/StyleSinger/stylesinger.py:119-187)
 # ------------------------------------------------------------------------------------------------

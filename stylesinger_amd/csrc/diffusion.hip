@@ -376,6 +376,57 @@ extern "C" int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int 
   return ws_layout(net, B, T, nullptr).bytes;
 }
 
+// One reverse step of the mel net at network time `t` with explicit update coefficients
+//   x0 = clamp(recip*x - recipm1*eps, -1, 1) ; x <- c1*x0 + c2*x + sigma*z
+static int mel_step(const ss_wavenet* net, float* x, const int32_t* lens, int B, int T, const WsLayout& w, int t, float recip,
+                    float recipm1, float c1, float c2, float sigma, const float* noise_t, uint64_t seed,
+                    const uint64_t* seed_dev, uint32_t step_id, hipStream_t stream) {
+  const int C = net->C, M = net->in_dim;
+  // x = relu(input_projection(x_t))  (net.py:114-117)
+  ss_conv_gemm_args a = base_args(B, T, lens);
+  a.A = x;
+  a.lda = M;
+  a.a_batch_stride = (int64_t)T * M;
+  a.Cin = M;
+  a.W = net->w_in;
+  a.N = C;
+  a.Np = round_up32(C);
+  a.Kp = round_up32(M);
+  a.epi = SS_EPI_STORE;
+  a.bias = net->b_in;
+  a.act = SS_ACT_RELU;
+  a.C = w.X;
+  a.ldc = C;
+  a.c_batch_stride = (int64_t)T * C;
+  SS_PROPAGATE(ss_conv_gemm(&a, stream));
+  SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream));
+  // eps = output_projection(.) fused with the posterior step (shallow_diffusion_tts.py:130-162)
+  ss_conv_gemm_args f = base_args(B, T, lens);
+  f.A = w.G;
+  f.lda = C;
+  f.a_batch_stride = (int64_t)T * C;
+  f.Cin = C;
+  f.W = net->w_final;
+  f.N = M;
+  f.Np = round_up32(M);
+  f.Kp = round_up32(C);
+  f.epi = SS_EPI_DDPM;
+  f.bias = net->b_final;
+  f.C = x;
+  f.ldc = M;
+  f.c_batch_stride = (int64_t)T * M;
+  f.ddpm_recip = recip;
+  f.ddpm_recipm1 = recipm1;
+  f.ddpm_c1 = c1;
+  f.ddpm_c2 = c2;
+  f.ddpm_sigma = sigma;
+  f.noise = noise_t;
+  f.seed = seed;
+  f.seed_dev = seed_dev;
+  f.step = step_id;
+  return ss_conv_gemm(&f, stream);
+}
+
 extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
                                  const float* noise, uint64_t seed, const uint64_t* seed_dev, int step_lo, int step_hi,
                                  int do_precompute, void* ws, int64_t ws_bytes, void* stream_) {
@@ -386,52 +437,39 @@ extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* c
   SS_CHECK_ARG(net->n_groups <= 1, "ss_meldiff_sample: grouped nets are only supported by the f0 sampler");
   const WsLayout w = ws_layout(net, B, T, ws);
   SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_meldiff_sample: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
-  const int C = net->C, M = net->in_dim;
+  const int M = net->in_dim;
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
-  for (int t = step_hi - 1; t >= step_lo; --t) {
-    // x = relu(input_projection(x_t))  (net.py:114-117)
-    ss_conv_gemm_args a = base_args(B, T, lens);
-    a.A = x;
-    a.lda = M;
-    a.a_batch_stride = (int64_t)T * M;
-    a.Cin = M;
-    a.W = net->w_in;
-    a.N = C;
-    a.Np = round_up32(C);
-    a.Kp = round_up32(M);
-    a.epi = SS_EPI_STORE;
-    a.bias = net->b_in;
-    a.act = SS_ACT_RELU;
-    a.C = w.X;
-    a.ldc = C;
-    a.c_batch_stride = (int64_t)T * C;
-    SS_PROPAGATE(ss_conv_gemm(&a, stream));
-    SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream));
-    // eps = output_projection(.) fused with p_sample (shallow_diffusion_tts.py:130-162)
-    ss_conv_gemm_args f = base_args(B, T, lens);
-    f.A = w.G;
-    f.lda = C;
-    f.a_batch_stride = (int64_t)T * C;
-    f.Cin = C;
-    f.W = net->w_final;
-    f.N = M;
-    f.Np = round_up32(M);
-    f.Kp = round_up32(C);
-    f.epi = SS_EPI_DDPM;
-    f.bias = net->b_final;
-    f.C = x;
-    f.ldc = M;
-    f.c_batch_stride = (int64_t)T * M;
-    f.ddpm_recip = net->sqrt_recip_ac[t];
-    f.ddpm_recipm1 = net->sqrt_recipm1_ac[t];
-    f.ddpm_c1 = net->post_c1[t];
-    f.ddpm_c2 = net->post_c2[t];
-    f.ddpm_sigma = t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f;
-    f.noise = noise ? noise + (int64_t)t * B * T * M : nullptr;
-    f.seed = seed;
-    f.seed_dev = seed_dev;
-    f.step = (uint32_t)t;
-    SS_PROPAGATE(ss_conv_gemm(&f, stream));
+  for (int t = step_hi - 1; t >= step_lo; --t)
+    SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
+                          t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f, noise ? noise + (int64_t)t * B * T * M : nullptr, seed,
+                          seed_dev, (uint32_t)t, stream));
+  return SS_OK;
+}
+
+// Strided deterministic sampler (DDIM, eta = 0) over the SAME denoiser: visits network times ts[0] > ts[1] > ... and jumps
+// x_{ts[i]} -> x_{ts[i+1]} (-> x_0 after the last).  With x0 = clamp(...), eps' = (x - sqrt(ac_t) x0)/sqrt(1-ac_t):
+//   x_prev = sqrt(ac_prev) x0 + sqrt(1-ac_prev) eps' = c1 x0 + c2 x,  c2 = sqrt((1-ac_prev)/(1-ac_t)), c1 = sqrt(ac_prev) - c2 sqrt(ac_t)
+// i.e. the DDPM epilogue with other coefficients and sigma = 0.  The reference has no such sampler (BASELINE config 5
+// "new; no reference sampler"): parity is against oracle/restatement.py::mel_ddim only.
+extern "C" int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
+                                      const int32_t* ts, int n_ts, const float* alphas_cumprod, int do_precompute, void* ws,
+                                      int64_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SS_CHECK_ARG(net && x && cond && ws && ts && alphas_cumprod && n_ts > 0, "ss_meldiff_sample_ddim: null pointer");
+  SS_CHECK_ARG(net->n_groups <= 1 && net->L > 0 && net->L <= SS_MAX_LAYERS, "ss_meldiff_sample_ddim: bad net");
+  const WsLayout w = ws_layout(net, B, T, ws);
+  SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_meldiff_sample_ddim: workspace too small");
+  for (int i = 0; i < n_ts; ++i)
+    SS_CHECK_ARG(ts[i] >= 0 && ts[i] < net->steps && (i == 0 || ts[i] < ts[i - 1]), "ss_meldiff_sample_ddim: ts must be strictly decreasing in [0,steps)");
+  if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
+  for (int i = 0; i < n_ts; ++i) {
+    const int t = ts[i];
+    const float ac_t = alphas_cumprod[t];
+    const float ac_p = (i + 1 < n_ts) ? alphas_cumprod[ts[i + 1]] : 1.0f;
+    const float c2 = sqrtf((1.0f - ac_p) / (1.0f - ac_t));
+    const float c1 = sqrtf(ac_p) - c2 * sqrtf(ac_t);
+    SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], c1, c2, 0.0f, nullptr, 0, nullptr,
+                          (uint32_t)t, stream));
   }
   return SS_OK;
 }

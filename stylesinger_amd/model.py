@@ -441,8 +441,14 @@ class StyleSingerHIP(torch.nn.Module):
                                      L.ptr(pl.lens2), 2 * B, T, L.ptr(zs), L.ptr(us), seed + 17, sdp, 0, net.steps, 1,
                                      L.ptr(pl.ws_f0), pl.ws_f0_bytes, L.stream_ptr()), "f0 pair")
 
-    def _run_mel(self, pl, seed, tape=None):
-        """q_sample + the shallow reverse loop (batch halves on two streams)."""
+    def ddim_timesteps(self, n):
+        """n network times, strictly decreasing from K-1 to 0 (uniform stride)."""
+        K = self.hp["K_step"]
+        return sorted({int(round(v)) for v in np.linspace(0, K - 1, max(1, min(n, K)))}, reverse=True)
+
+    def _run_mel(self, pl, seed, tape=None, ddim_ts=None):
+        """q_sample + the shallow reverse loop (batch halves on two streams); `ddim_ts` switches to the strided
+        deterministic sampler (BASELINE config 5)."""
         lib, pk, hp = _lib(), self._pk, self.hp
         B, T, M = pl.B, pl.T, hp["audio_num_mel_bins"]
         net = pk["mel"]["net"]
@@ -453,6 +459,17 @@ class StyleSingerHIP(torch.nn.Module):
         zq_n, zs_n = tape if tape is not None else (None, None)
         L.check(lib.ss_mel_qsample(L.ptr(pl.coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), seed + 23, sdp,
                                    L.ptr(pl.xm), B, T, M, L.stream_ptr()), "qsample")
+        if ddim_ts is not None:
+            ts = np.ascontiguousarray(np.asarray(ddim_ts, dtype=np.int32))
+            ac = np.ascontiguousarray(self.p("postdiff.alphas_cumprod").detach().cpu().numpy().astype(np.float32))
+            if len(pl.ws_mel) != 1:
+                wsb = lib.ss_wavenet_workspace_bytes(C_byref(net), B, T)
+                wsp = torch.empty(wsb, device=pl.xm.device, dtype=torch.uint8)
+            else:
+                wsb, wsp = pl.ws_mel[0]
+            L.check(lib.ss_meldiff_sample_ddim(C_byref(net), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, L.hptr(ts), len(ts),
+                                               L.hptr(ac), 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff ddim")
+            return
         nsplit = len(pl.ws_mel)
         main = torch.cuda.current_stream()
         side = self._streams(nsplit) if nsplit > 1 else [main]
@@ -475,7 +492,8 @@ class StyleSingerHIP(torch.nn.Module):
         """Mirror of StyleSinger.forward (modules/StyleSinger/stylesinger.py:119-187), inference branch only.
 
         Extra keyword arguments: `noise` (dict from synth.draw_acoustic_noise: a recorded noise tape for
-        parity tests; default = on-device Philox), `seed` (Philox seed)."""
+        parity tests; default = on-device Philox), `seed` (Philox seed), `sampler="ddim", ddim_steps=n` (strided
+        deterministic mel sampler, BASELINE config 5; default = the reference's 100-step ancestral sampler)."""
         if not infer or f0 is not None or uv is not None:
             raise NotImplementedError("StyleSingerHIP implements the inference path only (infer=True, f0/uv predicted)")
         self._ensure_packed()
@@ -682,7 +700,13 @@ class StyleSingerHIP(torch.nn.Module):
         ret["diff_cond"] = cond.clone()
         pl.coarse_mel.copy_(coarse_mel)
         K = hp["K_step"]
-        if noise is not None:
+        ddim_ts = self.ddim_timesteps(int(kwargs["ddim_steps"])) if kwargs.get("sampler") == "ddim" else None
+        if ddim_ts is not None:
+            zq_n = None
+            if noise is not None:
+                zq_n = noise["mel"]["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
+            self._run_mel(pl, seed, (zq_n, None), ddim_ts=ddim_ts)
+        elif noise is not None:
             nz = noise["mel"]
             zq_n = nz["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
             zs_n = nz["z_steps"].to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()

@@ -223,3 +223,32 @@ def test_single_utterance_entrypoint_matches_batched_path():
     res = inf.infer_batch(batch, noise=noise, vocoder_noise=vnoise)
     assert wav1.shape == (40 * 256,)
     assert abs(wav1 - res["wav"][0].cpu().numpy()).max() <= 1e-5
+
+
+def test_ddim_sampler_matches_oracle():
+    """BASELINE config 5 sampler (50-step-style DDIM over the same denoiser; here 6 of 24 steps). No reference sampler
+    exists: parity is against oracle.restatement.mel_ddim on the oracle's own coarse mel / condition."""
+    hp = config.make_hparams(dict(timesteps=24, K_step=24, f0_timesteps=3))
+    sd = synth.synth_acoustic_state_dict(hp, 41)
+    B, T = 2, 120
+    batch = synth.synth_batch(B, T, 6, 90, hp, 41)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(42), B, T, 3, 24)
+    dev = torch.device("cuda:0")
+    model = StyleSingerHIP(None, hparams=hp)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    ret = model(b["txt_tokens"], mel2ph=b["mel2ph"], spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
+                ref_f0=b["ref_f0"], global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"],
+                noise=noise, sampler="ddim", ddim_steps=6)
+    ts = model.ddim_timesteps(6)
+    assert ts[0] == 23 and ts[-1] == 0 and len(ts) == 6
+
+    class OneDraw:
+        def randn(self, *shape):
+            return noise["mel"]["z_q"].clone()
+    with torch.no_grad():
+        ref = R.mel_ddim(sd, hp, ret["fs2_mel"].cpu(), ret["diff_cond"].cpu(), OneDraw(), ts)
+    l1 = (ret["mel_out"].cpu() - ref).abs().mean().item()
+    print(f"ddim: mel L1 {l1:.3e}")
+    assert l1 <= MEL_L1_TOL
