@@ -68,16 +68,29 @@ def kernel_roofline(infer, B, T, iters=20):
             L.wino_gate(X, packs[f"w_dil_wino.{l}"], G, dilation=d, **kw)
         else:
             L.conv_gemm(X, packs[f"w_dil.{l}"], G, taps=(-d, 0, d), **kw)
-    for l in range(4):
+    for l in range(Lyr):
         launch(l)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(iters):
-        launch(i % Lyr)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    # back-to-back launches: one pass over the 20 layers captured in a hipGraph (the Python ctypes call costs about as much
+    # host time as the kernel runs, so a plain Python loop would time the host), replayed `iters` times between two events
+    # on the capture stream.
+    graph = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(graph, stream=st):
+            for l in range(Lyr):
+                launch(l)
+        graph.replay()
+        st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for i in range(iters):
+            graph.replay()
+        e1.record(st)
+        st.synchronize()
+    torch.cuda.current_stream().wait_stream(st)
+    sec = e0.elapsed_time(e1) * 1e-3 / (iters * Lyr)
     flops = 2.0 * B * T * (3 * C) * (2 * C)
     # traffic: FETCH_SIZE + WRITE_SIZE of this launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_mel_gate.md):
     # 27.9 MB fetched (uncorrected; wide reads are tallied at 1/2 on gfx950) + 12.3 MB written; algorithmic bytes 50.7 MB.
