@@ -333,6 +333,9 @@ int ss_hifigan_source(const ss_hifigan* hg, const float* f0, int B, int T, const
 
 /* utility: y = clip(x, lo, hi) ; fill ; philox normal fill (for tests/bench inputs on device) */
 int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, void* stream);
+/* output writer (utils/audio.py:12-17 save_wav): pcm = (int16) trunc(wav * scale), scale = 32767 (or 32767 / max|wav| when
+ * out_wav_norm is set); saturating. */
+int ss_wav_to_pcm16(const float* wav, int16_t* pcm, int64_t n, float scale, void* stream);
 int ss_fill_normal(float* x, int64_t n, uint64_t seed, const uint64_t* seed_dev, uint64_t offset, void* stream);
 
 #ifdef __cplusplus

@@ -403,6 +403,23 @@ extern "C" int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, 
   return SS_OK;
 }
 
+// int16 PCM exactly as numpy's `(wav * 32767).astype(np.int16)` computes it for in-range samples (utils/audio.py:12-17):
+// fp32 multiply, then truncation toward zero. Out-of-range products saturate instead of wrapping.
+__global__ void pcm16_kernel(const float* __restrict__ x, int16_t* __restrict__ y, int64_t n, float scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = x[i] * scale;
+    v = fminf(fmaxf(v, -32768.0f), 32767.0f);
+    y[i] = (int16_t)(int)v;
+  }
+}
+
+extern "C" int ss_wav_to_pcm16(const float* wav, int16_t* pcm, int64_t n, float scale, void* stream) {
+  SS_CHECK_ARG(wav && pcm && n > 0, "ss_wav_to_pcm16: bad args");
+  hipLaunchKernelGGL(pcm16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, wav, pcm, n, scale);
+  SS_CHECK_LAUNCH("ss_wav_to_pcm16");
+  return SS_OK;
+}
+
 extern "C" int ss_fill_normal(float* x, int64_t n, uint64_t seed, const uint64_t* seed_dev, uint64_t offset, void* stream) {
   SS_CHECK_ARG(x && n > 0, "ss_fill_normal: bad args");
   hipLaunchKernelGGL(fill_normal_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, seed,

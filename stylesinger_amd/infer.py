@@ -58,6 +58,18 @@ class StyleSingerInfer:
         L.check(L.load().ss_clip(L.ptr(mel), L.ptr(mel_c), mel.numel(), float(hp["mel_vmin"]), float(hp["mel_vmax"]), L.stream_ptr()), "ss_clip")
         return self.vocoder.spec2wav_batch(mel_c, f0, lens=lens, noise=noise, seed=seed)
 
+    @torch.no_grad()
+    def infer_batch_to_files(self, batch, names, writer, seed=None):
+        """Batched form of the reference's test step + after_infer (tasks/StyleSinger/stylesinger.py:186-275), which
+        is limited to batch size 1: run the batch, vocode it, quantise to PCM16 on the device, crop each item to its own
+        frame count and queue the files on `writer` (a writer.WavWriter)."""
+        from .writer import wav_to_pcm16
+        res = self.infer_batch(batch, seed=seed)
+        hop = self.vocoder.model.hop
+        pcm = wav_to_pcm16(res["wav"], res["lens"], hop, norm=bool(self.hparams.get("out_wav_norm", False)))
+        writer.submit_batch(names, pcm, res["lens"], hop)
+        return res
+
     # ---- the reference's single-utterance surface ---------------------------------------------
     def input_to_batch(self, item):
         """inference/StyleSinger.py:139-172 (f0 must already be the normalised/interpolated log2 contour)."""

@@ -88,6 +88,7 @@ class _DiffPlan:
             self.ws_mel.append((wsb, torch.empty(wsb, device=dev, dtype=torch.uint8)))
         self.g_f0 = None
         self.g_mel = None
+        self.g_ddim = {}
 
 
 def _capture(fn):
@@ -276,6 +277,8 @@ class StyleSingerHIP(torch.nn.Module):
             net.log_alpha, net.log_1m_alpha = host("log_alpha"), host("log_1_min_alpha")
             net.log_cumprod_alpha, net.log_1m_cumprod_alpha = host("log_cumprod_alpha"), host("log_1_min_cumprod_alpha")
         sched = {k: self.p(f"{gen}.{k}").detach().cpu() for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod")}
+        if not f0:
+            sched["alphas_cumprod_np"] = np.ascontiguousarray(self.p(f"{gen}.alphas_cumprod").detach().cpu().numpy().astype(np.float32))
         return dict(net=net, keep=keep, sched=sched, packs=packs)
 
     def _pack_fft(self, prefix, n_layers):
@@ -461,7 +464,7 @@ class StyleSingerHIP(torch.nn.Module):
                                    L.ptr(pl.xm), B, T, M, L.stream_ptr()), "qsample")
         if ddim_ts is not None:
             ts = np.ascontiguousarray(np.asarray(ddim_ts, dtype=np.int32))
-            ac = np.ascontiguousarray(self.p("postdiff.alphas_cumprod").detach().cpu().numpy().astype(np.float32))
+            ac = pk["mel"]["sched"]["alphas_cumprod_np"]  # host table, read by the loop driver at launch time
             if len(pl.ws_mel) != 1:
                 wsb = lib.ss_wavenet_workspace_bytes(C_byref(net), B, T)
                 wsp = torch.empty(wsb, device=pl.xm.device, dtype=torch.uint8)
@@ -487,13 +490,66 @@ class StyleSingerHIP(torch.nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------------
     @torch.no_grad()
+    def encode_style(self, ref_mels, ref_f0):
+        """Residual Style Adaptor + RQ lookup + `l1` (a5, a6 and the first line of a7; lse.py:103-129, RQ.py:226-270,
+        stylesinger.py:189-196) for a batch of references. The result depends on the reference only, so a style-transfer
+        sweep (BASELINE config 5) computes it once per reference and passes it to forward(style_cache=...)."""
+        self._ensure_packed()
+        lib, hp, pk = _lib(), self.hp, self._pk
+        st = L.stream_ptr
+        H = hp["hidden_size"]
+        dev = ref_mels.device
+        B = ref_mels.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        ref_mels = ref_mels.contiguous().float()
+        Tr = ref_mels.shape[1]
+        if ref_f0.dim() == 1:
+            ref_f0 = ref_f0[None]
+        ref_f0 = ref_f0.contiguous().float()
+        lens_r = torch.empty(B, device=dev, dtype=torch.int32)
+        L.check(lib.ss_ref_lens(L.ptr(ref_mels), B, Tr, 80, L.ptr(lens_r), st()), "ref_lens")
+        xr = ref_mels.clone()
+        acts = torch.empty(B, Tr, 80, **f32)
+        wn_out = torch.zeros(B, Tr, 80, **f32)
+        for i, w in enumerate(pk["wn"]):
+            inl = w["inl"]
+            L.conv_gemm(xr, inl.W, acts, B=B, T=Tr, Cin=80, N=80, Np=inl.Np, Kp=inl.Kp, taps=(-1, 0, 1), lens=lens_r,
+                        epi=L.EPI_GATE, gate_mode=1, bias=inl.bias, ldc=80, mask_rows=False)
+            if w["res"] is not None:
+                self._gemm(acts, w["res"], xr, B, Tr, lens=lens_r, R=xr)
+            self._gemm(acts, w["skip"], wn_out, B, Tr, lens=lens_r, accumulate=True)
+        L.check(lib.ss_add_rowscalar(L.ptr(wn_out), L.ptr(ref_f0), B, Tr, 80, L.ptr(lens_r), st()), "add f0")
+        h80 = torch.empty(B, Tr, 80, **f32)
+        h160 = torch.empty(B, Tr, 160, **f32)
+        for blk in pk["cb"]:
+            L.layernorm(wn_out, *blk["ln"], B=B, T=Tr, C_=80, out=h80)
+            self._gemm(h80, blk["c1"], h160, B, Tr, lens=lens_r, act=L.ACT_GELU, pre_scale=blk["c1"].k ** -0.5, mask_rows=False)
+            self._gemm(h160, blk["c2"], wn_out, B, Tr, lens=lens_r, R=wn_out)
+        L.layernorm(wn_out, *pk["cb_ln"], B=B, T=Tr, C_=80, out=h80, lens=lens_r, mask_rows=True)
+        pre_rq = torch.empty(B, Tr, H, **f32)
+        self._gemm(h80, pk["cb_post"], pre_rq, B, Tr, lens=lens_r)
+        zq = torch.empty(B, Tr, H, **f32)
+        codes = torch.empty(B, Tr, hp["rq_depth"], device=dev, dtype=torch.int64)
+        L.check(lib.ss_rq_lookup(L.ptr(pre_rq), L.ptr(pk["codebooks"]), L.ptr(zq), L.ptr(codes), B * Tr, H, hp["nRQ"], hp["rq_depth"], st()), "rq")
+        cat = torch.empty(B, Tr, 2 * H, **f32)
+        cat[:, :, :H].copy_(zq)
+        pos_r = torch.empty(B, Tr, device=dev, dtype=torch.int32)
+        tabr = self._pos(Tr + 2, dev)
+        L.check(lib.ss_make_positions(None, L.ptr(zq), H, Tr * H, L.ptr(pos_r), B, Tr, st()), "pos style")
+        L.check(lib.ss_table_add(L.ptr(pos_r), L.ptr(tabr), tabr.shape[0], L.ptr(cat) + 4 * H, 2 * H, Tr * 2 * H, B, Tr, H, None, 1.0, 0, st()), "pos add")
+        sty = torch.empty(B, Tr, H, **f32)
+        self._gemm(cat, pk["l1"], sty, B, Tr, mask_rows=False)
+        return dict(sty=sty, lens_r=lens_r, ref_f0=ref_f0, style_pre_rq=pre_rq, rq_codes=codes, style_rq=zq)
+
+    @torch.no_grad()
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, emo_embed=None, ref_mels=None, ref_f0=None, f0=None, uv=None,
                 skip_decoder=False, global_steps=0, infer=False, note=None, note_dur=None, note_type=None, **kwargs):
         """Mirror of StyleSinger.forward (modules/StyleSinger/stylesinger.py:119-187), inference branch only.
 
         Extra keyword arguments: `noise` (dict from synth.draw_acoustic_noise: a recorded noise tape for
         parity tests; default = on-device Philox), `seed` (Philox seed), `sampler="ddim", ddim_steps=n` (strided
-        deterministic mel sampler, BASELINE config 5; default = the reference's 100-step ancestral sampler)."""
+        deterministic mel sampler, BASELINE config 5; default = the reference's 100-step ancestral sampler),
+        `style_cache` (the dict encode_style() returned for these references: skips the style encoder)."""
         if not infer or f0 is not None or uv is not None:
             raise NotImplementedError("StyleSingerHIP implements the inference path only (infer=True, f0/uv predicted)")
         self._ensure_packed()
@@ -569,47 +625,12 @@ class StyleSingerHIP(torch.nn.Module):
         # UMLN (a4): DistributionUncertainty returns x unchanged when not training (umln.py:48-50)
 
         # ---- Residual Style Adaptor (a5,a6) + style-to-content attention (a7) ----
-        ref_mels = ref_mels.contiguous().float()
-        Tr = ref_mels.shape[1]
-        if ref_f0.dim() == 1:
-            ref_f0 = ref_f0[None]
-        ref_f0 = ref_f0.contiguous().float()
-        ret["ref_f0"] = ref_f0
-        lens_r = torch.empty(B, device=dev, dtype=torch.int32)
-        L.check(lib.ss_ref_lens(L.ptr(ref_mels), B, Tr, 80, L.ptr(lens_r), st()), "ref_lens")
-        xr = ref_mels.clone()
-        acts = torch.empty(B, Tr, 80, **f32)
-        wn_out = torch.zeros(B, Tr, 80, **f32)
-        for i, w in enumerate(pk["wn"]):
-            inl = w["inl"]
-            L.conv_gemm(xr, inl.W, acts, B=B, T=Tr, Cin=80, N=80, Np=inl.Np, Kp=inl.Kp, taps=(-1, 0, 1), lens=lens_r,
-                        epi=L.EPI_GATE, gate_mode=1, bias=inl.bias, ldc=80, mask_rows=False)
-            if w["res"] is not None:
-                self._gemm(acts, w["res"], xr, B, Tr, lens=lens_r, R=xr)
-            self._gemm(acts, w["skip"], wn_out, B, Tr, lens=lens_r, accumulate=True)
-        L.check(lib.ss_add_rowscalar(L.ptr(wn_out), L.ptr(ref_f0), B, Tr, 80, L.ptr(lens_r), st()), "add f0")
-        h80 = torch.empty(B, Tr, 80, **f32)
-        h160 = torch.empty(B, Tr, 160, **f32)
-        for blk in pk["cb"]:
-            L.layernorm(wn_out, *blk["ln"], B=B, T=Tr, C_=80, out=h80)
-            self._gemm(h80, blk["c1"], h160, B, Tr, lens=lens_r, act=L.ACT_GELU, pre_scale=blk["c1"].k ** -0.5, mask_rows=False)
-            self._gemm(h160, blk["c2"], wn_out, B, Tr, lens=lens_r, R=wn_out)
-        L.layernorm(wn_out, *pk["cb_ln"], B=B, T=Tr, C_=80, out=h80, lens=lens_r, mask_rows=True)
-        pre_rq = torch.empty(B, Tr, H, **f32)
-        self._gemm(h80, pk["cb_post"], pre_rq, B, Tr, lens=lens_r)
-        ret["style_pre_rq"] = pre_rq
-        zq = torch.empty(B, Tr, H, **f32)
-        codes = torch.empty(B, Tr, hp["rq_depth"], device=dev, dtype=torch.int64)
-        L.check(lib.ss_rq_lookup(L.ptr(pre_rq), L.ptr(pk["codebooks"]), L.ptr(zq), L.ptr(codes), B * Tr, H, hp["nRQ"], hp["rq_depth"], st()), "rq")
-        ret["rq_codes"], ret["style_rq"], ret["rq_loss"] = codes, zq, 0.0
-        cat = torch.empty(B, Tr, 2 * H, **f32)
-        cat[:, :, :H].copy_(zq)
-        pos_r = torch.empty(B, Tr, device=dev, dtype=torch.int32)
-        tabr = self._pos(Tr + 2, dev)
-        L.check(lib.ss_make_positions(None, L.ptr(zq), H, Tr * H, L.ptr(pos_r), B, Tr, st()), "pos style")
-        L.check(lib.ss_table_add(L.ptr(pos_r), L.ptr(tabr), tabr.shape[0], L.ptr(cat) + 4 * H, 2 * H, Tr * 2 * H, B, Tr, H, None, 1.0, 0, st()), "pos add")
-        sty = torch.empty(B, Tr, H, **f32)
-        self._gemm(cat, pk["l1"], sty, B, Tr, mask_rows=False)
+        sc = kwargs.get("style_cache")
+        if sc is None:
+            sc = self.encode_style(ref_mels, ref_f0)
+        sty, lens_r, Tr = sc["sty"], sc["lens_r"], sc["sty"].shape[1]
+        ret["ref_f0"], ret["style_pre_rq"] = sc["ref_f0"], sc["style_pre_rq"]
+        ret["rq_codes"], ret["style_rq"], ret["rq_loss"] = sc["rq_codes"], sc["style_rq"], 0.0
         xs = dec.clone()
         q = torch.empty(B, T, H, **f32)
         kv = torch.empty(B, Tr, 2 * H, **f32)
@@ -702,10 +723,16 @@ class StyleSingerHIP(torch.nn.Module):
         K = hp["K_step"]
         ddim_ts = self.ddim_timesteps(int(kwargs["ddim_steps"])) if kwargs.get("sampler") == "ddim" else None
         if ddim_ts is not None:
-            zq_n = None
             if noise is not None:
                 zq_n = noise["mel"]["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
-            self._run_mel(pl, seed, (zq_n, None), ddim_ts=ddim_ts)
+                self._run_mel(pl, seed, (zq_n, None), ddim_ts=ddim_ts)
+            elif graphs:  # one captured graph per (B, T, number of sampler steps)
+                key = len(ddim_ts)
+                if key not in pl.g_ddim:
+                    pl.g_ddim[key] = _capture(lambda: self._run_mel(pl, seed, ddim_ts=ddim_ts))
+                pl.g_ddim[key].replay()
+            else:
+                self._run_mel(pl, seed, ddim_ts=ddim_ts)
         elif noise is not None:
             nz = noise["mel"]
             zq_n = nz["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()

@@ -252,3 +252,67 @@ def test_ddim_sampler_matches_oracle():
     l1 = (ret["mel_out"].cpu() - ref).abs().mean().item()
     print(f"ddim: mel L1 {l1:.3e}")
     assert l1 <= MEL_L1_TOL
+
+
+def test_pcm16_writer_matches_numpy_cast(tmp_path):
+    """ss_wav_to_pcm16 == numpy `(wav * 32767).astype(np.int16)` (utils/audio.py:12-17), bit exact; per-item crop."""
+    import numpy as np
+    from scipy.io import wavfile
+    from stylesinger_amd.writer import WavWriter, wav_to_pcm16
+    g = torch.Generator().manual_seed(3)
+    wav = (torch.rand(3, 5 * 256, generator=g) * 2 - 1) * 0.999
+    lens = torch.tensor([5, 3, 4], dtype=torch.int32)
+    pcm = wav_to_pcm16(wav.cuda(), lens.cuda(), 256)
+    ref = (wav.numpy().copy() * 32767).astype(np.int16)
+    for b in range(3):
+        n = int(lens[b]) * 256
+        assert np.array_equal(pcm[b, :n].cpu().numpy(), ref[b, :n])
+        assert int(pcm[b, n:].abs().sum()) == 0
+    pn = wav_to_pcm16(wav.cuda(), None, 256, norm=True).cpu().numpy()
+    w = wav.numpy().copy()
+    refn = np.stack([((w[b] / np.abs(w[b]).max()) * 32767).astype(np.int16) for b in range(3)])
+    assert np.abs(pn.astype(np.int32) - refn.astype(np.int32)).max() <= 1   # x/peak*32767 vs x*(32767/peak): <= 1 LSB
+    wr = WavWriter(str(tmp_path), 48000)
+    wr.submit_batch(["u0", "u1", "u2"], pcm, lens.cuda(), 256)
+    wr.close()
+    sr, back = wavfile.read(str(tmp_path / "u1.wav"))
+    assert sr == 48000 and np.array_equal(back, ref[1, :3 * 256])
+
+
+def test_style_transfer_sweep_equals_uncached_batches():
+    """BASELINE config 5 driver: cached per-reference style encodings + DDIM + (optionally) hipGraph replay must give
+    exactly what an uncached forward of the same (target x references) batch gives; every pair is produced once."""
+    from stylesinger_amd.infer import StyleSingerInfer
+    from stylesinger_amd.sweep import style_transfer_sweep
+    hp = config.make_hparams(dict(timesteps=8, K_step=8, f0_timesteps=3))
+    sd = synth.synth_acoustic_state_dict(hp, 5)
+    vsd = synth.synth_vocoder_state_dict(None, 5)
+    inf = StyleSingerInfer(hp, device="cuda:0", model_state=sd, vocoder_state=vsd)
+    refs, targets = [], []
+    for i, Tr in enumerate((40, 52, 40)):
+        it = synth.synth_utterance(100 + i, 16, 4, Tr, hp, 5)
+        refs.append({k: it[k] for k in ("ref_mels", "ref_f0", "spk_embed", "emo_embed")})
+    for j, (T, Tp) in enumerate(((48, 5), (64, 6))):
+        it = synth.synth_utterance(200 + j, T, Tp, 8, hp, 5)
+        targets.append({k: it[k] for k in ("txt_tokens", "note", "note_dur", "note_type", "mel2ph")})
+    got = {}
+    n_pairs, n_frames = style_transfer_sweep(inf, refs, targets, batch=2, ddim_steps=4, seed=77,
+                                             emit=lambda r, t, mel, f0, wav: got.__setitem__((r, t), (mel.clone(), f0.clone(), wav.clone())))
+    assert n_pairs == 6 and n_frames == 3 * (48 + 64) and len(got) == 6
+    dev = inf.device
+    for t, tgt in enumerate(targets):
+        for ridx in ([0, 1], [2]):
+            nb = len(ridx)
+            Tr = max(refs[i]["ref_mels"].shape[0] for i in ridx)
+            rm = torch.stack([torch.nn.functional.pad(refs[i]["ref_mels"], (0, 0, 0, Tr - refs[i]["ref_mels"].shape[0])) for i in ridx])
+            rf = torch.stack([torch.nn.functional.pad(refs[i]["ref_f0"], (0, Tr - refs[i]["ref_f0"].shape[0])) for i in ridx])
+            rep = lambda x: x[None].expand(nb, *x.shape).contiguous().to(dev)
+            out = inf.model(rep(tgt["txt_tokens"]), mel2ph=rep(tgt["mel2ph"]), spk_embed=torch.stack([refs[i]["spk_embed"] for i in ridx]).to(dev),
+                            emo_embed=torch.stack([refs[i]["emo_embed"] for i in ridx]).to(dev), ref_mels=rm.to(dev), ref_f0=rf.to(dev),
+                            global_steps=320000, infer=True, note=rep(tgt["note"]), note_dur=rep(tgt["note_dur"]), note_type=rep(tgt["note_type"]),
+                            sampler="ddim", ddim_steps=4, seed=77)
+            for k, r in enumerate(ridx):
+                mel, f0, wav = got[(r, t)]
+                assert (mel - out["mel_out"][k]).abs().max().item() <= 1e-5, (r, t)
+                assert (f0 - out["f0_denorm"][k]).abs().max().item() <= 1e-3
+                assert wav.shape[0] == mel.shape[0] * 256 and torch.isfinite(wav).all()

@@ -91,3 +91,37 @@ def test_vocoder_registry_surface():
     vsd = synth.synth_vocoder_state_dict()
     g.load_state_dict(vsd, strict=True)
     assert g.hop == 256
+
+
+def test_sweep_plan_covers_every_pair_exactly_once():
+    """BASELINE config 5 sharding: references rank::world (tasks/tts/tts_base.py:132), one target x `batch` refs per batch."""
+    from stylesinger_amd.sweep import bucket_frames, sweep_plan
+    n_refs, n_tgt, world, batch = 13, 5, 4, 3
+    seen = set()
+    for rank in range(world):
+        for t, refs in sweep_plan(n_refs, n_tgt, rank, world, batch):
+            assert 1 <= len(refs) <= batch
+            for r in refs:
+                assert r % world == rank
+                assert (r, t) not in seen
+                seen.add((r, t))
+    assert len(seen) == n_refs * n_tgt
+    # the BASELINE sizes: 256 x 256 over 8 GPUs -> 8192 pairs per GPU
+    assert sum(len(r) for _, r in sweep_plan(256, 256, 3, 8, 8)) == 8192
+    assert bucket_frames(1500, 64) == 1536 and bucket_frames(1536, 64) == 1536 and bucket_frames(7, 1) == 7
+
+
+def test_wav_writer_emits_pcm16_riff(tmp_path):
+    """write_wav_pcm16 must be readable as what scipy.io.wavfile.write produces for int16 (utils/audio.py:12-17)."""
+    import numpy as np
+    from scipy.io import wavfile
+    from stylesinger_amd.writer import write_wav_pcm16
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-32768, 32767, size=4801, dtype=np.int16)
+    p = tmp_path / "a.wav"
+    write_wav_pcm16(str(p), pcm, 48000)
+    sr, back = wavfile.read(str(p))
+    assert sr == 48000 and back.dtype == np.int16 and np.array_equal(back, pcm)
+    q = tmp_path / "b.wav"
+    wavfile.write(str(q), 48000, pcm)
+    assert p.read_bytes() == q.read_bytes()
