@@ -111,6 +111,10 @@ typedef struct ss_conv_gemm_args {
    * independent f0 denoisers (same shapes, different weights) share every launch: 2x the blocks per kernel. */
   int32_t group_size;
   int64_t w_group_stride, bias_group_stride, a_bias_group_stride;
+  /* matrix precision: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = both operands rounded to bf16 (RNE) on the way
+   * into v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 prologue/epilogue (BASELINE config 4) */
+  int32_t mfma_bf16;
+  int32_t reserved0;
 } ss_conv_gemm_args;
 
 int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
@@ -246,6 +250,11 @@ typedef struct ss_wavenet {
   int64_t gs_w_dil_wino;
   int64_t gs_w_in, gs_b_in, gs_uv_embed, gs_dstep, gs_w_dil, gs_w_out, gs_b_out, gs_w_cond, gs_b_cond, gs_w_skip, gs_b_skip,
       gs_w_final, gs_b_final;
+  /* 1 = run the hidden-to-hidden GEMMs (conditioner projection, dilated conv, output projection, skip projection) with
+   * bf16 operands (ss_conv_gemm_args.mfma_bf16); the input and final projections, which touch the diffusion state, the
+   * sampler update and all accumulations stay fp32. Winograd weights are ignored in this mode. */
+  int32_t mfma_bf16;
+  int32_t reserved0;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */
@@ -318,6 +327,9 @@ typedef struct ss_hifigan {
   const float* b_post;
   const float* src_w; /* SourceModuleHnNSF.l_linear.weight [9] */
   const float* src_b; /* [1] */
+  /* 1 = bf16-operand MFMA for conv_pre, the transposed convs and the residual blocks (conv_post and the NSF source stay fp32) */
+  int32_t mfma_bf16;
+  int32_t reserved0;
 } ss_hifigan;
 
 int64_t ss_hifigan_workspace_bytes(const ss_hifigan* hg, int B, int T);

@@ -48,8 +48,26 @@ def sinpos(probe_nonzero, dim):
     return tab[pos]
 
 
-def conv1d_cl(x, w, b, dilation=1):
+# BASELINE config 4 ("bf16 MFMA"): with set_matmul_rounding("bf16") the GEMMs the HIP path runs on bf16 matrix cores see
+# both operands rounded to bf16 (round-to-nearest-even, exactly what v_cvt_pk_bf16_f32 does) and accumulate in fp32; every
+# other operation stays fp32. The reference has no such mode: this switch is the only oracle for it.
+_ROUND = None
+
+
+def set_matmul_rounding(mode):
+    global _ROUND
+    assert mode in (None, "fp32", "bf16")
+    _ROUND = None if mode in (None, "fp32") else mode
+
+
+def _r(x):
+    return x.bfloat16().float() if _ROUND == "bf16" else x
+
+
+def conv1d_cl(x, w, b, dilation=1, rounded=False):
     """'same' Conv1d on channels-last input; w is the torch [Cout, Cin, k] parameter."""
+    if rounded:
+        x, w = _r(x), _r(w)
     k = w.shape[-1]
     pad = (k - 1) // 2 * dilation
     return F.conv1d(x.transpose(1, 2), w, b, padding=pad, dilation=dilation).transpose(1, 2)
@@ -280,14 +298,14 @@ def residual_stack(sd, prefix, x, cond, demb, L, cycle):
         p = f"{prefix}.residual_layers.{l}"
         d = 2 ** (l % cycle)
         ds = F.linear(demb, sd[p + ".diffusion_projection.weight"], sd[p + ".diffusion_projection.bias"])[:, None, :]
-        c = conv1d_cl(cond, sd[p + ".conditioner_projection.weight"], sd[p + ".conditioner_projection.bias"])
-        y = conv1d_cl(x + ds, sd[p + ".dilated_conv.weight"], sd[p + ".dilated_conv.bias"], dilation=d) + c
+        c = conv1d_cl(cond, sd[p + ".conditioner_projection.weight"], sd[p + ".conditioner_projection.bias"], rounded=True)
+        y = conv1d_cl(x + ds, sd[p + ".dilated_conv.weight"], sd[p + ".dilated_conv.bias"], dilation=d, rounded=True) + c
         y = torch.sigmoid(y[..., :C]) * torch.tanh(y[..., C:])
-        y = conv1d_cl(y, sd[p + ".output_projection.weight"], sd[p + ".output_projection.bias"])
+        y = conv1d_cl(y, sd[p + ".output_projection.weight"], sd[p + ".output_projection.bias"], rounded=True)
         x = (x + y[..., :C]) / math.sqrt(2.0)
         skip = skip + y[..., C:]
     h = skip / math.sqrt(L)
-    h = conv1d_cl(h, sd[prefix + ".skip_projection.weight"], sd[prefix + ".skip_projection.bias"])
+    h = conv1d_cl(h, sd[prefix + ".skip_projection.weight"], sd[prefix + ".skip_projection.bias"], rounded=True)
     return F.relu(h)
 
 
@@ -521,10 +539,10 @@ def hifigan_forward(vsd, cfg, mel, f0, tape):
     har = nsf_source(vsd, cfg, f0, tape)
     rates, ks = cfg["upsample_rates"], cfg["upsample_kernel_sizes"]
     nk = len(cfg["resblock_kernel_sizes"])
-    x = F.conv1d(mel.transpose(1, 2), weight_norm_fold(vsd, "conv_pre"), vsd["conv_pre.bias"], padding=3)
+    x = F.conv1d(_r(mel.transpose(1, 2)), _r(weight_norm_fold(vsd, "conv_pre")), vsd["conv_pre.bias"], padding=3)
     for i, (u, k) in enumerate(zip(rates, ks)):
         x = F.leaky_relu(x, 0.1)
-        x = F.conv_transpose1d(x, weight_norm_fold(vsd, f"ups.{i}"), vsd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+        x = F.conv_transpose1d(_r(x), _r(weight_norm_fold(vsd, f"ups.{i}")), vsd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
         if i + 1 < len(rates):
             s = int(np.prod(rates[i + 1:]))
             xs_ = F.conv1d(har[:, None, :], vsd[f"noise_convs.{i}.weight"], vsd[f"noise_convs.{i}.bias"], stride=s, padding=s // 2)
@@ -537,10 +555,10 @@ def hifigan_forward(vsd, cfg, mel, f0, tape):
             for m, d in enumerate(cfg["resblock_dilation_sizes"][j]):
                 p = f"resblocks.{i * nk + j}"
                 t = F.leaky_relu(y, 0.1)
-                t = F.conv1d(t, weight_norm_fold(vsd, f"{p}.convs1.{m}"), vsd[f"{p}.convs1.{m}.bias"], dilation=d,
+                t = F.conv1d(_r(t), _r(weight_norm_fold(vsd, f"{p}.convs1.{m}")), vsd[f"{p}.convs1.{m}.bias"], dilation=d,
                              padding=(kk * d - d) // 2)
                 t = F.leaky_relu(t, 0.1)
-                t = F.conv1d(t, weight_norm_fold(vsd, f"{p}.convs2.{m}"), vsd[f"{p}.convs2.{m}.bias"], padding=(kk - 1) // 2)
+                t = F.conv1d(_r(t), _r(weight_norm_fold(vsd, f"{p}.convs2.{m}")), vsd[f"{p}.convs2.{m}.bias"], padding=(kk - 1) // 2)
                 y = t + y
             acc = y if acc is None else acc + y
         x = acc / nk

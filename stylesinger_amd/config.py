@@ -43,6 +43,9 @@ DEFAULT_HPARAMS = dict(
     spec_min=SPEC_MIN, spec_max=SPEC_MAX, mel_vmin=-6.0, mel_vmax=1.5,
     audio_sample_rate=48000, hop_size=256, vocoder="HifiGAN_NSF", use_nsf=True, seed=1234,
     vocab_size=61,  # ZH_checkpoint_phone_set.json (58) + <pad>,<EOS>,<UNK> (utils/text/text_encoder.py:11)
+    # not a reference key: "fp32" (exact fp32 MFMA, the parity default) or "bf16" (BASELINE config 4: bf16 operands on
+    # the matrix cores for the denoisers' hidden GEMMs and the vocoder convs, fp32 accumulate / sampler / state)
+    mfma_precision="fp32",
 )
 
 # The released HiFi-GAN config ships only inside the un-vendored checkpoint
@@ -50,7 +53,7 @@ DEFAULT_HPARAMS = dict(
 DEFAULT_VOCODER = dict(
     resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
     resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
-    use_pitch_embed=True, audio_sample_rate=48000, harmonic_num=8,
+    use_pitch_embed=True, audio_sample_rate=48000, harmonic_num=8, mfma_precision="fp32",
 )
 
 

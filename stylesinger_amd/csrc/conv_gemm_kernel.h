@@ -22,6 +22,7 @@
 #include "../../include/stylesinger_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -35,7 +36,10 @@ constexpr int LDS_LD = BK;  // floats; no padding: the 16-B slots of a row are X
 // one row) is conflict-free too. Dropping the +4 padding cuts a 64x128 tile to 48 KiB -> 3 blocks per CU.
 __device__ __forceinline__ int lds_slot(int row, int slot) { return row * LDS_LD + ((slot ^ ((row >> 1) & 7)) << 2); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+// BF16 = true: same staging and epilogues, but both operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way
+// from LDS to the matrix core and the products run on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) - BASELINE config 4.
+// The matrix pipe is then ~16x faster than the fp32 form, so the loop is latency bound and prefetches two chunks ahead.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool BF16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles,
                                                         int n_tiles, int dbg) {
   constexpr int WTM = BM / WAVES_M;  // rows per wave
@@ -114,6 +118,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 ra[A_F4], rb[B_F4];
   float4 rpb;
+  u32x4 ra2[BF16 ? A_F4 : 1], rb2[BF16 ? B_F4 : 1];  // second register stage of the bf16 loop
+  float4 rpb2;
 
   // K-chunk cursor (uniform): chunk c = (tap, ci0); advanced incrementally, no division in the loop
   struct Cursor { int tap, ci0; };
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 
   // Issue the fetches of a chunk. Nothing here depends on loaded data, so no s_waitcnt is placed before the
   // MFMAs that follow in program order: the L2/HBM latency hides under them.
-  auto load_a = [&](const Cursor& k) {
+  auto load_a_to = [&](const Cursor& k, u32x4* ra, float4& rpb) {
     const int ci = k.ci0 + st_c4 * 4;
     const bool ci_ok = ci < a.Cin;  // only false in the zero-padded tail of a Cin that is not a multiple of 32
     const int chunk_off = (a.tap_off[k.tap] * a.lda + k.ci0) * 4;
@@ -134,13 +140,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     for (int i = 0; i < A_F4; ++i)
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_off0 + i * a_pass + chunk_off) | oob, 0, 0);
   };
-  auto load_b = [&](int c) {
+  auto load_b_to = [&](int c, u32x4* rb) {
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off0 + i * w_pass + c * (BK * 4), 0, 0);
   };
+  auto load_a = [&](const Cursor& k) { load_a_to(k, ra, rpb); };
+  auto load_b = [&](int c) { load_b_to(c, rb); };
   // A prologue: lrelu((x + bias) * scale) on real elements, exact 0 on padding; branch-free
   // (lrelu(x,s) = max(x,0) + s*min(x,0), identity for s = 1), then the swizzled LDS write.
-  auto store_a = [&](int buf, const Cursor& k) {
+  auto store_a_from = [&](int buf, const Cursor& k, const u32x4* ra, const float4& rpb) {
     float* Ad = As + buf * BM * LDS_LD;
     const int r0 = t0 + st_row + a.tap_off[k.tap];
     const bool c_ok = k.ci0 + st_c4 * 4 < a.Cin;
@@ -156,12 +164,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       *reinterpret_cast<float4*>(Ad + lds_slot(st_row + i * RP, st_c4)) = v;
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b_from = [&](int buf, const u32x4* rb) {
     float* Bd = Bs + buf * BN * LDS_LD;
 #pragma unroll
     for (int i = 0; i < B_F4; ++i)
       *reinterpret_cast<float4*>(Bd + lds_slot(st_row + i * RP, st_c4)) = __builtin_bit_cast(float4, rb[i]);
   };
+  auto store_a = [&](int buf, const Cursor& k) { store_a_from(buf, k, ra, rpb); };
+  auto store_b = [&](int buf) { store_b_from(buf, rb); };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -206,12 +216,70 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       }
     }
   };
+  // bf16 form: two fragment quads (k = 8q+4h+s for q, q+1) give the 8 K values a lane feeds to one 32x32x16 op; A and
+  // B use the same K assignment, which is all the sum needs.
+  auto pack8 = [](const float4& u, const float4& v) {
+    bf16x8 r;
+    r[0] = (__bf16)u.x; r[1] = (__bf16)u.y; r[2] = (__bf16)u.z; r[3] = (__bf16)u.w;
+    r[4] = (__bf16)v.x; r[5] = (__bf16)v.y; r[6] = (__bf16)v.z; r[7] = (__bf16)v.w;
+    return r;
+  };
+  auto mfma_pair_bf16 = [&](const float4 (&a0)[TM], const float4 (&a1)[TM], const float4 (&b0)[TN], const float4 (&b1)[TN]) {
+    bf16x8 av[TM], bv[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) av[m] = pack8(a0[m], a1[m]);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) bv[n] = pack8(b0[n], b1[n]);
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+  };
+  auto compute_chunk_bf16 = [&](int cur) {
+    const float* Ac = As + cur * BM * LDS_LD;
+    const float* Bc = Bs + cur * BN * LDS_LD;
+    float4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    read_frags(Ac, Bc, 0, af0, bf0);
+    read_frags(Ac, Bc, 1, af1, bf1);
+    mfma_pair_bf16(af0, af1, bf0, bf1);
+    read_frags(Ac, Bc, 2, af0, bf0);
+    read_frags(Ac, Bc, 3, af1, bf1);
+    mfma_pair_bf16(af0, af1, bf0, bf1);
+  };
   // Main loop. The MFMA stream of a chunk (4 groups of 4*TM*TN matrix ops, 64 cycles each) is the clock; every
   // other instruction of the chunk is placed BETWEEN groups so that it issues in the shadow of in-flight MFMAs
   // (one wave per SIMD cannot rely on other waves to fill the pipe):
   //   [frags q0,q1] [A fetch c+1] G0 [frags q2] [W fetch c+1] G1 [frags q3] G2 [prologue + LDS write c+1] G3 | barrier
   // The last chunk is peeled so the steady-state body is one straight-line block.
   const unsigned long long ts1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+  if constexpr (BF16) {
+    // chunk j's registers live in stage j&1 ((ra,rb) = stage 0, (ra2,rb2) = stage 1); in iteration c the fetch of chunk
+    // c+2 is issued, chunk c is multiplied from LDS[c&1], then chunk c+1 (fetched one iteration ago) moves to LDS.
+    Cursor k1 = kc, k2;
+    advance(k1);
+    k2 = k1;
+    if (nchunks > 1) { load_a_to(k1, ra2, rpb2); load_b_to(1, rb2); }
+    int c = 0;
+    auto body = [&](u32x4* raN, float4& rpbN, u32x4* rbN, u32x4* raNN, float4& rpbNN, u32x4* rbNN) {
+      if (c + 2 < nchunks) {
+        advance(k2);
+        load_a_to(k2, raNN, rpbNN);
+        load_b_to(c + 2, rbNN);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk_bf16(c & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_a_from((c + 1) & 1, k1, raN, rpbN);
+      store_b_from((c + 1) & 1, rbN);
+      k1 = k2;
+      __syncthreads();
+      ++c;
+    };
+    while (c + 1 < nchunks) {
+      body(ra2, rpb2, rb2, ra, rpb, rb);
+      if (c + 1 < nchunks) body(ra, rpb, rb, ra2, rpb2, rb2);
+    }
+  } else
   for (int c = 0; c + 1 < nchunks; ++c) {
     const int cur = c & 1;
     const float* Ac = As + cur * BM * LDS_LD;
@@ -278,7 +346,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  {
+  if constexpr (BF16) {
+    compute_chunk_bf16((nchunks - 1) & 1);
+  } else {
     const int cur = (nchunks - 1) & 1;
     const float* Ac = As + cur * BM * LDS_LD;
     const float* Bc = Bs + cur * BN * LDS_LD;
@@ -491,7 +561,7 @@ inline int dbg_flags() {
   return v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool BF16 = false>
 int launch(const ss_conv_gemm_args& a, hipStream_t stream) {
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
@@ -502,11 +572,11 @@ int launch(const ss_conv_gemm_args& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI, BF16>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, stream, a,
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI, BF16>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, stream, a,
                      m_tiles_per_item, m_tiles, n_tiles, dbg_flags());
   SS_CHECK_LAUNCH("ss_conv_gemm");
   return SS_OK;
@@ -516,6 +586,22 @@ int launch(const ss_conv_gemm_args& a, hipStream_t stream) {
 template <int EPI>
 int launch_tile(int tile, const ss_conv_gemm_args& a, hipStream_t stream) {
   constexpr bool G = EPI == SS_EPI_GATE;  // GATE needs an even number of 32-col blocks per wave
+  if (a.mfma_bf16) {  // bf16-operand form: the production tiles only
+    switch (tile) {
+      case SS_TILE_128x128: return launch<128, 128, 2, 2, EPI, true>(a, stream);
+      case SS_TILE_64x128: return launch<64, 128, 2, 2, EPI, true>(a, stream);
+      case SS_TILE_128x64: return launch<128, 64, 4, 1, EPI, true>(a, stream);
+      case SS_TILE_64x64:
+        if constexpr (!G) return launch<64, 64, 2, 2, EPI, true>(a, stream);
+        break;
+      case SS_TILE_128x32:
+        if constexpr (!G) return launch<128, 32, 4, 1, EPI, true>(a, stream);
+        break;
+      default: break;
+    }
+    ss_set_error("ss_conv_gemm: tile %d has no bf16 form (epilogue %d)", tile, EPI);
+    return SS_ERR_ARG;
+  }
   switch (tile) {
     case SS_TILE_128x128: return launch<128, 128, 2, 2, EPI>(a, stream);
     case SS_TILE_64x128: return launch<64, 128, 2, 2, EPI>(a, stream);

@@ -82,6 +82,7 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
   a.ldc = NE;
   a.c_batch_stride = (int64_t)T * NE;
   a.mask_rows = 0;
+  a.mfma_bf16 = net->mfma_bf16;
   if (net->n_groups > 1) {
     a.group_size = B / net->n_groups;
     a.w_group_stride = net->gs_w_cond;
@@ -120,12 +121,13 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     a.C = w.G;
     a.ldc = C;
     a.c_batch_stride = (int64_t)T * C;
+    a.mfma_bf16 = net->mfma_bf16;
     if (net->n_groups > 1) {
       a.group_size = B / net->n_groups;
       a.w_group_stride = net->gs_w_dil;
       a.a_bias_group_stride = net->gs_dstep;
     }
-    if (net->w_dil_wino[l]) {  // Winograd F(2,3): pairs of frames (t, t+d) from 4 products instead of 6
+    if (net->w_dil_wino[l] && !net->mfma_bf16) {  // Winograd F(2,3): pairs of frames (t, t+d) from 4 products instead of 6
       a.W = net->w_dil_wino[l];
       a.w_group_stride = net->gs_w_dil_wino;
       SS_PROPAGATE(ss_wino_gate(&a, d, stream));
@@ -156,6 +158,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     o.ldc2 = C;
     o.c2_batch_stride = (int64_t)T * C;
     o.accumulate = l > 0;
+    o.mfma_bf16 = net->mfma_bf16;
     if (net->n_groups > 1) {
       o.group_size = B / net->n_groups;
       o.w_group_stride = net->gs_w_out;
@@ -180,6 +183,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
   s.C = w.G;
   s.ldc = C;
   s.c_batch_stride = (int64_t)T * C;
+  s.mfma_bf16 = net->mfma_bf16;
   if (net->n_groups > 1) {
     s.group_size = B / net->n_groups;
     s.w_group_stride = net->gs_w_skip;

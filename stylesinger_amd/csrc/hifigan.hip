@@ -320,8 +320,9 @@ inline ss_conv_gemm_args base_args(int B, int T, const int32_t* lens) {
 }
 
 int conv_same(const float* A, int B, int Trows, int C, const int32_t* lens, const float* W, const float* bias, int k, int d,
-              float lrelu, const float* R, float post_scale, int accumulate, float* out, hipStream_t stream) {
+              float lrelu, const float* R, float post_scale, int accumulate, float* out, int bf16, hipStream_t stream) {
   ss_conv_gemm_args a = base_args(B, Trows, lens);
+  a.mfma_bf16 = bf16;
   a.A = A;
   a.lda = C;
   a.a_batch_stride = (int64_t)Trows * C;
@@ -415,6 +416,7 @@ extern "C" int ss_hifigan_forward(const ss_hifigan* hg, const float* mel, const 
     a.C = w.pre;
     a.ldc = hg->c0;
     a.c_batch_stride = (int64_t)T * hg->c0;
+    a.mfma_bf16 = hg->mfma_bf16;
     SS_PROPAGATE(ss_conv_gemm(&a, stream));
   }
 
@@ -449,6 +451,7 @@ extern "C" int ss_hifigan_forward(const ss_hifigan* hg, const float* mel, const 
       a.C = w.x + (g == 0 ? 0 : (int64_t)nph0 * cout);
       a.ldc = u * cout;
       a.c_batch_stride = (int64_t)rows_in * u * cout;
+      a.mfma_bf16 = hg->mfma_bf16;
       SS_PROPAGATE(ss_conv_gemm(&a, stream));
     }
     R *= u;
@@ -473,14 +476,14 @@ extern "C" int ss_hifigan_forward(const ss_hifigan* hg, const float* mel, const 
       for (int m = 0; m < 3; ++m) {
         const int d = hg->rb_d[j][m];
         SS_PROPAGATE(conv_same(xin, B, rows_out, cout, lens_out, hg->w_rb1[i][j][m], hg->b_rb1[i][j][m], k, d, 0.1f,
-                               nullptr, 1.0f, 0, w.ta, stream));
+                               nullptr, 1.0f, 0, w.ta, hg->mfma_bf16, stream));
         if (m < 2) {
           SS_PROPAGATE(conv_same(w.ta, B, rows_out, cout, lens_out, hg->w_rb2[i][j][m], hg->b_rb2[i][j][m], k, 1, 0.1f, xin,
-                                 1.0f, 0, w.tb, stream));
+                                 1.0f, 0, w.tb, hg->mfma_bf16, stream));
           xin = w.tb;
         } else {
           SS_PROPAGATE(conv_same(w.ta, B, rows_out, cout, lens_out, hg->w_rb2[i][j][m], hg->b_rb2[i][j][m], k, 1, 0.1f, xin,
-                                 inv, j > 0, w.xs, stream));
+                                 inv, j > 0, w.xs, hg->mfma_bf16, stream));
         }
       }
     }

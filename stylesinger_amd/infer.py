@@ -27,7 +27,10 @@ class StyleSingerInfer:
         self.model = self.build_model(dictionary, model_state)
         self.model.eval()
         self.model.to(self.device)
-        self.vocoder = get_vocoder_cls(self.hparams)(config=make_vocoder_config(vocoder_config), state_dict=vocoder_state,
+        vcfg = make_vocoder_config(vocoder_config)
+        if not (vocoder_config and "mfma_precision" in vocoder_config):
+            vcfg["mfma_precision"] = self.hparams.get("mfma_precision", "fp32")
+        self.vocoder = get_vocoder_cls(self.hparams)(config=vcfg, state_dict=vocoder_state,
                                                      device=self.device, hparams=self.hparams)
 
     def build_model(self, dictionary=None, state=None):

@@ -45,6 +45,7 @@ class ConvGemmArgs(C.Structure):
         ("ddpm_recip", C.c_float), ("ddpm_recipm1", C.c_float), ("ddpm_c1", C.c_float), ("ddpm_c2", C.c_float),
         ("ddpm_sigma", C.c_float), ("noise", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("step", C.c_uint32), ("tile", C.c_int32),
         ("group_size", C.c_int32), ("w_group_stride", C.c_int64), ("bias_group_stride", C.c_int64), ("a_bias_group_stride", C.c_int64),
+        ("mfma_bf16", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -59,7 +60,8 @@ class WaveNet(C.Structure):
         ("log_alpha", _vp), ("log_1m_alpha", _vp), ("log_cumprod_alpha", _vp), ("log_1m_cumprod_alpha", _vp),
         ("n_groups", C.c_int32), ("w_dil_wino", _vp * SS_MAX_LAYERS), ("gs_w_dil_wino", C.c_int64),
     ] + [(n, C.c_int64) for n in ("gs_w_in", "gs_b_in", "gs_uv_embed", "gs_dstep", "gs_w_dil", "gs_w_out", "gs_b_out", "gs_w_cond",
-                                  "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")]
+                                  "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")] \
+        + [("mfma_bf16", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class HifiGan(C.Structure):
@@ -72,7 +74,7 @@ class HifiGan(C.Structure):
         ("w_noise", _vp * SS_HG_MAX_UPS), ("b_noise", _vp * SS_HG_MAX_UPS),
         ("w_rb1", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS), ("b_rb1", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS),
         ("w_rb2", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS), ("b_rb2", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS),
-        ("w_post", _vp), ("b_post", _vp), ("src_w", _vp), ("src_b", _vp),
+        ("w_post", _vp), ("b_post", _vp), ("src_w", _vp), ("src_b", _vp), ("mfma_bf16", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -181,7 +183,7 @@ def conv_gemm(A, W, out, **kw):
 def _fill_args(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,), lens=None, a_bias=None, a_scale=1.0,
                a_lrelu=1.0, epi=EPI_STORE, bias=None, pre_scale=1.0, act=ACT_NONE, act_slope=0.0, E=None, lde=0, e_bs=0,
                gate_mode=0, R=None, ldr=0, r_bs=None, post_scale=1.0, accumulate=False, mask_rows=True, ldc=None, c_bs=None,
-               C2=None, ldc2=0, c2_bs=0, Nh=0, tile=0, group_size=0, w_gs=0, bias_gs=0, a_bias_gs=0):
+               C2=None, ldc2=0, c2_bs=0, Nh=0, tile=0, group_size=0, w_gs=0, bias_gs=0, a_bias_gs=0, bf16=False):
     a = ConvGemmArgs()
     a.A = ptr(A); a.lda = lda if lda is not None else Cin
     a.a_batch_stride = a_bs if a_bs is not None else T * a.lda
@@ -198,6 +200,7 @@ def _fill_args(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,
     a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
     a.C2 = ptr(C2); a.ldc2 = ldc2; a.c2_batch_stride = c2_bs; a.Nh = Nh; a.tile = tile
     a.group_size = group_size; a.w_group_stride = w_gs; a.bias_group_stride = bias_gs; a.a_bias_group_stride = a_bias_gs
+    a.mfma_bf16 = 1 if bf16 else 0
     return a
 
 

@@ -130,6 +130,9 @@ class StyleSingerHIP(torch.nn.Module):
         self.use_graphs = os.environ.get("SS_GRAPHS", "auto")
         # Winograd F(2,3) for the denoisers' 3-tap dilated convs (1.5x fewer matrix ops, fp32-rounding-equal results)
         self.use_wino = os.environ.get("SS_WINO", "1") not in ("0", "off", "false")
+        self.bf16 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16"
+        if self.bf16:
+            self.use_wino = False  # the transform would amplify the operand rounding; the matrix pipe is not the limit in bf16
         self._plans = {}
 
     # ---- state_dict contract ------------------------------------------------------------------
@@ -265,6 +268,7 @@ class StyleSingerHIP(torch.nn.Module):
                 ptr_, gs = place(f"w_dil_wino.{l}")
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
+        net.mfma_bf16 = 1 if self.bf16 else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):
             arr = np.ascontiguousarray(self.p(f"{gen}.{name}").detach().cpu().numpy().astype(np.float32))

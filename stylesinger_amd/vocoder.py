@@ -80,6 +80,8 @@ class HifiGanGeneratorHIP(torch.nn.Module):
         rates, ks = h["upsample_rates"], h["upsample_kernel_sizes"]
         hg.n_ups, hg.n_kernels, hg.c0 = len(rates), len(h["resblock_kernel_sizes"]), h["upsample_initial_channel"]
         hg.sr, hg.harmonics = h["audio_sample_rate"], h["harmonic_num"]
+        import os
+        hg.mfma_bf16 = 1 if os.environ.get("SS_PRECISION", h.get("mfma_precision", "fp32")) == "bf16" else 0
         for i, (u, k) in enumerate(zip(rates, ks)):
             hg.up_rate[i], hg.up_k[i] = u, k
         for i in range(len(rates), L.SS_HG_MAX_UPS):

@@ -283,3 +283,86 @@ def test_grouped_launch_uses_per_item_weight_sets():
     L.conv_gemm(x.to(dv), Wp, out, B=B, T=T, Cin=C, N=C, Np=Wp.shape[1], Kp=Wp.shape[2] // 3, taps=(-1, 0, 1), lens=lens.to(dv),
                 bias=bp, group_size=2, w_gs=Wp[0].numel(), bias_gs=bp[0].numel())
     assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+def _bf(x):
+    return x.bfloat16().float()
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k,dil,tile", [
+    (2, 70, 256, 256, 3, 2, 0), (1, 130, 32, 64, 1, 1, 0), (1, 130, 64, 64, 1, 1, 3), (2, 90, 32, 128, 3, 1, 2), (1, 300, 32, 32, 11, 5, 5),
+    (1, 300, 64, 64, 7, 3, 4), (2, 129, 128, 128, 5, 1, 1), (1, 64, 80, 256, 7, 1, 0), (3, 33, 256, 512, 9, 1, 0),
+])
+def test_conv_gemm_bf16_operands_store(B, T, Cin, Cout, k, dil, tile):
+    """mfma_bf16 = 1: operands rounded to bf16 (RNE) after the fp32 prologue, fp32 accumulate and epilogue. Reference = fp32
+    conv of the rounded operands; the only difference left is the accumulation order (tolerance 2e-5 on O(1) outputs).
+    Chunk counts 1, 2, 3, 5, 7, 11, 20, 21, 24, 72 exercise the two-stage prefetch loop for odd and even trip counts."""
+    d = dev()
+    x = _rand(B, T, Cin, seed=21)
+    ab = _rand(Cin, seed=22, scale=0.3)
+    w = _rand(Cout, Cin, k, seed=23, scale=1 / math.sqrt(Cin * k))
+    b = _rand(Cout, seed=24, scale=0.1)
+    r = _rand(B, T, Cout, seed=25)
+    lens = torch.tensor([T - 3 * i for i in range(B)], dtype=torch.int32)
+    xa = _bf(F.leaky_relu((x + ab) * 0.9, 0.1))
+    ref = F.gelu(_ref_conv(xa, _bf(w), b, dil, lens) * 0.5) + r
+    for i in range(B):
+        ref[i, int(lens[i]):] = 0
+    W = L.pack_conv_weight(w.to(d))
+    out = torch.full((B, T, Cout), 7.0, device=d)
+    L.conv_gemm(x.to(d), W, out, B=B, T=T, Cin=Cin, N=Cout, Np=W.shape[0], Kp=W.shape[1] // k,
+                taps=[(j - (k - 1) // 2) * dil for j in range(k)], lens=lens.to(d), a_bias=ab.to(d), a_scale=0.9, a_lrelu=0.1,
+                bias=L.pack_bias(b.to(d)), pre_scale=0.5, act=L.ACT_GELU, R=r.to(d), ldr=Cout, tile=tile, bf16=True)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+    # and it is NOT the fp32 result (the rounding is really applied)
+    ref32 = F.gelu(_ref_conv(F.leaky_relu((x + ab) * 0.9, 0.1), w, b, dil, lens) * 0.5) + r
+    for i in range(B):
+        ref32[i, int(lens[i]):] = 0
+    assert (out.cpu() - ref32).abs().max().item() > 1e-4
+
+
+@pytest.mark.parametrize("C", [256, 192])
+def test_conv_gemm_bf16_operands_gate_and_resskip(C):
+    d = dev()
+    B, T = 2, 100
+    x = _rand(B, T, C, seed=31)
+    w = _rand(2 * C, C, 3, seed=32, scale=1 / math.sqrt(3 * C))
+    b = _rand(2 * C, seed=33, scale=0.1)
+    e = _rand(B, T, 2 * C, seed=34)
+    lens = torch.tensor([T, T - 17], dtype=torch.int32)
+    y = _ref_conv(_bf(x), _bf(w), b, 2, lens) + e
+    g_ref = torch.sigmoid(y[..., :C]) * torch.tanh(y[..., C:])
+    W = L.pack_conv_weight(w.to(d), interleave_half=C)
+    bias = L.pack_bias(b.to(d), interleave_half=C)
+    Np = W.shape[0]
+    ep = torch.zeros(B, T, Np)
+    for p in range(Np // 64):
+        n = min(32, C - p * 32)
+        if n <= 0:
+            break
+        ep[..., (2 * p) * 32:(2 * p) * 32 + n] = e[..., p * 32:p * 32 + n]
+        ep[..., (2 * p + 1) * 32:(2 * p + 1) * 32 + n] = e[..., C + p * 32:C + p * 32 + n]
+    g = torch.empty(B, T, C, device=d)
+    L.conv_gemm(x.to(d), W, g, B=B, T=T, Cin=C, N=C, Np=Np, Kp=W.shape[1] // 3, taps=(-2, 0, 2), lens=lens.to(d), epi=L.EPI_GATE,
+                bias=bias, E=ep.to(d), lde=Np, e_bs=T * Np, ldc=C, mask_rows=False, bf16=True)
+    for i in range(B):
+        n = int(lens[i])
+        assert (g[i, :n].cpu() - g_ref[i, :n]).abs().max().item() < 2e-5
+    wo = _rand(2 * C, C, 1, seed=35, scale=1 / math.sqrt(C))
+    bo = _rand(2 * C, seed=36, scale=0.1)
+    xs = _rand(B, T, C, seed=37)
+    sk = _rand(B, T, C, seed=38)
+    gv = g_ref.clone()
+    for i in range(B):
+        gv[i, int(lens[i]):] = 0
+    yo = F.conv1d(_bf(gv).transpose(1, 2), _bf(wo), bo).transpose(1, 2)
+    x_ref = (xs + yo[..., :C]) / math.sqrt(2.0)
+    s_ref = sk + yo[..., C:]
+    Wo = L.pack_conv_weight(wo.to(d))
+    xd, sd_ = xs.to(d).clone(), sk.to(d).clone()
+    L.conv_gemm(gv.to(d), Wo, xd, B=B, T=T, Cin=C, N=2 * C, Np=Wo.shape[0], Kp=Wo.shape[1], lens=lens.to(d), epi=L.EPI_RESSKIP,
+                bias=L.pack_bias(bo.to(d)), Nh=C, R=xd, ldr=C, ldc=C, post_scale=1 / math.sqrt(2.0), C2=sd_, ldc2=C, c2_bs=T * C,
+                accumulate=True, mask_rows=False, bf16=True)
+    assert (xd.cpu() - x_ref).abs().max().item() < 2e-5
+    assert (sd_.cpu() - s_ref).abs().max().item() < 2e-5

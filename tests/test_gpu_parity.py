@@ -316,3 +316,62 @@ def test_style_transfer_sweep_equals_uncached_batches():
                 assert (mel - out["mel_out"][k]).abs().max().item() <= 1e-5, (r, t)
                 assert (f0 - out["f0_denorm"][k]).abs().max().item() <= 1e-3
                 assert wav.shape[0] == mel.shape[0] * 256 and torch.isfinite(wav).all()
+
+
+class _ListTape:
+    """Replays a fixed list of noise tensors (for checking one stage of the path in isolation)."""
+
+    def __init__(self, items):
+        self.items = list(items)
+
+    def randn(self, *shape):
+        t = self.items.pop(0)
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.clone()
+
+    rand = randn
+
+
+BF16_MEL_L1_TOL = 1e-3   # bf16-operand mode vs the oracle with the same operand rounding (only rounding-boundary flips and
+#                          accumulation order differ); the fp32 result is ~1e-2 away, reported below for information
+
+
+def test_bf16_mfma_mode_matches_rounded_oracle():
+    """BASELINE config 4 ("bf16 MFMA"): hidden GEMMs of the denoisers and the vocoder convs on v_mfma_f32_32x32x16_bf16.
+    The mel denoiser and the vocoder are checked stage by stage against oracle.restatement with set_matmul_rounding("bf16")
+    on the HIP path's own stage inputs, so discrete pitch decisions upstream cannot mask a kernel error."""
+    from stylesinger_amd.infer import StyleSingerInfer
+    K, S = 12, 4
+    hp = config.make_hparams(dict(timesteps=K, K_step=K, f0_timesteps=S, mfma_precision="bf16"))
+    sd = synth.synth_acoustic_state_dict(hp, 51)
+    vsd = synth.synth_vocoder_state_dict(None, 51)
+    B, T = 2, 96
+    batch = synth.synth_batch(B, T, 6, 80, hp, 51)
+    tape = synth.NoiseTape(52)
+    noise = synth.draw_acoustic_noise(tape, B, T, S, K)
+    vnoise = synth.draw_vocoder_noise(tape, B, T * 256)
+    inf = StyleSingerInfer(hp, device="cuda:0", model_state=sd, vocoder_state=vsd)
+    assert inf.model.bf16 and not inf.model.use_wino
+    b = {k: v.cuda() for k, v in batch.items()}
+    res = inf.infer_batch(b, noise=noise, vocoder_noise=vnoise)
+    ret = res["model_out"]
+    nz = noise["mel"]
+    draws = [nz["z_q"].reshape(B, 1, 80, T)] + [nz["z_steps"][K - 1 - i].reshape(B, 1, 80, T) for i in range(K)]
+    try:
+        R.set_matmul_rounding("bf16")
+        with torch.no_grad():
+            mel_ref = R.mel_diffusion(sd, hp, ret["fs2_mel"].cpu(), ret["diff_cond"].cpu(), _ListTape(draws))
+            mel_c = ret["mel_out"].cpu().clamp(hp["mel_vmin"], hp["mel_vmax"])
+            wav_ref, _ = R.hifigan_forward(vsd, inf.vocoder.config, mel_c, ret["f0_denorm"].cpu(),
+                                           _ListTape([vnoise["rand_ini"], vnoise["sine_noise"], torch.zeros(B, T * 256, 1)]))
+    finally:
+        R.set_matmul_rounding(None)
+    with torch.no_grad():
+        mel_f32 = R.mel_diffusion(sd, hp, ret["fs2_mel"].cpu(), ret["diff_cond"].cpu(), _ListTape(draws))
+    l1 = (ret["mel_out"].cpu() - mel_ref).abs().mean().item()
+    l1_f32 = (ret["mel_out"].cpu() - mel_f32).abs().mean().item()
+    ew = (res["wav"].cpu() - wav_ref).abs().max().item()
+    print(f"bf16 mode: mel L1 vs rounded oracle {l1:.3e} (vs fp32 oracle {l1_f32:.3e}); wav max err vs rounded oracle {ew:.3e}")
+    assert l1 <= BF16_MEL_L1_TOL
+    assert l1_f32 > l1          # the mode really is bf16
+    assert ew <= 5e-3           # |wav| <= 1
