@@ -277,6 +277,12 @@ int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* cond, const 
 int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
                            const int32_t* ts, int n_ts, const float* alphas_cumprod, int precompute_cond, void* ws,
                            int64_t ws_bytes, void* stream);
+
+/* PLMS ("pndm_speedup") sampler of the reference: modules/diff/shallow_diffusion_tts.py:165-197 (p_sample_plms) driven as
+ * in :254-260 - network times reversed(range(0, steps, interval)), 4-deep eps history, two network evaluations on the
+ * first step. `hist` = device scratch of 6*B*T*in_dim floats. alphas_cumprod: HOST table [steps]. */
+int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T, int interval,
+                           const float* alphas_cumprod, int precompute, float* hist, void* ws, int64_t ws_bytes, void* stream);
 /* q_sample + norm_spec: x = sqrt_ac*((mel-min)/(max-min)*2-1) + sqrt_1mac*z  (shallow_diffusion_tts.py:199-204,271-272) */
 int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac, float sqrt_1mac,
                    const float* noise, uint64_t seed, const uint64_t* seed_dev, float* x, int B, int T, int M, void* stream);

@@ -107,14 +107,44 @@ def run_vocoder_case(name, B, T, seed=1234):
     print(f"[gen_golden] {name}: wav {tuple(wav.shape)} draws={len(tape.log)}")
 
 
+def run_plms_case(name, T, steps_mel, interval, seed=1234):
+    """The reference's PLMS sampler (GaussianDiffusion.p_sample_plms, shallow_diffusion_tts.py:165-197) driven exactly as
+    GaussianDiffusion.forward drives it under hparams['pndm_speedup'] (:239-260), on the StyleSinger model's own `postdiff`
+    (DiffusionDecoder inherits the method). B = 1: the reference's `max(t - interval, 0)` only works for one utterance."""
+    from collections import deque
+    model, hp, sd = build_reference(steps_mel, 2, seed)
+    pd = model.postdiff
+    g = torch.Generator().manual_seed(seed + 11)
+    coarse = (torch.randn(1, T, 80, generator=g) * 0.8 - 3.0).clamp(-6, 0.5)
+    cond = torch.randn(1, T, 256, generator=g) * 0.5
+    tape = synth.NoiseTape(seed + 3)
+    with torch.no_grad(), tape_rng(tape):
+        t = pd.K_step
+        fs2 = pd.norm_spec(coarse).transpose(1, 2)[:, None, :, :]
+        x = pd.q_sample(x_start=fs2, t=torch.tensor([t - 1]).long())
+        pd.noise_list = deque(maxlen=4)
+        for i in reversed(range(0, t, interval)):
+            x = pd.p_sample_plms(x, torch.full((1,), i, dtype=torch.long), interval, cond.transpose(1, 2))
+        mel = pd.denorm_spec(x[:, 0].transpose(1, 2))
+    torch.save(dict(meta=dict(T=T, steps_mel=steps_mel, interval=interval, seed=seed, tape_seed=seed + 3, tape_log=tape.log),
+                    inp=dict(coarse_mel=coarse, cond=cond), out=dict(mel_out=mel.clone())), os.path.join(GOLD, name + ".pt"))
+    print(f"[gen_golden] {name}: mel {tuple(mel.shape)} draws={len(tape.log)}")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-plms" in sys.argv:
+        run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)
+        run_plms_case("plms_t24_k12_i4", T=24, steps_mel=12, interval=4)
+        return
     run_acoustic_case("acoustic_tiny_s4", B=1, T=48, Tp=6, Tr=40, steps_mel=4, steps_f0=4)
     run_acoustic_case("acoustic_b2_s3", B=2, T=40, Tp=5, Tr=36, steps_mel=3, steps_f0=3)
     run_acoustic_case("acoustic_dur_s2", B=1, T=0, Tp=7, Tr=32, steps_mel=2, steps_f0=2, give_mel2ph=False)
     run_acoustic_case("acoustic_t64_s100", B=1, T=64, Tp=8, Tr=48, steps_mel=100, steps_f0=100, keep_stages=False)
     run_vocoder_case("vocoder_t12", B=1, T=12)
     run_vocoder_case("vocoder_b2_t9", B=2, T=9)
+    run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)
+    run_plms_case("plms_t24_k12_i4", T=24, steps_mel=12, interval=4)
 
 
 if __name__ == "__main__":

@@ -451,6 +451,43 @@ def mel_ddim(sd, hp, coarse_mel, cond, tape, ts):
     return (x + 1) / 2 * (smax - smin) + smin
 
 
+def mel_plms(sd, hp, coarse_mel, cond, tape, interval):
+    """PLMS sampler: modules/diff/shallow_diffusion_tts.py:165-197 (p_sample_plms) driven as GaussianDiffusion.forward does
+    with hparams['pndm_speedup'] = interval (:239-260). Pinned by tests/golden/plms_*.pt (the reference's own method)."""
+    g = lambda k: sd[f"postdiff.{k}"]
+    smin, smax = g("spec_min")[0], g("spec_max")[0]
+    K = hp["K_step"]
+    B, T, M = coarse_mel.shape
+    x = (coarse_mel - smin) / (smax - smin) * 2 - 1
+    zq = tape.randn(B, 1, M, T)[:, 0].transpose(1, 2)
+    x = g("sqrt_alphas_cumprod")[K - 1] * x + g("sqrt_one_minus_alphas_cumprod")[K - 1] * zq
+    ac = g("alphas_cumprod")
+
+    def x_pred(x, eps, t, tp):
+        a_t, a_p = ac[t], ac[tp]
+        a_t_sq, a_p_sq = a_t.sqrt(), a_p.sqrt()
+        delta = (a_p - a_t) * ((1 / (a_t_sq * (a_t_sq + a_p_sq))) * x - 1 / (a_t_sq * (((1 - a_p) * a_t).sqrt() + ((1 - a_t) * a_p).sqrt())) * eps)
+        return x + delta
+
+    hist = []
+    for t_ in reversed(range(0, K, interval)):
+        tp = max(t_ - interval, 0)
+        eps = diffnet(sd, hp, x, torch.full((B,), t_, dtype=torch.long), cond)
+        if len(hist) == 0:
+            xp = x_pred(x, eps, t_, tp)
+            eps_prev = diffnet(sd, hp, xp, torch.full((B,), tp, dtype=torch.long), cond)
+            prime = (eps + eps_prev) / 2
+        elif len(hist) == 1:
+            prime = (3 * eps - hist[-1]) / 2
+        elif len(hist) == 2:
+            prime = (23 * eps - 16 * hist[-1] + 5 * hist[-2]) / 12
+        else:
+            prime = (55 * eps - 59 * hist[-1] + 37 * hist[-2] - 9 * hist[-3]) / 24
+        x = x_pred(x, prime, t_, tp)
+        hist = (hist + [eps])[-4:]
+    return (x + 1) / 2 * (smax - smin) + smin
+
+
 # ------------------------------------------------------------------------------------------------
 # top level: StyleSinger.forward(infer=True)  (modules/StyleSinger/stylesinger.py:119-187)
 # ------------------------------------------------------------------------------------------------

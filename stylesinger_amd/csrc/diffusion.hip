@@ -380,15 +380,12 @@ extern "C" int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int 
   return ws_layout(net, B, T, nullptr).bytes;
 }
 
-// One reverse step of the mel net at network time `t` with explicit update coefficients
-//   x0 = clamp(recip*x - recipm1*eps, -1, 1) ; x <- c1*x0 + c2*x + sigma*z
-static int mel_step(const ss_wavenet* net, float* x, const int32_t* lens, int B, int T, const WsLayout& w, int t, float recip,
-                    float recipm1, float c1, float c2, float sigma, const float* noise_t, uint64_t seed,
-                    const uint64_t* seed_dev, uint32_t step_id, hipStream_t stream) {
+// x_in -> relu(input_projection) -> residual stack; leaves relu(skip_projection(.)) in w.G  (net.py:114-127)
+static int mel_net_body(const ss_wavenet* net, const float* x_in, const int32_t* lens, int B, int T, const WsLayout& w, int t,
+                        hipStream_t stream) {
   const int C = net->C, M = net->in_dim;
-  // x = relu(input_projection(x_t))  (net.py:114-117)
   ss_conv_gemm_args a = base_args(B, T, lens);
-  a.A = x;
+  a.A = x_in;
   a.lda = M;
   a.a_batch_stride = (int64_t)T * M;
   a.Cin = M;
@@ -403,7 +400,39 @@ static int mel_step(const ss_wavenet* net, float* x, const int32_t* lens, int B,
   a.ldc = C;
   a.c_batch_stride = (int64_t)T * C;
   SS_PROPAGATE(ss_conv_gemm(&a, stream));
-  SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream));
+  return run_residual_stack(net, t, lens, B, T, w, stream);
+}
+
+// eps_out [B][T][M] = DiffNet(x_in, t, cond)  (plain output projection, for samplers that keep a history of eps)
+static int mel_eps(const ss_wavenet* net, const float* x_in, float* eps_out, const int32_t* lens, int B, int T, const WsLayout& w,
+                   int t, hipStream_t stream) {
+  const int C = net->C, M = net->in_dim;
+  SS_PROPAGATE(mel_net_body(net, x_in, lens, B, T, w, t, stream));
+  ss_conv_gemm_args f = base_args(B, T, lens);
+  f.A = w.G;
+  f.lda = C;
+  f.a_batch_stride = (int64_t)T * C;
+  f.Cin = C;
+  f.W = net->w_final;
+  f.N = M;
+  f.Np = round_up32(M);
+  f.Kp = round_up32(C);
+  f.epi = SS_EPI_STORE;
+  f.bias = net->b_final;
+  f.C = eps_out;
+  f.ldc = M;
+  f.c_batch_stride = (int64_t)T * M;
+  f.mask_rows = 0;
+  return ss_conv_gemm(&f, stream);
+}
+
+// One reverse step of the mel net at network time `t` with explicit update coefficients
+//   x0 = clamp(recip*x - recipm1*eps, -1, 1) ; x <- c1*x0 + c2*x + sigma*z
+static int mel_step(const ss_wavenet* net, float* x, const int32_t* lens, int B, int T, const WsLayout& w, int t, float recip,
+                    float recipm1, float c1, float c2, float sigma, const float* noise_t, uint64_t seed,
+                    const uint64_t* seed_dev, uint32_t step_id, hipStream_t stream) {
+  const int C = net->C, M = net->in_dim;
+  SS_PROPAGATE(mel_net_body(net, x, lens, B, T, w, t, stream));
   // eps = output_projection(.) fused with the posterior step (shallow_diffusion_tts.py:130-162)
   ss_conv_gemm_args f = base_args(B, T, lens);
   f.A = w.G;
@@ -474,6 +503,74 @@ extern "C" int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const flo
     const float c1 = sqrtf(ac_p) - c2 * sqrtf(ac_t);
     SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], c1, c2, 0.0f, nullptr, 0, nullptr,
                           (uint32_t)t, stream));
+  }
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PLMS / "pndm_speedup" sampler of the reference (shallow_diffusion_tts.py:165-197 p_sample_plms, loop :254-260):
+//   x_prev = x + (a_prev - a_t) * (kx * x - ke * eps'),  eps' = linear multistep combination of the eps history.
+// The reference runs it for one utterance at a time (its `max(t - interval, 0)` on a tensor only works for B = 1).
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void plms_update_kernel(const float* __restrict__ x, float* __restrict__ x_out, const float* __restrict__ e0,
+                                   const float* __restrict__ e1, const float* __restrict__ e2, const float* __restrict__ e3,
+                                   int order, float d, float kx, float ke, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float n0 = e0[i];
+    float prime;
+    switch (order) {  // same operation order as the reference expressions (:186-193)
+      case 0: prime = n0; break;
+      case 1: prime = (n0 + e1[i]) / 2.0f; break;
+      case 2: prime = (3.0f * n0 - e1[i]) / 2.0f; break;
+      case 3: prime = (23.0f * n0 - 16.0f * e1[i] + 5.0f * e2[i]) / 12.0f; break;
+      default: prime = (55.0f * n0 - 59.0f * e1[i] + 37.0f * e2[i] - 9.0f * e3[i]) / 24.0f; break;
+    }
+    const float xv = x[i];
+    x_out[i] = xv + d * (kx * xv - ke * prime);
+  }
+}
+}  // namespace
+
+extern "C" int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
+                                      int interval, const float* alphas_cumprod, int do_precompute, float* hist, void* ws,
+                                      int64_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SS_CHECK_ARG(net && x && cond && ws && hist && alphas_cumprod, "ss_meldiff_sample_plms: null pointer");
+  SS_CHECK_ARG(net->n_groups <= 1 && net->L > 0 && net->L <= SS_MAX_LAYERS, "ss_meldiff_sample_plms: bad net");
+  SS_CHECK_ARG(interval >= 1 && interval < net->steps, "ss_meldiff_sample_plms: interval=%d must be in [1, steps)", interval);
+  const WsLayout w = ws_layout(net, B, T, ws);
+  SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_meldiff_sample_plms: workspace too small");
+  const int64_t n = (int64_t)B * T * net->in_dim;
+  float* slot[5];
+  for (int i = 0; i < 5; ++i) slot[i] = hist + i * n;  // ring of eps(x_t, t): the current one + the last 4
+  float* x_pred = hist + 5 * n;
+  if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  int n_hist = 0, cur = 0;
+  const int t_first = (net->steps - 1) / interval * interval;  // reversed(range(0, K, interval))
+  for (int t = t_first; t >= 0; t -= interval) {
+    const int tp = t - interval > 0 ? t - interval : 0;
+    const float a_t = alphas_cumprod[t], a_p = alphas_cumprod[tp];
+    const float a_t_sq = sqrtf(a_t), a_p_sq = sqrtf(a_p);
+    const float d = a_p - a_t;
+    const float kx = 1.0f / (a_t_sq * (a_t_sq + a_p_sq));
+    const float ke = 1.0f / (a_t_sq * (sqrtf((1.0f - a_p) * a_t) + sqrtf((1.0f - a_t) * a_p)));
+    float* e0 = slot[cur];
+    SS_PROPAGATE(mel_eps(net, x, e0, lens, B, T, w, t, stream));
+    auto h = [&](int back) { return slot[(cur + 5 - back) % 5]; };
+    if (n_hist == 0) {
+      hipLaunchKernelGGL(plms_update_kernel, dim3(blocks), dim3(256), 0, stream, x, x_pred, e0, e0, e0, e0, 0, d, kx, ke, n);
+      float* e_prev = slot[(cur + 1) % 5];  // scratch: overwritten by the next step's eps
+      SS_PROPAGATE(mel_eps(net, x_pred, e_prev, lens, B, T, w, tp, stream));
+      hipLaunchKernelGGL(plms_update_kernel, dim3(blocks), dim3(256), 0, stream, x, x, e0, e_prev, e0, e0, 1, d, kx, ke, n);
+    } else {
+      const int order = n_hist == 1 ? 2 : n_hist == 2 ? 3 : 4;
+      hipLaunchKernelGGL(plms_update_kernel, dim3(blocks), dim3(256), 0, stream, x, x, e0, h(1), h(2), h(3), order, d, kx, ke, n);
+    }
+    SS_CHECK_LAUNCH("ss_meldiff_sample_plms");
+    if (n_hist < 4) ++n_hist;
+    cur = (cur + 1) % 5;
   }
   return SS_OK;
 }

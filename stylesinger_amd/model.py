@@ -89,6 +89,7 @@ class _DiffPlan:
         self.g_f0 = None
         self.g_mel = None
         self.g_ddim = {}
+        self.plms_hist = None
 
 
 def _capture(fn):
@@ -453,9 +454,9 @@ class StyleSingerHIP(torch.nn.Module):
         K = self.hp["K_step"]
         return sorted({int(round(v)) for v in np.linspace(0, K - 1, max(1, min(n, K)))}, reverse=True)
 
-    def _run_mel(self, pl, seed, tape=None, ddim_ts=None):
+    def _run_mel(self, pl, seed, tape=None, ddim_ts=None, plms_interval=None):
         """q_sample + the shallow reverse loop (batch halves on two streams); `ddim_ts` switches to the strided
-        deterministic sampler (BASELINE config 5)."""
+        deterministic sampler (BASELINE config 5), `plms_interval` to the reference's PLMS sampler (pndm_speedup)."""
         lib, pk, hp = _lib(), self._pk, self.hp
         B, T, M = pl.B, pl.T, hp["audio_num_mel_bins"]
         net = pk["mel"]["net"]
@@ -466,14 +467,21 @@ class StyleSingerHIP(torch.nn.Module):
         zq_n, zs_n = tape if tape is not None else (None, None)
         L.check(lib.ss_mel_qsample(L.ptr(pl.coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), seed + 23, sdp,
                                    L.ptr(pl.xm), B, T, M, L.stream_ptr()), "qsample")
-        if ddim_ts is not None:
-            ts = np.ascontiguousarray(np.asarray(ddim_ts, dtype=np.int32))
+        if ddim_ts is not None or plms_interval is not None:
             ac = pk["mel"]["sched"]["alphas_cumprod_np"]  # host table, read by the loop driver at launch time
             if len(pl.ws_mel) != 1:
                 wsb = lib.ss_wavenet_workspace_bytes(C_byref(net), B, T)
                 wsp = torch.empty(wsb, device=pl.xm.device, dtype=torch.uint8)
             else:
                 wsb, wsp = pl.ws_mel[0]
+        if plms_interval is not None:
+            if pl.plms_hist is None:
+                pl.plms_hist = torch.empty(6 * B * T * M, device=pl.xm.device, dtype=torch.float32)
+            L.check(lib.ss_meldiff_sample_plms(C_byref(net), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, int(plms_interval),
+                                               L.hptr(ac), 1, L.ptr(pl.plms_hist), L.ptr(wsp), wsb, L.stream_ptr()), "meldiff plms")
+            return
+        if ddim_ts is not None:
+            ts = np.ascontiguousarray(np.asarray(ddim_ts, dtype=np.int32))
             L.check(lib.ss_meldiff_sample_ddim(C_byref(net), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, L.hptr(ts), len(ts),
                                                L.hptr(ac), 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff ddim")
             return
@@ -491,6 +499,29 @@ class StyleSingerHIP(torch.nn.Module):
                                               L.ptr(zparts[i]), seed + 29 + 7919 * b0, sdp, 0, K, 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff")
         for sd_ in set(side) - {main}:
             main.wait_stream(sd_)
+
+    @torch.no_grad()
+    def mel_stage(self, coarse_mel, cond, lens=None, z_q=None, z_steps=None, sampler="ddpm", ddim_steps=None, plms_interval=None, seed=1234):
+        """The shallow mel diffusion alone (a11 output -> a12): coarse mel [B,T,80] + condition [B,T,256] -> mel [B,T,80].
+        z_q [B,1,80,T] / z_steps [K,B,1,80,T]: optional recorded noise (reference layout); default device Philox."""
+        self._ensure_packed()
+        lib, pk, hp = _lib(), self._pk, self.hp
+        dev = coarse_mel.device
+        B, T, M = coarse_mel.shape
+        K = hp["K_step"]
+        pl = self._plan(B, T, dev)
+        pl.lens.copy_(lens if lens is not None else torch.full((B,), T, device=dev, dtype=torch.int32))
+        pl.seed.fill_(seed)
+        pl.cond_mel.copy_(cond)
+        pl.coarse_mel.copy_(coarse_mel)
+        zq_n = None if z_q is None else z_q.to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
+        zs_n = None if z_steps is None else z_steps.to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()
+        self._run_mel(pl, seed, (zq_n, zs_n), ddim_ts=self.ddim_timesteps(ddim_steps) if sampler == "ddim" else None,
+                      plms_interval=plms_interval if sampler == "plms" else None)
+        mel_out = torch.empty(B, T, M, device=dev, dtype=torch.float32)
+        L.check(lib.ss_mel_denorm(L.ptr(pl.xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(pl.lens),
+                                  L.stream_ptr()), "denorm")
+        return mel_out
 
     # ---- forward ----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -553,7 +584,9 @@ class StyleSingerHIP(torch.nn.Module):
         Extra keyword arguments: `noise` (dict from synth.draw_acoustic_noise: a recorded noise tape for
         parity tests; default = on-device Philox), `seed` (Philox seed), `sampler="ddim", ddim_steps=n` (strided
         deterministic mel sampler, BASELINE config 5; default = the reference's 100-step ancestral sampler),
-        `style_cache` (the dict encode_style() returned for these references: skips the style encoder)."""
+        `sampler="plms", plms_interval=n` (the reference's PLMS sampler, hparams['pndm_speedup'],
+        shallow_diffusion_tts.py:165-197), `style_cache` (the dict encode_style() returned for these references: skips
+        the style encoder)."""
         if not infer or f0 is not None or uv is not None:
             raise NotImplementedError("StyleSingerHIP implements the inference path only (infer=True, f0/uv predicted)")
         self._ensure_packed()
@@ -726,7 +759,11 @@ class StyleSingerHIP(torch.nn.Module):
         pl.coarse_mel.copy_(coarse_mel)
         K = hp["K_step"]
         ddim_ts = self.ddim_timesteps(int(kwargs["ddim_steps"])) if kwargs.get("sampler") == "ddim" else None
-        if ddim_ts is not None:
+        plms = kwargs.get("plms_interval", hp.get("pndm_speedup")) if kwargs.get("sampler", "plms" if hp.get("pndm_speedup") else None) == "plms" else None
+        if plms:
+            zq_n = None if noise is None else noise["mel"]["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
+            self._run_mel(pl, seed, (zq_n, None), plms_interval=int(plms))
+        elif ddim_ts is not None:
             if noise is not None:
                 zq_n = noise["mel"]["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
                 self._run_mel(pl, seed, (zq_n, None), ddim_ts=ddim_ts)

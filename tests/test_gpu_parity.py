@@ -375,3 +375,30 @@ def test_bf16_mfma_mode_matches_rounded_oracle():
     assert l1 <= BF16_MEL_L1_TOL
     assert l1_f32 > l1          # the mode really is bf16
     assert ew <= 5e-3           # |wav| <= 1
+
+
+@pytest.mark.parametrize("name", ["plms_t40_k20_i3", "plms_t24_k12_i4"])
+def test_plms_sampler_matches_reference_golden(name):
+    """ss_meldiff_sample_plms vs the REAL reference's p_sample_plms loop (fixture from oracle/gen_golden.py); also batched
+    (B = 3 copies with different lengths), which the reference's implementation cannot run."""
+    case = harness.load_case(name)
+    meta = case["meta"]
+    hp = config.make_hparams(dict(timesteps=meta["steps_mel"], K_step=meta["steps_mel"], f0_timesteps=2))
+    sd = synth.synth_acoustic_state_dict(hp, meta["seed"])
+    dev = torch.device("cuda:0")
+    model = StyleSingerHIP(None, hparams=hp)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    T = meta["T"]
+    zq = synth.NoiseTape(meta["tape_seed"]).randn(1, 1, 80, T)
+    mel = model.mel_stage(case["inp"]["coarse_mel"].to(dev), case["inp"]["cond"].to(dev), z_q=zq, sampler="plms",
+                          plms_interval=meta["interval"])
+    l1 = (mel.cpu() - case["out"]["mel_out"]).abs().mean().item()
+    print(f"{name}: mel L1 {l1:.3e}")
+    assert l1 <= MEL_L1_TOL
+    lens = torch.tensor([T, T - 5, T - 11], dtype=torch.int32, device=dev)
+    mel3 = model.mel_stage(case["inp"]["coarse_mel"].expand(3, -1, -1).contiguous().to(dev), case["inp"]["cond"].expand(3, -1, -1).contiguous().to(dev),
+                           lens=lens, z_q=zq.expand(3, -1, -1, -1).contiguous(), sampler="plms", plms_interval=meta["interval"])
+    assert (mel3[0] - mel[0]).abs().max().item() <= 1e-5
+    # shorter items see zero padding instead of the reference's frames -> only frames far from the cut can be compared
+    assert mel3[2, T - 11:].abs().max().item() == 0.0
