@@ -33,6 +33,17 @@ class StyleSingerInfer:
         self.vocoder = get_vocoder_cls(self.hparams)(config=vcfg, state_dict=vocoder_state,
                                                      device=self.device, hparams=self.hparams)
 
+    @classmethod
+    def from_checkpoints(cls, hparams, exp_dir, vocoder_dir, device=None, dictionary=None):
+        """Build from the reference's on-disk checkpoints (inference/StyleSinger.py:34-39 + hifigan_nsf.py:46-61):
+        `exp_dir` = checkpoints/<exp_name> (newest model_ckpt_steps_*.ckpt), `vocoder_dir` = hparams['vocoder_ckpt']."""
+        from . import ckpt
+        state, _ = ckpt.read_state(exp_dir, "model")
+        if state is None:
+            raise FileNotFoundError(f"| ckpt not found in {exp_dir}.")
+        vstate, vcfg = ckpt.load_vocoder_ckpt(vocoder_dir)
+        return cls(hparams, device=device, model_state=state, vocoder_state=vstate, vocoder_config=vcfg, dictionary=dictionary)
+
     def build_model(self, dictionary=None, state=None):
         model = StyleSingerHIP(dictionary, hparams=self.hparams)
         if state is not None:

@@ -125,3 +125,53 @@ def test_wav_writer_emits_pcm16_riff(tmp_path):
     q = tmp_path / "b.wav"
     wavfile.write(str(q), 48000, pcm)
     assert p.read_bytes() == q.read_bytes()
+
+
+def test_checkpoint_intake_reads_both_reference_layouts(tmp_path):
+    """ckpt.load_ckpt follows utils/commons/ckpt_utils.py:26-67: newest step wins, flat and nested state_dict layouts,
+    strict=False drops shape mismatches; the vocoder loader follows hifigan_nsf.py:24-61 (yaml and json flavours)."""
+    import yaml
+    from stylesinger_amd import ckpt
+    from stylesinger_amd.model import StyleSingerHIP
+    from stylesinger_amd.vocoder import HifiGanGeneratorHIP
+    hp = config.make_hparams(dict(timesteps=4, K_step=4, f0_timesteps=4))
+    sd = synth.synth_acoustic_state_dict(hp, 3)
+    exp = tmp_path / "exp"
+    exp.mkdir()
+    old = {k: torch.zeros_like(v) for k, v in sd.items()}
+    torch.save({"state_dict": {"model": old}, "optimizer_states": [1, 2, 3]}, exp / "model_ckpt_steps_1000.ckpt")
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "global_step": 2000}, exp / "model_ckpt_steps_2000.ckpt")
+    assert [os.path.basename(p) for p in ckpt.get_all_ckpts(str(exp))] == ["model_ckpt_steps_2000.ckpt", "model_ckpt_steps_1000.ckpt"]
+    m = StyleSingerHIP(None, hparams=hp)
+    path = ckpt.load_ckpt(m, str(exp), "model", strict=True)
+    assert path.endswith("2000.ckpt")
+    got = m.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    # nested layout + explicit file + strict=False with one mismatched shape
+    bad = dict(sd)
+    bad["mel_out.bias"] = torch.zeros(7)
+    torch.save({"state_dict": {"model": bad}}, exp / "other.ckpt")
+    m2 = StyleSingerHIP(None, hparams=hp)
+    ckpt.load_ckpt(m2, str(exp / "other.ckpt"), "model", strict=False)
+    assert torch.equal(m2.state_dict()["encoder.embed_tokens.weight"], sd["encoder.embed_tokens.weight"])
+    assert ckpt.load_ckpt(m2, str(tmp_path / "nothing"), force=False) is None
+    with pytest.raises(FileNotFoundError):
+        ckpt.load_ckpt(m2, str(tmp_path / "nothing"))
+    n = ckpt.strip(str(exp), str(tmp_path / "infer.pt"))
+    assert n == len(sd) and set(torch.load(tmp_path / "infer.pt")["state_dict"]["model"]) == set(sd)
+    # vocoder: yaml flavour and json flavour
+    cfg = config.make_vocoder_config()
+    vsd = synth.synth_vocoder_state_dict(cfg, 3)
+    vy = tmp_path / "voc_yaml"
+    vy.mkdir()
+    yaml.safe_dump(cfg, open(vy / "config.yaml", "w"))
+    torch.save({"state_dict": {"model_gen": vsd}}, vy / "model_ckpt_steps_5.ckpt")
+    vj = tmp_path / "voc_json"
+    vj.mkdir()
+    json.dump(cfg, open(vj / "config.json", "w"))
+    torch.save({"generator": vsd}, vj / "generator_v1")
+    for d in (vy, vj):
+        st, c = ckpt.load_vocoder_ckpt(str(d))
+        g = HifiGanGeneratorHIP(c)
+        g.load_state_dict(st, strict=True)
+        assert c["upsample_rates"] == cfg["upsample_rates"]
