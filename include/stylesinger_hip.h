@@ -351,6 +351,12 @@ int ss_hifigan_source(const ss_hifigan* hg, const float* f0, int B, int T, const
 
 /* utility: y = clip(x, lo, hi) ; fill ; philox normal fill (for tests/bench inputs on device) */
 int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, void* stream);
+/* reference-audio front end (utils/audios/__init__.py:36-84 librosa_wav2spec): the windowed DFT and the mel filterbank
+ * are two ss_conv_gemm launches (frames = 4 taps over the waveform viewed as [L/hop][hop]); these two kernels are the
+ * element-wise steps between and after them: |X| from the (re | im) column blocks, and log10(max(eps, .)). */
+int ss_spec_magnitude(const float* S, float* P, int64_t rows, int lds, int ldp, int nbins, int sin_off, void* stream);
+int ss_log10_floor(const float* x, float* y, int64_t n, float eps, void* stream);
+
 /* output writer (utils/audio.py:12-17 save_wav): pcm = (int16) trunc(wav * scale), scale = 32767 (or 32767 / max|wav| when
  * out_wav_norm is set); saturating. */
 int ss_wav_to_pcm16(const float* wav, int16_t* pcm, int64_t n, float scale, void* stream);

@@ -403,6 +403,42 @@ extern "C" int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, 
   return SS_OK;
 }
 
+// |X| of a DFT stored as two column blocks (real part at [0,nbins), imaginary part at [sin_off, sin_off+nbins)):
+// P[r][f] = sqrt(re^2 + im^2), columns [nbins, ldp) are written as 0 (they are the K padding of the mel GEMM).
+__global__ void spec_mag_kernel(const float* __restrict__ S, float* __restrict__ P, int64_t rows, int lds, int ldp, int nbins,
+                                int sin_off) {
+  const int64_t n = rows * ldp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ldp;
+    const int f = (int)(i - r * ldp);
+    float v = 0.f;
+    if (f < nbins) {
+      const float re = S[r * lds + f], im = S[r * lds + sin_off + f];
+      v = sqrtf(re * re + im * im);
+    }
+    P[i] = v;
+  }
+}
+
+__global__ void log10_floor_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float eps) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = log10f(fmaxf(eps, x[i]));
+}
+
+extern "C" int ss_spec_magnitude(const float* S, float* P, int64_t rows, int lds, int ldp, int nbins, int sin_off, void* stream) {
+  SS_CHECK_ARG(S && P && rows > 0 && nbins > 0 && nbins <= ldp && sin_off + nbins <= lds, "ss_spec_magnitude: bad args");
+  hipLaunchKernelGGL(spec_mag_kernel, dim3(grid_for(rows * ldp)), dim3(256), 0, (hipStream_t)stream, S, P, rows, lds, ldp, nbins, sin_off);
+  SS_CHECK_LAUNCH("ss_spec_magnitude");
+  return SS_OK;
+}
+
+extern "C" int ss_log10_floor(const float* x, float* y, int64_t n, float eps, void* stream) {
+  SS_CHECK_ARG(x && y && n > 0, "ss_log10_floor: bad args");
+  hipLaunchKernelGGL(log10_floor_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, eps);
+  SS_CHECK_LAUNCH("ss_log10_floor");
+  return SS_OK;
+}
+
 // int16 PCM exactly as numpy's `(wav * 32767).astype(np.int16)` computes it for in-range samples (utils/audio.py:12-17):
 // fp32 multiply, then truncation toward zero. Out-of-range products saturate instead of wrapping.
 __global__ void pcm16_kernel(const float* __restrict__ x, int16_t* __restrict__ y, int64_t n, float scale) {

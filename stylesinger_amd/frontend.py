@@ -1,0 +1,115 @@
+"""Reference-audio mel front end on the GPU (first item).
+
+Mirror of `utils/audios/__init__.py:36-84 librosa_wav2spec` as the entrypoint uses it (`inference/StyleSinger.py:106-118`,
+hparams of egs/stylesinger.yaml:29-37: 48 kHz, fft 1024, hop 256, win 1024, 80 mels, 20 Hz - 24 kHz, eps 1e-6, no
+loudness norm): centred STFT with zero ("constant") padding and a periodic Hann window, magnitude, Slaney-normalised mel
+filterbank (librosa 0.8.0 defaults: htk=False, norm='slaney'), log10(max(eps, .)).
+
+MI355X mapping: with hop | fft the frame matrix never exists - the waveform is viewed channels-last as [L/hop][hop] and a
+frame is 4 consecutive rows, i.e. the windowed real DFT is a 4-tap implicit-GEMM conv (K = 1024, N = 513 cos + 513 sin
+columns) on the exact-fp32 MFMA path of `ss_conv_gemm`; the hardware range check of the buffer loads IS the centre padding.
+The mel projection is a second GEMM (K = 513 -> 544, N = 80); |X| and log10 are two small element-wise kernels.
+The speaker / emotion encoders and the f0 tracker of `preprocess_input` remain outside (un-vendored third-party models).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import make_hparams
+
+FRONTEND_DEFAULTS = dict(fft_size=1024, win_size=1024, fmin=20, fmax=24000, mel_eps=1e-6)
+
+
+def _hz_to_mel(f):
+    """Slaney scale (librosa.core.convert.hz_to_mel, htk=False): linear below 1 kHz, log above."""
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with its 0.8.0 defaults (htk=False, norm='slaney') -> [n_mels, 1+n_fft/2]."""
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+class MelFrontendHIP:
+    def __init__(self, hparams=None, device="cuda"):
+        hp = dict(FRONTEND_DEFAULTS)
+        hp.update(make_hparams(hparams))
+        if hparams:
+            hp.update({k: hparams[k] for k in FRONTEND_DEFAULTS if k in hparams})
+        self.sr, self.hop, self.n_fft, self.n_mels = hp["audio_sample_rate"], hp["hop_size"], hp["fft_size"], hp["audio_num_mel_bins"]
+        self.eps = float(hp["mel_eps"])
+        if hp["win_size"] != self.n_fft or self.n_fft % self.hop:
+            raise NotImplementedError("MelFrontendHIP: needs win_size == fft_size and hop_size | fft_size (the reference's setting)")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.StyleSingerHipError("MelFrontendHIP needs a GPU: there is no CPU path")
+        self.taps = self.n_fft // self.hop
+        self.nbins = self.n_fft // 2 + 1
+        self.nb_pad = L.round_up(self.nbins, 32)
+        k = np.arange(self.n_fft, dtype=np.float64)
+        win = 0.5 - 0.5 * np.cos(2 * np.pi * k / self.n_fft)           # scipy.signal.get_window('hann', N, fftbins=True)
+        ang = 2 * np.pi * np.outer(np.arange(self.nbins, dtype=np.float64), k) / self.n_fft
+        basis = np.zeros((2 * self.nb_pad, self.n_fft), dtype=np.float64)
+        basis[:self.nbins] = np.cos(ang) * win
+        basis[self.nb_pad:self.nb_pad + self.nbins] = -np.sin(ang) * win
+        # conv weight [Cout][Cin = hop][k = taps]: sample index inside the frame = tap * hop + ci
+        w = torch.from_numpy(basis.astype(np.float32)).reshape(2 * self.nb_pad, self.taps, self.hop).permute(0, 2, 1).contiguous()
+        self.W_dft = L.pack_conv_weight(w.to(self.device))
+        fb = np.zeros((self.n_mels, self.nb_pad), dtype=np.float32)
+        fb[:, :self.nbins] = mel_filterbank(self.sr, self.n_fft, self.n_mels, hp["fmin"], hp["fmax"])
+        self.W_mel = L.pack_conv_weight(torch.from_numpy(fb)[:, :, None].contiguous().to(self.device))
+
+    @torch.no_grad()
+    def wav2mel(self, wav, lens=None):
+        """wav fp32 [B, L] on the device (lens = valid samples per item, default L) -> (mel [B, T, 80], frames int32 [B]),
+        T = 1 + L // hop frames as librosa.stft(center=True) yields; frames past an item's own count are 0."""
+        wav = wav.to(self.device).float()
+        B, Ls = wav.shape
+        hop, taps = self.hop, self.taps
+        R = (Ls + hop - 1) // hop
+        if R * hop != Ls:
+            wav = torch.nn.functional.pad(wav, (0, R * hop - Ls))
+        wav = wav.contiguous()
+        n = torch.full((B,), Ls, device=self.device, dtype=torch.int64) if lens is None else lens.to(self.device).to(torch.int64)
+        if lens is not None:  # samples past an item's length are not part of it
+            wav = wav * (torch.arange(R * hop, device=self.device)[None, :] < n[:, None])
+        rows = ((n + hop - 1) // hop).to(torch.int32)
+        frames = (n // hop + 1).to(torch.int32)
+        T = Ls // hop + 1
+        lib = L.load()
+        S = torch.empty(B, T, 2 * self.nb_pad, device=self.device, dtype=torch.float32)
+        L.conv_gemm(wav, self.W_dft, S, B=B, T=T, Cin=hop, N=2 * self.nb_pad, Np=self.W_dft.shape[0], Kp=self.W_dft.shape[1] // taps,
+                    lda=hop, a_bs=R * hop, taps=tuple(j - taps // 2 for j in range(taps)), lens=rows, mask_rows=False)
+        P = torch.empty(B, T, self.nb_pad, device=self.device, dtype=torch.float32)
+        L.check(lib.ss_spec_magnitude(L.ptr(S), L.ptr(P), B * T, 2 * self.nb_pad, self.nb_pad, self.nbins, self.nb_pad, L.stream_ptr()), "mag")
+        mel = torch.empty(B, T, self.n_mels, device=self.device, dtype=torch.float32)
+        L.conv_gemm(P, self.W_mel, mel, B=B, T=T, Cin=self.nb_pad, N=self.n_mels, Np=self.W_mel.shape[0], Kp=self.W_mel.shape[1],
+                    mask_rows=False)
+        L.check(lib.ss_log10_floor(L.ptr(mel), L.ptr(mel), mel.numel(), self.eps, L.stream_ptr()), "log10")
+        mel.masked_fill_((torch.arange(T, device=self.device)[None, :] >= frames[:, None])[:, :, None], 0.0)
+        return mel, frames
