@@ -193,10 +193,12 @@ def main():
         out = {
             "metric": "mel-frames/sec (end-to-end infer incl. vocoder)", "value": value, "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random weights + inputs; no checkpoint ships)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if infer.model.bf16 else "f32", "data": "synthetic (seeded random weights + inputs; no checkpoint ships)",
             "config": {"workload": f"batch={B}x{T / 187.5:.1f}s utterances per GPU (T={T} frames, Tp={Tp}, Tr={Tr}), "
                                    f"{args.diff_steps} mel + 2x{args.diff_steps} f0 diffusion steps + HiFi-GAN-NSF, fp32",
                        "global_batch": B * world, "frames_per_utterance": T, "parallelism": f"dp{world}",
+                       "diffusion_loops": "hipGraph replay" if infer.model._want_graphs(B, T) else "eager launches",
+                       "mfma_precision": "bf16" if infer.model.bf16 else "fp32",
                        "algorithmic_gflop_per_frame": flop_per_frame / 1e9,
                        "executed_gflop_per_frame": exec_flop_per_frame / 1e9,
                        "e2e_fraction_of_fp32_mfma_peak_algorithmic": value / world * flop_per_frame / PEAK_FP32_MFMA,

@@ -429,3 +429,35 @@ def test_mel_frontend_matches_oracle():
         print(f"frontend item {b}: frames {ref.shape[0]} max err {err.max():.3e} mean err {err.mean():.3e} (mel range {ref.min():.2f}..{ref.max():.2f})")
         assert err.max() <= 1e-4 and err.mean() <= 1e-5
         assert mel[b, ref.shape[0]:].abs().max().item() == 0.0 if ref.shape[0] < mel.shape[1] else True
+
+
+def test_c2_full_size_batch_items_equal_single_runs():
+    """BASELINE configs[1] shape (B=8 x T=1500 frames, Tp=28, Tr=1500) - too large for the CPU oracle in a test, so the
+    size-independent property is used: every utterance of the batch must equal its own B=1 run on the same noise tape
+    (the reference only ever runs B=1). 3+3+3 diffusion steps keep it to seconds; integers exact, mel to 1e-5."""
+    hp = config.make_hparams(dict(timesteps=3, K_step=3, f0_timesteps=3))
+    sd = synth.synth_acoustic_state_dict(hp, 61)
+    B, T, Tp, Tr = 8, 1500, 28, 1500
+    batch = synth.synth_batch(B, T, Tp, Tr, hp, 61)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(62), B, T, 3, 3)
+    dev = torch.device("cuda:0")
+    model = StyleSingerHIP(None, hparams=hp)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+
+    def run(b, nz):
+        bb = {k: v.to(dev) for k, v in b.items()}
+        return model(bb["txt_tokens"], mel2ph=bb["mel2ph"], spk_embed=bb["spk_embed"], emo_embed=bb["emo_embed"], ref_mels=bb["ref_mels"],
+                     ref_f0=bb["ref_f0"], global_steps=320000, infer=True, note=bb["note"], note_dur=bb["note_dur"], note_type=bb["note_type"], noise=nz)
+    full = run(batch, noise)
+    assert torch.isfinite(full["mel_out"]).all()
+    for i in (0, 5, 7):
+        one_b = {k: v[i:i + 1] for k, v in batch.items()}
+        nz = {net: {k: (v[:, i:i + 1] if k in ("z_steps", "u_steps") else v[i:i + 1]) for k, v in noise[net].items()} for net in ("f0_a", "f0_b")}
+        nz["mel"] = dict(z_q=noise["mel"]["z_q"][i:i + 1], z_steps=noise["mel"]["z_steps"][:, i:i + 1])
+        one = run(one_b, nz)
+        assert torch.equal(one["rq_codes"][0], full["rq_codes"][i])
+        assert torch.equal(one["uv_a"][0], full["uv_a"][i]) and torch.equal(one["uv_b"][0], full["uv_b"][i])
+        assert torch.equal(one["pitch_coarse"][0], full["pitch_coarse"][i])
+        e = (one["mel_out"][0] - full["mel_out"][i]).abs().max().item()
+        assert e <= 1e-5, (i, e)
