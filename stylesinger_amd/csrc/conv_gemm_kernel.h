@@ -130,19 +130,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 
   // Issue the fetches of a chunk. Nothing here depends on loaded data, so no s_waitcnt is placed before the
   // MFMAs that follow in program order: the L2/HBM latency hides under them.
-  auto load_a_to = [&](const Cursor& k, u32x4* ra, float4& rpb) {
+  // `dead` = 0x80000000 turns the whole fetch into out-of-range reads (return 0, no memory traffic): the bf16 loop issues
+  // its prefetch unconditionally so that no control-flow join hides the in-flight count from the s_waitcnt insertion.
+  auto load_a_to = [&](const Cursor& k, u32x4* ra, float4& rpb, int dead = 0) {
     const int ci = k.ci0 + st_c4 * 4;
     const bool ci_ok = ci < a.Cin;  // only false in the zero-padded tail of a Cin that is not a multiple of 32
     const int chunk_off = (a.tap_off[k.tap] * a.lda + k.ci0) * 4;
-    const int oob = ci_ok ? 0 : (int)0x80000000;  // OR-ed into the offset: one branch-free load either way
-    rpb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, ci * 4, 0, 0));
+    const int oob = (ci_ok ? 0 : (int)0x80000000) | dead;  // OR-ed into the offset: one branch-free load either way
+    rpb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, (ci * 4) | dead, 0, 0));
 #pragma unroll
     for (int i = 0; i < A_F4; ++i)
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_off0 + i * a_pass + chunk_off) | oob, 0, 0);
   };
-  auto load_b_to = [&](int c, u32x4* rb) {
+  auto load_b_to = [&](int c, u32x4* rb, int dead = 0) {
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off0 + i * w_pass + c * (BK * 4), 0, 0);
+    for (int i = 0; i < B_F4; ++i)
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (w_off0 + i * w_pass + c * (BK * 4)) | dead, 0, 0);
   };
   auto load_a = [&](const Cursor& k) { load_a_to(k, ra, rpb); };
   auto load_b = [&](int c) { load_b_to(c, rb); };
@@ -261,11 +264,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     if (nchunks > 1) { load_a_to(k1, ra2, rpb2); load_b_to(1, rb2); }
     int c = 0;
     auto body = [&](u32x4* raN, float4& rpbN, u32x4* rbN, u32x4* raNN, float4& rpbNN, u32x4* rbNN) {
-      if (c + 2 < nchunks) {
-        advance(k2);
-        load_a_to(k2, raNN, rpbNN);
-        load_b_to(c + 2, rbNN);
-      }
+      const bool more = c + 2 < nchunks;
+      const int dead = more ? 0 : (int)0x80000000;
+      if (more) advance(k2);  // scalar bookkeeping only
+      load_a_to(k2, raNN, rpbNN, dead);
+      load_b_to(more ? c + 2 : 0, rbNN, dead);
       __builtin_amdgcn_sched_barrier(0);
       compute_chunk_bf16(c & 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -275,10 +278,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       __syncthreads();
       ++c;
     };
-    while (c + 1 < nchunks) {
+    // nchunks-1 bodies in all; pairs run as one straight-line loop body (no branch inside: the accumulators stay in
+    // AGPRs and the s_waitcnt insertion sees exact in-flight counts), an odd one is peeled after the loop.
+    const int nbodies = nchunks - 1;
+    for (int i = 0; i + 2 <= nbodies; i += 2) {
       body(ra2, rpb2, rb2, ra, rpb, rb);
-      if (c + 1 < nchunks) body(ra, rpb, rb, ra2, rpb2, rb2);
+      body(ra, rpb, rb, ra2, rpb2, rb2);
     }
+    if (nbodies & 1) body(ra2, rpb2, rb2, ra, rpb, rb);
   } else
   for (int c = 0; c + 1 < nchunks; ++c) {
     const int cur = c & 1;
