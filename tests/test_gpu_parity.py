@@ -461,3 +461,35 @@ def test_c2_full_size_batch_items_equal_single_runs():
         assert torch.equal(one["pitch_coarse"][0], full["pitch_coarse"][i])
         e = (one["mel_out"][0] - full["mel_out"][i]).abs().max().item()
         assert e <= 1e-5, (i, e)
+
+
+def test_batch_with_an_empty_item_leaves_the_others_untouched():
+    """Edge case of the batched path (the reference is B=1 and never sees it): an item that is all padding (no phonemes, no
+    frames) must produce zeros / finite values and must not disturb its neighbours."""
+    hp = config.make_hparams(dict(timesteps=3, K_step=3, f0_timesteps=3))
+    sd = synth.synth_acoustic_state_dict(hp, 71)
+    B, T = 3, 50
+    batch = synth.synth_batch(B, T, 6, 40, hp, 71)
+    for k in ("txt_tokens", "note", "note_type", "mel2ph"):
+        batch[k][1] = 0
+    batch["note_dur"][1] = 0.0
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(72), B, T, 3, 3)
+    dev = torch.device("cuda:0")
+    model = StyleSingerHIP(None, hparams=hp)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+
+    def run(b, nz):
+        bb = {k: v.to(dev) for k, v in b.items()}
+        return model(bb["txt_tokens"], mel2ph=bb["mel2ph"], spk_embed=bb["spk_embed"], emo_embed=bb["emo_embed"], ref_mels=bb["ref_mels"],
+                     ref_f0=bb["ref_f0"], global_steps=320000, infer=True, note=bb["note"], note_dur=bb["note_dur"], note_type=bb["note_type"], noise=nz)
+    full = run(batch, noise)
+    assert full["lens"].tolist() == [T, 0, T]
+    assert torch.isfinite(full["mel_out"]).all() and torch.isfinite(full["f0_denorm"]).all()
+    assert full["mel_out"][1].abs().max().item() == 0.0
+    for i in (0, 2):
+        nz = {net: {k: (v[:, i:i + 1] if k in ("z_steps", "u_steps") else v[i:i + 1]) for k, v in noise[net].items()} for net in ("f0_a", "f0_b")}
+        nz["mel"] = dict(z_q=noise["mel"]["z_q"][i:i + 1], z_steps=noise["mel"]["z_steps"][:, i:i + 1])
+        one = run({k: v[i:i + 1] for k, v in batch.items()}, nz)
+        assert (one["mel_out"][0] - full["mel_out"][i]).abs().max().item() <= 1e-5
+        assert torch.equal(one["uv_a"][0], full["uv_a"][i])
