@@ -54,9 +54,9 @@ enum {
 };
 enum { SS_ACT_NONE_ = 0, SS_ACT_RELU_ = 1, SS_ACT_GELU_ = 2, SS_ACT_MISH_ = 3, SS_ACT_TANH_ = 4, SS_ACT_LRELU_ = 5 };
 
-enum { SS_TILE_AUTO = 0, SS_TILE_128x128 = 1, SS_TILE_64x128 = 2, SS_TILE_64x64 = 3, SS_TILE_128x64 = 4, SS_TILE_128x32 = 5,
-       SS_TILE_96x256 = 6, SS_TILE_96x128 = 7, SS_TILE_64x256 = 8, SS_TILE_256x32 = 9, SS_TILE_256x64 = 10,
-       SS_TILE_64x64_2W = 11 /* 2 waves of 32x64 */, SS_TILE_128x128_8W = 12 /* 8 waves of 32x64 */ };
+/* (the 96x256 / 96x128 / 64x256 / 256x32 / 256x64 / 2-wave / 8-wave tiles measured in round 1 were all slower at this
+ * path's shapes and are no longer built - DESIGN.md §6) */
+enum { SS_TILE_AUTO = 0, SS_TILE_128x128 = 1, SS_TILE_64x128 = 2, SS_TILE_64x64 = 3, SS_TILE_128x64 = 4, SS_TILE_128x32 = 5 };
 
 typedef struct ss_conv_gemm_args {
   /* A operand */

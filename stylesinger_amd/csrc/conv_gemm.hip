@@ -36,7 +36,7 @@ extern "C" int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream_) {
     else if (gate || blocks(64, 128) >= 384) tile = SS_TILE_64x128;
     else tile = SS_TILE_64x64;
   }
-  if (gate && (tile == SS_TILE_128x32 || tile == SS_TILE_64x64 || tile == SS_TILE_256x32)) tile = SS_TILE_64x128;
+  if (gate && (tile == SS_TILE_128x32 || tile == SS_TILE_64x64)) tile = SS_TILE_64x128;
   switch (a.epi) {
     case SS_EPI_STORE: return ss_conv_gemm_launch_store(tile, a, stream);
     case SS_EPI_GATE: return ss_conv_gemm_launch_gate(tile, a, stream);

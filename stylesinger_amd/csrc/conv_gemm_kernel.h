@@ -613,20 +613,11 @@ int launch_tile(int tile, const ss_conv_gemm_args& a, hipStream_t stream) {
     case SS_TILE_128x128: return launch<128, 128, 2, 2, EPI>(a, stream);
     case SS_TILE_64x128: return launch<64, 128, 2, 2, EPI>(a, stream);
     case SS_TILE_128x64: return launch<128, 64, 4, 1, EPI>(a, stream);
-    case SS_TILE_96x256: return launch<96, 256, 1, 4, EPI>(a, stream);
-    case SS_TILE_96x128: return launch<96, 128, 1, 2, EPI>(a, stream);
-    case SS_TILE_64x256: return launch<64, 256, 1, 4, EPI>(a, stream);
-    case SS_TILE_256x64: return launch<256, 64, 4, 1, EPI>(a, stream);
-    case SS_TILE_64x64_2W: return launch<64, 64, 2, 1, EPI>(a, stream);
-    case SS_TILE_128x128_8W: return launch<128, 128, 4, 2, EPI>(a, stream);
     case SS_TILE_64x64:
       if constexpr (!G) return launch<64, 64, 2, 2, EPI>(a, stream);
       break;
     case SS_TILE_128x32:
       if constexpr (!G) return launch<128, 32, 4, 1, EPI>(a, stream);
-      break;
-    case SS_TILE_256x32:
-      if constexpr (!G) return launch<256, 32, 4, 1, EPI>(a, stream);
       break;
     default: break;
   }
