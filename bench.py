@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=1500, help="mel frames per utterance (1500 = 8 s)")
     ap.add_argument("--diff-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=750)
+    ap.add_argument("--cpu-frames", type=int, default=3000, help="frames of the single utterance the CPU oracle is timed on (~20 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads for the CPU oracle; 16 is the fastest setting on the 2x64-core EPYC GPU-box host "
                          "(tools/cpu_threads.py: 8:0.38s 16:0.35s 32:0.78s 64:2.0s 128:5.0s per 10 steps)")
