@@ -354,9 +354,9 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
   const int pairs_per_item = ss_cdiv(a.T, 2 * dilation) * dilation;
   const int p_tiles_per_item = ss_cdiv(pairs_per_item, BP);
   const int p_tiles = p_tiles_per_item * a.B;
-  // tile choice: 64x128 (TN=2) has twice the MFMAs per barrier; use it when its (coarser) tiles still balance:
-  // blocks/CU close below an integer is good, e.g. mel C2: 384 blocks on 256 CUs = 1.5 -> makespan 2 units of a
-  // 2x faster-per-flop tile; f0 pair: 564 -> 3 units: worse than the fine 1128-block grid.
+  // tile choice: 64x128 (TN=2) has twice the MFMAs per barrier but 228 registers (2 blocks/CU); 64x64 (TN=1) runs 3
+  // blocks/CU. A makespan model picks; measured with tools/kbench.py (graph-timed): mel C2 (768 / 384 blocks) 92.6 vs
+  // 92.8 us, f0 pair (1152 / 576 blocks) 120.8 vs 112.5 us -> TN=1 for mel, TN=2 for the f0 pair.
   int tn = a.tile == SS_TILE_64x128 ? 2 : a.tile == SS_TILE_64x64 ? 1 : 0;
   if (tn == 0) {
     const long b2 = (long)p_tiles * ss_cdiv(a.Np, 128), b1 = (long)p_tiles * (a.Np / 64);

@@ -13,16 +13,30 @@ from stylesinger_amd import lib as L  # noqa: E402
 
 
 def timeit(fn, iters):
+    """Back-to-back launches: `fn` captured 10x into a hipGraph (a Python loop of ctypes calls would time the host for
+    kernels of ~100 us), replayed between two events on the capture stream."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    reps = 10
+    graph = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(graph, stream=st):
+            for _ in range(reps):
+                fn()
+        graph.replay()
+        st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = max(1, iters // reps)
+        e0.record(st)
+        for _ in range(n):
+            graph.replay()
+        e1.record(st)
+        st.synchronize()
+    torch.cuda.current_stream().wait_stream(st)
+    return e0.elapsed_time(e1) * 1e-3 / (n * reps)
 
 
 def main():
