@@ -68,7 +68,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   const int t0 = (mt % m_tiles_per_item) * BM;
   const int n0 = nt * BN;
 
+#ifdef SS_KERNEL_TIMESTAMPS  // per-wave phase stamps for tools/phase_times.py; never compiled into the shipped library
   const unsigned long long ts0 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -254,7 +256,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // (one wave per SIMD cannot rely on other waves to fill the pipe):
   //   [frags q0,q1] [A fetch c+1] G0 [frags q2] [W fetch c+1] G1 [frags q3] G2 [prologue + LDS write c+1] G3 | barrier
   // The last chunk is peeled so the steady-state body is one straight-line block.
+#ifdef SS_KERNEL_TIMESTAMPS
   const unsigned long long ts1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+#endif
   if constexpr (BF16) {
     // chunk j's registers live in stage j&1 ((ra,rb) = stage 0, (ra2,rb2) = stage 1); in iteration c the fetch of chunk
     // c+2 is issued, chunk c is multiplied from LDS[c&1], then chunk c+1 (fetched one iteration ago) moves to LDS.
@@ -373,7 +377,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // ------------------------------------------------------------------------------------------
   // Epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // ------------------------------------------------------------------------------------------
+#ifdef SS_KERNEL_TIMESTAMPS
   const unsigned long long ts2 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+#endif
   // Every epilogue is two-phase: (1) issue ALL the global reads it needs into registers, (2) compute + store.
   // The output may alias the inputs (in-place residual updates), so the compiler cannot hoist a load above a
   // store by itself; without the split every element pays a full load round trip.
@@ -550,6 +556,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       }
     }
   }
+#ifdef SS_KERNEL_TIMESTAMPS
   if ((dbg & 16) && EPI == SS_EPI_GATE && a.C2 && lane == 0) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(a.C2) + ((size_t)blockIdx.x * (NT / 64) + wave) * 8;
     o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_readcyclecounter();
@@ -557,15 +564,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
     o[6] = blockIdx.x;
   }
+#else
+  (void)dbg;
+#endif
 }
 
 inline int dbg_flags() {
+#ifdef SS_KERNEL_TIMESTAMPS
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("SS_DBG");
     v = e ? atoi(e) : 0;
   }
   return v;
+#else
+  return 0;
+#endif
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool BF16 = false>

@@ -1,4 +1,6 @@
-"""Debug: per-wave timestamps of the gate kernel (needs SS_DBG=16): entry / loop start / loop end / exit."""
+"""Debug: per-wave timestamps of the gate kernel: entry / loop start / loop end / exit.
+Needs a library built with -DSS_KERNEL_TIMESTAMPS (SS_EXTRA_HIPCC_FLAGS=-DSS_KERNEL_TIMESTAMPS python -m stylesinger_amd.build)
+and SS_DBG=16 at run time; the shipped library carries no instrumentation."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
