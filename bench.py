@@ -123,7 +123,7 @@ def cpu_baseline(hp, frames, threads):
         mel = ret["mel_out"].clamp(hp["mel_vmin"], hp["mel_vmax"])
         R.hifigan_forward(vsd, cfg, mel, ret["f0_denorm"], tape)
         dt = time.time() - t0
-    return dict(value=frames / dt, unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=frames / dt, unit="mel-frames/s", cores=torch.get_num_threads(), host_logical_cpus=os.cpu_count(), kind="port",
                 sample=f"B=1, T={frames} frames, {hp['K_step']}+2x{hp['f0_timesteps']} diffusion steps + HiFi-GAN-NSF, fp32, "
                        f"oracle/restatement.py (torch CPU, {torch.get_num_threads()} threads), {dt:.1f} s")
 
