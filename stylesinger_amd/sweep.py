@@ -8,7 +8,10 @@ keeps the per-reference cache local to one GPU:
     per reference (n_refs times instead of n_refs * n_targets) and its output stays resident in HBM;
   * a batch is ONE target score x `batch` references, so every item of a batch has the same frame count (no padding waste)
     and the hipGraphs of the f0 diffusions / DDIM mel sampler are keyed by (batch, T bucket, steps) and replayed;
-  * the mel sampler is the strided deterministic DDIM (`ss_meldiff_sample_ddim`), default 50 network evaluations.
+  * the mel sampler is the strided deterministic DDIM (`ss_meldiff_sample_ddim`), default 50 network evaluations;
+  * default batch = 32 references per target (the per-rank share of a 256-reference sweep on 8 GPUs): the denoiser GEMMs
+    then run 4 rounds of blocks per launch instead of one, where they reach their large-size efficiency (DESIGN.md §5,
+    "Size dependence": 73 % of the fp32 roof at 12 000 rows per launch, 101 % algorithmic at 180 000).
 """
 import torch
 
@@ -57,7 +60,7 @@ class StyleCache:
 
 
 @torch.no_grad()
-def style_transfer_sweep(infer, refs, targets, rank=0, world=1, batch=8, ddim_steps=50, t_bucket=1, vocode=True, emit=None, seed=None):
+def style_transfer_sweep(infer, refs, targets, rank=0, world=1, batch=32, ddim_steps=50, t_bucket=1, vocode=True, emit=None, seed=None):
     """refs[i] = dict(ref_mels [Tr,80], ref_f0 [Tr], spk_embed [256], emo_embed [256]);
     targets[j] = dict(txt_tokens [Tp], note [Tp], note_dur [Tp], note_type [Tp], mel2ph [T]).
     Calls emit(ref_idx, target_idx, mel [T,80], f0 [T], wav [T*hop] or None) per pair; returns the number of pairs done and
