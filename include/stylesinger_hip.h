@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 3 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 

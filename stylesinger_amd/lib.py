@@ -19,6 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
+ABI_VERSION = 3  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -129,6 +130,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.ss_abi_version() != ABI_VERSION:
+        raise StyleSingerHipError(f"libstylesinger_hip.so has ABI {lib.ss_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     sizes = (C.c_int64 * 3)()
     if lib.ss_struct_sizes(sizes, 3) != 0:
         raise StyleSingerHipError("ss_struct_sizes failed")
