@@ -138,8 +138,6 @@ def load():
     mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan))
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
-    if lib.ss_abi_version() != 1:
-        raise StyleSingerHipError("ABI version mismatch")
     _lib = lib
     return lib
 
