@@ -218,6 +218,26 @@ __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args 
   for (int k = 0; k < kchunks; ++k) chunk(std::integral_constant<int, 1>{}, acc[1], k);
   for (int k = 0; k < kchunks; ++k) chunk(std::integral_constant<int, 2>{}, acc[2], k);
   for (int k = 0; k + 1 < kchunks; ++k) chunk(std::integral_constant<int, 3>{}, acc[3], k);
+  // Epilogue operands from HBM (the hoisted conditioner slab, 40 KB row stride -> every element is its own miss) are
+  // fetched BEFORE the last chunk's MFMAs, into the staging registers that chunk no longer needs, so the ~2 us miss
+  // latency hides under 1024+ MFMA cycles instead of stalling every block of the (single) round at the same time.
+  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+  auto frame_of = [&](int pl) {
+    const int p = p0 + wm * 32 + pl;
+    return ((p >> log2d) << (log2d + 1)) + (p & (d - 1));
+  };
+  float pe[TN == 1 ? 32 : 1];  // (TN=2 has no spare registers: 228 of 256 at 2 waves/SIMD; it fetches in the epilogue)
+  if constexpr (TN == 1) {  // frames t and t+d of this wave's operand
+    const int pc = n0 + wn * 32 + l31;
+    const bool col_ok = ((n0 >> 1) + l31) < a.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = frame_of((r & 3) + 8 * (r >> 2) + 4 * lh);
+      pe[r] = (Eb && col_ok && t < a.T) ? Eb[(int64_t)t * a.lde + pc] : 0.f;
+      pe[16 + r] = (Eb && col_ok && t + d < a.T) ? Eb[(int64_t)(t + d) * a.lde + pc] : 0.f;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   {  // last chunk: nothing left to fetch
     const int cur = c & 1;
     const float* Ac = As + cur * BP * LD;
@@ -235,13 +255,8 @@ __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args 
   }
 
   // ---- epilogue: output transform z[t] = m0+m1+m2, z[t+d] = m1-m2-m3, conditioner addend, gate ----
-  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
   float* Cb = a.C + (int64_t)b * a.c_batch_stride;
   const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
-  auto frame_of = [&](int pl) {
-    const int p = p0 + wm * 32 + pl;
-    return ((p >> log2d) << (log2d + 1)) + (p & (d - 1));
-  };
   if constexpr (TN == 2) {
     // the wave owns both gate operands of channels [oc0, oc0+32): columns pc0 (first operand) and pc0+32 (second)
     const int pc0 = n0 + wn * 64 + l31;
@@ -289,11 +304,8 @@ __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args 
       const int t = frame_of(pl);
       const float z0 = acc[0][0][r] + acc[1][0][r] + acc[2][0][r];
       const float z1 = acc[1][0][r] - acc[2][0][r] - acc[3][0][r];
-      float e0 = bs, e1 = bs;
-      if (Eb && col_ok) {
-        if (t < a.T) e0 += Eb[(int64_t)t * a.lde + pc];
-        if (t + d < a.T) e1 += Eb[(int64_t)(t + d) * a.lde + pc];
-      }
+      const float e0 = bs + pe[r], e1 = bs + pe[16 + r];  // prefetched under the last chunk
+      (void)t;
       const float u0 = use_sig ? ss_sigmoid_fast(z0 + e0) : ss_tanh_fast(z0 + e0);
       const float u1 = use_sig ? ss_sigmoid_fast(z1 + e1) : ss_tanh_fast(z1 + e1);
       if (wn == 0) {
