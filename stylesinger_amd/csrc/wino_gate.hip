@@ -226,8 +226,24 @@ __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args 
     const int p = p0 + wm * 32 + pl;
     return ((p >> log2d) << (log2d + 1)) + (p & (d - 1));
   };
-  float pe[TN == 1 ? 32 : 1];  // (TN=2 has no spare registers: 228 of 256 at 2 waves/SIMD; it fetches in the epilogue)
-  if constexpr (TN == 1) {  // frames t and t+d of this wave's operand
+  float pe[TN == 2 ? 64 : 32];
+  if constexpr (TN == 2) {  // frame t of both gate operands through a buffer resource (1 address register per load);
+    // frame t+d is fetched in the epilogue: 228 of the 256 registers of a 2-waves/SIMD kernel are taken
+    const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(Eb ? Eb : Wg), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+    const int pc0 = n0 + wn * 64 + l31;
+    const int dead = (((pc0 >> 6) * 32 + l31) < a.N) ? 0 : (int)0x80000000;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = frame_of((r & 3) + 8 * (r >> 2) + 4 * lh);
+      const int off = ((t * a.lde + pc0) * 4) | dead;
+      pe[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 0, 0));
+      pe[16 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off + 128, 0, 0));
+      const int off2 = (((t + d) * a.lde + pc0) * 4) | dead;
+      pe[32 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off2, 0, 0));
+      pe[48 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off2 + 128, 0, 0));
+    }
+  } else {  // frames t and t+d of this wave's operand
     const int pc = n0 + wn * 32 + l31;
     const bool col_ok = ((n0 >> 1) + l31) < a.N;
 #pragma unroll
@@ -269,10 +285,8 @@ __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args 
       float e0[16], e1[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int t = frame_of((r & 3) + 8 * (r >> 2) + 4 * lh) + half * d;
-        const bool ok = Eb && t < a.T;
-        e0[r] = ok ? Eb[(int64_t)t * a.lde + pc0] : 0.f;
-        e1[r] = ok ? Eb[(int64_t)t * a.lde + pc0 + 32] : 0.f;
+        e0[r] = pe[32 * half + r];  // prefetched under the last chunk
+        e1[r] = pe[32 * half + 16 + r];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -360,7 +374,8 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
   SS_CHECK_ARG(dilation >= 1 && (dilation & (dilation - 1)) == 0 && dilation <= 64, "ss_wino_gate: dilation %d must be a power of two", dilation);
   SS_CHECK_ARG((a.Kp % BK) == 0 && a.Kp >= a.Cin && (a.Cin & 3) == 0 && (a.lda & 3) == 0, "ss_wino_gate: bad K dims");
   SS_CHECK_ARG((a.Np % 64) == 0 && 2 * a.N <= a.Np, "ss_wino_gate: Np=%d must be a multiple of 64 and >= 2*N", a.Np);
-  SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31), "ss_wino_gate: item too large for 32-bit offsets");
+  SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (!a.E || (int64_t)a.T * a.lde * 4 < (1ll << 31)),
+               "ss_wino_gate: item too large for 32-bit offsets");
   int log2d = 0;
   while ((1 << log2d) < dilation) ++log2d;
   const int pairs_per_item = ss_cdiv(a.T, 2 * dilation) * dilation;
