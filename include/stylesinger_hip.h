@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 3 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer */
+#define SS_ABI_VERSION 4 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -255,6 +255,12 @@ typedef struct ss_wavenet {
    * sampler update and all accumulations stay fp32. Winograd weights are ignored in this mode. */
   int32_t mfma_bf16;
   int32_t reserved0;
+  /* optional deferred-skip form: w_skipall = the skip halves of all output projections side by side, packed
+   * [round_up32(C)][L*C] (column l*C + ci = output_projection_l.weight[C + n][ci]); b_skipall[n] = sum_l bias_l[C + n].
+   * When set, the per-layer output projection only computes the residual half and the skip sum is one GEMM per step. */
+  const float* w_skipall;
+  const float* b_skipall;
+  int64_t gs_w_skipall, gs_b_skipall;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -22,6 +22,7 @@ struct WsLayout {
   float* G;   // [B*T][C]
   float* S;   // [B*T][C]
   float* O;   // [B*T][4]   (f0 net output)
+  float* GA;  // [B*T][L*C] gate outputs of ALL layers (deferred-skip mode only, else null)
   int64_t bytes;
 };
 
@@ -42,6 +43,7 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.G = take(rows * net->C);
   w.S = take(rows * net->C);
   w.O = take(rows * 4);
+  w.GA = net->w_skipall ? take(rows * net->L * net->C) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -91,7 +93,10 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
   return ss_conv_gemm(&a, stream);
 }
 
-// the L residual layers + skip projection; X in/out, leaves relu(skip_projection) in G
+// the L residual layers + skip projection; X in/out, leaves relu(skip_projection) in G.
+// Deferred-skip mode (net->w_skipall set): the per-layer output projection only runs its residual half (N = C, no skip
+// read-modify-write), every layer's gate output is kept ([rows][L*C]) and the skip sum of all layers is ONE GEMM with
+// K = L*C at the end of the stack - same products, summed in one accumulator chain instead of layer by layer.
 int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w,
                        hipStream_t stream) {
   const int C = net->C, L = net->L;
@@ -118,9 +123,12 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     a.E = w.E + (int64_t)l * 2 * C;
     a.lde = NE;
     a.e_batch_stride = (int64_t)T * NE;
-    a.C = w.G;
-    a.ldc = C;
-    a.c_batch_stride = (int64_t)T * C;
+    const bool defer = net->w_skipall != nullptr;  // see the note above run_residual_stack
+    const int ldg = defer ? L * C : C;
+    float* Gl = defer ? w.GA + (int64_t)l * C : w.G;
+    a.C = Gl;
+    a.ldc = ldg;
+    a.c_batch_stride = (int64_t)T * ldg;
     a.mfma_bf16 = net->mfma_bf16;
     if (net->n_groups > 1) {
       a.group_size = B / net->n_groups;
@@ -136,12 +144,13 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     }
     // y = output_projection(g) ; x = (x + y[:C]) / sqrt(2) ; skip += y[C:]   (net.py:75-77)
     ss_conv_gemm_args o = base_args(B, T, lens);
-    o.A = w.G;
-    o.lda = C;
-    o.a_batch_stride = (int64_t)T * C;
+    o.A = Gl;
+    o.lda = ldg;
+    o.a_batch_stride = (int64_t)T * ldg;
     o.Cin = C;
     o.W = net->w_out[l];
-    o.N = 2 * C;
+    o.N = defer ? C : 2 * C;  // deferred skip: only the residual half (the first C packed rows) runs per layer
+    if (defer) o.tile = SS_TILE_64x64;
     o.Np = 2 * C;
     o.Kp = round_up32(C);
     o.epi = SS_EPI_RESSKIP;
@@ -157,7 +166,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     o.C2 = w.S;
     o.ldc2 = C;
     o.c2_batch_stride = (int64_t)T * C;
-    o.accumulate = l > 0;
+    o.accumulate = defer ? 0 : l > 0;
     o.mfma_bf16 = net->mfma_bf16;
     if (net->n_groups > 1) {
       o.group_size = B / net->n_groups;
@@ -165,6 +174,30 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       o.bias_group_stride = net->gs_b_out;
     }
     SS_PROPAGATE(ss_conv_gemm(&o, stream));
+  }
+  if (net->w_skipall) {  // S = sum_l skip_l = [g_0 | g_1 | ... | g_{L-1}] . [W_skip_0 ; ... ; W_skip_{L-1}]^T + sum_l b_skip_l
+    ss_conv_gemm_args k = base_args(B, T, lens);
+    k.A = w.GA;
+    k.lda = L * C;
+    k.a_batch_stride = (int64_t)T * L * C;
+    k.Cin = L * C;
+    k.W = net->w_skipall;
+    k.N = C;
+    k.Np = round_up32(C);
+    k.Kp = L * C;
+    k.epi = SS_EPI_STORE;
+    k.bias = net->b_skipall;
+    k.C = w.S;
+    k.ldc = C;
+    k.c_batch_stride = (int64_t)T * C;
+    k.tile = SS_TILE_64x64;
+    k.mfma_bf16 = net->mfma_bf16;
+    if (net->n_groups > 1) {
+      k.group_size = B / net->n_groups;
+      k.w_group_stride = net->gs_w_skipall;
+      k.bias_group_stride = net->gs_b_skipall;
+    }
+    SS_PROPAGATE(ss_conv_gemm(&k, stream));
   }
   // x = relu(skip_projection(sum(skip) / sqrt(L)))   (net.py:124-127)
   ss_conv_gemm_args s = base_args(B, T, lens);

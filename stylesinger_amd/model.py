@@ -131,6 +131,8 @@ class StyleSingerHIP(torch.nn.Module):
         self.use_graphs = os.environ.get("SS_GRAPHS", "auto")
         # Winograd F(2,3) for the denoisers' 3-tap dilated convs (1.5x fewer matrix ops, fp32-rounding-equal results)
         self.use_wino = os.environ.get("SS_WINO", "1") not in ("0", "off", "false")
+        # per-layer output projection = residual half only; skip sum of all layers as one K = L*C GEMM per step
+        self.defer_skip = os.environ.get("SS_DEFER_SKIP", "1") not in ("0", "off", "false")
         self.bf16 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16"
         if self.bf16:
             self.use_wino = False  # the transform would amplify the operand rounding; the matrix pipe is not the limit in bf16
@@ -227,6 +229,11 @@ class StyleSingerHIP(torch.nn.Module):
                 t[f"w_dil_wino.{l}"] = L.pack_conv_weight(wt, interleave_half=C)
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
+        if self.defer_skip:  # skip halves of all output projections side by side: [C][L*C], column l*C + ci
+            wsk = torch.cat([self.p(f"{prefix}.residual_layers.{l}.output_projection.weight")[C:, :, 0] for l in range(Lyr)], dim=1)
+            bsk = torch.stack([self.p(f"{prefix}.residual_layers.{l}.output_projection.bias")[C:] for l in range(Lyr)]).sum(0)
+            t["w_skipall"] = L.pack_conv_weight(wsk[:, :, None].contiguous())
+            t["b_skipall"] = L.pack_bias(bsk.contiguous())
         t["dstep"] = dstep
         t["w_cond"] = torch.cat(wc_rows, 0).contiguous()
         t["b_cond"] = torch.cat(bc_rows, 0).contiguous()
@@ -256,7 +263,8 @@ class StyleSingerHIP(torch.nn.Module):
             keep.append(tt)
             return tt.data_ptr(), gs
 
-        for key in ("w_in", "b_in", "dstep", "w_cond", "b_cond", "w_skip", "b_skip", "w_final", "b_final") + (("uv_embed",) if f0 else ()):
+        for key in ("w_in", "b_in", "dstep", "w_cond", "b_cond", "w_skip", "b_skip", "w_final", "b_final") + (("uv_embed",) if f0 else ()) \
+                + (("w_skipall", "b_skipall") if self.defer_skip else ()):
             ptr_, gs = place(key)
             setattr(net, key, ptr_)
             setattr(net, "gs_" + key, gs)
