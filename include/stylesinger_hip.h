@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 4 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip */
+#define SS_ABI_VERSION 5 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -261,6 +261,11 @@ typedef struct ss_wavenet {
   const float* w_skipall;
   const float* b_skipall;
   int64_t gs_w_skipall, gs_b_skipall;
+  /* 1 = w_skipall / b_skipall are pre-multiplied by skip_projection / sqrt(L) (no nonlinearity sits between the skip sum
+   * and skip_projection, net.py:124-126): the K = L*C GEMM + ReLU then IS the stack output and the skip_projection
+   * launch disappears. */
+  int32_t skipall_folded;
+  int32_t reserved1;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -197,6 +197,11 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       k.w_group_stride = net->gs_w_skipall;
       k.bias_group_stride = net->gs_b_skipall;
     }
+    if (net->skipall_folded) {  // w_skipall already carries skip_projection / sqrt(L): this GEMM + ReLU is the stack's output
+      k.act = SS_ACT_RELU;
+      k.C = w.G;
+      return ss_conv_gemm(&k, stream);
+    }
     SS_PROPAGATE(ss_conv_gemm(&k, stream));
   }
   // x = relu(skip_projection(sum(skip) / sqrt(L)))   (net.py:124-127)

@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 4  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 5  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -63,7 +63,7 @@ class WaveNet(C.Structure):
     ] + [(n, C.c_int64) for n in ("gs_w_in", "gs_b_in", "gs_uv_embed", "gs_dstep", "gs_w_dil", "gs_w_out", "gs_b_out", "gs_w_cond",
                                   "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")] \
         + [("mfma_bf16", C.c_int32), ("reserved0", C.c_int32), ("w_skipall", _vp), ("b_skipall", _vp),
-           ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64)]
+           ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class HifiGan(C.Structure):

@@ -134,6 +134,9 @@ class StyleSingerHIP(torch.nn.Module):
         # per-layer output projection = residual half only; skip sum of all layers as one K = L*C GEMM per step
         self.defer_skip = os.environ.get("SS_DEFER_SKIP", "1") not in ("0", "off", "false")
         self.bf16 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16"
+        # fold skip_projection / sqrt(L) into the skip-all weights (fp32 mode only: in bf16 mode the operand rounding of the
+        # two separate GEMMs is part of the stated arithmetic)
+        self.fold_skip = self.defer_skip and not self.bf16 and os.environ.get("SS_FOLD_SKIP", "1") not in ("0", "off", "false")
         if self.bf16:
             self.use_wino = False  # the transform would amplify the operand rounding; the matrix pipe is not the limit in bf16
         self._plans = {}
@@ -232,6 +235,12 @@ class StyleSingerHIP(torch.nn.Module):
         if self.defer_skip:  # skip halves of all output projections side by side: [C][L*C], column l*C + ci
             wsk = torch.cat([self.p(f"{prefix}.residual_layers.{l}.output_projection.weight")[C:, :, 0] for l in range(Lyr)], dim=1)
             bsk = torch.stack([self.p(f"{prefix}.residual_layers.{l}.output_projection.bias")[C:] for l in range(Lyr)]).sum(0)
+            if self.fold_skip:  # skip_projection(sum/sqrt(L)) is linear in the g_l: fold it into the weights (float64 product)
+                ws_ = self.p(prefix + ".skip_projection.weight")[:, :, 0].double()
+                bs_ = self.p(prefix + ".skip_projection.bias").double()
+                r = 1.0 / math.sqrt(Lyr)
+                bsk = (ws_ @ bsk.double() * r + bs_).float()
+                wsk = (ws_ @ wsk.double() * r).float()
             t["w_skipall"] = L.pack_conv_weight(wsk[:, :, None].contiguous())
             t["b_skipall"] = L.pack_bias(bsk.contiguous())
         t["dstep"] = dstep
@@ -278,6 +287,7 @@ class StyleSingerHIP(torch.nn.Module):
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
         net.mfma_bf16 = 1 if self.bf16 else 0
+        net.skipall_folded = 1 if self.fold_skip else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):
             arr = np.ascontiguousarray(self.p(f"{gen}.{name}").detach().cpu().numpy().astype(np.float32))
