@@ -381,14 +381,15 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
   const int pairs_per_item = ss_cdiv(a.T, 2 * dilation) * dilation;
   const int p_tiles_per_item = ss_cdiv(pairs_per_item, BP);
   const int p_tiles = p_tiles_per_item * a.B;
-  // tile choice: 64x128 (TN=2) has twice the MFMAs per barrier but 228 registers (2 blocks/CU); 64x64 (TN=1) runs 3
-  // blocks/CU. A makespan model picks; measured with tools/kbench.py (graph-timed): mel C2 (768 / 384 blocks) 92.6 vs
-  // 92.8 us, f0 pair (1152 / 576 blocks) 120.8 vs 112.5 us -> TN=1 for mel, TN=2 for the f0 pair.
+  // tile choice: 64x128 (TN=2) has twice the MFMAs per barrier but 256 registers (2 blocks/CU = 512 slots); 64x64 (TN=1)
+  // runs 3 blocks/CU (768 slots). Measured with tools/kbench.py (graph-timed, after the addend prefetch): mel C2
+  // (752 / 376 blocks) TN=1 84.0 us; f0 pair (1152 / 576 blocks) TN=1 104.7 vs TN=2 112.0 us -> TN=1 while its grid is
+  // at most two rounds; beyond that a makespan model picks (TN=2 wins once there are many rounds).
   int tn = a.tile == SS_TILE_64x128 ? 2 : a.tile == SS_TILE_64x64 ? 1 : 0;
   if (tn == 0) {
     const long b2 = (long)p_tiles * ss_cdiv(a.Np, 128), b1 = (long)p_tiles * (a.Np / 64);
     const double t2 = (double)ss_cdiv(b2, 256) * 2.0 / 0.92, t1 = (double)ss_cdiv(b1, 256) * 1.0 / 0.75;
-    tn = ((a.Np % 128) == 0 && t2 <= t1) ? 2 : 1;
+    tn = ((a.Np % 128) == 0 && b1 > 2 * 768 && t2 <= t1) ? 2 : 1;
   }
   if (tn == 2) {
     SS_CHECK_ARG((a.Np % 128) == 0, "ss_wino_gate: TN=2 needs Np multiple of 128");
