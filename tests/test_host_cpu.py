@@ -175,3 +175,27 @@ def test_checkpoint_intake_reads_both_reference_layouts(tmp_path):
         g = HifiGanGeneratorHIP(c)
         g.load_state_dict(st, strict=True)
         assert c["upsample_rates"] == cfg["upsample_rates"]
+
+
+def test_frontend_host_tables_match_the_oracle():
+    """The host-built tables of the GPU mel front end (Slaney filterbank) against oracle/frontend.py, itself pinned by
+    librosa's documented known answers; pure numpy, no GPU."""
+    import numpy as np
+    from oracle import frontend as F
+    from stylesinger_amd.frontend import mel_filterbank
+    for sr, n_fft, n_mels, fmin, fmax in ((48000, 1024, 80, 20, 24000), (22050, 2048, 128, 0.0, 11025.0), (22050, 1024, 80, 80, 7600)):
+        a = mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+        b = F.mel_basis(sr, n_fft, n_mels, fmin, fmax)
+        assert a.shape == b.shape == (n_mels, 1 + n_fft // 2)
+        assert np.abs(a - b).max() <= 1e-7
+
+
+def test_sampler_schedules_and_mode_flags():
+    from stylesinger_amd.model import StyleSingerHIP
+    m = StyleSingerHIP(None, hparams=config.make_hparams(dict(timesteps=100, K_step=100, f0_timesteps=100)))
+    ts = m.ddim_timesteps(50)
+    assert ts[0] == 99 and ts[-1] == 0 and len(ts) == 50 and all(a > b for a, b in zip(ts, ts[1:]))
+    assert m.ddim_timesteps(1000) == list(range(99, -1, -1)) and m.ddim_timesteps(1) == [0]
+    assert not m.bf16 and m.use_wino and m.defer_skip and m.fold_skip
+    mb = StyleSingerHIP(None, hparams=config.make_hparams(dict(mfma_precision="bf16")))
+    assert mb.bf16 and not mb.use_wino and mb.defer_skip and not mb.fold_skip
