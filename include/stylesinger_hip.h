@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 5 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection */
+#define SS_ABI_VERSION 6 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -290,9 +290,10 @@ int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const float* cond, c
                            int64_t ws_bytes, void* stream);
 
 /* PLMS ("pndm_speedup") sampler of the reference: modules/diff/shallow_diffusion_tts.py:165-197 (p_sample_plms) driven as
- * in :254-260 - network times reversed(range(0, steps, interval)), 4-deep eps history, two network evaluations on the
- * first step. `hist` = device scratch of 6*B*T*in_dim floats. alphas_cumprod: HOST table [steps]. */
-int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T, int interval,
+ * in :254-260 - network times reversed(range(0, step_hi, interval)) with step_hi = K_step (the shallow-diffusion depth x
+ * was q-sampled to; <= steps), 4-deep eps history, two network evaluations on the first step. `hist` = device scratch of
+ * 6*B*T*in_dim floats. alphas_cumprod: HOST table [steps]. */
+int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T, int step_hi, int interval,
                            const float* alphas_cumprod, int precompute, float* hist, void* ws, int64_t ws_bytes, void* stream);
 /* q_sample + norm_spec: x = sqrt_ac*((mel-min)/(max-min)*2-1) + sqrt_1mac*z  (shallow_diffusion_tts.py:199-204,271-272) */
 int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac, float sqrt_1mac,
@@ -372,6 +373,9 @@ int ss_log10_floor(const float* x, float* y, int64_t n, float eps, void* stream)
  * out_wav_norm is set); saturating. */
 int ss_wav_to_pcm16(const float* wav, int16_t* pcm, int64_t n, float scale, void* stream);
 int ss_fill_normal(float* x, int64_t n, uint64_t seed, const uint64_t* seed_dev, uint64_t offset, void* stream);
+/* x[b][t] ~ N(0,1) for t < T with Philox counter (t/4, b): the values of the first T' <= T columns do not depend on T, so
+ * padding the frame axis to a hipGraph bucket leaves the noise of the real frames unchanged. ld = row stride (floats). */
+int ss_fill_normal_rows(float* x, int B, int T, int ld, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,9 +40,14 @@ def tape_rng(tape):
         torch.randn, torch.rand, torch.randn_like, torch.rand_like = o
 
 
-def build_reference(steps_mel, steps_f0, seed=1234):
-    R = refimport.load(dict(timesteps=steps_mel, K_step=steps_mel, f0_timesteps=steps_f0))
-    hp = config.make_hparams(dict(timesteps=steps_mel, K_step=steps_mel, f0_timesteps=steps_f0))
+def build_reference(steps_mel, steps_f0, seed=1234, hp_over=None):
+    """`hp_over`: further hparams overrides (K_step < timesteps, decoder='prodiff', schedule_type ...). The reference reads
+    the GLOBAL hparams dict at construction, so the keys a previous case may have changed are always reset here."""
+    over = dict(timesteps=steps_mel, K_step=steps_mel, f0_timesteps=steps_f0, decoder="diffsinger", schedule_type="linear",
+                timescale=1)
+    over.update(hp_over or {})
+    R = refimport.load(over)
+    hp = config.make_hparams(over)
     model = R["StyleSinger"](refimport.FakeDict(hp["vocab_size"]))
     sd = synth.synth_acoustic_state_dict(hp, seed)
     model.load_state_dict(sd, strict=True)
@@ -50,8 +55,8 @@ def build_reference(steps_mel, steps_f0, seed=1234):
     return model, hp, sd
 
 
-def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True, seed=1234, keep_stages=True):
-    model, hp, sd = build_reference(steps_mel, steps_f0, seed)
+def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True, seed=1234, keep_stages=True, hp_over=None):
+    model, hp, sd = build_reference(steps_mel, steps_f0, seed, hp_over)
     batch = synth.synth_batch(B, T, Tp, Tr, hp, seed)
     tape = synth.NoiseTape(seed + 1)
     stages = {}
@@ -64,7 +69,8 @@ def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True,
         hooks.append(model.encoder.register_forward_hook(grab("encoder_out")))
         hooks.append(model.style_extractor.encoder.register_forward_hook(grab("style_pre_rq")))
         hooks.append(model.style_extractor.register_forward_hook(grab("style_rq", lambda o: o[0])))
-        hooks.append(model.ln_proj.register_forward_hook(grab("diff_cond")))
+        if hasattr(model, "ln_proj"):
+            hooks.append(model.ln_proj.register_forward_hook(grab("diff_cond")))
         hooks.append(model.decoder.register_forward_hook(grab("decoder_out")))
     with torch.no_grad(), tape_rng(tape):
         ret = model(batch["txt_tokens"], mel2ph=batch["mel2ph"] if give_mel2ph else None, spk_embed=batch["spk_embed"],
@@ -78,7 +84,7 @@ def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True,
         out["dur_choice"] = ret["dur_choice"].clone()
     out.update(stages)
     meta = dict(B=B, T=T, Tp=Tp, Tr=Tr, steps_mel=steps_mel, steps_f0=steps_f0, give_mel2ph=give_mel2ph, seed=seed,
-                tape_seed=seed + 1, tape_log=tape.log)
+                tape_seed=seed + 1, tape_log=tape.log, hp_over=dict(hp_over or {}))
     torch.save(dict(meta=meta, out=out), os.path.join(GOLD, name + ".pt"))
     print(f"[gen_golden] {name}: T_out={out['mel_out'].shape[1]} draws={len(tape.log)} keys={sorted(out)}")
 
@@ -107,12 +113,12 @@ def run_vocoder_case(name, B, T, seed=1234):
     print(f"[gen_golden] {name}: wav {tuple(wav.shape)} draws={len(tape.log)}")
 
 
-def run_plms_case(name, T, steps_mel, interval, seed=1234):
+def run_plms_case(name, T, steps_mel, interval, seed=1234, k_step=None):
     """The reference's PLMS sampler (GaussianDiffusion.p_sample_plms, shallow_diffusion_tts.py:165-197) driven exactly as
     GaussianDiffusion.forward drives it under hparams['pndm_speedup'] (:239-260), on the StyleSinger model's own `postdiff`
     (DiffusionDecoder inherits the method). B = 1: the reference's `max(t - interval, 0)` only works for one utterance."""
     from collections import deque
-    model, hp, sd = build_reference(steps_mel, 2, seed)
+    model, hp, sd = build_reference(steps_mel, 2, seed, dict(K_step=k_step) if k_step else None)
     pd = model.postdiff
     g = torch.Generator().manual_seed(seed + 11)
     coarse = (torch.randn(1, T, 80, generator=g) * 0.8 - 3.0).clamp(-6, 0.5)
@@ -126,9 +132,60 @@ def run_plms_case(name, T, steps_mel, interval, seed=1234):
         for i in reversed(range(0, t, interval)):
             x = pd.p_sample_plms(x, torch.full((1,), i, dtype=torch.long), interval, cond.transpose(1, 2))
         mel = pd.denorm_spec(x[:, 0].transpose(1, 2))
-    torch.save(dict(meta=dict(T=T, steps_mel=steps_mel, interval=interval, seed=seed, tape_seed=seed + 3, tape_log=tape.log),
+    torch.save(dict(meta=dict(T=T, steps_mel=steps_mel, interval=interval, seed=seed, tape_seed=seed + 3, tape_log=tape.log,
+                              k_step=k_step or steps_mel),
                     inp=dict(coarse_mel=coarse, cond=cond), out=dict(mel_out=mel.clone())), os.path.join(GOLD, name + ".pt"))
     print(f"[gen_golden] {name}: mel {tuple(mel.shape)} draws={len(tape.log)}")
+
+
+def run_emotion_case(name, n_partials, seed=1234):
+    """The reference emotion encoder (data_gen/tts/emotion/model.py:11-78) on synthetic 40-mel partials, driven as
+    inference.py:39-53,139-151 drives it: `inference()` on the [P,160,40] batch, mean over partials, L2 normalise."""
+    refimport.load()
+    import numpy as np
+    from data_gen.tts.emotion.model import EmotionEncoder
+    enc = EmotionEncoder(torch.device("cpu"), torch.device("cpu"))
+    sd = synth.synth_emotion_state_dict(seed)
+    enc.load_state_dict(sd, strict=True)
+    enc.eval()
+    frames = synth.synth_emotion_frames(n_partials, seed=seed)
+    with torch.no_grad():
+        partial = enc.inference(frames)
+        full = enc(frames)
+    raw = np.mean(partial.numpy(), axis=0)
+    embed = raw / np.linalg.norm(raw, 2)
+    torch.save(dict(meta=dict(n_partials=n_partials, seed=seed, keys=[[k, list(v.shape)] for k, v in enc.state_dict().items()]),
+                    out=dict(partial_embeds=partial.clone(), embed=torch.from_numpy(embed), forward_embeds=full.clone())),
+               os.path.join(GOLD, name + ".pt"))
+    print(f"[gen_golden] {name}: partial {tuple(partial.shape)}")
+
+
+def dump_extra_param_specs():
+    """Pin the ProDiff-decoder and emotion-encoder state_dict contracts (names + shapes) next to the main ones."""
+    import json
+    model, hp, sd = build_reference(8, 2, 1234, dict(decoder="prodiff", schedule_type="vpsde"))
+    from data_gen.tts.emotion.model import EmotionEncoder
+    enc = EmotionEncoder(torch.device("cpu"), torch.device("cpu"))
+    path = os.path.join(GOLD, "param_spec.json")
+    d = json.load(open(path))
+    d["acoustic_prodiff"] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    d["emotion"] = [[k, list(v.shape)] for k, v in enc.state_dict().items()]
+    json.dump(d, open(path, "w"))
+    print(f"[gen_golden] param_spec.json: +acoustic_prodiff ({len(d['acoustic_prodiff'])}) +emotion ({len(d['emotion'])})")
+
+
+def round2_cases():
+    # BASELINE config 4's schedule: 1000 mel steps (sqrt_recip coefficients reach ~3e6, shallow_diffusion_tts.py:99-119)
+    run_acoustic_case("acoustic_t32_mel1000", B=1, T=32, Tp=4, Tr=32, steps_mel=1000, steps_f0=4, keep_stages=False)
+    # PLMS with a shallow depth K_step < timesteps (ADVICE r1)
+    run_plms_case("plms_t32_k12of20_i3", T=32, steps_mel=20, interval=3, k_step=12)
+    # ProDiff teacher decoder (modules/diff/prodiff.py:59-221): 8 steps, x0-prediction, both schedules
+    run_acoustic_case("prodiff_t40_vpsde", B=1, T=40, Tp=5, Tr=36, steps_mel=8, steps_f0=3, keep_stages=False,
+                      hp_over=dict(decoder="prodiff", schedule_type="vpsde"))
+    run_acoustic_case("prodiff_b2_t32_linear", B=2, T=32, Tp=4, Tr=30, steps_mel=8, steps_f0=3, keep_stages=False,
+                      hp_over=dict(decoder="prodiff", schedule_type="linear"))
+    run_emotion_case("emotion_p5", n_partials=5)
+    dump_extra_param_specs()
 
 
 def main():
@@ -136,6 +193,13 @@ def main():
     if "--only-plms" in sys.argv:
         run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)
         run_plms_case("plms_t24_k12_i4", T=24, steps_mel=12, interval=4)
+        return
+    if "--round2" in sys.argv:
+        round2_cases()
+        return
+    if "--emotion" in sys.argv:
+        run_emotion_case("emotion_p5", n_partials=5)
+        dump_extra_param_specs()
         return
     run_acoustic_case("acoustic_tiny_s4", B=1, T=48, Tp=6, Tr=40, steps_mel=4, steps_f0=4)
     run_acoustic_case("acoustic_b2_s3", B=2, T=40, Tp=5, Tr=36, steps_mel=3, steps_f0=3)
@@ -145,6 +209,7 @@ def main():
     run_vocoder_case("vocoder_b2_t9", B=2, T=9)
     run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)
     run_plms_case("plms_t24_k12_i4", T=24, steps_mel=12, interval=4)
+    round2_cases()
 
 
 if __name__ == "__main__":

@@ -15,7 +15,8 @@ def load_case(name):
 
 
 def case_setup(meta):
-    hp = config.make_hparams(dict(timesteps=meta["steps_mel"], K_step=meta["steps_mel"], f0_timesteps=meta["steps_f0"]))
+    hp = config.make_hparams(dict(timesteps=meta["steps_mel"], K_step=meta["steps_mel"], f0_timesteps=meta["steps_f0"],
+                                  **meta.get("hp_over", {})))
     sd = synth.synth_acoustic_state_dict(hp, meta["seed"])
     batch = synth.synth_batch(meta["B"], meta["T"], meta["Tp"], meta["Tr"], hp, meta["seed"])
     return hp, sd, batch

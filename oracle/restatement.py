@@ -429,6 +429,26 @@ def mel_diffusion(sd, hp, coarse_mel, cond, tape, trace=None):
     return (x + 1) / 2 * (smax - smin) + smin
 
 
+def prodiff_sample(sd, hp, cond, tape, trace=None):
+    """ProDiffusion.forward infer branch (modules/diff/prodiff.py:205-221): x ~ N(0,1); for t = T-1..0 the denoiser predicts
+    x0 DIRECTLY (:150-153, no clamp) and q_posterior_sample (:141-148) draws x_{t-1}; norm/denorm are identities (:223-227).
+    The posterior noise is drawn at every step, t = 0 included (multiplied by 0 there)."""
+    g = lambda k: sd[f"diff_decoder.{k}"]
+    B, T, _ = cond.shape
+    M = hp["audio_num_mel_bins"]
+    x = tape.randn(B, 1, M, T)[:, 0].transpose(1, 2)
+    for i in reversed(range(int(hp["timesteps"]))):
+        t = torch.full((B,), i, dtype=torch.long)
+        x0 = diffnet(sd, hp, x, t, cond, prefix="diff_decoder.denoise_fn")
+        mean = g("posterior_mean_coef1")[i] * x0 + g("posterior_mean_coef2")[i] * x
+        z = tape.randn(B, 1, M, T)[:, 0].transpose(1, 2)
+        nz = 0.0 if i == 0 else 1.0
+        x = mean + nz * (0.5 * g("posterior_log_variance_clipped")[i]).exp() * z
+        if trace is not None:
+            trace.append((i, x.clone()))
+    return x
+
+
 def mel_ddim(sd, hp, coarse_mel, cond, tape, ts):
     """Deterministic strided sampler (DDIM, eta=0; Song et al. 2021 eq. 12) over the reference's DiffNet and schedule.
     NOT in the reference (BASELINE config 5 is "new; no reference sampler"): this restatement is the only oracle."""
@@ -528,6 +548,9 @@ def acoustic_forward(sd, hp, inp, tape, mel2ph=None, stages=None):
     ret["pitch_coarse"] = coarse
     pitch_emb = sd["pitch_embed.weight"][coarse]
     ret["decoder_inp"] = dec_inp = (dec_inp + spk + pitch_emb + emo + style) * keep
+    if hp.get("decoder", "diffsinger") == "prodiff":  # stylesinger.py:175-177: the diffusion decoder takes decoder_inp as its condition
+        ret["mel_out"] = prodiff_sample(sd, hp, dec_inp, tape)
+        return ret
     pad = dec_inp.abs().sum(-1) == 0
     ret["decoder_out"] = h = fft_blocks(sd, "decoder", dec_inp, pad, hp["dec_layers"], hp["num_heads"], True)
     ret["fs2_mel"] = coarse_mel = F.linear(h, sd["mel_out.weight"], sd["mel_out.bias"]) * keep
@@ -537,6 +560,45 @@ def acoustic_forward(sd, hp, inp, tape, mel2ph=None, stages=None):
     ret["diff_cond"] = cond = F.linear(gcat, sd["ln_proj.weight"], sd["ln_proj.bias"])
     ret["mel_out"] = mel_diffusion(sd, hp, coarse_mel, cond, tape)
     return ret
+
+
+# ------------------------------------------------------------------------------------------------
+# emotion encoder (input producer): data_gen/tts/emotion/model.py:11-78, inference.py:39-53,139-151
+# ------------------------------------------------------------------------------------------------
+def emotion_lstm(esd, frames, layers=3):
+    """nn.LSTM(40, 256, 3, batch_first=True) restated step by step (gate order i, f, g, o; torch.nn.LSTM docs);
+    frames [P, n_frames, 40] -> final hidden state of the last layer [P, 256] (= EmotionEncoder.inference, model.py:62-78)."""
+    x = frames
+    for l in range(layers):
+        w_ih, w_hh = esd[f"lstm.weight_ih_l{l}"], esd[f"lstm.weight_hh_l{l}"]
+        b = esd[f"lstm.bias_ih_l{l}"] + esd[f"lstm.bias_hh_l{l}"]
+        H = w_hh.shape[1]
+        P, n, _ = x.shape
+        xp = F.linear(x, w_ih, b)  # [P, n, 4H]
+        h = torch.zeros(P, H)
+        c = torch.zeros(P, H)
+        outs = []
+        for t in range(n):
+            gts = xp[:, t] + F.linear(h, w_hh)
+            i, f, g, o = gts[:, :H], gts[:, H:2 * H], gts[:, 2 * H:3 * H], gts[:, 3 * H:]
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        x = torch.stack(outs, 1)
+    return x[:, -1]
+
+
+def emotion_embed(esd, frames):
+    """embed_utterance's tail (inference.py:147-151): mean of the partial embeddings, L2-normalised."""
+    partial = emotion_lstm(esd, frames)
+    raw = partial.mean(0)
+    return raw / raw.norm(2), partial
+
+
+def emotion_forward(esd, frames):
+    """EmotionEncoder.forward (model.py:40-60): relu(linear(h_last)), L2-normalised per row (training-time embedding)."""
+    e = F.relu(F.linear(emotion_lstm(esd, frames), esd["linear.weight"], esd["linear.bias"]))
+    return e / e.norm(dim=1, keepdim=True)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -543,9 +543,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
           const float mean = a.ddpm_c1 * x0 + a.ddpm_c2 * x;
           float z = zv[r];
           if (a.ddpm_sigma != 0.f && !a.noise) {
-            const int64_t idx = ((int64_t)b * a.T + row) * a.N + col;
-            uint32_t o[4];
-            rng.gen((uint32_t)idx, (uint32_t)(idx >> 32), a.step, 0x4d454c44u, o);
+            uint32_t o[4];  // counter = (element of the item, item): the draw does not depend on how far T is padded
+            rng.gen((uint32_t)(row * a.N + col), (uint32_t)b, a.step, 0x4d454c44u, o);
             float z1;
             ss_boxmuller(o[0], o[1], z, z1);
           }

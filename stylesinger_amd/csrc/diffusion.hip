@@ -282,7 +282,7 @@ __global__ void f0_update_kernel(const float* __restrict__ O, float* __restrict_
     }
     if (!noise || !gumbel_u) {
       uint32_t o[4];
-      rng.gen((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)step, 0x46305556u, o);
+      rng.gen((uint32_t)t, (uint32_t)b, (uint32_t)step, 0x46305556u, o);  // counter = (frame, item): invariant to T padding
       float z0, z1;
       ss_boxmuller(o[0], o[1], z0, z1);
       if (!noise) z = z0;
@@ -327,9 +327,10 @@ __global__ void f0_update_kernel(const float* __restrict__ O, float* __restrict_
 __global__ void mel_qsample_kernel(const float* __restrict__ mel, const float* __restrict__ smin,
                                    const float* __restrict__ smax, float sa, float s1, const float* __restrict__ noise,
                                    uint64_t seed, const uint64_t* __restrict__ seed_dev, float* __restrict__ x, int64_t rows,
-                                   int M) {
+                                   int T, int M) {
   const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
   const int64_t n = rows * M;
+  const int64_t per_item = (int64_t)T * M;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % M);
     const float xs = (mel[i] - smin[c]) / (smax[c] - smin[c]) * 2.0f - 1.0f;
@@ -337,7 +338,7 @@ __global__ void mel_qsample_kernel(const float* __restrict__ mel, const float* _
     if (noise) z = noise[i];
     else {
       uint32_t o[4];
-      rng.gen((uint32_t)i, (uint32_t)(i >> 32), 0xffffffffu, 0x4d454c44u, o);
+      rng.gen((uint32_t)(i % per_item), (uint32_t)(i / per_item), 0xffffffffu, 0x4d454c44u, o);  // (element of item, item)
       float z1;
       ss_boxmuller(o[0], o[1], z, z1);
     }
@@ -571,12 +572,13 @@ __global__ void plms_update_kernel(const float* __restrict__ x, float* __restric
 }  // namespace
 
 extern "C" int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
-                                      int interval, const float* alphas_cumprod, int do_precompute, float* hist, void* ws,
-                                      int64_t ws_bytes, void* stream_) {
+                                      int step_hi, int interval, const float* alphas_cumprod, int do_precompute, float* hist,
+                                      void* ws, int64_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SS_CHECK_ARG(net && x && cond && ws && hist && alphas_cumprod, "ss_meldiff_sample_plms: null pointer");
   SS_CHECK_ARG(net->n_groups <= 1 && net->L > 0 && net->L <= SS_MAX_LAYERS, "ss_meldiff_sample_plms: bad net");
-  SS_CHECK_ARG(interval >= 1 && interval < net->steps, "ss_meldiff_sample_plms: interval=%d must be in [1, steps)", interval);
+  SS_CHECK_ARG(step_hi >= 1 && step_hi <= net->steps, "ss_meldiff_sample_plms: step_hi=%d must be in [1, steps]", step_hi);
+  SS_CHECK_ARG(interval >= 1 && interval < step_hi, "ss_meldiff_sample_plms: interval=%d must be in [1, step_hi)", interval);
   const WsLayout w = ws_layout(net, B, T, ws);
   SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_meldiff_sample_plms: workspace too small");
   const int64_t n = (int64_t)B * T * net->in_dim;
@@ -586,7 +588,7 @@ extern "C" int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const flo
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
   const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   int n_hist = 0, cur = 0;
-  const int t_first = (net->steps - 1) / interval * interval;  // reversed(range(0, K, interval))
+  const int t_first = (step_hi - 1) / interval * interval;  // reversed(range(0, K_step, interval)), shallow_diffusion_tts.py:254-260
   for (int t = t_first; t >= 0; t -= interval) {
     const int tp = t - interval > 0 ? t - interval : 0;
     const float a_t = alphas_cumprod[t], a_p = alphas_cumprod[tp];
@@ -670,7 +672,7 @@ extern "C" int ss_mel_qsample(const float* coarse_mel, const float* spec_min, co
                               int T, int M, void* stream) {
   SS_CHECK_ARG(coarse_mel && spec_min && spec_max && x, "ss_mel_qsample: null pointer");
   hipLaunchKernelGGL(mel_qsample_kernel, dim3(grid_for((int64_t)B * T * M)), dim3(256), 0, (hipStream_t)stream, coarse_mel,
-                     spec_min, spec_max, sqrt_ac, sqrt_1mac, noise, seed, seed_dev, x, (int64_t)B * T, M);
+                     spec_min, spec_max, sqrt_ac, sqrt_1mac, noise, seed, seed_dev, x, (int64_t)B * T, T, M);
   SS_CHECK_LAUNCH("ss_mel_qsample");
   return SS_OK;
 }

@@ -264,6 +264,22 @@ __global__ void fill_normal_kernel(float* __restrict__ x, int64_t n, uint64_t se
   }
 }
 
+__global__ void fill_normal_rows_kernel(float* __restrict__ x, int B, int T, int ld, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
+  const int q = (T + 3) / 4;
+  const int64_t n = (int64_t)B * q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / q), t4 = (int)(i % q);
+    uint32_t o[4];
+    rng.gen((uint32_t)t4, (uint32_t)b, 0x46494c4cu, 1u, o);
+    float z[4];
+    ss_boxmuller(o[0], o[1], z[0], z[1]);
+    ss_boxmuller(o[2], o[3], z[2], z[3]);
+    for (int k = 0; k < 4; ++k)
+      if (t4 * 4 + k < T) x[(int64_t)b * ld + t4 * 4 + k] = z[k];
+  }
+}
+
 inline int grid_for(int64_t work_items, int block = 256, int cap = 8192) {
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;
@@ -453,6 +469,14 @@ extern "C" int ss_wav_to_pcm16(const float* wav, int16_t* pcm, int64_t n, float 
   SS_CHECK_ARG(wav && pcm && n > 0, "ss_wav_to_pcm16: bad args");
   hipLaunchKernelGGL(pcm16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, wav, pcm, n, scale);
   SS_CHECK_LAUNCH("ss_wav_to_pcm16");
+  return SS_OK;
+}
+
+extern "C" int ss_fill_normal_rows(float* x, int B, int T, int ld, uint64_t seed, const uint64_t* seed_dev, void* stream) {
+  SS_CHECK_ARG(x && B > 0 && T > 0 && ld >= T, "ss_fill_normal_rows: bad args");
+  hipLaunchKernelGGL(fill_normal_rows_kernel, dim3(grid_for((int64_t)B * ((T + 3) / 4))), dim3(256), 0, (hipStream_t)stream, x, B, T, ld,
+                     seed, seed_dev);
+  SS_CHECK_LAUNCH("ss_fill_normal_rows");
   return SS_OK;
 }
 

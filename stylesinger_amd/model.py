@@ -8,6 +8,7 @@ the class and keep `load_ckpt(model, ..., 'model', strict=False)`.
 All arithmetic runs in libstylesinger_hip.so (hand-written gfx950 kernels) through `lib.py`; torch is
 used for device buffers, views/concats (data movement only) and the stream.  There is no CPU path.
 """
+import collections
 import math
 
 import numpy as np
@@ -90,6 +91,19 @@ class _DiffPlan:
         self.g_mel = None
         self.g_ddim = {}
         self.plms_hist = None
+        self.uses = 0   # forwards that asked for this shape (auto mode captures on the second one)
+        self.bytes = sum(t.numel() * t.element_size() for t in vars(self).values() if torch.is_tensor(t)) \
+            + sum(w.numel() for _, w in self.ws_mel)
+
+
+def _pad_frames(x, T, dim=-1):
+    """Zero-pad axis `dim` of x to T frames (hipGraph bucket padding; padded frames are masked everywhere)."""
+    n = x.shape[dim]
+    if n == T:
+        return x
+    pad = [0, 0] * x.dim()
+    pad[2 * (x.dim() - 1 - (dim % x.dim())) + 1] = T - n
+    return torch.nn.functional.pad(x, pad)
 
 
 def _capture(fn):
@@ -139,7 +153,14 @@ class StyleSingerHIP(torch.nn.Module):
         self.fold_skip = self.defer_skip and not self.bf16 and os.environ.get("SS_FOLD_SKIP", "1") not in ("0", "off", "false")
         if self.bf16:
             self.use_wino = False  # the transform would amplify the operand rounding; the matrix pipe is not the limit in bf16
-        self._plans = {}
+        # diffusion plans (workspaces + captured hipGraphs) are keyed by (B, T bucket): frames are padded up to a multiple of
+        # `t_bucket` (padding = mel2ph 0, masked everywhere, so the valid frames are unchanged) and the cache is an LRU bounded
+        # by bytes; in "auto" mode a shape is captured on its SECOND use (the first use of a shape runs eagerly: capture costs
+        # a warm-up pass + ~13k recorded launches, which a one-off shape never earns back).
+        self.t_bucket = max(1, int(os.environ.get("SS_T_BUCKET", hp.get("t_bucket", 64))))
+        self.plan_bytes = int(float(os.environ.get("SS_PLAN_GIB", "24")) * 2 ** 30)
+        self._plans = collections.OrderedDict()
+        self.n_captures = 0
 
     # ---- state_dict contract ------------------------------------------------------------------
     @staticmethod
@@ -384,6 +405,8 @@ class StyleSingerHIP(torch.nn.Module):
         self._packed_version = self._weights_version
         self._pack_device = dev
         self._pos_table = None
+        # captured hipGraphs carry the OLD packed-weight pointers in their kernel arguments: drop every plan with them
+        self._plans.clear()
         torch.cuda.synchronize()
 
     def _ensure_packed(self):
@@ -437,24 +460,41 @@ class StyleSingerHIP(torch.nn.Module):
         return x
 
     # ---- diffusion loops on a plan -------------------------------------------------------------------
-    def _plan(self, B, T, dev):
-        key = (B, T, dev.index)
-        if key not in self._plans:
-            if len(self._plans) >= 8:
-                self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = _DiffPlan(self, B, T, dev)
-        return self._plans[key]
+    def bucket_frames(self, T):
+        b = self.t_bucket
+        return T if b <= 1 else (T + b - 1) // b * b
 
-    def _want_graphs(self, B, T):
+    def _plan(self, B, T, dev):
+        """LRU cache of diffusion plans keyed by (B, T, device), bounded by `plan_bytes` of workspace."""
+        key = (B, T, dev.index)
+        pl = self._plans.get(key)
+        if pl is None:
+            pl = _DiffPlan(self, B, T, dev)
+            self._plans[key] = pl
+            total = sum(p.bytes for p in self._plans.values())
+            while total > self.plan_bytes and len(self._plans) > 1:
+                _, old = self._plans.popitem(last=False)   # least recently used
+                total -= old.bytes
+        else:
+            self._plans.move_to_end(key)
+        return pl
+
+    def _want_graphs(self, pl):
         if self.use_graphs in ("1", "on", "true", True):
             return True
         if self.use_graphs in ("0", "off", "false", False):
             return False
-        # auto: every shape is captured on first use (north_star: "the diffusion inner loop captured as a hipGraph").
-        # Measured on MI355X: -2 % wall time at B*T = 750 (launch-bound 25 us kernels), +-0 at B*T = 12 000 (GPU-bound).
-        return True
+        # auto (north_star: "the diffusion inner loop captured as a hipGraph"): capture once a shape comes back
+        return pl.uses >= 2
 
-    def _run_f0_pair(self, pl, seed, tape=None):
+    def _capture(self, fn):
+        self.n_captures += 1
+        return _capture(fn)
+
+    # Philox keys: the host part of every key is a CONSTANT per call site and all per-call variation comes from the device
+    # word pl.seed, so that a captured graph (host arguments frozen at capture) and the eager launches draw the same noise
+    # for the same `seed`, whatever was run before.
+    def _run_f0_pair(self, pl, tape=None):
         """Both joint f0/uv samplers in ONE grouped loop (they are independent given their conditions)."""
         lib, pk = _lib(), self._pk
         B, T = pl.B, pl.T
@@ -464,9 +504,9 @@ class StyleSingerHIP(torch.nn.Module):
         if tape is not None:
             zs, us = tape  # [S][2B][T], [S][2B][2][T]
         else:
-            L.check(lib.ss_fill_normal(L.ptr(pl.f02), 2 * B * T, seed + 11, sdp, 0, L.stream_ptr()), "z0")
+            L.check(lib.ss_fill_normal_rows(L.ptr(pl.f02), 2 * B, T, T, 11, sdp, L.stream_ptr()), "z0")
         L.check(lib.ss_f0diff_sample(C_byref(net), L.ptr(pl.f02), L.ptr(pl.uv2), L.ptr(pl.cond2), L.ptr(pl.lo2), L.ptr(pl.hi2),
-                                     L.ptr(pl.lens2), 2 * B, T, L.ptr(zs), L.ptr(us), seed + 17, sdp, 0, net.steps, 1,
+                                     L.ptr(pl.lens2), 2 * B, T, L.ptr(zs), L.ptr(us), 17, sdp, 0, net.steps, 1,
                                      L.ptr(pl.ws_f0), pl.ws_f0_bytes, L.stream_ptr()), "f0 pair")
 
     def ddim_timesteps(self, n):
@@ -474,7 +514,7 @@ class StyleSingerHIP(torch.nn.Module):
         K = self.hp["K_step"]
         return sorted({int(round(v)) for v in np.linspace(0, K - 1, max(1, min(n, K)))}, reverse=True)
 
-    def _run_mel(self, pl, seed, tape=None, ddim_ts=None, plms_interval=None):
+    def _run_mel(self, pl, tape=None, ddim_ts=None, plms_interval=None):
         """q_sample + the shallow reverse loop (batch halves on two streams); `ddim_ts` switches to the strided
         deterministic sampler (BASELINE config 5), `plms_interval` to the reference's PLMS sampler (pndm_speedup)."""
         lib, pk, hp = _lib(), self._pk, self.hp
@@ -485,7 +525,7 @@ class StyleSingerHIP(torch.nn.Module):
         s1 = float(pk["mel"]["sched"]["sqrt_one_minus_alphas_cumprod"][K - 1])
         sdp = L.ptr(pl.seed)
         zq_n, zs_n = tape if tape is not None else (None, None)
-        L.check(lib.ss_mel_qsample(L.ptr(pl.coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), seed + 23, sdp,
+        L.check(lib.ss_mel_qsample(L.ptr(pl.coarse_mel), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), sa, s1, L.ptr(zq_n), 23, sdp,
                                    L.ptr(pl.xm), B, T, M, L.stream_ptr()), "qsample")
         if ddim_ts is not None or plms_interval is not None:
             ac = pk["mel"]["sched"]["alphas_cumprod_np"]  # host table, read by the loop driver at launch time
@@ -497,7 +537,7 @@ class StyleSingerHIP(torch.nn.Module):
         if plms_interval is not None:
             if pl.plms_hist is None:
                 pl.plms_hist = torch.empty(6 * B * T * M, device=pl.xm.device, dtype=torch.float32)
-            L.check(lib.ss_meldiff_sample_plms(C_byref(net), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, int(plms_interval),
+            L.check(lib.ss_meldiff_sample_plms(C_byref(net), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, K, int(plms_interval),
                                                L.hptr(ac), 1, L.ptr(pl.plms_hist), L.ptr(wsp), wsb, L.stream_ptr()), "meldiff plms")
             return
         if ddim_ts is not None:
@@ -516,7 +556,7 @@ class StyleSingerHIP(torch.nn.Module):
             wsb, wsp = pl.ws_mel[i]
             with torch.cuda.stream(strm):
                 L.check(lib.ss_meldiff_sample(C_byref(net), L.ptr(pl.xm[b0:]), L.ptr(pl.cond_mel[b0:]), L.ptr(pl.lens[b0:]), nb, T,
-                                              L.ptr(zparts[i]), seed + 29 + 7919 * b0, sdp, 0, K, 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff")
+                                              L.ptr(zparts[i]), 29 + 7919 * b0, sdp, 0, K, 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff")
         for sd_ in set(side) - {main}:
             main.wait_stream(sd_)
 
@@ -536,7 +576,7 @@ class StyleSingerHIP(torch.nn.Module):
         pl.coarse_mel.copy_(coarse_mel)
         zq_n = None if z_q is None else z_q.to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
         zs_n = None if z_steps is None else z_steps.to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()
-        self._run_mel(pl, seed, (zq_n, zs_n), ddim_ts=self.ddim_timesteps(ddim_steps) if sampler == "ddim" else None,
+        self._run_mel(pl, (zq_n, zs_n), ddim_ts=self.ddim_timesteps(ddim_steps) if sampler == "ddim" else None,
                       plms_interval=plms_interval if sampler == "plms" else None)
         mel_out = torch.empty(B, T, M, device=dev, dtype=torch.float32)
         L.check(lib.ss_mel_denorm(L.ptr(pl.xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(pl.lens),
@@ -674,8 +714,14 @@ class StyleSingerHIP(torch.nn.Module):
         else:
             mel2ph = mel2ph.contiguous()
             T = mel2ph.shape[1]
-            L.check(lib.ss_count_nonzero_i64(L.ptr(mel2ph), L.ptr(lens_t), B, T, st()), "lens_t")
             ret["dur"] = logdur
+        # hipGraph bucket: run the frame axis padded to a multiple of t_bucket (padding = mel2ph 0 -> masked like any
+        # batch padding); the plan/graph cache is then keyed by the bucket and every frame-level output is cropped back.
+        T_out = T
+        T = self.bucket_frames(T_out)
+        if T != T_out:
+            mel2ph = _pad_frames(mel2ph, T).contiguous()
+        L.check(lib.ss_count_nonzero_i64(L.ptr(mel2ph), L.ptr(lens_t), B, T, st()), "lens_t")
         ret["mel2ph"] = mel2ph
         dec = torch.empty(B, T, H, **f32)
         L.check(lib.ss_gather_expand(L.ptr(enc), L.ptr(mel2ph), L.ptr(dec), B, Tp, T, H, st()), "expand")
@@ -710,6 +756,7 @@ class StyleSingerHIP(torch.nn.Module):
         midi = torch.empty(B, T, device=dev, dtype=torch.int64)
         L.check(lib.ss_gather_expand_i64(L.ptr(note), L.ptr(mel2ph), L.ptr(midi), B, Tp, T, st()), "midi")
         pl = self._plan(B, T, dev)
+        pl.uses += 1
         pl.lens2[:B].copy_(lens_t)
         pl.lens2[B:].copy_(lens_t)
         pl.seed.fill_(seed)
@@ -719,22 +766,25 @@ class StyleSingerHIP(torch.nn.Module):
         pl.cond_a.copy_(dec)  # = decoder_inp * tgt_nonpadding (the gather already wrote 0 on padding)
         L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), None, L.ptr(emo), L.ptr(style), L.ptr(pl.cond_b), B, T, H, L.ptr(lens_t), st()), "cond_b")
         pl.uv2.zero_()
-        graphs = noise is None and self._want_graphs(B, T)
+        graphs = noise is None and self._want_graphs(pl)
+
+        def tape_t(x):  # recorded noise [..., T_out] (reference layout) -> device fp32, frame axis padded to the bucket
+            return _pad_frames(x.to(dev).float(), T)
         if noise is not None:
             S = pk["f0_pair"]["net"].steps
             na, nb_ = noise["f0_a"], noise["f0_b"]
-            pl.f0[0].copy_(na["z0"].to(dev).reshape(B, T).float())
-            pl.f0[1].copy_(nb_["z0"].to(dev).reshape(B, T).float())
-            zs = torch.cat([na["z_steps"].to(dev).reshape(S, B, T), nb_["z_steps"].to(dev).reshape(S, B, T)], 1).contiguous().float()
-            us = torch.cat([na["u_steps"].to(dev).reshape(S, B, 2, T), nb_["u_steps"].to(dev).reshape(S, B, 2, T)], 1).contiguous().float()
-            self._run_f0_pair(pl, seed, (zs, us))
+            pl.f0[0].copy_(tape_t(na["z0"]).reshape(B, T))
+            pl.f0[1].copy_(tape_t(nb_["z0"]).reshape(B, T))
+            zs = torch.cat([tape_t(na["z_steps"]).reshape(S, B, T), tape_t(nb_["z_steps"]).reshape(S, B, T)], 1).contiguous()
+            us = torch.cat([tape_t(na["u_steps"]).reshape(S, B, 2, T), tape_t(nb_["u_steps"]).reshape(S, B, 2, T)], 1).contiguous()
+            self._run_f0_pair(pl, (zs, us))
         elif graphs:
             if pl.g_f0 is None:
-                pl.g_f0 = _capture(lambda: self._run_f0_pair(pl, seed))
+                pl.g_f0 = self._capture(lambda: self._run_f0_pair(pl))
                 pl.uv2.zero_()
             pl.g_f0.replay()
         else:
-            self._run_f0_pair(pl, seed)
+            self._run_f0_pair(pl)
         res = {"f0_a": (pl.f0[0].clone(), pl.uv[0].clone()), "f0_b": (pl.f0[1].clone(), pl.uv[1].clone())}
         ret["gdiff1"] = ret["mdiff1"] = ret["gdiff2"] = ret["mdiff2"] = 0.0
         pitch_pred = torch.empty(B, T, 2, **f32)
@@ -751,7 +801,7 @@ class StyleSingerHIP(torch.nn.Module):
         L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), L.ptr(pitch_emb), L.ptr(emo), L.ptr(style), L.ptr(dec_inp), B, T, H, L.ptr(lens_t), st()), "dec_inp")
         ret["decoder_inp"] = dec_inp
         if skip_decoder:
-            return ret
+            return self._crop_frames(ret, T, T_out)
 
         # ---- FFT decoder -> coarse mel (a10) ----
         xd = dec_inp.clone()
@@ -769,7 +819,7 @@ class StyleSingerHIP(torch.nn.Module):
         ret["x_mask"] = (mel2ph > 0).float()[:, :, None]
         if not (global_steps > hp["diff_start"]):
             ret["mel_out"] = coarse_mel
-            return ret
+            return self._crop_frames(ret, T, T_out)
 
         # ---- condition projection (a11) + shallow mel diffusion (a12) ----
         gcat = torch.cat([coarse_mel, dec_inp, spk[:, None, :].expand(-1, T, -1), emo[:, None, :].expand(-1, T, -1), style], -1).contiguous()
@@ -780,31 +830,30 @@ class StyleSingerHIP(torch.nn.Module):
         K = hp["K_step"]
         ddim_ts = self.ddim_timesteps(int(kwargs["ddim_steps"])) if kwargs.get("sampler") == "ddim" else None
         plms = kwargs.get("plms_interval", hp.get("pndm_speedup")) if kwargs.get("sampler", "plms" if hp.get("pndm_speedup") else None) == "plms" else None
+        def mel_tape(x, lead):  # [*lead, B, 1, M, T_out] -> [*lead, B, T, M] on the device
+            return _pad_frames(x.to(dev).float().reshape(*lead, B, M, T_out), T).transpose(-1, -2).contiguous()
         if plms:
-            zq_n = None if noise is None else noise["mel"]["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
-            self._run_mel(pl, seed, (zq_n, None), plms_interval=int(plms))
+            zq_n = None if noise is None else mel_tape(noise["mel"]["z_q"], ())
+            self._run_mel(pl, (zq_n, None), plms_interval=int(plms))
         elif ddim_ts is not None:
             if noise is not None:
-                zq_n = noise["mel"]["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
-                self._run_mel(pl, seed, (zq_n, None), ddim_ts=ddim_ts)
-            elif graphs:  # one captured graph per (B, T, number of sampler steps)
+                self._run_mel(pl, (mel_tape(noise["mel"]["z_q"], ()), None), ddim_ts=ddim_ts)
+            elif graphs:  # one captured graph per (B, T bucket, number of sampler steps)
                 key = len(ddim_ts)
                 if key not in pl.g_ddim:
-                    pl.g_ddim[key] = _capture(lambda: self._run_mel(pl, seed, ddim_ts=ddim_ts))
+                    pl.g_ddim[key] = self._capture(lambda: self._run_mel(pl, ddim_ts=ddim_ts))
                 pl.g_ddim[key].replay()
             else:
-                self._run_mel(pl, seed, ddim_ts=ddim_ts)
+                self._run_mel(pl, ddim_ts=ddim_ts)
         elif noise is not None:
             nz = noise["mel"]
-            zq_n = nz["z_q"].to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
-            zs_n = nz["z_steps"].to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()
-            self._run_mel(pl, seed, (zq_n, zs_n))
+            self._run_mel(pl, (mel_tape(nz["z_q"], ()), mel_tape(nz["z_steps"], (K,))))
         elif graphs:
             if pl.g_mel is None:
-                pl.g_mel = _capture(lambda: self._run_mel(pl, seed))
+                pl.g_mel = self._capture(lambda: self._run_mel(pl))
             pl.g_mel.replay()
         else:
-            self._run_mel(pl, seed)
+            self._run_mel(pl)
         xm = pl.xm
         mel_out = torch.empty(B, T, M, **f32)
         # the reference does not mask padded frames here (shallow_diffusion_tts.py:305-306); with per-item
@@ -813,6 +862,18 @@ class StyleSingerHIP(torch.nn.Module):
         ret["mel_out"] = mel_out
         ret["diff"] = 0.0
         ret["lens"] = lens_t
+        return self._crop_frames(ret, T, T_out)
+
+    _FRAME_KEYS = ("mel2ph", "style", "pitch_pred", "f0_denorm", "f0_denorm_pred", "pitch_coarse", "f0_a", "uv_a", "f0_b", "uv_b",
+                   "decoder_inp", "decoder_out", "fs2_mel", "x_mask", "diff_cond", "mel_out")
+
+    @classmethod
+    def _crop_frames(cls, ret, T, T_out):
+        """Undo the bucket padding: frame-level outputs back to the caller's frame count."""
+        if T != T_out:
+            for k in cls._FRAME_KEYS:
+                if k in ret:
+                    ret[k] = ret[k][:, :T_out].contiguous()
         return ret
 
 

@@ -2,7 +2,7 @@
 
 `load_ckpt(model, ..., 'model', strict=False)` (utils/commons/ckpt_utils.py:26-67) makes parameter
 NAMES and SHAPES the weight interface.  This module regenerates that list from the
-hyper-parameters; tests/test_spec.py pins it against a dump of the reference's own
+hyper-parameters; tests/test_host_cpu.py::test_param_spec_matches_reference_dump pins it against a dump of the reference's own
 `StyleSinger(...).state_dict()` / `HifiGanGenerator(...).state_dict()` (tests/golden/param_spec.json).
 """
 
@@ -109,11 +109,32 @@ def acoustic_spec(hp):
         out += [(f"{gen}.{b}", (S0,)) for b in MULTI_BUFFERS + GAUSS_BUFFERS]
         _wavenet(f"{gen}._denoise_fn", C0, L0, H, 1, 3, True, out)
     out.append(("embed_positions._float_tensor", (1,)))
+    if hp.get("decoder", "diffsinger") == "prodiff":
+        # ProDiffusion (modules/diff/prodiff.py:59-117, built at stylesinger.py:111-117): no ln_proj / postdiff; the
+        # schedule has timesteps + 1 entries (:69-71)
+        n = hp["timesteps"] + 1
+        out += [("diff_decoder.timesteps", ()), ("diff_decoder.timescale", ())]
+        out += [(f"diff_decoder.{b}", (n,)) for b in GAUSS_BUFFERS]
+        out += [("diff_decoder.spec_min", (1, 1, hp["keep_bins"])), ("diff_decoder.spec_max", (1, 1, hp["keep_bins"]))]
+        _wavenet("diff_decoder.denoise_fn", hp["residual_channels"], hp["residual_layers"], H, M, M, False, out)
+        return out
     cond_hs = M + 4 * H
     out += [("ln_proj.weight", (H, cond_hs)), ("ln_proj.bias", (H,))]
     out += [(f"postdiff.{b}", (hp["timesteps"],)) for b in GAUSS_BUFFERS]
     out += [("postdiff.spec_min", (1, 1, hp["keep_bins"])), ("postdiff.spec_max", (1, 1, hp["keep_bins"]))]
     _wavenet("postdiff.denoise_fn", hp["residual_channels"], hp["residual_layers"], H, M, M, False, out)
+    return out
+
+
+def emotion_spec(hidden=256, n_mel=40, layers=3, embed=256):
+    """EmotionEncoder.state_dict() (data_gen/tts/emotion/model.py:11-31): the two cosine-similarity scalars (training
+    loss only), the 3-layer LSTM and the linear layer."""
+    out = [("similarity_weight", (1,)), ("similarity_bias", (1,))]
+    for l in range(layers):
+        cin = n_mel if l == 0 else hidden
+        out += [(f"lstm.weight_ih_l{l}", (4 * hidden, cin)), (f"lstm.weight_hh_l{l}", (4 * hidden, hidden)),
+                (f"lstm.bias_ih_l{l}", (4 * hidden,)), (f"lstm.bias_hh_l{l}", (4 * hidden,))]
+    out += [("linear.weight", (embed, hidden)), ("linear.bias", (embed,))]
     return out
 
 

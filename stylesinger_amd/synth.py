@@ -45,6 +45,45 @@ def gaussian_schedule(timesteps, max_beta):
     return {k: torch.tensor(v, dtype=torch.float32) for k, v in d.items()}
 
 
+def prodiff_betas(schedule_mode, timesteps, min_beta=0.1, max_beta=40.0, s=0.008):
+    """get_noise_schedule_list (modules/diff/prodiff.py:28-49) as ProDiffusion.__init__ calls it (:69-75: timesteps + 1
+    entries, min_beta = 0.1, max_beta = 40)."""
+    if schedule_mode == "linear":
+        return np.linspace(0.000001, 0.01, timesteps)
+    if schedule_mode == "cosine":
+        steps = timesteps + 1
+        x = np.linspace(0, steps, steps)
+        ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+        ac = ac / ac[0]
+        return np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999)
+    if schedule_mode == "vpsde":
+        t = np.arange(1, timesteps + 1)
+        return 1.0 - np.exp(-min_beta / timesteps - 0.5 * (max_beta - min_beta) * (2 * t - 1) / (timesteps ** 2))
+    raise NotImplementedError(schedule_mode)
+
+
+def prodiff_schedule(hp):
+    """Buffers of ProDiffusion (modules/diff/prodiff.py:77-113), float64 numpy then fp32 like the reference."""
+    betas = prodiff_betas(hp["schedule_type"], hp["timesteps"] + 1)
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+    d = {
+        "betas": betas, "alphas_cumprod": ac, "alphas_cumprod_prev": ac_prev,
+        "sqrt_alphas_cumprod": np.sqrt(ac), "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": np.log(1.0 - ac), "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / ac - 1), "posterior_variance": pv,
+        "posterior_log_variance_clipped": np.log(np.maximum(pv, 1e-20)),
+        "posterior_mean_coef1": betas * np.sqrt(ac_prev) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+    }
+    out = {k: torch.tensor(v, dtype=torch.float32) for k, v in d.items()}
+    out["timesteps"] = torch.tensor(int(hp["timesteps"]), dtype=torch.float32)
+    out["timescale"] = torch.tensor(hp.get("timescale", 1), dtype=torch.float32)
+    return out
+
+
 def multinomial_schedule(timesteps, max_beta):
     betas = np.linspace(1e-4, max_beta, timesteps)
     alphas = torch.tensor((1.0 - betas).astype("float64"))
@@ -107,9 +146,18 @@ def synth_acoustic_state_dict(hp=None, seed=1234):
     sd = {}
     sched_f0 = {**multinomial_schedule(hp["f0_timesteps"], hp["f0_max_beta"]),
                 **gaussian_schedule(hp["f0_timesteps"], hp["f0_max_beta"])}
-    sched_mel = gaussian_schedule(hp["timesteps"], hp["max_beta"])
+    prodiff = hp.get("decoder", "diffsinger") == "prodiff"
+    sched_mel = prodiff_schedule(hp) if prodiff else gaussian_schedule(hp["timesteps"], hp["max_beta"])
     for name, shape in _spec.acoustic_spec(hp):
         head = name.split(".")[0]
+        if head == "diff_decoder":
+            leaf = name.split(".", 1)[1]
+            if leaf in sched_mel:
+                sd[name] = sched_mel[leaf].clone()
+                continue
+            if leaf in ("spec_min", "spec_max"):
+                sd[name] = torch.tensor(hp[leaf], dtype=torch.float32)[None, None, :hp["keep_bins"]]
+                continue
         if head in ("f0_gen", "f0_gen_inpainte"):
             rest = name[len(head) + 1:]
             if rest.startswith("_denoise_fn."):
@@ -135,6 +183,25 @@ def synth_acoustic_state_dict(hp=None, seed=1234):
             continue
         sd[name] = _init_tensor(name, tuple(shape), seed).contiguous()
     return sd
+
+
+def synth_emotion_state_dict(seed=1234):
+    """Seeded weights of the emotion encoder (data_gen/tts/emotion/model.py:11-31): U(-1/sqrt(H), 1/sqrt(H)) like nn.LSTM."""
+    sd = {}
+    for name, shape in _spec.emotion_spec():
+        if name.startswith("similarity_"):
+            sd[name] = torch.tensor([10.0 if name.endswith("weight") else -5.0])
+            continue
+        g = _gen(seed, "emotion." + name)
+        sd[name] = ((torch.rand(shape, generator=g) * 2 - 1) / 16.0).contiguous()
+    return sd
+
+
+def synth_emotion_frames(n_partials, n_frames=160, n_mel=40, seed=1234):
+    """Stand-in for audio.wav_to_mel_spectrogram partials (librosa power mel of 16 kHz speech, un-vendored): positive,
+    heavy-tailed values of the same order (1e-5 .. 1)."""
+    g = _gen(seed, "emotion.frames")
+    return torch.exp(torch.randn(n_partials, n_frames, n_mel, generator=g) * 1.5 - 6.0)
 
 
 def synth_vocoder_state_dict(cfg=None, seed=1234):

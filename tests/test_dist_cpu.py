@@ -18,11 +18,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_items=6):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    items = list(range(6))  # 6 utterances, item i has length 10+i
+    items = list(range(n_items))  # item i has length 10+i
 
     def infer_fn(mine):
         T = 16
@@ -56,11 +56,33 @@ def test_two_rank_gloo_shard_and_gather():
         p.join(60)
         assert p.exitcode == 0
     for rank, first_vals, lens_all, local, wshape in res:
-        # gathered order = rank-major: rank0's items (0,2,4) then rank1's (1,3,5)
-        assert first_vals == [1.0, 3.0, 5.0, 2.0, 4.0, 6.0]
-        assert lens_all == [10, 12, 14, 11, 13, 15]
+        # the gathered batch comes back in ITEM order on every rank
+        assert first_vals == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+        assert lens_all == [10, 11, 12, 13, 14, 15]
         assert local == list(range(rank, 6, 2))
         assert wshape == (3, 64)
+
+
+def test_two_rank_gloo_uneven_shards():
+    """7 items over 2 ranks: rank 1 holds one item fewer; its shard is padded with an empty slot so that the single
+    all_gather sees equal shapes (unequal B_local would hang the collective). Lengths travel bit-exact."""
+    world, n = 2, 7
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ssd.shard_slots(n, world) == 4 and ssd.gathered_order(n, world) == [0, 2, 4, 6, 1, 3, 5, -1]
+    for rank, first_vals, lens_all, local, wshape in res:
+        assert first_vals == [float(i + 1) for i in range(n)]
+        assert lens_all == [10 + i for i in range(n)]
+        assert local == list(range(rank, n, 2))
+        assert wshape == (len(local), 64)
 
 
 def test_single_process_is_identity():
