@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 6 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows */
+#define SS_ABI_VERSION 6 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -114,7 +114,9 @@ typedef struct ss_conv_gemm_args {
   /* matrix precision: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = both operands rounded to bf16 (RNE) on the way
    * into v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 prologue/epilogue (BASELINE config 4) */
   int32_t mfma_bf16;
-  int32_t reserved0;
+  /* DDPM epilogue variant: 0 = v is the predicted NOISE (x0 = clamp(recip*x - recipm1*v, -1, 1), shallow_diffusion_tts.py:130-153);
+   * 1 = v is the predicted x0 itself, no clamp (ProDiffusion.p_sample, modules/diff/prodiff.py:150-153) */
+  int32_t ddpm_x0_pred;
 } ss_conv_gemm_args;
 
 int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
@@ -295,6 +297,14 @@ int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const float* cond, c
  * 6*B*T*in_dim floats. alphas_cumprod: HOST table [steps]. */
 int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T, int step_hi, int interval,
                            const float* alphas_cumprod, int precompute, float* hist, void* ws, int64_t ws_bytes, void* stream);
+/* ProDiff teacher sampler (modules/diff/prodiff.py:205-221 with p_sample :150-153 and q_posterior_sample :141-148): the
+ * denoiser predicts x0 directly; x_{t-1} = c1[t]*x0 + c2[t]*x_t + sigma[t]*z for t = n_steps-1 ... 0.
+ *   x [B][T][80] in: x_T ~ N(0,1) (filled by the caller) ; out: the mel (norm/denorm are identities there, :223-227)
+ *   c1, c2, sigma: HOST arrays [n_steps] (posterior_mean_coef1/2, exp(0.5*posterior_log_variance_clipped), sigma[0] = 0)
+ *   noise [n_steps][B][T][80] tape or NULL -> Philox */
+int ss_prodiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T, const float* noise,
+                      uint64_t seed, const uint64_t* seed_dev, int n_steps, const float* c1, const float* c2, const float* sigma,
+                      int precompute_cond, void* ws, int64_t ws_bytes, void* stream);
 /* q_sample + norm_spec: x = sqrt_ac*((mel-min)/(max-min)*2-1) + sqrt_1mac*z  (shallow_diffusion_tts.py:199-204,271-272) */
 int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac, float sqrt_1mac,
                    const float* noise, uint64_t seed, const uint64_t* seed_dev, float* x, int B, int T, int M, void* stream);
@@ -368,6 +378,18 @@ int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, void* strea
  * element-wise steps between and after them: |X| from the (re | im) column blocks, and log10(max(eps, .)). */
 int ss_spec_magnitude(const float* S, float* P, int64_t rows, int lds, int ldp, int nbins, int sin_off, void* stream);
 int ss_log10_floor(const float* x, float* y, int64_t n, float eps, void* stream);
+
+/* Emotion encoder (input producer; data_gen/tts/emotion/model.py:11-78 = nn.LSTM(40, 256, 3) + Linear, inference.py:39-53,
+ * 139-151). One LSTM layer's recurrence as a persistent launch (one workgroup per sequence):
+ *   xproj  [P][n][H][4] = x_t . W_ih^T + b_ih + b_hh for every step, gate-interleaved (i,f,g,o per hidden unit) - one
+ *          ss_conv_gemm over all P*n rows with the weight rows permuted to 4*j + gate;
+ *   w_hh_packed [H (k)][H (j)][4 (gate)] = weight_hh[gate*H + j][k];
+ *   h_seq  [P][n][H] every hidden state (input of the next layer) or NULL ; h_last [P][H] final hidden state or NULL. */
+int ss_lstm_layer(const float* xproj, const float* w_hh_packed, float* h_seq, float* h_last, int P, int n, int H, void* stream);
+/* out[C] = normalise(mean over rows of x[rows][C])  (embed_utterance, inference.py:147-151) */
+int ss_mean_l2norm(const float* x, float* out, int rows, int C, void* stream);
+/* y[r][:] = x[r][:] / ||x[r][:]||_2  (EmotionEncoder.forward, model.py:57-58) */
+int ss_l2norm_rows(const float* x, float* y, int rows, int C, void* stream);
 
 /* output writer (utils/audio.py:12-17 save_wav): pcm = (int16) trunc(wav * scale), scale = 32767 (or 32767 / max|wav| when
  * out_wav_norm is set); saturating. */

@@ -154,7 +154,16 @@ def run_emotion_case(name, n_partials, seed=1234):
         full = enc(frames)
     raw = np.mean(partial.numpy(), axis=0)
     embed = raw / np.linalg.norm(raw, 2)
-    torch.save(dict(meta=dict(n_partials=n_partials, seed=seed, keys=[[k, list(v.shape)] for k, v in enc.state_dict().items()]),
+    slices = {}
+    try:  # the partial-slicing rule (inference.py:56-108), pinned for a few utterance lengths
+        from data_gen.tts.emotion import inference as einf
+        for n in (1000, 25600, 40000, 100000, 128000, 131111):
+            w, m = einf.compute_partial_slices(n)
+            slices[n] = ([(int(x.start), int(x.stop)) for x in w], [(int(x.start), int(x.stop)) for x in m])
+    except Exception as e:  # noqa: BLE001
+        print("[gen_golden] compute_partial_slices not importable:", e)
+    torch.save(dict(meta=dict(n_partials=n_partials, seed=seed, keys=[[k, list(v.shape)] for k, v in enc.state_dict().items()],
+                              partial_slices=slices),
                     out=dict(partial_embeds=partial.clone(), embed=torch.from_numpy(embed), forward_embeds=full.clone())),
                os.path.join(GOLD, name + ".pt"))
     print(f"[gen_golden] {name}: partial {tuple(partial.shape)}")

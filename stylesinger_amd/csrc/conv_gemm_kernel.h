@@ -540,6 +540,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
           const float x = xv[r];
           float x0 = a.ddpm_recip * x - a.ddpm_recipm1 * eps;
           x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+          if (a.ddpm_x0_pred) x0 = eps;  // the network output IS x0 (ProDiffusion.p_sample, prodiff.py:150-153), no clamp
           const float mean = a.ddpm_c1 * x0 + a.ddpm_c2 * x;
           float z = zv[r];
           if (a.ddpm_sigma != 0.f && !a.noise) {

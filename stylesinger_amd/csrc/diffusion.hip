@@ -469,7 +469,7 @@ static int mel_eps(const ss_wavenet* net, const float* x_in, float* eps_out, con
 //   x0 = clamp(recip*x - recipm1*eps, -1, 1) ; x <- c1*x0 + c2*x + sigma*z
 static int mel_step(const ss_wavenet* net, float* x, const int32_t* lens, int B, int T, const WsLayout& w, int t, float recip,
                     float recipm1, float c1, float c2, float sigma, const float* noise_t, uint64_t seed,
-                    const uint64_t* seed_dev, uint32_t step_id, hipStream_t stream) {
+                    const uint64_t* seed_dev, uint32_t step_id, hipStream_t stream, int x0_pred = 0) {
   const int C = net->C, M = net->in_dim;
   SS_PROPAGATE(mel_net_body(net, x, lens, B, T, w, t, stream));
   // eps = output_projection(.) fused with the posterior step (shallow_diffusion_tts.py:130-162)
@@ -496,6 +496,7 @@ static int mel_step(const ss_wavenet* net, float* x, const int32_t* lens, int B,
   f.seed = seed;
   f.seed_dev = seed_dev;
   f.step = step_id;
+  f.ddpm_x0_pred = x0_pred;
   return ss_conv_gemm(&f, stream);
 }
 
@@ -515,6 +516,24 @@ extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* c
     SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
                           t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f, noise ? noise + (int64_t)t * B * T * M : nullptr, seed,
                           seed_dev, (uint32_t)t, stream));
+  return SS_OK;
+}
+
+// ProDiff teacher sampler: same launches as ss_meldiff_sample, the final GEMM's epilogue takes the network output as x0.
+extern "C" int ss_prodiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
+                                 const float* noise, uint64_t seed, const uint64_t* seed_dev, int n_steps, const float* c1,
+                                 const float* c2, const float* sigma, int do_precompute, void* ws, int64_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SS_CHECK_ARG(net && x && cond && ws && c1 && c2 && sigma, "ss_prodiff_sample: null pointer");
+  SS_CHECK_ARG(net->n_groups <= 1 && net->L > 0 && net->L <= SS_MAX_LAYERS && (net->C % 32) == 0, "ss_prodiff_sample: bad net");
+  SS_CHECK_ARG(n_steps >= 1 && n_steps <= net->steps, "ss_prodiff_sample: n_steps=%d outside [1, %d]", n_steps, net->steps);
+  const WsLayout w = ws_layout(net, B, T, ws);
+  SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_prodiff_sample: workspace too small");
+  const int M = net->in_dim;
+  if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
+  for (int t = n_steps - 1; t >= 0; --t)
+    SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, 0.0f, 0.0f, c1[t], c2[t], t > 0 ? sigma[t] : 0.0f,
+                          noise ? noise + (int64_t)t * B * T * M : nullptr, seed, seed_dev, (uint32_t)t, stream, 1));
   return SS_OK;
 }
 

@@ -38,8 +38,15 @@ def gather_mels(mel, f0, lens, group=None):
     payload[:, :, :M] = mel
     payload[:, :, M] = f0
     payload[:, :, M + 1] = lens.to(torch.int32).view(torch.float32)[:, None]
-    out = torch.empty(W * Bl, T, M + 2, device=mel.device, dtype=torch.float32)
-    dist.all_gather_into_tensor(out, payload, group=group)
+    if dist.get_backend(group) == "gloo" and payload.is_cuda:
+        # orchestration tests on one device run over gloo, whose collectives take host buffers; RCCL (backend "nccl") gathers
+        # the device buffer directly over xGMI
+        host = torch.empty(W * Bl, T, M + 2, dtype=torch.float32)
+        dist.all_gather_into_tensor(host, payload.cpu(), group=group)
+        out = host.to(mel.device)
+    else:
+        out = torch.empty(W * Bl, T, M + 2, device=mel.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(out, payload, group=group)
     return out[:, :, :M].contiguous(), out[:, :, M].contiguous(), out[:, 0, M + 1].contiguous().view(torch.int32)
 
 

@@ -46,7 +46,7 @@ class ConvGemmArgs(C.Structure):
         ("ddpm_recip", C.c_float), ("ddpm_recipm1", C.c_float), ("ddpm_c1", C.c_float), ("ddpm_c2", C.c_float),
         ("ddpm_sigma", C.c_float), ("noise", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("step", C.c_uint32), ("tile", C.c_int32),
         ("group_size", C.c_int32), ("w_group_stride", C.c_int64), ("bias_group_stride", C.c_int64), ("a_bias_group_stride", C.c_int64),
-        ("mfma_bf16", C.c_int32), ("reserved0", C.c_int32),
+        ("mfma_bf16", C.c_int32), ("ddpm_x0_pred", C.c_int32),
     ]
 
 

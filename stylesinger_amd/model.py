@@ -128,6 +128,7 @@ class StyleSingerHIP(torch.nn.Module):
         if dictionary is not None:
             hp["vocab_size"] = len(dictionary)
         self.hp = hp
+        self.prodiff = hp.get("decoder", "diffsinger") == "prodiff"
         self.hidden_size = hp["hidden_size"]
         self.out_dims = out_dims or hp["audio_num_mel_bins"]
         self._names = []
@@ -396,11 +397,18 @@ class StyleSingerHIP(torch.nn.Module):
         # the two f0 denoisers have identical shapes and schedules -> one grouped descriptor (items [0,B): agnostic
         # net, [B,2B): specific net): every launch of the f0 loops carries 2x the blocks.
         pk["f0_pair"] = self._pack_wavenet(["gm_diffnet", "gm_diffnet_inpainte"], "f0_gen", *f0_args)
-        pk["mel"] = self._pack_wavenet(["postdiff.denoise_fn"], "postdiff", hp["residual_channels"], hp["residual_layers"],
-                                       hp["dilation_cycle_length"], hp["timesteps"], hp["audio_num_mel_bins"], hp["audio_num_mel_bins"], False)
-        pk["ln_proj"] = self._pack_conv("ln_proj.weight", "ln_proj.bias")
-        pk["spec_min"] = self.p("postdiff.spec_min").reshape(-1).contiguous()
-        pk["spec_max"] = self.p("postdiff.spec_max").reshape(-1).contiguous()
+        mel_args = (hp["residual_channels"], hp["residual_layers"], hp["dilation_cycle_length"], hp["timesteps"],
+                    hp["audio_num_mel_bins"], hp["audio_num_mel_bins"], False)
+        if self.prodiff:  # hparams['decoder'] == 'prodiff' (stylesinger.py:111-117): the DiffNet conditioned on decoder_inp itself
+            pk["mel"] = self._pack_wavenet(["diff_decoder.denoise_fn"], "diff_decoder", *mel_args)
+            g = lambda k: np.ascontiguousarray(self.p("diff_decoder." + k).detach().cpu().numpy().astype(np.float32))
+            pk["prodiff_sched"] = dict(c1=g("posterior_mean_coef1"), c2=g("posterior_mean_coef2"),
+                                       sigma=np.ascontiguousarray(np.exp(0.5 * g("posterior_log_variance_clipped")).astype(np.float32)))
+        else:
+            pk["mel"] = self._pack_wavenet(["postdiff.denoise_fn"], "postdiff", *mel_args)
+            pk["ln_proj"] = self._pack_conv("ln_proj.weight", "ln_proj.bias")
+            pk["spec_min"] = self.p("postdiff.spec_min").reshape(-1).contiguous()
+            pk["spec_max"] = self.p("postdiff.spec_max").reshape(-1).contiguous()
         self._pk = pk
         self._packed_version = self._weights_version
         self._pack_device = dev
@@ -801,6 +809,39 @@ class StyleSingerHIP(torch.nn.Module):
         L.check(lib.ss_add_bcast_mask(L.ptr(dec), L.ptr(spk), L.ptr(pitch_emb), L.ptr(emo), L.ptr(style), L.ptr(dec_inp), B, T, H, L.ptr(lens_t), st()), "dec_inp")
         ret["decoder_inp"] = dec_inp
         if skip_decoder:
+            return self._crop_frames(ret, T, T_out)
+        if self.prodiff:
+            # ---- ProDiff teacher decoder (stylesinger.py:175-177, modules/diff/prodiff.py:205-221): decoder_inp is the condition
+            M = hp["audio_num_mel_bins"]
+            S = int(hp["timesteps"])
+            pl.cond_mel.copy_(dec_inp)
+            sch = pk["prodiff_sched"]
+            wsb, wsp = pl.ws_mel[0] if len(pl.ws_mel) == 1 else (None, None)
+            if wsp is None:
+                wsb = lib.ss_wavenet_workspace_bytes(C_byref(pk["mel"]["net"]), B, T)
+                wsp = torch.empty(wsb, device=dev, dtype=torch.uint8)
+
+            def run_prodiff(zs=None):
+                if zs is None:
+                    L.check(lib.ss_fill_normal_rows(L.ptr(pl.xm), B, T * M, T * M, 31, L.ptr(pl.seed), st()), "x_T")
+                L.check(lib.ss_prodiff_sample(C_byref(pk["mel"]["net"]), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, L.ptr(zs),
+                                              37, L.ptr(pl.seed), S, L.hptr(sch["c1"]), L.hptr(sch["c2"]), L.hptr(sch["sigma"]), 1,
+                                              L.ptr(wsp), wsb, st()), "prodiff")
+            if noise is not None:
+                to_btm = lambda x, lead: _pad_frames(x.to(dev).float().reshape(*lead, B, M, T_out), T).transpose(-1, -2).contiguous()
+                pl.xm.copy_(to_btm(noise["mel"]["z_q"], ()))
+                run_prodiff(to_btm(noise["mel"]["z_steps"], (S,)))
+            elif graphs:
+                if pl.g_mel is None:
+                    pl.g_mel = self._capture(run_prodiff)
+                pl.g_mel.replay()
+            else:
+                run_prodiff()
+            mel_out = torch.empty(B, T, M, **f32)
+            # the reference leaves padded frames unmasked (prodiff.py:219-220); frames past lens[b] are written as 0 here
+            L.check(lib.ss_add_bcast_mask(L.ptr(pl.xm), None, None, None, None, L.ptr(mel_out), B, T, M, L.ptr(lens_t), st()), "mel mask")
+            ret["mel_out"] = mel_out
+            ret["lens"] = lens_t
             return self._crop_frames(ret, T, T_out)
 
         # ---- FFT decoder -> coarse mel (a10) ----

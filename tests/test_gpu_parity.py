@@ -11,8 +11,11 @@ from stylesinger_amd import config, synth  # noqa: E402
 from stylesinger_amd.model import StyleSingerHIP  # noqa: E402
 from stylesinger_amd.vocoder import HifiGAN  # noqa: E402
 
-MEL_L1_TOL = 1e-4      # north_star: mel L1 <= 1e-4 vs the reference (fp32)
-STAGE_TOL = 2e-4       # max-abs on intermediate activations (O(1) magnitudes)
+MEL_L1_TOL = 1e-5      # north_star asks mel L1 <= 1e-4 vs the reference (fp32); measured 3e-7..8e-7 on MI355X -> 10x margin only
+WAV_TOL = 1e-5         # waveform max-abs vs the reference (measured 2e-7)
+STAGE_TOL = 5e-5       # max-abs on intermediate activations of O(1) magnitude
+# per-case overrides of the mel L1 bound (north_star's own bound where the chain is long; tightened once measured)
+CASE_MEL_L1_TOL = {"acoustic_t32_mel1000": 1e-4}
 
 
 def _run_hip(meta):
@@ -42,7 +45,9 @@ def _run_hip(meta):
     return ret, tape
 
 
-@pytest.mark.parametrize("name", ["acoustic_tiny_s4", "acoustic_b2_s3", "acoustic_dur_s2", "acoustic_t64_s100"])
+@pytest.mark.parametrize("name", ["acoustic_tiny_s4", "acoustic_b2_s3", "acoustic_dur_s2", "acoustic_t64_s100",
+                                  "acoustic_t32_mel1000",      # BASELINE config 4's schedule: 1000 mel steps, coefficients up to ~3e6
+                                  "prodiff_t40_vpsde", "prodiff_b2_t32_linear"])   # hparams['decoder'] = 'prodiff' (8 teacher steps)
 def test_acoustic_hip_matches_reference_golden(name):
     case = harness.load_case(name)
     meta, gold = case["meta"], case["out"]
@@ -56,14 +61,16 @@ def test_acoustic_hip_matches_reference_golden(name):
                           ("diff_cond", "diff_cond"), ("pitch_pred", "pitch_pred")]:
         if k_gold in gold:
             err = (ret[k_hip].cpu() - gold[k_gold]).abs().max().item()
+            print(f"{name}: {k_hip} max abs err {err:.3e}")
             assert err <= STAGE_TOL, f"{name}:{k_hip} max abs err {err:.3e}"
     uv_flip = ((ret["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).float().mean().item()
     assert uv_flip == 0.0, f"voicing flips {uv_flip}"
     assert torch.allclose(ret["f0_denorm"].cpu(), gold["f0_denorm"], rtol=2e-4, atol=1e-2)
     l1 = (ret["mel_out"].cpu() - gold["mel_out"]).abs().mean().item()
     mx = (ret["mel_out"].cpu() - gold["mel_out"]).abs().max().item()
-    print(f"{name}: mel L1 {l1:.3e} max {mx:.3e}")
-    assert l1 <= MEL_L1_TOL, f"{name}: mel L1 {l1:.3e}"
+    f0e = (ret["f0_denorm"].cpu() - gold["f0_denorm"]).abs().max().item()
+    print(f"{name}: mel L1 {l1:.3e} max {mx:.3e}; f0_denorm max abs err {f0e:.3e} Hz")
+    assert l1 <= CASE_MEL_L1_TOL.get(name, MEL_L1_TOL), f"{name}: mel L1 {l1:.3e}"
 
 
 @pytest.mark.parametrize("name", ["vocoder_t12", "vocoder_b2_t9"])
@@ -80,11 +87,11 @@ def test_vocoder_hip_matches_reference_golden(name):
     e_h = (har.cpu() - case["out"]["har"]).abs().max().item()
     e_w = (wav.cpu() - case["out"]["wav"]).abs().max().item()
     print(f"{name}: har max err {e_h:.3e} wav max err {e_w:.3e}")
-    assert e_h <= 2e-4     # fp32 sin of a ~1e3-rad phase: 1 ulp of the argument is ~6e-5
-    assert e_w <= 5e-4     # waveform in [-1,1] after 4 upsampling stages
+    assert e_h <= 2e-6     # harmonic source (measured 3e-8)
+    assert e_w <= WAV_TOL  # waveform in [-1,1] after 4 upsampling stages
     if B == 1:
         w1 = voc.spec2wav(case["inp"]["mel"][0].numpy(), f0=case["inp"]["f0"][0].numpy(), noise=noise)
-        assert abs(w1 - case["out"]["wav"][0].numpy()).max() <= 5e-4
+        assert abs(w1 - case["out"]["wav"][0].numpy()).max() <= WAV_TOL
 
 
 def test_ragged_batch_equals_per_item_runs():
@@ -377,13 +384,13 @@ def test_bf16_mfma_mode_matches_rounded_oracle():
     assert ew <= 5e-3           # |wav| <= 1
 
 
-@pytest.mark.parametrize("name", ["plms_t40_k20_i3", "plms_t24_k12_i4"])
+@pytest.mark.parametrize("name", ["plms_t40_k20_i3", "plms_t24_k12_i4", "plms_t32_k12of20_i3"])  # last: K_step 12 < timesteps 20
 def test_plms_sampler_matches_reference_golden(name):
     """ss_meldiff_sample_plms vs the REAL reference's p_sample_plms loop (fixture from oracle/gen_golden.py); also batched
     (B = 3 copies with different lengths), which the reference's implementation cannot run."""
     case = harness.load_case(name)
     meta = case["meta"]
-    hp = config.make_hparams(dict(timesteps=meta["steps_mel"], K_step=meta["steps_mel"], f0_timesteps=2))
+    hp = config.make_hparams(dict(timesteps=meta["steps_mel"], K_step=meta.get("k_step", meta["steps_mel"]), f0_timesteps=2))
     sd = synth.synth_acoustic_state_dict(hp, meta["seed"])
     dev = torch.device("cuda:0")
     model = StyleSingerHIP(None, hparams=hp)

@@ -43,6 +43,60 @@ def test_param_spec_matches_reference_dump(golden_dir):
     assert [[k, list(s)] for k, s in minev] == ref["vocoder"]
 
 
+def test_prodiff_and_emotion_specs_match_reference_dump(golden_dir):
+    """hparams['decoder'] = 'prodiff' (stylesinger.py:111-117) and the emotion encoder (data_gen/tts/emotion/model.py)."""
+    ref = json.load(open(os.path.join(golden_dir, "param_spec.json")))
+    hp = config.make_hparams(dict(decoder="prodiff", timesteps=8, K_step=8, f0_timesteps=2, schedule_type="vpsde"))
+    assert [[k, list(s)] for k, s in spec.acoustic_spec(hp)] == ref["acoustic_prodiff"]
+    assert [[k, list(s)] for k, s in spec.emotion_spec()] == ref["emotion"]
+    sd = synth.synth_acoustic_state_dict(hp, 3)
+    assert set(sd) == {k for k, _ in ref["acoustic_prodiff"]} and sd["diff_decoder.betas"].shape == (9,)
+
+
+def test_emotion_partial_slices_match_reference(golden_dir):
+    """emotion.compute_partial_slices vs the reference's (inference.py:56-108) for several utterance lengths."""
+    from stylesinger_amd import emotion
+    case = torch.load(os.path.join(golden_dir, "emotion_p5.pt"), weights_only=False)
+    assert case["meta"]["partial_slices"]
+    for n, (wav_ref, mel_ref) in case["meta"]["partial_slices"].items():
+        wav, mel = emotion.compute_partial_slices(n)
+        assert [(s.start, s.stop) for s in wav] == [tuple(x) for x in wav_ref], n
+        assert [(s.start, s.stop) for s in mel] == [tuple(x) for x in mel_ref], n
+
+
+def test_plan_cache_is_lru_bounded_by_bytes():
+    """The plan / hipGraph cache of StyleSingerHIP (host logic only): frames are bucketed, plans evicted least-recently-used."""
+    from stylesinger_amd.model import StyleSingerHIP, _pad_frames
+    hp = config.make_hparams(dict(timesteps=2, K_step=2, f0_timesteps=2))
+    m = StyleSingerHIP(None, hparams=hp)
+    assert m.t_bucket == 64 and [m.bucket_frames(t) for t in (1, 64, 65, 1500)] == [64, 64, 128, 1536]
+    x = torch.arange(6.0).reshape(1, 2, 3)
+    assert _pad_frames(x, 5).shape == (1, 2, 5) and _pad_frames(x, 4, dim=1).shape == (1, 4, 3)
+    assert torch.equal(_pad_frames(x, 5)[..., :3], x) and _pad_frames(x, 5)[..., 3:].abs().sum() == 0
+
+    class FakePlan:
+        def __init__(self, b):
+            self.bytes, self.uses = b, 0
+    import stylesinger_amd.model as M
+    orig = M._DiffPlan
+    M._DiffPlan = lambda model, B, T, dev: FakePlan(B * T)
+    try:
+        m.plan_bytes = 1000
+        dev = torch.device("cuda", 0)
+        a = m._plan(1, 400, dev); b = m._plan(1, 500, dev)
+        assert list(m._plans) == [(1, 400, 0), (1, 500, 0)]
+        assert m._plan(1, 400, dev) is a                       # hit: moves to the recent end
+        m._plan(1, 300, dev)                                   # 400 + 500 + 300 > 1000 -> evicts the LRU one (500)
+        assert list(m._plans) == [(1, 400, 0), (1, 300, 0)]
+        m.use_graphs = "auto"
+        a.uses = 1
+        assert not m._want_graphs(a)
+        a.uses = 2
+        assert m._want_graphs(a)                               # captured on the second use of a shape
+    finally:
+        M._DiffPlan = orig
+
+
 def test_hparams_match_reference_dump(golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "hparams.json")))
     hp = config.make_hparams()
