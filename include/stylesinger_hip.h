@@ -36,6 +36,9 @@ int ss_abi_version(void);
 int ss_device_info(int dev, int* n_cu, char* arch, int arch_len);
 /* out[0..2] = sizeof(ss_conv_gemm_args), sizeof(ss_wavenet), sizeof(ss_hifigan): lets a binding verify its mirror */
 int ss_struct_sizes(int64_t* out, int n);
+/* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
+ * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3) */
+int ss_set_tuning(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------
  * Generic fp32-MFMA implicit-GEMM 1-D convolution / linear layer.

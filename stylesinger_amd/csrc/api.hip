@@ -13,6 +13,21 @@ void ss_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ss_last_error(void) { return g_err; }
+
+SsTuning g_ss_tuning = {0};
+
+extern "C" int ss_set_tuning(const char* key, int value) {
+  if (!key) {
+    ss_set_error("ss_set_tuning: null key");
+    return SS_ERR_ARG;
+  }
+  if (strcmp(key, "wave_prio") == 0 && value >= 0 && value <= 2) {
+    g_ss_tuning.wave_prio = value;
+    return SS_OK;
+  }
+  ss_set_error("ss_set_tuning: unknown key/value %s=%d", key, value);
+  return SS_ERR_ARG;
+}
 extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
 
 extern "C" int ss_device_info(int dev, int* n_cu, char* arch, int arch_len) {

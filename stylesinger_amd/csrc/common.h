@@ -38,6 +38,21 @@ void ss_set_error(const char* fmt, ...);
 
 static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Run-time tuning knobs (ss_set_tuning): process-wide, read at launch time, never change results.
+//   wave_prio: 0 = all waves at priority 0; 1 = static s_setprio((blockIdx / 256) % 3); 2 = s_setprio(blockIdx % 3).
+//     The blocks sharing a CU then differ in priority, so the matrix pipe of a SIMD serves them one after the other instead
+//     of round-robin: their non-MFMA phases (staging, barrier) stop coinciding (launch structure).
+struct SsTuning { int wave_prio; };
+extern SsTuning g_ss_tuning;
+
+// static per-block wave priority (wave-uniform; s_setprio takes an immediate)
+__device__ __forceinline__ void ss_apply_wave_prio(int mode) {
+  if (mode == 0) return;
+  const int p = mode == 1 ? (int)((blockIdx.x >> 8) % 3u) : (int)(blockIdx.x % 3u);
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+}
+
 // ----------------------------------------------------------------------------------------------
 // Device math. Activations follow the torch CPU definitions the reference relies on.
 // ----------------------------------------------------------------------------------------------

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 #ifdef SS_KERNEL_TIMESTAMPS  // per-wave phase stamps for tools/phase_times.py; never compiled into the shipped library
   const unsigned long long ts0 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
 #endif
+  ss_apply_wave_prio(dbg & 3);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -564,21 +565,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
     o[6] = blockIdx.x;
   }
-#else
-  (void)dbg;
 #endif
 }
 
-inline int dbg_flags() {
+inline int dbg_flags() {  // bits 0-1: wave priority mode (ss_set_tuning); bit 4: timestamps (debug builds only)
 #ifdef SS_KERNEL_TIMESTAMPS
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("SS_DBG");
-    v = e ? atoi(e) : 0;
+    v = e ? (atoi(e) & ~3) : 0;
   }
-  return v;
+  return v | (g_ss_tuning.wave_prio & 3);
 #else
-  return 0;
+  return g_ss_tuning.wave_prio & 3;
 #endif
 }
 

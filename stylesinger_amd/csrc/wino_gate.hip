@@ -33,8 +33,9 @@ __device__ __forceinline__ int lds_slot(int row, int slot) { return row * LD + (
 // barrier: best for the mel net where 384 tiles still fill the chip).
 template <int TN>
 __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args a, int p_tiles_per_item, int p_tiles,
-                                                        int n_tiles, int log2d) {
+                                                        int n_tiles, int log2d, int prio_mode) {
   constexpr int BN = 64 * TN;
+  ss_apply_wave_prio(prio_mode);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BP][LD]
   float* Bs = smem + 2 * BP * LD;    // [2][BN][LD]
@@ -396,12 +397,12 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
     const int n_tiles = a.Np / 128;
     const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
     const size_t lds = (size_t)2 * (BP + 128) * LD * sizeof(float);
-    hipLaunchKernelGGL(wino_gate_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d);
+    hipLaunchKernelGGL(wino_gate_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
   } else {
     const int n_tiles = a.Np / 64;
     const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
     const size_t lds = (size_t)2 * (BP + 64) * LD * sizeof(float);
-    hipLaunchKernelGGL(wino_gate_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d);
+    hipLaunchKernelGGL(wino_gate_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
   }
   SS_CHECK_LAUNCH("ss_wino_gate");
   return SS_OK;

@@ -52,14 +52,14 @@ class StyleSingerInfer:
 
     # ---- batched, device resident -------------------------------------------------------------
     @torch.no_grad()
-    def infer_batch(self, batch, noise=None, vocoder_noise=None, seed=None, vocode=True):
+    def infer_batch(self, batch, noise=None, vocoder_noise=None, seed=None, vocode=True, plan_slot=0):
         """batch: dict of device tensors (txt_tokens, note, note_dur, note_type, spk_embed, emo_embed, ref_mels,
         ref_f0, optional mel2ph).  Returns dict(mel [B,T,80], f0 [B,T], lens int32 [B], wav [B,T*hop])."""
         hp = self.hparams
         seed = hp["seed"] if seed is None else seed
         out = self.model(batch["txt_tokens"], mel2ph=batch.get("mel2ph"), spk_embed=batch["spk_embed"], emo_embed=batch["emo_embed"],
                          ref_mels=batch["ref_mels"], ref_f0=batch["ref_f0"], global_steps=320000, infer=True, note=batch["note"],
-                         note_dur=batch["note_dur"], note_type=batch["note_type"], noise=noise, seed=seed)
+                         note_dur=batch["note_dur"], note_type=batch["note_type"], noise=noise, seed=seed, plan_slot=plan_slot)
         res = dict(mel=out["mel_out"], f0=out["f0_denorm"], lens=out["lens"], model_out=out)
         if vocode:
             res["wav"] = self.vocode(out["mel_out"], out["f0_denorm"], out["lens"], noise=vocoder_noise, seed=seed + 101)

@@ -140,6 +140,9 @@ def load():
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
+    prio = os.environ.get("SS_WAVE_PRIO")
+    if prio is not None:
+        check(lib.ss_set_tuning(b"wave_prio", int(prio)), "ss_set_tuning")
     return lib
 
 

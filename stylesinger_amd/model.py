@@ -134,7 +134,7 @@ class StyleSingerHIP(torch.nn.Module):
         self._names = []
         for name, shape in _spec.acoustic_spec(hp):
             self._names.append(name)
-            self.register_buffer(self._mangle(name), torch.zeros(*shape), persistent=True)
+            self.register_buffer(self._mangle(name), torch.zeros(tuple(shape)), persistent=True)
         self._packed_version = -1
         self._weights_version = 0
         self._pk = None
@@ -472,9 +472,10 @@ class StyleSingerHIP(torch.nn.Module):
         b = self.t_bucket
         return T if b <= 1 else (T + b - 1) // b * b
 
-    def _plan(self, B, T, dev):
-        """LRU cache of diffusion plans keyed by (B, T, device), bounded by `plan_bytes` of workspace."""
-        key = (B, T, dev.index)
+    def _plan(self, B, T, dev, slot=0):
+        """LRU cache of diffusion plans keyed by (B, T, device, slot), bounded by `plan_bytes` of workspace. `slot` separates
+        the workspaces of forwards that run CONCURRENTLY on different HIP streams (forward(plan_slot=...))."""
+        key = (B, T, dev.index) if slot == 0 else (B, T, dev.index, slot)
         pl = self._plans.get(key)
         if pl is None:
             pl = _DiffPlan(self, B, T, dev)
@@ -653,7 +654,8 @@ class StyleSingerHIP(torch.nn.Module):
         parity tests; default = on-device Philox), `seed` (Philox seed), `sampler="ddim", ddim_steps=n` (strided
         deterministic mel sampler, BASELINE config 5; default = the reference's 100-step ancestral sampler),
         `sampler="plms", plms_interval=n` (the reference's PLMS sampler, hparams['pndm_speedup'],
-        shallow_diffusion_tts.py:165-197), `style_cache` (the dict encode_style() returned for these references: skips
+        shallow_diffusion_tts.py:165-197), `plan_slot` (workspace/graph set to use: give concurrent forwards on different streams
+        different slots), `style_cache` (the dict encode_style() returned for these references: skips
         the style encoder)."""
         if not infer or f0 is not None or uv is not None:
             raise NotImplementedError("StyleSingerHIP implements the inference path only (infer=True, f0/uv predicted)")
@@ -763,7 +765,7 @@ class StyleSingerHIP(torch.nn.Module):
         # ---- pitch: two joint Gaussian/multinomial diffusions (a8) + post-processing (a9) ----
         midi = torch.empty(B, T, device=dev, dtype=torch.int64)
         L.check(lib.ss_gather_expand_i64(L.ptr(note), L.ptr(mel2ph), L.ptr(midi), B, Tp, T, st()), "midi")
-        pl = self._plan(B, T, dev)
+        pl = self._plan(B, T, dev, int(kwargs.get("plan_slot", 0)))
         pl.uses += 1
         pl.lens2[:B].copy_(lens_t)
         pl.lens2[B:].copy_(lens_t)

@@ -14,8 +14,8 @@ from stylesinger_amd.vocoder import HifiGAN  # noqa: E402
 MEL_L1_TOL = 1e-5      # north_star asks mel L1 <= 1e-4 vs the reference (fp32); measured 3e-7..8e-7 on MI355X -> 10x margin only
 WAV_TOL = 1e-5         # waveform max-abs vs the reference (measured 2e-7)
 STAGE_TOL = 5e-5       # max-abs on intermediate activations of O(1) magnitude
-# per-case overrides of the mel L1 bound (north_star's own bound where the chain is long; tightened once measured)
-CASE_MEL_L1_TOL = {"acoustic_t32_mel1000": 1e-4}
+# per-case overrides of the mel L1 bound (none needed: the 1000-step chain measures 1.0e-6 on MI355X)
+CASE_MEL_L1_TOL = {}
 
 
 def _run_hip(meta):

@@ -48,7 +48,10 @@ def main():
     ap.add_argument("--net", default="both", help="mel|f0|both")
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--T", type=int, default=1500)
+    ap.add_argument("--prio", type=int, default=-1, help="ss_set_tuning('wave_prio', N)")
     a = ap.parse_args()
+    if a.prio >= 0:
+        L.check(L.load().ss_set_tuning(b"wave_prio", a.prio), "ss_set_tuning")
     if a.sweep:
         import subprocess
         for t in a.sweep.split(","):

@@ -3,8 +3,11 @@ import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stylesinger_amd import lib as L
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kbench import timeit
 
+if len(sys.argv) > 1:
+    L.check(L.load().ss_set_tuning(b"wave_prio", int(sys.argv[1])), "ss_set_tuning")
 d = torch.device("cuda:0")
 for (name, B, T, C, Lyr) in (("mel", 8, 1500, 256, 20), ("f0", 16, 1500, 192, 10)):
     lens = torch.full((B,), T, device=d, dtype=torch.int32)

@@ -5,8 +5,9 @@ ctrs=()
 while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
 shift
 cd /tmp && export TMPDIR=/tmp
+# the command runs from /tmp: give script paths relative to the repo root as $GRAFT_REPO_ROOT/...
 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$out -o $out -- "$@" > /tmp/pmc_$out.log 2>&1
-tail -2 /tmp/pmc_$out.log
+grep -E "TF/s|rror|No such" /tmp/pmc_$out.log | tail -4
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, glob, collections
