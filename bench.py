@@ -344,9 +344,10 @@ def main():
             wav = run_step(i, r)
             frames_local += last["frames"] if sweep_mode else B * T
             if args.checksum and i == args.steps - 1 and not sweep_mode:
-                mel_items += [float(x) for x in last["mel"].double().sum(dim=(1, 2)).cpu()]
+                mel_items.append(last["mel"])   # summed after the final sync (the step may still be running on its own stream)
     sync()
     dt = time.perf_counter() - t0
+    mel_items = [float(x) for m in mel_items for x in m.double().sum(dim=(1, 2)).cpu()]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         if backend == "gloo":

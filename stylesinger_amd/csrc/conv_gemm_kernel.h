@@ -117,6 +117,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   const int w_off0 = ((n0 + st_row) * ldw + st_c4 * 4) * 4;
   const int w_pass = RP * ldw * 4;
   const float pro_scale = a.a_scale, pro_slope = a.a_lrelu;
+  // A-prologue form (wave-uniform). VALU instructions are NOT free beside v_mfma_f32_32x32x2_f32 (tools/ubench/mfma_valu.hip:
+  // ~2.8 matrix-pipe cycles per VALU op beyond the first two per MFMA), so layers without a prologue must not pay for one:
+  //   0 = none (no bias, scale 1, slope 1): registers go to LDS untouched - the range-checked fetch already returned 0 on padding
+  //   1 = leaky-relu only, slope in (0,1]: max(v, slope*v) (== max(v,0) + slope*min(v,0) bit for bit; keeps 0 at 0)
+  //   2 = general: lrelu((v + bias) * scale), explicit zero on padding
+  const int pro_mode = (abiasg || pro_scale != 1.0f) ? 2 : (pro_slope == 1.0f ? 0 : (pro_slope > 0.0f && pro_slope < 1.0f ? 1 : 2));
 
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 ra[A_F4], rb[B_F4];
@@ -135,12 +141,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // MFMAs that follow in program order: the L2/HBM latency hides under them.
   // `dead` = 0x80000000 turns the whole fetch into out-of-range reads (return 0, no memory traffic): the bf16 loop issues
   // its prefetch unconditionally so that no control-flow join hides the in-flight count from the s_waitcnt insertion.
-  auto load_a_to = [&](const Cursor& k, u32x4* ra, float4& rpb, int dead = 0) {
+  auto load_a_pm = [&](const Cursor& k, u32x4* ra, float4& rpb, int dead, auto pm_tag) {
+    constexpr int PM = decltype(pm_tag)::value;
     const int ci = k.ci0 + st_c4 * 4;
     const bool ci_ok = ci < a.Cin;  // only false in the zero-padded tail of a Cin that is not a multiple of 32
     const int chunk_off = (a.tap_off[k.tap] * a.lda + k.ci0) * 4;
     const int oob = (ci_ok ? 0 : (int)0x80000000) | dead;  // OR-ed into the offset: one branch-free load either way
-    rpb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, (ci * 4) | dead, 0, 0));
+    if constexpr (PM == 2)  // only the general prologue has a bias to fetch
+      rpb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, (ci * 4) | dead, 0, 0));
 #pragma unroll
     for (int i = 0; i < A_F4; ++i)
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_off0 + i * a_pass + chunk_off) | oob, 0, 0);
@@ -150,12 +158,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     for (int i = 0; i < B_F4; ++i)
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (w_off0 + i * w_pass + c * (BK * 4)) | dead, 0, 0);
   };
+  auto load_a_to = [&](const Cursor& k, u32x4* ra, float4& rpb, int dead = 0) { load_a_pm(k, ra, rpb, dead, std::integral_constant<int, 2>{}); };
   auto load_a = [&](const Cursor& k) { load_a_to(k, ra, rpb); };
   auto load_b = [&](int c) { load_b_to(c, rb); };
   // A prologue: lrelu((x + bias) * scale) on real elements, exact 0 on padding; branch-free
   // (lrelu(x,s) = max(x,0) + s*min(x,0), identity for s = 1), then the swizzled LDS write.
-  auto store_a_from = [&](int buf, const Cursor& k, const u32x4* ra, const float4& rpb) {
+  auto store_a_from = [&](int buf, const Cursor& k, const u32x4* ra, const float4& rpb, auto pm_tag) {
+    constexpr int PM = decltype(pm_tag)::value;
     float* Ad = As + buf * BM * LDS_LD;
+    if constexpr (PM == 0) {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(Ad + lds_slot(st_row + i * RP, st_c4)) = __builtin_bit_cast(float4, ra[i]);
+      return;
+    }
+    if constexpr (PM == 1) {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        float4 v = __builtin_bit_cast(float4, ra[i]);
+        v.x = fmaxf(v.x, pro_slope * v.x); v.y = fmaxf(v.y, pro_slope * v.y);
+        v.z = fmaxf(v.z, pro_slope * v.z); v.w = fmaxf(v.w, pro_slope * v.w);
+        *reinterpret_cast<float4*>(Ad + lds_slot(st_row + i * RP, st_c4)) = v;
+      }
+      return;
+    }
     const int r0 = t0 + st_row + a.tap_off[k.tap];
     const bool c_ok = k.ci0 + st_c4 * 4 < a.Cin;
 #pragma unroll
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     for (int i = 0; i < B_F4; ++i)
       *reinterpret_cast<float4*>(Bd + lds_slot(st_row + i * RP, st_c4)) = __builtin_bit_cast(float4, rb[i]);
   };
-  auto store_a = [&](int buf, const Cursor& k) { store_a_from(buf, k, ra, rpb); };
+  auto store_a = [&](int buf, const Cursor& k) { store_a_from(buf, k, ra, rpb, std::integral_constant<int, 2>{}); };
   auto store_b = [&](int buf) { store_b_from(buf, rb); };
 
   f32x16 acc[TM][TN];
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       __builtin_amdgcn_sched_barrier(0);
       compute_chunk_bf16(c & 1);
       __builtin_amdgcn_sched_barrier(0);
-      store_a_from((c + 1) & 1, k1, raN, rpbN);
+      store_a_from((c + 1) & 1, k1, raN, rpbN, std::integral_constant<int, 2>{});
       store_b_from((c + 1) & 1, rbN);
       k1 = k2;
       __syncthreads();
@@ -291,29 +316,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       body(ra, rpb, rb, ra2, rpb2, rb2);
     }
     if (nbodies & 1) body(ra2, rpb2, rb2, ra, rpb, rb);
-  } else
-  for (int c = 0; c + 1 < nchunks; ++c) {
-    const int cur = c & 1;
-    const float* Ac = As + cur * BM * LDS_LD;
-    const float* Bc = Bs + cur * BN * LDS_LD;
-    float4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-    read_frags(Ac, Bc, 0, af0, bf0);
-    read_frags(Ac, Bc, 1, af1, bf1);
-    advance(kc);
-    load_a(kc);
-    __builtin_amdgcn_sched_barrier(0);  // pin: fetches are ISSUED here, two MFMA groups before their first use
-    mfma_group(af0, bf0);
-    read_frags(Ac, Bc, 2, af0, bf0);
-    load_b(c + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(af1, bf1);
-    read_frags(Ac, Bc, 3, af1, bf1);
-    mfma_group(af0, bf0);
-    __builtin_amdgcn_sched_barrier(0);  // pin: the LDS writes of chunk c+1 go in the shadow of the last group
-    store_a(cur ^ 1, kc);
-    store_b(cur ^ 1);
-    mfma_group(af1, bf1);
-    __syncthreads();
+  } else {
+    // two chunks per loop iteration so that the LDS buffer index is a compile-time constant: every fragment / staging address
+    // is then one per-thread base register + an immediate offset (no per-chunk address arithmetic on the VALU)
+    // (the prologue form is dispatched OUTSIDE the loop: one branch-free loop copy per form - a branch inside the body makes
+    //  the compiler bounce the accumulators through VGPRs and wait for all outstanding loads at the join)
+    auto run_loop = [&](auto pm_tag) {
+      auto body = [&](auto cur_tag, int c) {
+        constexpr int cur = decltype(cur_tag)::value;
+        const float* Ac = As + cur * BM * LDS_LD;
+        const float* Bc = Bs + cur * BN * LDS_LD;
+        float4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+        read_frags(Ac, Bc, 0, af0, bf0);
+        read_frags(Ac, Bc, 1, af1, bf1);
+        advance(kc);
+        load_a_pm(kc, ra, rpb, 0, pm_tag);
+        __builtin_amdgcn_sched_barrier(0);  // pin: fetches are ISSUED here, two MFMA groups before their first use
+        mfma_group(af0, bf0);
+        read_frags(Ac, Bc, 2, af0, bf0);
+        load_b(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(af1, bf1);
+        read_frags(Ac, Bc, 3, af1, bf1);
+        mfma_group(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);  // pin: the LDS writes of chunk c+1 go in the shadow of the last group
+        store_a_from(cur ^ 1, kc, ra, rpb, pm_tag);
+        store_b(cur ^ 1);
+        mfma_group(af1, bf1);
+        __syncthreads();
+      };
+      int c = 0;
+      for (; c + 2 < nchunks; c += 2) {
+        body(std::integral_constant<int, 0>{}, c);
+        body(std::integral_constant<int, 1>{}, c + 1);
+      }
+      if (c + 1 < nchunks) body(std::integral_constant<int, 0>{}, c);
+    };
+    if (pro_mode == 0) run_loop(std::integral_constant<int, 0>{});
+    else if (pro_mode == 1) run_loop(std::integral_constant<int, 1>{});
+    else run_loop(std::integral_constant<int, 2>{});
   }
   // Epilogue operands that live in HBM (GATE: the hoisted conditioner slab E, 40 KB row stride; RESSKIP: x and the
   // skip accumulator) are fetched BEFORE the last chunk's MFMAs when they fit in registers, so their miss latency

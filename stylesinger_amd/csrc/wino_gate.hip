@@ -15,6 +15,7 @@
 // through LDS.  Main-loop skeleton (LDS swizzle, buffer-resource fetch, MFMA-shadow scheduling) = conv_gemm_kernel.h.
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
+#include <stdlib.h>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -346,6 +347,345 @@ __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Version 2 of the same kernel: identical tiles, staging layout and arithmetic; the instruction stream is on a VALU diet.
+// Measured (tools/ubench/mfma_valu.hip): a VALU instruction issued beside v_mfma_f32_32x32x2_f32 is NOT free on gfx950 - beyond
+// ~2 per MFMA each one costs ~2.8 cycles of the SIMD the matrix op runs on (SQ_VALU_MFMA_COEXEC_CYCLES reads 0 for this
+// kernel). Version 1 issues 62 VALU per 16-MFMA chunk plus ~1450 in prologue/epilogue (6.7 per MFMA overall). Here:
+//   * every fetch address is a per-thread byte offset held in a register + a wave-uniform SGPR offset (buffer soffset): the
+//     K-chunk and weight-chunk walks cost no VALU at all; the row offsets / padding masks of a Winograd component are
+//     computed once per component (between the component loops), not once per chunk;
+//   * the input transform is 2 ops per element:  (va +- vb) + mc*dstep  with mc = [row a valid] +- [row b valid];
+//   * chunks are processed in pairs so that the LDS double-buffer index is a compile-time constant (immediate offsets);
+//   * the epilogue computes one transcendental pair per activation (tanh(x) = 2*sigmoid(2x) - 1, selected per wave by a
+//     multiplier instead of evaluating both branches), takes the frame index of every accumulator row once, and fetches the
+//     conditioner addend through a buffer resource with 32-bit offsets.
+// Requires Cin % 32 == 0 and an even number of K chunks (true for both denoisers: C = 256 / 192); the launcher falls back to
+// version 1 otherwise.
+template <int TN>
+__global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_args a, int p_tiles_per_item, int p_tiles,
+                                                           int n_tiles, int log2d, int prio_mode) {
+  constexpr int BN = 64 * TN;
+  ss_apply_wave_prio(prio_mode);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][BP][LD]
+  float* Bs = smem + 2 * BP * LD;    // [2][BN][LD]
+
+  const int id = blockIdx.x;
+  const int grp = id / (8 * n_tiles);
+  const int rem = id % (8 * n_tiles);
+  const int pt = grp * 8 + (rem & 7);
+  const int nt = rem >> 3;
+  if (pt >= p_tiles) return;
+  const int b = pt / p_tiles_per_item;
+  const int p0 = (pt % p_tiles_per_item) * BP;
+  const int n0 = nt * BN;
+  const int d = 1 << log2d;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+  const float* Wg = a.W + (int64_t)grp_w * a.w_group_stride;
+  const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;
+  const int kchunks = a.Kp / BK;
+  const int ldw = 4 * a.Kp;
+
+  auto uniform_ptr = [](const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Wg), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(abiasg ? abiasg : Wg), 0, __builtin_amdgcn_readfirstlane(abiasg ? a.Cin * 4 : 0), 0x00020000);
+
+  const int st_c4 = tid & 7;
+  const int st_row = tid >> 3;  // 0..31; two passes cover the 64 pair rows / 64 weight rows
+  // frame of pair p: t = p + (p & ~(d-1))   (= (p >> log2d) * 2d + (p & (d-1)))
+  int t_of[2], rowoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = p0 + st_row + i * 32;
+    t_of[i] = p + (p & ~(d - 1));
+    rowoff[i] = (t_of[i] * a.lda + st_c4 * 4) * 4;
+  }
+  int w_voff[2 * TN];
+#pragma unroll
+  for (int i = 0; i < 2 * TN; ++i) w_voff[i] = ((n0 + st_row + i * 32) * ldw + st_c4 * 4) * 4;
+  const int bias_voff = st_c4 * 16;
+  const int lda4 = a.lda * 4;
+
+  // Winograd component j: staged row = y[t + oa] + sgn * y[t + ob],  y = x + dstep on real frames, 0 on padding
+  //   j0: y[t-d] - y[t+d]   j1: y[t] + y[t+d]   j2: y[t+d] - y[t]   j3: y[t] - y[t+2d]
+  struct Comp { int va[2], vb[2]; float mc[2]; float sgn; };
+  auto comp_of = [&](int j) {
+    Comp c;
+    const int oa = (j == 0) ? -d : (j == 2) ? d : 0;
+    const int ob = (j == 3) ? 2 * d : (j == 2) ? 0 : d;
+    c.sgn = (j == 1) ? 1.0f : -1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      c.va[i] = rowoff[i] + oa * lda4;
+      c.vb[i] = rowoff[i] + ob * lda4;
+      const bool oka = (unsigned)(t_of[i] + oa) < (unsigned)len, okb = (unsigned)(t_of[i] + ob) < (unsigned)len;
+      c.mc[i] = (oka ? 1.0f : 0.0f) + (okb ? c.sgn : 0.0f);  // dstep enters once per valid fetched row, with that row's sign
+    }
+    return c;
+  };
+
+  u32x4 ra[2][2], rb[2 * TN];
+  float4 rpb;
+  auto load_a = [&](const Comp& c, int ci0b) {  // ci0b = byte offset of the K chunk inside a row (wave-uniform -> SGPR soffset)
+    rpb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, bias_voff, ci0b, 0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, c.va[i], ci0b, 0);
+      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, c.vb[i], ci0b, 0);
+    }
+  };
+  auto load_b = [&](int cb) {  // cb = byte offset of the weight chunk inside a packed row (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], cb, 0);
+  };
+  const int a_wr = lds_slot(st_row, st_c4), a_wr1 = lds_slot(st_row + 32, st_c4);  // (row >> 1) & 7 differs by 0 mod 8 for +32
+  auto store_a = [&](float* Ad, const Comp& c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 va = __builtin_bit_cast(float4, ra[i][0]);
+      const float4 vb = __builtin_bit_cast(float4, ra[i][1]);
+      float4 v;
+      v.x = fmaf(c.mc[i], rpb.x, fmaf(c.sgn, vb.x, va.x));
+      v.y = fmaf(c.mc[i], rpb.y, fmaf(c.sgn, vb.y, va.y));
+      v.z = fmaf(c.mc[i], rpb.z, fmaf(c.sgn, vb.z, va.z));
+      v.w = fmaf(c.mc[i], rpb.w, fmaf(c.sgn, vb.w, va.w));
+      *reinterpret_cast<float4*>(Ad + (i == 0 ? a_wr : a_wr1)) = v;
+    }
+  };
+  auto store_b = [&](float* Bd) {
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i)
+      *reinterpret_cast<float4*>(Bd + lds_slot(st_row + i * 32, st_c4)) = __builtin_bit_cast(float4, rb[i]);
+  };
+
+  f32x16 acc[4][TN];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+  Comp cc = comp_of(0);
+  load_a(cc, 0);
+  load_b(0);
+  store_a(As, cc);
+  store_b(Bs);
+  __syncthreads();
+
+  const int swz = (l31 >> 1) & 7;
+  const int a_row = (wm * 32 + l31) * LD;
+  const int b_row = (wn * 32 * TN + l31) * LD;
+  struct BF { float4 v[TN]; };
+  auto read_frags = [&](const float* Ac, const float* Bc, int q, float4& af, BF& bf) {
+    const int so = ((2 * q + lh) ^ swz) << 2;
+    af = *reinterpret_cast<const float4*>(Ac + a_row + so);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) bf.v[n] = *reinterpret_cast<const float4*>(Bc + b_row + n * 32 * LD + so);
+  };
+  auto mfma4 = [&](f32x16 (&c)[TN], const float4& af, const BF& bf) {
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.v[n].x, c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.v[n].y, c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.v[n].z, c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.v[n].w, c[n], 0, 0, 0);
+  };
+
+  // One K chunk: MFMAs of the chunk in LDS buffer CUR into `cacc`; the NEXT chunk (component parameters `nx`, K byte offset
+  // `nci0b`, weight byte offset `ncb`) is fetched / transformed / written to buffer CUR^1 in the shadow of the MFMAs.
+  auto chunk = [&](auto cur_tag, f32x16 (&cacc)[TN], const Comp& nx, int nci0b, int ncb) {
+    constexpr int CUR = decltype(cur_tag)::value;
+    const float* Ac = As + CUR * BP * LD;
+    const float* Bc = Bs + CUR * BN * LD;
+    float4 af0, af1;
+    BF bf0, bf1;
+    read_frags(Ac, Bc, 0, af0, bf0);
+    read_frags(Ac, Bc, 1, af1, bf1);
+    load_a(nx, nci0b);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cacc, af0, bf0);
+    read_frags(Ac, Bc, 2, af0, bf0);
+    load_b(ncb);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cacc, af1, bf1);
+    read_frags(Ac, Bc, 3, af1, bf1);
+    mfma4(cacc, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(As + (CUR ^ 1) * BP * LD, nx);
+    store_b(Bs + (CUR ^ 1) * BN * LD);
+    mfma4(cacc, af1, bf1);
+    __syncthreads();
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  // component J: kchunks chunks (even), pairs (buffer 0, buffer 1); the last chunk of the component stages the first chunk of
+  // component J+1 (its parameters are computed here, between the loops, never inside one)
+  const int kb = a.Kp * 4;  // bytes of one component in a packed weight row
+  auto component = [&](f32x16 (&cacc)[TN], int j) {
+    const Comp nxt = comp_of(j + 1);
+    const int wbase = j * kb;
+    int k = 0;
+    for (; k + 2 < kchunks; k += 2) {
+      chunk(C0{}, cacc, cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
+      chunk(C1{}, cacc, cc, (k + 2) * (BK * 4), wbase + (k + 2) * (BK * 4));
+    }
+    chunk(C0{}, cacc, cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
+    chunk(C1{}, cacc, nxt, 0, wbase + kb);
+    cc = nxt;
+  };
+  component(acc[0], 0);
+  component(acc[1], 1);
+  component(acc[2], 2);
+  {  // component 3: the very last chunk has nothing left to stage
+    const int wbase = 3 * kb;
+    int k = 0;
+    for (; k + 2 < kchunks; k += 2) {
+      chunk(C0{}, acc[3], cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
+      chunk(C1{}, acc[3], cc, (k + 2) * (BK * 4), wbase + (k + 2) * (BK * 4));
+    }
+    chunk(C0{}, acc[3], cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
+  }
+
+  // ---- frame index / byte offsets of the accumulator rows this lane owns: row r -> pair (r&3) + 8*(r>>2) + 4*lh of the wave tile
+  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+  const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(Eb ? Eb : Wg), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+  const int pbase = p0 + wm * 32 + 4 * lh;
+  int tfr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int p = pbase + (r & 3) + 8 * (r >> 2);
+    tfr[r] = p + (p & ~(d - 1));
+  }
+  const int lde4 = a.lde * 4;
+  // Conditioner addend (hoisted E slab, 40 KB row stride) fetched BEFORE the last chunk's MFMAs: its miss latency hides under them.
+  float pe[TN == 2 ? 64 : 32];
+  if constexpr (TN == 2) {
+    const int pc0 = n0 + wn * 64 + l31;
+    const int colb = pc0 * 4 + ((((pc0 >> 6) * 32 + l31) < a.N) ? 0 : (int)0x80000000);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int off = tfr[r] * lde4 + colb;
+      const int off2 = off + d * lde4;  // frame t+d: in the VGPR offset so that the range check sees the row (t+d may be >= T)
+      pe[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 0, 0));
+      pe[16 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 128, 0));
+      pe[32 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off2, 0, 0));
+      pe[48 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off2, 128, 0));
+    }
+  } else {
+    const int pc = n0 + wn * 32 + l31;
+    const int colb = pc * 4 + ((((n0 >> 1) + l31) < a.N) ? 0 : (int)0x80000000);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int off = tfr[r] * lde4 + colb;
+      pe[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 0, 0));
+      pe[16 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off + d * lde4, 0, 0));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {  // last chunk (buffer 1: 4*kchunks chunks in all, kchunks even)
+    const float* Ac = As + BP * LD;
+    const float* Bc = Bs + BN * LD;
+    float4 af0, af1;
+    BF bf0, bf1;
+    read_frags(Ac, Bc, 0, af0, bf0);
+    read_frags(Ac, Bc, 1, af1, bf1);
+    mfma4(acc[3], af0, bf0);
+    read_frags(Ac, Bc, 2, af0, bf0);
+    mfma4(acc[3], af1, bf1);
+    read_frags(Ac, Bc, 3, af1, bf1);
+    mfma4(acc[3], af0, bf0);
+    mfma4(acc[3], af1, bf1);
+  }
+
+  // ---- epilogue: output transform z[t] = m0+m1+m2, z[t+d] = m1-m2-m3, conditioner addend, gate ----
+  float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+  const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+  // sigmoid(x) = rcp(1 + exp(-x)); tanh(x) = 2*sigmoid(2x) - 1: one exp + one rcp either way, selected by (mul, scale, shift)
+  auto act = [](float x, float mul, float sc, float sh) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(x * mul)), sc, sh); };
+  if constexpr (TN == 2) {
+    const int pc0 = n0 + wn * 64 + l31;
+    const int oc = (pc0 >> 6) * 32 + l31;
+    if (oc >= a.N) return;
+    const float b0 = a.bias ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc0] : 0.f;
+    const float b1 = a.bias ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc0 + 32] : 0.f;
+    const bool sig_first = a.gate_mode == 0;
+    const float m0 = sig_first ? -1.0f : -2.0f, s0 = sig_first ? 1.0f : 2.0f, h0 = sig_first ? 0.0f : -1.0f;
+    const float m1 = sig_first ? -2.0f : -1.0f, s1 = sig_first ? 2.0f : 1.0f, h1 = sig_first ? -1.0f : 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // half 0: frame t, half 1: frame t+d
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = tfr[r] + half * d;
+        if (t >= a.T) continue;
+        const float z0 = half == 0 ? acc[0][0][r] + acc[1][0][r] + acc[2][0][r] : acc[1][0][r] - acc[2][0][r] - acc[3][0][r];
+        const float z1 = half == 0 ? acc[0][1][r] + acc[1][1][r] + acc[2][1][r] : acc[1][1][r] - acc[2][1][r] - acc[3][1][r];
+        const float v0 = z0 + b0 + pe[32 * half + r], v1 = z1 + b1 + pe[32 * half + 16 + r];
+        float g = act(v0, m0, s0, h0) * act(v1, m1, s1, h1);
+        if (t >= row_lim) g = 0.f;
+        Cb[(int64_t)t * a.ldc + oc] = g;
+      }
+    }
+  } else {
+    // wave wn=0 holds the first gate operand of channels [oc0, oc0+32), wave wn=1 the second; wn=0 finishes frame t,
+    // wn=1 frame t+d, and the partners' activations travel through LDS.
+    __syncthreads();  // every wave is done with the operand tiles: reuse LDS as the exchange buffer
+    float* X0 = smem;                // [2 wm][32 pairs][33]: second-operand activation of frame t   (written by wn=1)
+    float* X1 = smem + 2 * 32 * 33;  // [2 wm][32 pairs][33]: first-operand activation of frame t+d  (written by wn=0)
+    const int pc = n0 + wn * 32 + l31;  // packed column
+    const int oc = (n0 >> 1) + l31;     // output channel
+    const bool col_ok = oc < a.N;
+    const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc] : 0.f;
+    const bool use_sig = (wn == 0) == (a.gate_mode == 0);  // wave-uniform
+    const float am = use_sig ? -1.0f : -2.0f, as = use_sig ? 1.0f : 2.0f, ah = use_sig ? 0.0f : -1.0f;
+    float* xw = (wn == 0 ? X1 : X0) + (wm * 32 + 4 * lh) * 33 + l31;  // what this wave publishes
+    float mine[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pl = (r & 3) + 8 * (r >> 2);
+      const float z0 = acc[0][0][r] + acc[1][0][r] + acc[2][0][r];
+      const float z1 = acc[1][0][r] - acc[2][0][r] - acc[3][0][r];
+      const float u0 = act(z0 + (bs + pe[r]), am, as, ah);
+      const float u1 = act(z1 + (bs + pe[16 + r]), am, as, ah);
+      mine[r] = wn == 0 ? u0 : u1;
+      xw[pl * 33] = wn == 0 ? u1 : u0;
+    }
+    __syncthreads();
+    if (!col_ok) return;
+    const float* xr = (wn == 0 ? X0 : X1) + (wm * 32 + 4 * lh) * 33 + l31;
+    const int tsh = wn == 0 ? 0 : d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pl = (r & 3) + 8 * (r >> 2);
+      const int t = tfr[r] + tsh;
+      if (t >= a.T) continue;
+      float g = mine[r] * xr[pl * 33];
+      if (t >= row_lim) g = 0.f;
+      Cb[(int64_t)t * a.ldc + oc] = g;
+    }
+  }
+}
+
 // g0 = w0, g1 = (w0+w1+w2)/2, g2 = (w0-w1+w2)/2, g3 = w2   (src [rows][3] -> dst [rows][4], rows = Cout*Cin)
 __global__ void wino_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
@@ -392,17 +732,22 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
     const double t2 = (double)ss_cdiv(b2, 256) * 2.0 / 0.92, t1 = (double)ss_cdiv(b1, 256) * 1.0 / 0.75;
     tn = ((a.Np % 128) == 0 && b1 > 2 * 768 && t2 <= t1) ? 2 : 1;
   }
+  // version 2 (VALU diet) needs whole 32-channel K chunks and an even chunk count; SS_WINO_V1=1 forces the first version (A/B)
+  static const bool force_v1 = getenv("SS_WINO_V1") != nullptr;
+  const bool v2 = !force_v1 && (a.Cin % BK) == 0 && a.Kp == a.Cin && ((a.Kp / BK) % 2) == 0;
   if (tn == 2) {
     SS_CHECK_ARG((a.Np % 128) == 0, "ss_wino_gate: TN=2 needs Np multiple of 128");
     const int n_tiles = a.Np / 128;
     const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
     const size_t lds = (size_t)2 * (BP + 128) * LD * sizeof(float);
-    hipLaunchKernelGGL(wino_gate_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
+    if (v2) hipLaunchKernelGGL(wino_gate_kernel_v2<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
+    else hipLaunchKernelGGL(wino_gate_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
   } else {
     const int n_tiles = a.Np / 64;
     const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
     const size_t lds = (size_t)2 * (BP + 64) * LD * sizeof(float);
-    hipLaunchKernelGGL(wino_gate_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
+    if (v2) hipLaunchKernelGGL(wino_gate_kernel_v2<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
+    else hipLaunchKernelGGL(wino_gate_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
   }
   SS_CHECK_LAUNCH("ss_wino_gate");
   return SS_OK;
