@@ -62,11 +62,11 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SS_BENCH_PIPELINE", "0")),
                     help="1 = vocode batch i on a second stream while the diffusion loops of batch i+1 run (all K batches still "
                          "finish inside the timed region)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SS_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SS_BENCH_STREAMS", "3")),
                     help="batches in flight per GPU: consecutive steps (independent batches) are issued round-robin on N HIP streams, each "
                          "with its own workspace / hipGraph set, so one batch's kernel ramps and tails are filled by the other's blocks "
-                         "(all K batches still start and finish inside the timed region; measured on MI355X at C2: 1 stream 440 ms/step, "
-                         "2: 392, 3: 383, 4: 380). 1 = strictly one batch at a time.")
+                         "(all K batches still start and finish inside the timed region; measured on MI355X at C2 with the round-2 kernels: "
+                         "1 stream 400 ms/step, 2: 360-367, 3: 358, 4: 358). 1 = strictly one batch at a time.")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="extra thread count for the CPU oracle sweep; 16 is the fastest setting on the 2x64-core EPYC GPU-box host")
     return ap.parse_args()

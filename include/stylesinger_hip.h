@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 6 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM */
+#define SS_ABI_VERSION 7 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -34,7 +34,8 @@ const char* ss_last_error(void);
 int ss_abi_version(void);
 /* number of compute units / name of device `dev` (sanity: must be gfx950) */
 int ss_device_info(int dev, int* n_cu, char* arch, int arch_len);
-/* out[0..2] = sizeof(ss_conv_gemm_args), sizeof(ss_wavenet), sizeof(ss_hifigan): lets a binding verify its mirror */
+/* out[0..2] = sizeof(ss_conv_gemm_args), sizeof(ss_wavenet), sizeof(ss_hifigan) (+ out[3] = sizeof(ss_gemm_bf16_args) when n >= 4):
+ * lets a binding verify its mirror */
 int ss_struct_sizes(int64_t* out, int n);
 /* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
  * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3) */
@@ -132,6 +133,58 @@ int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
 int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* stream);
 /* src [Cout][Cin][3] -> dst [Cout][Cin][4]: g0=w0, g1=(w0+w1+w2)/2, g2=(w0-w1+w2)/2, g3=w2 */
 int ss_wino_weight_transform(const float* src, float* dst, int Cout, int Cin, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16-operand GEMM/conv for the denoisers' hidden layers (BASELINE config 4): A and W are bf16 IN HBM (rounded once where
+ * they are produced: weights by ss_to_bf16 at pack time = the "bf16 weight copies", activations by the producing epilogue),
+ * fp32 accumulate on v_mfma_f32_32x32x16_bf16, K chunks of 64. Same tap / zero-padding / grouped-launch semantics as
+ * ss_conv_gemm. Arithmetic contract: RNE rounding of both matmul operands, everything else fp32 (net.py:58-130 otherwise).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  SS_HEPI_STORE = 0, /* C fp32 = act(acc + bias), rows >= lens[b] written as 0 when mask_rows                               */
+  SS_HEPI_GATE = 1,  /* paired 32-col blocks + fp32 addend E -> sigmoid*tanh (gate_mode as SS_EPI_GATE), C is BF16 [.][ldc]  */
+  SS_HEPI_RESX = 2   /* X fp32 in place: x = (x + acc + bias) * post_scale ; Y bf16 = x + next_bias (next layer's operand)   */
+};
+typedef struct ss_gemm_bf16_args {
+  const uint16_t* A;      /* bf16 [B][T][lda] */
+  int64_t a_batch_stride; /* elements */
+  int32_t lda;            /* elements, multiple of 8 */
+  int32_t K;              /* channels per tap, multiple of 64 */
+  int32_t ntaps;          /* 1..4 */
+  int32_t tap_off[4];
+  const int32_t* lens;
+  int32_t B, T;
+  const uint16_t* W; /* bf16 packed [Np][ntaps*K] (ss_pack_conv_weight layout, converted by ss_to_bf16) */
+  int64_t w_group_stride;
+  int32_t N, Np;
+  int32_t epi;
+  int32_t act; /* STORE: SS_ACT_* */
+  const float* bias;
+  int64_t bias_group_stride;
+  const float* E;
+  int32_t lde;
+  int32_t gate_mode;
+  int64_t e_batch_stride;
+  float* X;
+  int64_t x_batch_stride;
+  int32_t ldx;
+  float post_scale;
+  const float* next_bias; /* [N] or NULL */
+  int64_t next_bias_group_stride;
+  uint16_t* Y; /* bf16 [B][T][ldy] or NULL */
+  int64_t y_batch_stride;
+  int32_t ldy;
+  int32_t ldc;
+  void* C; /* STORE: float*, GATE: uint16_t* */
+  int64_t c_batch_stride;
+  int32_t mask_rows;
+  int32_t group_size;
+} ss_gemm_bf16_args;
+int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
+/* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights
+ * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
+int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
+               int group_size, int64_t bias_group_stride, void* stream);
 
 /* Weight packing (device -> device).  src is the torch parameter layout [Cout][Cin][k] (conv1d,
  * k=1 for nn.Linear [out][in]).  dst is [Np][k*Kp] with zero fill.  If scale0 != NULL (from
@@ -271,6 +324,14 @@ typedef struct ss_wavenet {
    * launch disappears. */
   int32_t skipall_folded;
   int32_t reserved1;
+  /* optional bf16 copies of the hidden-layer weights (same packed layouts, ss_to_bf16). When w_dil_h[0] is set and mfma_bf16 = 1
+   * the residual stack runs on ss_gemm_bf16: activations travel between the layers as bf16 (y = x + dstep, gate outputs) and
+   * the workspace carries the bf16 planes. w_out_h = residual half only ([C][C]); needs the deferred-skip form (w_skipall_h). */
+  const uint16_t* w_dil_h[SS_MAX_LAYERS];
+  const uint16_t* w_out_h[SS_MAX_LAYERS];
+  const uint16_t* w_skipall_h;
+  const uint16_t* w_cond_h;
+  int64_t gs_w_dil_h, gs_w_out_h, gs_w_skipall_h, gs_w_cond_h;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

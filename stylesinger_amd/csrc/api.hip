@@ -54,5 +54,6 @@ extern "C" int ss_struct_sizes(int64_t* out, int n) {
   out[0] = (int64_t)sizeof(ss_conv_gemm_args);
   out[1] = (int64_t)sizeof(ss_wavenet);
   out[2] = (int64_t)sizeof(ss_hifigan);
+  if (n >= 4) out[3] = (int64_t)sizeof(ss_gemm_bf16_args);
   return SS_OK;
 }

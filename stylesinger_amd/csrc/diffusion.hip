@@ -23,8 +23,14 @@ struct WsLayout {
   float* S;   // [B*T][C]
   float* O;   // [B*T][4]   (f0 net output)
   float* GA;  // [B*T][L*C] gate outputs of ALL layers (deferred-skip mode only, else null)
+  // bf16-in-HBM mode (net->w_dil_h set): the hidden activations travel as bf16
+  uint16_t* Yh;     // [B*T][C]        x + dstep of the next layer (the dilated conv's operand)
+  uint16_t* GAh;    // [B*T][L*C]      gate outputs of all layers
+  uint16_t* condh;  // [B*T][cond_dim] conditioner
   int64_t bytes;
 };
+
+inline bool hmode(const ss_wavenet* net) { return net->mfma_bf16 && net->w_dil_h[0] && net->w_skipall_h && net->w_cond_h; }
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -43,7 +49,11 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.G = take(rows * net->C);
   w.S = take(rows * net->C);
   w.O = take(rows * 4);
-  w.GA = net->w_skipall ? take(rows * net->L * net->C) : nullptr;
+  const bool h = hmode(net);
+  w.GA = (net->w_skipall && !h) ? take(rows * net->L * net->C) : nullptr;
+  w.Yh = h ? (uint16_t*)take((rows * net->C + 1) / 2) : nullptr;
+  w.GAh = h ? (uint16_t*)take((rows * net->L * net->C + 1) / 2) : nullptr;
+  w.condh = h ? (uint16_t*)take((rows * net->cond_dim + 1) / 2) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -66,10 +76,43 @@ inline ss_conv_gemm_args base_args(int B, int T, const int32_t* lens) {
 inline int round_up32(int x) { return (x + 31) / 32 * 32; }
 
 // E = cond . Wc^T + (bc + b_dil)  for all layers at once
+inline ss_gemm_bf16_args base_args_h(const ss_wavenet* net, int B, int T, const int32_t* lens) {
+  ss_gemm_bf16_args a;
+  memset(&a, 0, sizeof(a));
+  a.B = B;
+  a.T = T;
+  a.lens = lens;
+  a.ntaps = 1;
+  a.post_scale = 1.0f;
+  a.mask_rows = 1;
+  if (net->n_groups > 1) a.group_size = B / net->n_groups;
+  return a;
+}
+
 int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* lens, int B, int T, const WsLayout& w,
                     hipStream_t stream) {
-  ss_conv_gemm_args a = base_args(B, T, lens);
   const int NE = net->L * 2 * net->C;
+  if (hmode(net)) {  // cond rounded once to bf16, then E = cond . Wc^T + (bc + b_dil) on the bf16 kernel (fp32 out)
+    SS_PROPAGATE(ss_to_bf16(cond, nullptr, w.condh, B, T, net->cond_dim, net->cond_dim, net->cond_dim, nullptr, 0, 0, stream));
+    ss_gemm_bf16_args h = base_args_h(net, B, T, lens);
+    h.A = w.condh;
+    h.lda = net->cond_dim;
+    h.a_batch_stride = (int64_t)T * net->cond_dim;
+    h.K = net->cond_dim;
+    h.W = net->w_cond_h;
+    h.w_group_stride = net->gs_w_cond_h;
+    h.N = NE;
+    h.Np = NE;
+    h.epi = SS_HEPI_STORE;
+    h.bias = net->b_cond;
+    h.bias_group_stride = net->gs_b_cond;
+    h.C = w.E;
+    h.ldc = NE;
+    h.c_batch_stride = (int64_t)T * NE;
+    h.mask_rows = 0;
+    return ss_gemm_bf16(&h, stream);
+  }
+  ss_conv_gemm_args a = base_args(B, T, lens);
   a.A = cond;
   a.lda = net->cond_dim;
   a.a_batch_stride = (int64_t)T * net->cond_dim;
@@ -97,10 +140,93 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
 // Deferred-skip mode (net->w_skipall set): the per-layer output projection only runs its residual half (N = C, no skip
 // read-modify-write), every layer's gate output is kept ([rows][L*C]) and the skip sum of all layers is ONE GEMM with
 // K = L*C at the end of the stack - same products, summed in one accumulator chain instead of layer by layer.
+// bf16-in-HBM form of the stack: Yh = bf16(x + dstep_0) on entry; per layer gate (Yh -> GAh[l], bf16) and residual projection
+// (GAh[l] -> X fp32 in place, Yh = bf16(x + dstep_{l+1})); then the K = L*C skip GEMM -> S (fp32). Same operand roundings as
+// oracle/restatement.py with set_matmul_rounding("bf16") - each operand is rounded once, where it is produced.
+int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
+  const int C = net->C, L = net->L;
+  const int NE = L * 2 * C;
+  for (int l = 0; l < L; ++l) {
+    const int d = 1 << (l % net->dil_cycle);
+    ss_gemm_bf16_args g = base_args_h(net, B, T, lens);
+    g.A = w.Yh;
+    g.lda = C;
+    g.a_batch_stride = (int64_t)T * C;
+    g.K = C;
+    g.ntaps = 3;
+    g.tap_off[0] = -d;
+    g.tap_off[1] = 0;
+    g.tap_off[2] = d;
+    g.W = net->w_dil_h[l];
+    g.w_group_stride = net->gs_w_dil_h;
+    g.N = C;
+    g.Np = 2 * C;
+    g.epi = SS_HEPI_GATE;
+    g.gate_mode = 0;
+    g.E = w.E + (int64_t)l * 2 * C;
+    g.lde = NE;
+    g.e_batch_stride = (int64_t)T * NE;
+    g.C = w.GAh + (int64_t)l * C;
+    g.ldc = L * C;
+    g.c_batch_stride = (int64_t)T * L * C;
+    SS_PROPAGATE(ss_gemm_bf16(&g, stream));
+    ss_gemm_bf16_args o = base_args_h(net, B, T, lens);
+    o.A = w.GAh + (int64_t)l * C;
+    o.lda = L * C;
+    o.a_batch_stride = (int64_t)T * L * C;
+    o.K = C;
+    o.W = net->w_out_h[l];
+    o.w_group_stride = net->gs_w_out_h;
+    o.N = C;
+    o.Np = C;  // the residual half = the first C packed rows
+    o.epi = SS_HEPI_RESX;
+    o.bias = net->b_out[l];
+    o.bias_group_stride = net->gs_b_out;
+    o.X = w.X;
+    o.ldx = C;
+    o.x_batch_stride = (int64_t)T * C;
+    o.post_scale = 0.70710678118654752440f;
+    if (l + 1 < L) {
+      o.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
+      o.next_bias_group_stride = net->gs_dstep;
+      o.Y = w.Yh;
+      o.ldy = C;
+      o.y_batch_stride = (int64_t)T * C;
+    }
+    SS_PROPAGATE(ss_gemm_bf16(&o, stream));
+  }
+  ss_gemm_bf16_args k = base_args_h(net, B, T, lens);
+  k.A = w.GAh;
+  k.lda = L * C;
+  k.a_batch_stride = (int64_t)T * L * C;
+  k.K = L * C;
+  k.W = net->w_skipall_h;
+  k.w_group_stride = net->gs_w_skipall_h;
+  k.N = C;
+  k.Np = round_up32(C);
+  k.epi = SS_HEPI_STORE;
+  k.bias = net->b_skipall;
+  k.bias_group_stride = net->gs_b_skipall;
+  k.C = w.S;
+  k.ldc = C;
+  k.c_batch_stride = (int64_t)T * C;
+  return ss_gemm_bf16(&k, stream);
+}
+
+// Yh = bf16(X + dstep[step][0]) : the first layer's conv operand (bf16-in-HBM mode)
+int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
+  return ss_to_bf16(w.X, net->dstep + (int64_t)step * net->L * net->C, w.Yh, B, T, net->C, net->C, net->C, lens,
+                    net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);
+}
+
 int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w,
                        hipStream_t stream) {
   const int C = net->C, L = net->L;
   const int NE = L * 2 * C;
+  if (hmode(net)) {
+    SS_PROPAGATE(stack_entry_h(net, step, lens, B, T, w, stream));
+    SS_PROPAGATE(run_residual_stack_h(net, step, lens, B, T, w, stream));
+  } else
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % net->dil_cycle);
     // y = dilated_conv(x + dstep) + cond_proj ; g = sigmoid(y[:C]) * tanh(y[C:])   (net.py:66-73)
@@ -175,7 +301,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     }
     SS_PROPAGATE(ss_conv_gemm(&o, stream));
   }
-  if (net->w_skipall) {  // S = sum_l skip_l = [g_0 | g_1 | ... | g_{L-1}] . [W_skip_0 ; ... ; W_skip_{L-1}]^T + sum_l b_skip_l
+  if (net->w_skipall && !hmode(net)) {  // S = sum_l skip_l = [g_0 | g_1 | ... | g_{L-1}] . [W_skip_0 ; ... ; W_skip_{L-1}]^T + sum_l b_skip_l
     ss_conv_gemm_args k = base_args(B, T, lens);
     k.A = w.GA;
     k.lda = L * C;

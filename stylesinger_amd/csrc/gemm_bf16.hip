@@ -1,0 +1,369 @@
+// bf16-operand implicit-GEMM conv for the denoisers' hidden layers (BASELINE config 4: "bf16 MFMA").
+//
+//   out[b][t][n] = epi( sum_j sum_k A[b][t + tap_off[j]][k] * W[n][j][k] )        A, W: bf16 in HBM; fp32 accumulate
+//
+// Why a second GEMM kernel (the fp32 kernel has a BF16 template mode, conv_gemm_kernel.h): in that mode both operands travel
+// as fp32 (HBM -> LDS) and every wave rounds its own fragments on the way into the matrix core. v_mfma_f32_32x32x16_bf16 is
+// 16x faster than the fp32 form while a VALU instruction still costs ~2.8 SIMD cycles (tools/ubench/mfma_valu.hip), so those
+// conversions + the fp32 prologue (12 VALU per MFMA) bound the loop: 310 TF/s = 12 % of the bf16 roof at the C4 shape.
+// Here every operand is rounded ONCE where it is produced (weights at pack time: the "bf16 weight copies" of SURVEY.md §8f-3;
+// activations in the epilogue of the kernel that writes them) and stored as bf16 in HBM:
+//   * K chunks of 64 bf16 = the same 128-byte LDS rows / 16-byte-slot XOR swizzle as the fp32 kernel; staging is a plain
+//     16-byte copy (no VALU at all), fragments are one ds_read_b128 = 8 bf16 = one MFMA operand;
+//   * fetch addresses = per-thread VGPR offset + wave-uniform SGPR offset; two K chunks in flight in registers (the MFMA
+//     phase of a chunk is only ~512 cycles per wave); chunk pairs with compile-time LDS buffer index;
+//   * epilogues: GATE (conditioner addend, sigmoid*tanh, bf16 out), RESX (x <- (x + y)/sqrt(2) in fp32 AND the next layer's
+//     operand bf16(x + dstep_next)), STORE (bias, act, fp32 out).
+// Arithmetic contract = oracle/restatement.py with set_matmul_rounding("bf16"): RNE rounding of both matmul operands, exact
+// products, fp32 accumulation; everything outside the matmuls fp32.
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BKH = 64;  // bf16 per K chunk
+constexpr int LDH = 64;  // bf16 per LDS row (128 bytes)
+
+// byte offset of 16-byte slot `slot` of row `row` (slot ^ ((row >> 1) & 7): conflict-free ds_read_b128 / ds_write_b128, see
+// conv_gemm_kernel.h)
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * (LDH * 2) + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ uint16_t f2bf(float x) {  // RNE, like torch's .bfloat16()
+  return __builtin_bit_cast(uint16_t, (__bf16)x);
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int AP = BM / 32, BP = BN / 32;  // 16-byte loads per thread per chunk (256 threads x 16 B = 32 rows x 128 B per pass)
+  static_assert(EPI != SS_HEPI_GATE || TN % 2 == 0, "GATE pairs 32-column blocks");
+  extern __shared__ __attribute__((aligned(16))) char smem_h[];
+  char* As = smem_h;                        // [2][BM][128 B]
+  char* Bs = smem_h + 2 * BM * (LDH * 2);   // [2][BN][128 B]
+
+  const int id = blockIdx.x;
+  const int grp = id / (8 * n_tiles);
+  const int rem = id % (8 * n_tiles);
+  const int mt = grp * 8 + (rem & 7);
+  const int nt = rem >> 3;
+  if (mt >= m_tiles) return;
+  const int b = mt / m_tiles_per_item;
+  const int t0 = (mt % m_tiles_per_item) * BM;
+  const int n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+  const int nchunks_tap = a.K / BKH;
+  const int nchunks = a.ntaps * nchunks_tap;
+  const int ldw = a.ntaps * a.K;  // bf16 per packed weight row
+
+  auto uniform_ptr = [](const void* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  };
+  // range-checked fetches: rows outside [0, len) of the item read 0 (= the conv's zero padding), packed rows beyond Np read 0
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.W + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 2), 0x00020000);
+
+  const int st_slot = tid & 7, st_row = tid >> 3;  // 8 threads x 16 B cover one 128-byte chunk row; 32 rows per pass
+  int a_voff[AP], w_voff[BP], a_lds[AP], b_lds[BP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    a_voff[i] = ((t0 + st_row + i * 32) * a.lda + st_slot * 8) * 2;
+    a_lds[i] = lds_off(st_row + i * 32, st_slot);
+  }
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    w_voff[i] = ((n0 + st_row + i * 32) * ldw + st_slot * 8) * 2;
+    b_lds[i] = lds_off(st_row + i * 32, st_slot);
+  }
+  const int lda2 = a.lda * 2;
+
+  // chunk c = (tap, k0): SGPR byte offsets of the A fetch (tap row shift + channel offset) and of the W fetch
+  auto a_soff = [&](int c) {
+    const int tap = c / nchunks_tap, k0 = (c - tap * nchunks_tap) * BKH;
+    return a.tap_off[tap] * lda2 + k0 * 2;
+  };
+  u32x4 ra[2][AP], rb[2][BP];  // two register stages
+  auto fetch = [&](auto st_tag, int c, int dead) {
+    constexpr int ST = decltype(st_tag)::value;
+    // a negative tap shift must stay in the VGPR offset (the range check has to see the row): one v_add per load, only for taps
+    const int so = a_soff(c);
+#pragma unroll
+    for (int i = 0; i < AP; ++i) ra[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[i] + so) | dead, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i] | dead, c * (BKH * 2), 0);
+  };
+  auto stage = [&](auto st_tag, auto buf_tag) {
+    constexpr int ST = decltype(st_tag)::value;
+    constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<u32x4*>(As + BUF * BM * (LDH * 2) + a_lds[i]) = ra[ST][i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<u32x4*>(Bs + BUF * BN * (LDH * 2) + b_lds[i]) = rb[ST][i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int swz = (l31 >> 1) & 7;
+  const int a_row = (wm * 32 * TM + l31) * (LDH * 2);
+  const int b_row = (wn * 32 * TN + l31) * (LDH * 2);
+  auto compute = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const char* Ac = As + BUF * BM * (LDH * 2) + a_row;
+    const char* Bc = Bs + BUF * BN * (LDH * 2) + b_row;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // 4 k-steps of 16: lane (l31, lh) feeds k = 16*ks + 8*lh .. +8 of its row (same for A and B)
+      const int so = ((2 * ks + lh) ^ swz) << 4;
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) af[m] = *reinterpret_cast<const bf16x8*>(Ac + m * 32 * (LDH * 2) + so);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(Bc + n * 32 * (LDH * 2) + so);
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // chunk j lives in register stage j & 1 and LDS buffer j & 1. Iteration c: fetch chunk c+2 into stage c&1 (its old content,
+  // chunk c, went to LDS one iteration ago), multiply chunk c from LDS, then move chunk c+1 (stage (c+1)&1) to LDS.
+  fetch(I0{}, 0, 0);
+  stage(I0{}, I0{});
+  if (nchunks > 1) fetch(I1{}, 1, 0);
+  __syncthreads();
+  auto body = [&](auto par_tag, int c) {
+    constexpr int P = decltype(par_tag)::value;
+    const bool more = c + 2 < nchunks;
+    fetch(std::integral_constant<int, P>{}, more ? c + 2 : 0, more ? 0 : (int)0x80000000);  // unconditional: branch-free body
+    __builtin_amdgcn_sched_barrier(0);
+    compute(std::integral_constant<int, P>{});
+    __builtin_amdgcn_sched_barrier(0);
+    stage(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, P ^ 1>{});
+    __syncthreads();
+  };
+  // the fetch above overwrites stage P while ... chunk c (stage P) is already in LDS: safe. But stage(P^1) must read chunk c+1,
+  // fetched one iteration earlier into stage P^1: also safe.
+  int c = 0;
+  for (; c + 2 < nchunks; c += 2) {
+    body(I0{}, c);
+    body(I1{}, c + 1);
+  }
+  if (c + 1 < nchunks) {  // one body left (nchunks even): chunk c is in buffer 0, chunk c+1 in stage 1
+    compute(I0{});
+    stage(I1{}, I1{});
+    __syncthreads();
+    compute(I1{});
+  } else {
+    compute(I0{});  // nchunks odd: the last chunk sits in buffer 0
+  }
+
+  // ---------------------------------------------------------------- epilogue (C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*lh)
+  const int row_base = t0 + wm * 32 * TM + 4 * lh;
+  const int col_base = n0 + wn * 32 * TN;
+  const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+  if constexpr (EPI == SS_HEPI_STORE) {
+    float* Cb = (float*)a.C + (int64_t)b * a.c_batch_stride;
+    const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = col_base + n * 32 + l31;
+      if (col >= a.N) continue;
+      const float bs = biasg ? biasg[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+          if (row >= a.T) continue;
+          float v = ss_apply_act(acc[m][n][r] + bs, a.act, 0.f);
+          if (row >= row_lim) v = 0.f;
+          Cb[(int64_t)row * a.ldc + col] = v;
+        }
+    }
+  } else if constexpr (EPI == SS_HEPI_GATE) {
+    // two-phase per 32-row block (all addend loads of the block first, then compute + store: a load issued after a store to a
+    // possibly aliasing buffer would otherwise wait for a full round trip per element), 32-bit buffer addressing throughout
+    const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(Eb ? (const void*)Eb : (const void*)a.W), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr((uint16_t*)a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 2)), 0x00020000);
+    const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
+    const bool sig_first = a.gate_mode == 0;
+    const float m0 = sig_first ? -1.0f : -2.0f, s0 = sig_first ? 1.0f : 2.0f, h0 = sig_first ? 0.0f : -1.0f;
+    const float m1 = sig_first ? -2.0f : -1.0f, s1 = sig_first ? 2.0f : 1.0f, h1 = sig_first ? -1.0f : 0.0f;
+    auto act = [](float x, float mul, float sc, float sh) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(x * mul)), sc, sh); };
+    const int lde4 = a.lde * 4, ldc2 = a.ldc * 2;
+#pragma unroll
+    for (int n = 0; n < TN; n += 2) {
+      const int pc0 = col_base + n * 32 + l31;  // packed column of the first operand; the second sits 32 further
+      const int oc = (pc0 >> 6) * 32 + l31;     // output channel
+      const int dead = oc < a.N ? 0 : (int)0x80000000;
+      const float b0 = (biasg && !dead) ? biasg[pc0] : 0.f, b1 = (biasg && !dead) ? biasg[pc0 + 32] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const int row0 = row_base + m * 32;
+        const int eoff = (row0 * a.lde + pc0) * 4 | dead;
+        const int coff = (row0 * a.ldc + oc) * 2 | dead;
+        float e0[16], e1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = ((r & 3) + 8 * (r >> 2)) * lde4;
+          e0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff + ro, 0, 0));
+          e1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff + ro, 128, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          float g = act(acc[m][n][r] + b0 + e0[r], m0, s0, h0) * act(acc[m][n + 1][r] + b1 + e1[r], m1, s1, h1);
+          if (row0 + rr >= row_lim) g = 0.f;
+          __builtin_amdgcn_raw_buffer_store_b16(f2bf(g), rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
+        }
+      }
+    }
+  } else {  // SS_HEPI_RESX: x <- (x + acc + bias) * post_scale (fp32, in place); y = bf16(x_new + next_bias) for the next layer's conv
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.X + (int64_t)b * a.x_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldx * 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.Y ? (void*)(a.Y + (int64_t)b * a.y_batch_stride) : (void*)a.X), 0,
+        __builtin_amdgcn_readfirstlane(a.Y ? (int)((int64_t)a.T * a.ldy * 2) : 0), 0x00020000);
+    const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
+    const float* nbg = a.next_bias ? a.next_bias + (int64_t)grp_w * a.next_bias_group_stride : nullptr;
+    const int ldx4 = a.ldx * 4, ldy2 = a.ldy * 2;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = col_base + n * 32 + l31;
+      const int dead = col < a.N ? 0 : (int)0x80000000;
+      const float bs = (biasg && !dead) ? biasg[col] : 0.f;
+      const float nb = (nbg && !dead) ? nbg[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const int row0 = row_base + m * 32;
+        const int xoff = (row0 * a.ldx + col) * 4 | dead;
+        const int yoff = (row0 * a.ldy + col) * 2 | dead;
+        float xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          xv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, xoff + ((r & 3) + 8 * (r >> 2)) * ldx4, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          float xn = (xv[r] + (acc[m][n][r] + bs)) * a.post_scale;
+          const bool pad = row0 + rr >= row_lim;
+          if (pad) xn = 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xn), rsrc_x, xoff + rr * ldx4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b16(pad ? (uint16_t)0 : f2bf(xn + nb), rsrc_y, yoff + rr * ldy2, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int EPI>
+int launch_h(const ss_gemm_bf16_args& a, hipStream_t stream) {
+  const int m_tiles_per_item = ss_cdiv(a.T, BM);
+  const int m_tiles = m_tiles_per_item * a.B;
+  const int n_cols = (EPI == SS_HEPI_GATE) ? a.Np : a.N;
+  const int n_tiles = ss_cdiv(n_cols, BN);
+  const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
+  const size_t lds = (size_t)2 * (BM + BN) * (LDH * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(grid), dim3(256), lds, stream, a, m_tiles_per_item, m_tiles, n_tiles);
+  SS_CHECK_LAUNCH("ss_gemm_bf16");
+  return SS_OK;
+}
+
+template <int EPI>
+int launch_tiles(const ss_gemm_bf16_args& a, hipStream_t stream) {
+  const int n_cols = (EPI == SS_HEPI_GATE) ? a.Np : a.N;
+  const long big = (long)ss_cdiv(a.T, 128) * a.B * ss_cdiv(n_cols, 128);
+  if (big >= 512) return launch_h<128, 128, EPI>(a, stream);
+  return launch_h<64, 128, EPI>(a, stream);
+}
+
+// x[r][c] (+ bias[c]) -> bf16 ; rows >= lens[b] -> 0
+__global__ void to_bf16_kernel(const float* __restrict__ x, const float* __restrict__ bias, uint16_t* __restrict__ y, int B, int T, int C,
+                               int ldx, int ldy, const int32_t* __restrict__ lens, int group_size, int64_t bias_gs) {
+  const int64_t n = (int64_t)B * T * (C / 4);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (C / 4)) * 4;
+    const int64_t r = i / (C / 4);
+    const int b = (int)(r / T), t = (int)(r % T);
+    float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4);
+    if (bias) {
+      const float* bp = bias + (group_size > 0 ? (int64_t)(b / group_size) * bias_gs : 0) + c4;
+      v.x += bp[0]; v.y += bp[1]; v.z += bp[2]; v.w += bp[3];
+    }
+    if (lens && t >= lens[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    ushort4 o;
+    o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
+    *reinterpret_cast<ushort4*>(y + r * ldy + c4) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
+  SS_CHECK_ARG(args != nullptr, "ss_gemm_bf16: null args");
+  const ss_gemm_bf16_args& a = *args;
+  hipStream_t stream = (hipStream_t)stream_;
+  SS_CHECK_ARG(a.A && a.W, "ss_gemm_bf16: null A/W");
+  SS_CHECK_ARG(a.B > 0 && a.T > 0 && a.N > 0, "ss_gemm_bf16: bad dims B=%d T=%d N=%d", a.B, a.T, a.N);
+  SS_CHECK_ARG(a.ntaps >= 1 && a.ntaps <= 4, "ss_gemm_bf16: ntaps=%d out of range", a.ntaps);
+  SS_CHECK_ARG(a.K > 0 && (a.K % BKH) == 0 && (a.lda % 8) == 0, "ss_gemm_bf16: K=%d must be a multiple of 64, lda=%d of 8", a.K, a.lda);
+  SS_CHECK_ARG((a.Np & 31) == 0 && (a.epi == SS_HEPI_GATE ? (a.Np & 63) == 0 && 2 * a.N <= a.Np : a.Np >= a.N), "ss_gemm_bf16: bad Np=%d for N=%d", a.Np, a.N);
+  SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16: A/W must be 16-byte aligned");
+  SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldx * 4 < (1ll << 31) &&
+                   (int64_t)a.T * a.ldc * 4 < (1ll << 31), "ss_gemm_bf16: item too large for 32-bit offsets");
+  switch (a.epi) {
+    case SS_HEPI_STORE:
+      SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: STORE needs C");
+      return launch_tiles<SS_HEPI_STORE>(a, stream);
+    case SS_HEPI_GATE:
+      SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: GATE needs C");
+      return launch_tiles<SS_HEPI_GATE>(a, stream);
+    case SS_HEPI_RESX:
+      SS_CHECK_ARG(a.X != nullptr, "ss_gemm_bf16: RESX needs X");
+      return launch_tiles<SS_HEPI_RESX>(a, stream);
+    default: break;
+  }
+  ss_set_error("ss_gemm_bf16: bad epilogue %d", a.epi);
+  return SS_ERR_ARG;
+}
+
+extern "C" int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
+                          int group_size, int64_t bias_group_stride, void* stream) {
+  SS_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0, "ss_to_bf16: bad args");
+  const int64_t n = (int64_t)B * T * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipLaunchKernelGGL(to_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, lens, group_size,
+                     bias_group_stride);
+  SS_CHECK_LAUNCH("ss_to_bf16");
+  return SS_OK;
+}

@@ -579,19 +579,10 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
   }
   const int lde4 = a.lde * 4;
   // Conditioner addend (hoisted E slab, 40 KB row stride) fetched BEFORE the last chunk's MFMAs: its miss latency hides under them.
-  float pe[TN == 2 ? 64 : 32];
+  float pe[32];
   if constexpr (TN == 2) {
-    const int pc0 = n0 + wn * 64 + l31;
-    const int colb = pc0 * 4 + ((((pc0 >> 6) * 32 + l31) < a.N) ? 0 : (int)0x80000000);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int off = tfr[r] * lde4 + colb;
-      const int off2 = off + d * lde4;  // frame t+d: in the VGPR offset so that the range check sees the row (t+d may be >= T)
-      pe[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 0, 0));
-      pe[16 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 128, 0));
-      pe[32 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off2, 0, 0));
-      pe[48 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off2, 128, 0));
-    }
+    // (the 64 x 128 tile holds 128 accumulator registers: the addend is fetched in the epilogue, 32 values at a time, to stay
+    //  under 256 registers = 2 waves per SIMD; with many rounds per launch other workgroups cover the latency)
   } else {
     const int pc = n0 + wn * 32 + l31;
     const int colb = pc * 4 + ((((n0 >> 1) + l31) < a.N) ? 0 : (int)0x80000000);
@@ -632,15 +623,22 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
     const bool sig_first = a.gate_mode == 0;
     const float m0 = sig_first ? -1.0f : -2.0f, s0 = sig_first ? 1.0f : 2.0f, h0 = sig_first ? 0.0f : -1.0f;
     const float m1 = sig_first ? -2.0f : -1.0f, s1 = sig_first ? 2.0f : 1.0f, h1 = sig_first ? -1.0f : 0.0f;
+    const int colb = pc0 * 4;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {  // half 0: frame t, half 1: frame t+d
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int off = (tfr[r] + half * d) * lde4 + colb;
+        pe[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 0, 0));
+        pe[16 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off, 128, 0));
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int t = tfr[r] + half * d;
         if (t >= a.T) continue;
         const float z0 = half == 0 ? acc[0][0][r] + acc[1][0][r] + acc[2][0][r] : acc[1][0][r] - acc[2][0][r] - acc[3][0][r];
         const float z1 = half == 0 ? acc[0][1][r] + acc[1][1][r] + acc[2][1][r] : acc[1][1][r] - acc[2][1][r] - acc[3][1][r];
-        const float v0 = z0 + b0 + pe[32 * half + r], v1 = z1 + b1 + pe[32 * half + 16 + r];
+        const float v0 = z0 + b0 + pe[r], v1 = z1 + b1 + pe[16 + r];
         float g = act(v0, m0, s0, h0) * act(v1, m1, s1, h1);
         if (t >= row_lim) g = 0.f;
         Cb[(int64_t)t * a.ldc + oc] = g;
@@ -727,6 +725,8 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
   // (752 / 376 blocks) TN=1 84.0 us; f0 pair (1152 / 576 blocks) TN=1 104.7 vs TN=2 112.0 us -> TN=1 while its grid is
   // at most two rounds; beyond that a makespan model picks (TN=2 wins once there are many rounds).
   int tn = a.tile == SS_TILE_64x128 ? 2 : a.tile == SS_TILE_64x64 ? 1 : 0;
+  static const int env_tn = getenv("SS_WINO_TN") ? atoi(getenv("SS_WINO_TN")) : 0;  // experiments: force the tile of every auto launch
+  if (tn == 0 && (env_tn == 1 || env_tn == 2)) tn = env_tn;
   if (tn == 0) {
     const long b2 = (long)p_tiles * ss_cdiv(a.Np, 128), b1 = (long)p_tiles * (a.Np / 64);
     const double t2 = (double)ss_cdiv(b2, 256) * 2.0 / 0.92, t1 = (double)ss_cdiv(b1, 256) * 1.0 / 0.75;

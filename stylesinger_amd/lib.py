@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 6  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 7  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -63,7 +63,23 @@ class WaveNet(C.Structure):
     ] + [(n, C.c_int64) for n in ("gs_w_in", "gs_b_in", "gs_uv_embed", "gs_dstep", "gs_w_dil", "gs_w_out", "gs_b_out", "gs_w_cond",
                                   "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")] \
         + [("mfma_bf16", C.c_int32), ("reserved0", C.c_int32), ("w_skipall", _vp), ("b_skipall", _vp),
-           ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("reserved1", C.c_int32)]
+           ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("reserved1", C.c_int32),
+           ("w_dil_h", _vp * SS_MAX_LAYERS), ("w_out_h", _vp * SS_MAX_LAYERS), ("w_skipall_h", _vp), ("w_cond_h", _vp),
+           ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64)]
+
+
+class GemmBf16Args(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("a_batch_stride", C.c_int64), ("lda", C.c_int32), ("K", C.c_int32), ("ntaps", C.c_int32), ("tap_off", C.c_int32 * 4),
+        ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("W", _vp), ("w_group_stride", C.c_int64), ("N", C.c_int32), ("Np", C.c_int32),
+        ("epi", C.c_int32), ("act", C.c_int32), ("bias", _vp), ("bias_group_stride", C.c_int64), ("E", _vp), ("lde", C.c_int32),
+        ("gate_mode", C.c_int32), ("e_batch_stride", C.c_int64), ("X", _vp), ("x_batch_stride", C.c_int64), ("ldx", C.c_int32),
+        ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
+        ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
+    ]
+
+
+HEPI_STORE, HEPI_GATE, HEPI_RESX = 0, 1, 2
 
 
 class HifiGan(C.Structure):
@@ -133,10 +149,10 @@ def load():
         fn.argtypes = argtypes
     if lib.ss_abi_version() != ABI_VERSION:
         raise StyleSingerHipError(f"libstylesinger_hip.so has ABI {lib.ss_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
-    sizes = (C.c_int64 * 3)()
-    if lib.ss_struct_sizes(sizes, 3) != 0:
+    sizes = (C.c_int64 * 4)()
+    if lib.ss_struct_sizes(sizes, 4) != 0:
         raise StyleSingerHipError("ss_struct_sizes failed")
-    mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan))
+    mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan), C.sizeof(GemmBf16Args))
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
@@ -268,6 +284,16 @@ def pack_bias(b, *, b2=None, Np=None, interleave_half=0, repeat=1):
     dst = torch.empty(Np, device=b.device, dtype=torch.float32)
     check(load().ss_pack_bias(ptr(b), ptr(b2), ptr(dst), n, Np, interleave_half, repeat, stream_ptr()), "ss_pack_bias")
     return dst
+
+
+def to_bf16(x, bias=None, lens=None):
+    """fp32 device tensor [..., C] -> bf16 bits (torch.bfloat16 tensor, RNE) through ss_to_bf16 (B*T rows)."""
+    x = x.contiguous().float()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(load().ss_to_bf16(ptr(x), ptr(bias), ptr(y), 1, rows, Cc, Cc, Cc, ptr(lens), 0, 0, stream_ptr()), "ss_to_bf16")
+    return y
 
 
 def layernorm(x, gamma, beta, *, B, T, C_, out=None, lens=None, mask_rows=False, eps=1e-5):

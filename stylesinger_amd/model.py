@@ -152,6 +152,9 @@ class StyleSingerHIP(torch.nn.Module):
         # fold skip_projection / sqrt(L) into the skip-all weights (fp32 mode only: in bf16 mode the operand rounding of the
         # two separate GEMMs is part of the stated arithmetic)
         self.fold_skip = self.defer_skip and not self.bf16 and os.environ.get("SS_FOLD_SKIP", "1") not in ("0", "off", "false")
+        # bf16 mode: hidden-layer weights AND activations as bf16 in HBM (ss_gemm_bf16; SS_BF16_HBM=0 keeps the round-1 form
+        # that rounds fp32 operands inside the fp32 kernel's BF16 template mode); needs the deferred-skip layout
+        self.bf16_hbm = self.bf16 and self.defer_skip and os.environ.get("SS_BF16_HBM", "1") not in ("0", "off", "false")
         if self.bf16:
             self.use_wino = False  # the transform would amplify the operand rounding; the matrix pipe is not the limit in bf16
         # diffusion plans (workspaces + captured hipGraphs) are keyed by (B, T bucket): frames are padded up to a multiple of
@@ -252,6 +255,9 @@ class StyleSingerHIP(torch.nn.Module):
                 wt = torch.empty(2 * C, C, 4, device=dev)
                 L.check(L.load().ss_wino_weight_transform(L.ptr(wsrc), L.ptr(wt), 2 * C, C, L.stream_ptr()), "wino transform")
                 t[f"w_dil_wino.{l}"] = L.pack_conv_weight(wt, interleave_half=C)
+            if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
+                t[f"w_dil_h.{l}"] = L.to_bf16(dil.W)
+                t[f"w_out_h.{l}"] = L.to_bf16(out.W)
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
         if self.defer_skip:  # skip halves of all output projections side by side: [C][L*C], column l*C + ci
@@ -268,6 +274,9 @@ class StyleSingerHIP(torch.nn.Module):
         t["dstep"] = dstep
         t["w_cond"] = torch.cat(wc_rows, 0).contiguous()
         t["b_cond"] = torch.cat(bc_rows, 0).contiguous()
+        if self.bf16_hbm:
+            t["w_cond_h"] = L.to_bf16(t["w_cond"])
+            t["w_skipall_h"] = L.to_bf16(t["w_skipall"])
         skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
         fin = self._pack_conv(prefix + ".output_projection.weight", prefix + ".output_projection.bias")
         t["w_skip"], t["b_skip"], t["w_final"], t["b_final"] = skip.W, skip.bias, fin.W, fin.bias
@@ -308,6 +317,16 @@ class StyleSingerHIP(torch.nn.Module):
                 ptr_, gs = place(f"w_dil_wino.{l}")
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
+            if self.bf16_hbm:
+                for key, arr in (("w_dil_h", net.w_dil_h), ("w_out_h", net.w_out_h)):
+                    ptr_, gs = place(f"{key}.{l}")
+                    arr[l] = ptr_
+                    setattr(net, "gs_" + key, gs)
+        if self.bf16_hbm:
+            for key in ("w_cond_h", "w_skipall_h"):
+                ptr_, gs = place(key)
+                setattr(net, key, ptr_)
+                setattr(net, "gs_" + key, gs)
         net.mfma_bf16 = 1 if self.bf16 else 0
         net.skipall_folded = 1 if self.fold_skip else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)

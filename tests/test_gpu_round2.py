@@ -186,3 +186,91 @@ def test_bench_two_ranks_on_one_device_matches_single_process():
     one = _run_bench(["--gpus", "1", "--emulate-ranks", "2"] + small)
     assert one["n_gpus"] == 1 and len(one["checksum"]["mel_items"]) == 4
     assert two["checksum"]["mel_items"] == one["checksum"]["mel_items"], (two["checksum"], one["checksum"])
+
+
+def _gemm_bf16(A, Wp, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=0, E=None, lde=0, X=None, post_scale=1.0, next_bias=None, Y=None,
+               out=None, ldc=None, mask_rows=True):
+    import ctypes
+    from stylesinger_amd import lib as L
+    a = L.GemmBf16Args()
+    a.A, a.a_batch_stride, a.lda, a.K, a.ntaps = L.ptr(A), T * A.shape[-1], A.shape[-1], K, len(taps)
+    for i, o in enumerate(taps):
+        a.tap_off[i] = o
+    a.lens, a.B, a.T, a.W, a.N, a.Np, a.epi, a.act = L.ptr(lens), B, T, L.ptr(Wp), N, Np, epi, act
+    a.bias, a.E, a.lde, a.e_batch_stride, a.gate_mode = L.ptr(bias), L.ptr(E), lde, T * lde, 0
+    a.X, a.ldx, a.x_batch_stride, a.post_scale = L.ptr(X), (X.shape[-1] if X is not None else 0), (T * X.shape[-1] if X is not None else 0), post_scale
+    a.next_bias, a.Y = L.ptr(next_bias), L.ptr(Y)
+    a.ldy, a.y_batch_stride = (Y.shape[-1] if Y is not None else 0), (T * Y.shape[-1] if Y is not None else 0)
+    a.C, a.ldc = L.ptr(out), (ldc if ldc is not None else (out.shape[-1] if out is not None else 0))
+    a.c_batch_stride = T * a.ldc
+    a.mask_rows = int(mask_rows)
+    L.check(L.load().ss_gemm_bf16(ctypes.byref(a), L.stream_ptr()), "ss_gemm_bf16")
+
+
+@pytest.mark.parametrize("T,K", [(200, 256), (333, 192)])
+def test_gemm_bf16_kernel_matches_torch_on_bf16_operands(T, K):
+    """ss_gemm_bf16 (bf16 operands in HBM, fp32 accumulate) vs torch fp32 math on the SAME bf16-rounded operands: STORE with a
+    3-tap dilated conv, GATE with the fp32 addend, RESX with the next layer's bf16 operand. Products of bf16 numbers are exact in
+    fp32, so only the summation order differs (tolerance 2e-5 relative to sqrt(K)-sized sums)."""
+    from stylesinger_amd import lib as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(T + K)
+    B, C = 3, K
+    lens = torch.tensor([T, T - 37, 5], dtype=torch.int32, device=dev)
+    x = torch.randn(B, T, C, generator=g).to(dev)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    xh = L.to_bf16(x)                                    # the operand as it would sit in HBM
+    xr = xh.float()
+    d = 2
+    w = (torch.randn(2 * C, C, 3, generator=g) / (3 * C) ** 0.5).to(dev)
+    Wp = L.pack_conv_weight(w, interleave_half=C)        # [2C][3*Kp] gate-interleaved, fp32
+    Wh = L.to_bf16(Wp)
+    wr = w.to(torch.bfloat16).float()
+    # reference conv on rounded operands (zero padding outside [0, len))
+    y_ref = torch.nn.functional.conv1d(xr.transpose(1, 2), wr, padding=d, dilation=d).transpose(1, 2)   # [B,T,2C]
+    for b in range(B):   # frames near the end of a shorter item must see zeros beyond len: xr is already zero there
+        pass
+    E = torch.randn(B, T, 2 * C, generator=g).to(dev) * 0.5
+    # E in packed column order: block 2p = sigmoid half rows [32p, 32p+32), block 2p+1 = tanh half
+    Ep = torch.empty_like(E)
+    for p in range(C // 32):
+        Ep[..., 64 * p:64 * p + 32] = E[..., 32 * p:32 * p + 32]
+        Ep[..., 64 * p + 32:64 * p + 64] = E[..., C + 32 * p:C + 32 * p + 32]
+    G = torch.empty(B, T, C, device=dev, dtype=torch.bfloat16)
+    _gemm_bf16(xh, Wh, B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, E=Ep, lde=2 * C, out=G)
+    z = y_ref + E
+    g_ref = torch.sigmoid(z[..., :C]) * torch.tanh(z[..., C:])
+    for b in range(B):
+        g_ref[b, lens[b]:] = 0
+    assert (G.float() - g_ref).abs().max().item() <= 4e-3 + 1e-6            # one bf16 ulp of values in (-1, 1)
+    assert (G.float() - g_ref.to(torch.bfloat16).float()).abs().mean().item() <= 2e-4   # almost always the same bf16
+    # RESX: x <- (x + G . Wo^T + b) / sqrt(2); Y = bf16(x + next_bias)
+    wo = (torch.randn(C, C, 1, generator=g) / C ** 0.5).to(dev)
+    Woh = L.to_bf16(L.pack_conv_weight(wo))
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    nb = torch.randn(C, generator=g).to(dev)
+    X = torch.randn(B, T, C, generator=g).to(dev)
+    X0 = X.clone()
+    Y = torch.empty(B, T, C, device=dev, dtype=torch.bfloat16)
+    _gemm_bf16(G, Woh, B=B, T=T, K=C, taps=(0,), N=C, Np=Woh.shape[0], epi=L.HEPI_RESX, lens=lens, bias=L.pack_bias(bo), X=X,
+               post_scale=0.5 ** 0.5, next_bias=nb, Y=Y)
+    x_ref = (X0 + (G.float() @ wo[:, :, 0].to(torch.bfloat16).float().t() + bo)) * (0.5 ** 0.5)
+    for b in range(B):
+        x_ref[b, lens[b]:] = 0
+    assert (X - x_ref).abs().max().item() <= 2e-5 * (C ** 0.5)
+    y_ref2 = (x_ref + nb)
+    for b in range(B):
+        y_ref2[b, lens[b]:] = 0
+    assert (Y.float() - y_ref2).abs().max().item() <= 0.04 and (Y.float() - y_ref2.to(torch.bfloat16).float()).abs().mean().item() <= 1e-3
+    # STORE with ReLU on a K = 2*C, 1-tap GEMM
+    A2 = L.to_bf16(torch.randn(B, T, 2 * C, generator=g).to(dev))
+    w2 = (torch.randn(C, 2 * C, 1, generator=g) / (2 * C) ** 0.5).to(dev)
+    S = torch.empty(B, T, C, device=dev)
+    if (2 * C) % 64 == 0:
+        _gemm_bf16(A2, L.to_bf16(L.pack_conv_weight(w2)), B=B, T=T, K=2 * C, taps=(0,), N=C, Np=L.round_up(C, 32), epi=L.HEPI_STORE, lens=lens,
+                   bias=L.pack_bias(bo), act=L.ACT_RELU, out=S)
+        s_ref = torch.relu(A2.float() @ w2[:, :, 0].to(torch.bfloat16).float().t() + bo)
+        for b in range(B):
+            s_ref[b, lens[b]:] = 0
+        assert (S - s_ref).abs().max().item() <= 2e-5 * ((2 * C) ** 0.5)
