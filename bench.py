@@ -112,8 +112,17 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     dstep = packs["dstep"]
     wino = infer.model.use_wino and not bf16
 
+    hbm = bf16 and getattr(infer.model, "bf16_hbm", False)
+    if hbm:  # bf16 operands in HBM (ss_gemm_bf16): the operand X + dstep is already rounded by the producing epilogue
+        Xh = L.to_bf16(X)
+        Gh = torch.empty(B, T, C, device=dev, dtype=torch.bfloat16)
+
     def launch(l):
         d = 1 << (l % 4)
+        if hbm:
+            L.gemm_bf16(Xh, packs[f"w_dil_h.{l}"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
+                        E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, out=Gh)
+            return
         kw = dict(B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=dstep[0, l], epi=L.EPI_GATE, E=E[:, :, l * 2 * C:],
                   lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
         if wino:
@@ -145,7 +154,8 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     flops = 2.0 * B * T * (3 * C) * (2 * C)
     executed = flops * (4.0 / 6.0 if wino else 1.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
-    name = ("wino_gate_kernel (Winograd F(2,3)" if wino else "conv_gemm_kernel<64,128,2,2,GATE" + (",bf16> (direct" if bf16 else "> (direct"))
+    name = ("wino_gate_kernel_v2 (Winograd F(2,3)" if wino else "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct" if hbm else
+            "conv_gemm_kernel<64,128,2,2,GATE" + (",bf16> (direct" if bf16 else "> (direct"))
     # HBM traffic of this launch from the round's PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs,
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
     traffic = None
@@ -162,7 +172,8 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                 achieved=flops / sec / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=flops / sec / peak,
                 executed_mfma_frac=executed / sec / peak, executed_flops_per_launch=executed,
                 traffic=traffic, traffic_source=pmc_src, us_per_launch=sec * 1e6, flops_per_launch=flops,
-                launches_per_step=None, algorithmic_bytes_per_launch=4.0 * B * T * (C + 2 * C + C) + 4.0 * (4 if wino else 3) * C * 2 * C)
+                launches_per_step=None, algorithmic_bytes_per_launch=(B * T * (2.0 * C + 4.0 * 2 * C + 2.0 * C) + 2.0 * 3 * C * 2 * C) if hbm else
+                (4.0 * B * T * (C + 2 * C + C) + 4.0 * (4 if wino else 3) * C * 2 * C))
 
 
 def cpu_baseline(hp_over, extra_threads):

@@ -66,6 +66,37 @@ class StyleSingerInfer:
         return res
 
     @torch.no_grad()
+    def infer_batches(self, batches, in_flight=3, seed=None, vocode=True):
+        """Throughput form of infer_batch for a sequence of INDEPENDENT batches: batch i runs on HIP stream i % in_flight with
+        its own workspace / hipGraph set (`plan_slot`), so up to `in_flight` batches overlap on the device - one batch's
+        single-round kernel launches leave ramps and tails that the others' blocks fill (-10 % wall at C2).
+        Yields the result dicts in order; each result is complete (its stream has been waited for) when it is yielded."""
+        in_flight = max(1, int(in_flight))
+        if not hasattr(self, "_flight_streams") or len(self._flight_streams) < in_flight:
+            self._flight_streams = [torch.cuda.Stream(device=self.device) for _ in range(in_flight)]
+        seed = self.hparams["seed"] if seed is None else seed
+        main = torch.cuda.current_stream(self.device)
+        pending = []
+
+        def finish(entry):
+            res, strm = entry
+            main.wait_stream(strm)
+            return res
+        for i, batch in enumerate(batches):
+            strm = self._flight_streams[i % in_flight]
+            strm.wait_stream(main)   # the batch's inputs were produced on the caller's stream
+            with torch.cuda.stream(strm):
+                res = self.infer_batch(batch, seed=seed + i, vocode=vocode, plan_slot=i % in_flight)
+                for v in batch.values():
+                    if torch.is_tensor(v):
+                        v.record_stream(strm)
+            pending.append((res, strm))
+            if len(pending) >= in_flight:
+                yield finish(pending.pop(0))
+        while pending:
+            yield finish(pending.pop(0))
+
+    @torch.no_grad()
     def vocode(self, mel, f0, lens, noise=None, seed=1234):
         hp = self.hparams
         mel_c = torch.empty_like(mel)

@@ -296,6 +296,29 @@ def to_bf16(x, bias=None, lens=None):
     return y
 
 
+def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
+              next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0):
+    """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
+    a = GemmBf16Args()
+    a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
+    a.a_batch_stride = a_bs if a_bs is not None else T * a.lda
+    a.K = K; a.ntaps = len(taps)
+    for i, o in enumerate(taps):
+        a.tap_off[i] = int(o)
+    a.lens = ptr(lens); a.B = B; a.T = T; a.W = ptr(Wh); a.N = N; a.Np = Np; a.epi = epi; a.act = act
+    a.bias = ptr(bias); a.E = ptr(E); a.lde = lde; a.e_batch_stride = e_bs if e_bs is not None else T * lde; a.gate_mode = gate_mode
+    a.X = ptr(X)
+    if X is not None:
+        a.ldx = X.shape[-1]; a.x_batch_stride = T * a.ldx
+    a.post_scale = post_scale; a.next_bias = ptr(next_bias); a.Y = ptr(Y)
+    if Y is not None:
+        a.ldy = Y.shape[-1]; a.y_batch_stride = T * a.ldy
+    a.C = ptr(out); a.ldc = ldc if ldc is not None else (out.shape[-1] if out is not None else 0)
+    a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
+    a.mask_rows = int(mask_rows)
+    check(load().ss_gemm_bf16(C.byref(a), stream_ptr()), "ss_gemm_bf16")
+
+
 def layernorm(x, gamma, beta, *, B, T, C_, out=None, lens=None, mask_rows=False, eps=1e-5):
     out = x if out is None else out
     check(load().ss_layernorm(ptr(x), ptr(out), ptr(gamma), ptr(beta), B, T, C_, C_, C_, T * C_,

@@ -188,23 +188,9 @@ def test_bench_two_ranks_on_one_device_matches_single_process():
     assert two["checksum"]["mel_items"] == one["checksum"]["mel_items"], (two["checksum"], one["checksum"])
 
 
-def _gemm_bf16(A, Wp, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=0, E=None, lde=0, X=None, post_scale=1.0, next_bias=None, Y=None,
-               out=None, ldc=None, mask_rows=True):
-    import ctypes
+def _gemm_bf16(A, Wp, **kw):
     from stylesinger_amd import lib as L
-    a = L.GemmBf16Args()
-    a.A, a.a_batch_stride, a.lda, a.K, a.ntaps = L.ptr(A), T * A.shape[-1], A.shape[-1], K, len(taps)
-    for i, o in enumerate(taps):
-        a.tap_off[i] = o
-    a.lens, a.B, a.T, a.W, a.N, a.Np, a.epi, a.act = L.ptr(lens), B, T, L.ptr(Wp), N, Np, epi, act
-    a.bias, a.E, a.lde, a.e_batch_stride, a.gate_mode = L.ptr(bias), L.ptr(E), lde, T * lde, 0
-    a.X, a.ldx, a.x_batch_stride, a.post_scale = L.ptr(X), (X.shape[-1] if X is not None else 0), (T * X.shape[-1] if X is not None else 0), post_scale
-    a.next_bias, a.Y = L.ptr(next_bias), L.ptr(Y)
-    a.ldy, a.y_batch_stride = (Y.shape[-1] if Y is not None else 0), (T * Y.shape[-1] if Y is not None else 0)
-    a.C, a.ldc = L.ptr(out), (ldc if ldc is not None else (out.shape[-1] if out is not None else 0))
-    a.c_batch_stride = T * a.ldc
-    a.mask_rows = int(mask_rows)
-    L.check(L.load().ss_gemm_bf16(ctypes.byref(a), L.stream_ptr()), "ss_gemm_bf16")
+    L.gemm_bf16(A, Wp, **kw)
 
 
 @pytest.mark.parametrize("T,K", [(200, 256), (333, 192)])
@@ -274,3 +260,17 @@ def test_gemm_bf16_kernel_matches_torch_on_bf16_operands(T, K):
         for b in range(B):
             s_ref[b, lens[b]:] = 0
         assert (S - s_ref).abs().max().item() <= 2e-5 * ((2 * C) ** 0.5)
+
+
+def test_batches_in_flight_equal_sequential_runs():
+    """StyleSingerInfer.infer_batches (3 batches in flight on 3 streams, separate plan slots) == infer_batch one after the other."""
+    from stylesinger_amd.infer import StyleSingerInfer
+    hp = config.make_hparams(dict(timesteps=4, K_step=4, f0_timesteps=4))
+    inf = StyleSingerInfer(hp, device="cuda:0", model_state=synth.synth_acoustic_state_dict(hp, 9), vocoder_state=synth.synth_vocoder_state_dict(None, 9))
+    batches = [{k: v.cuda() for k, v in synth.synth_batch(2, 100 + 30 * (i % 2), 6, 64, hp, 300 + i).items()} for i in range(5)]
+    got = [r for r in inf.infer_batches(batches, in_flight=3, seed=40)]
+    torch.cuda.synchronize()
+    assert len(got) == 5
+    for i, b in enumerate(batches):
+        want = inf.infer_batch(b, seed=40 + i)
+        assert torch.equal(got[i]["mel"], want["mel"]) and torch.equal(got[i]["wav"], want["wav"]), i
