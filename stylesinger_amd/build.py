@@ -58,6 +58,26 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def build_clean(out_dir, jobs=None):
+    """From-clean build of every source into `out_dir` (no object cache): proves the tree compiles on this box as it is."""
+    os.makedirs(out_dir, exist_ok=True)
+    srcs = sources()
+
+    def one(src):
+        obj = os.path.join(out_dir, os.path.basename(src) + ".o")
+        r = subprocess.run([_hipcc()] + FLAGS + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        return obj
+    with cf.ThreadPoolExecutor(jobs or min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(one, srcs))
+    lib = os.path.join(out_dir, "libstylesinger_hip.so")
+    r = subprocess.run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    return lib
+
+
 def build(verbose=True, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sources()

@@ -17,6 +17,9 @@
 #include "../../include/stylesinger_hip.h"
 #include <stdlib.h>
 #include <type_traits>
+#ifndef SS_ABL
+#define SS_ABL 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -488,6 +491,8 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
   load_b(0);
   store_a(As, cc);
   store_b(Bs);
+  load_a(cc, BK * 4);   // chunk 1 stays in flight across the barrier: fetches run TWO chunks ahead of the MFMAs
+  load_b(BK * 4);
   __syncthreads();
 
   const int swz = (l31 >> 1) & 7;
@@ -501,6 +506,10 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
     for (int n = 0; n < TN; ++n) bf.v[n] = *reinterpret_cast<const float4*>(Bc + b_row + n * 32 * LD + so);
   };
   auto mfma4 = [&](f32x16 (&c)[TN], const float4& af, const BF& bf) {
+#if SS_ABL == 3
+    asm volatile("" ::"v"(af.x), "v"(af.y), "v"(af.z), "v"(af.w), "v"(bf.v[0].x), "v"(bf.v[0].y), "v"(bf.v[0].z), "v"(bf.v[0].w));
+    return;
+#endif
 #pragma unroll
     for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.v[n].x, c[n], 0, 0, 0);
 #pragma unroll
@@ -511,9 +520,13 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
     for (int n = 0; n < TN; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.v[n].w, c[n], 0, 0, 0);
   };
 
-  // One K chunk: MFMAs of the chunk in LDS buffer CUR into `cacc`; the NEXT chunk (component parameters `nx`, K byte offset
-  // `nci0b`, weight byte offset `ncb`) is fetched / transformed / written to buffer CUR^1 in the shadow of the MFMAs.
-  auto chunk = [&](auto cur_tag, f32x16 (&cacc)[TN], const Comp& nx, int nci0b, int ncb) {
+  // One K chunk g: MFMAs from LDS buffer CUR into `cacc`. In their shadow, after the second MFMA group: the registers (chunk g+1,
+  // fetched during chunk g-1; component parameters `st`) are transformed and written to buffer CUR^1, and the fetch of chunk g+2
+  // (component parameters `ld`, K byte offset `ci0b`, weight byte offset `cb`) is issued right behind them into the same
+  // registers. A fetch therefore has two groups of this chunk + two of the next (>= 1024 MFMA cycles of this wave, ~3x that of
+  // wall time with 3 waves per SIMD) before its data is needed, and stays in flight across the barrier. (Timing ablations,
+  // tools/ablate.sh: with the fetch issued at the top of the chunk that consumes it the loop waited ~10 us per launch for L2.)
+  auto chunk = [&](auto cur_tag, auto store_tag, auto load_tag, f32x16 (&cacc)[TN], const Comp& st, const Comp& ld, int ci0b, int cb) {
     constexpr int CUR = decltype(cur_tag)::value;
     const float* Ac = As + CUR * BP * LD;
     const float* Bc = Bs + CUR * BN * LD;
@@ -521,49 +534,68 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
     BF bf0, bf1;
     read_frags(Ac, Bc, 0, af0, bf0);
     read_frags(Ac, Bc, 1, af1, bf1);
-    load_a(nx, nci0b);
     __builtin_amdgcn_sched_barrier(0);
     mfma4(cacc, af0, bf0);
     read_frags(Ac, Bc, 2, af0, bf0);
-    load_b(ncb);
     __builtin_amdgcn_sched_barrier(0);
     mfma4(cacc, af1, bf1);
     read_frags(Ac, Bc, 3, af1, bf1);
-    mfma4(cacc, af0, bf0);
     __builtin_amdgcn_sched_barrier(0);
-    store_a(As + (CUR ^ 1) * BP * LD, nx);
-    store_b(Bs + (CUR ^ 1) * BN * LD);
+    if constexpr (decltype(store_tag)::value) {
+#if SS_ABL != 2
+      store_a(As + (CUR ^ 1) * BP * LD, st);
+      store_b(Bs + (CUR ^ 1) * BN * LD);
+#else
+      const u32x4 s0 = ra[0][0] + ra[0][1] + ra[1][0] + ra[1][1] + rb[0] + rb[1];
+      asm volatile("" ::"v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(rpb.x));
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);  // stores first, then the fetch into the SAME registers (a second register set would cost a wave per SIMD)
+    if constexpr (decltype(load_tag)::value) {
+#if SS_ABL != 1
+      load_a(ld, ci0b);
+      load_b(cb);
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cacc, af0, bf0);
     mfma4(cacc, af1, bf1);
+#if SS_ABL != 4
     __syncthreads();
+#endif
   };
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
-  // component J: kchunks chunks (even), pairs (buffer 0, buffer 1); the last chunk of the component stages the first chunk of
-  // component J+1 (its parameters are computed here, between the loops, never inside one)
-  const int kb = a.Kp * 4;  // bytes of one component in a packed weight row
+  using Yes = std::true_type;
+  using No = std::false_type;
+  // Component J = kchunks chunks (even), processed in (buffer 0, buffer 1) pairs. Chunk (J,k) stages chunk (J,k+1) and fetches chunk
+  // (J,k+2); the last two chunks of a component reach into component J+1, whose parameters are computed here, between the loops.
+  const int kb = a.Kp * 4;   // bytes of one component in a packed weight row
+  const int cs = BK * 4;     // bytes of one K chunk
   auto component = [&](f32x16 (&cacc)[TN], int j) {
     const Comp nxt = comp_of(j + 1);
     const int wbase = j * kb;
     int k = 0;
     for (; k + 2 < kchunks; k += 2) {
-      chunk(C0{}, cacc, cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
-      chunk(C1{}, cacc, cc, (k + 2) * (BK * 4), wbase + (k + 2) * (BK * 4));
+      chunk(C0{}, Yes{}, Yes{}, cacc, cc, cc, (k + 2) * cs, wbase + (k + 2) * cs);
+      chunk(C1{}, Yes{}, Yes{}, cacc, cc, cc, (k + 3) * cs, wbase + (k + 3) * cs);   // (k+3 <= kchunks-1 inside this loop)
     }
-    chunk(C0{}, cacc, cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
-    chunk(C1{}, cacc, nxt, 0, wbase + kb);
+    // k = kchunks - 2: stage (J, kchunks-1), fetch (J+1, 0); then k = kchunks - 1: stage (J+1, 0), fetch (J+1, 1)
+    chunk(C0{}, Yes{}, Yes{}, cacc, cc, nxt, 0, wbase + kb);
+    chunk(C1{}, Yes{}, Yes{}, cacc, nxt, nxt, cs, wbase + kb + cs);
     cc = nxt;
   };
   component(acc[0], 0);
   component(acc[1], 1);
   component(acc[2], 2);
-  {  // component 3: the very last chunk has nothing left to stage
+  {  // component 3: nothing left to fetch for its last two chunks, nothing to stage for the very last one
     const int wbase = 3 * kb;
     int k = 0;
     for (; k + 2 < kchunks; k += 2) {
-      chunk(C0{}, acc[3], cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
-      chunk(C1{}, acc[3], cc, (k + 2) * (BK * 4), wbase + (k + 2) * (BK * 4));
+      chunk(C0{}, Yes{}, Yes{}, acc[3], cc, cc, (k + 2) * cs, wbase + (k + 2) * cs);
+      chunk(C1{}, Yes{}, Yes{}, acc[3], cc, cc, (k + 3) * cs, wbase + (k + 3) * cs);
     }
-    chunk(C0{}, acc[3], cc, (k + 1) * (BK * 4), wbase + (k + 1) * (BK * 4));
+    chunk(C0{}, Yes{}, No{}, acc[3], cc, cc, 0, 0);
   }
 
   // ---- frame index / byte offsets of the accumulator rows this lane owns: row r -> pair (r&3) + 8*(r>>2) + 4*lh of the wave tile
@@ -745,7 +777,11 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
   } else {
     const int n_tiles = a.Np / 64;
     const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
-    const size_t lds = (size_t)2 * (BP + 64) * LD * sizeof(float);
+    static const size_t lds_pad = getenv("SS_WINO_LDS_PAD") ? (size_t)atoi(getenv("SS_WINO_LDS_PAD")) : 0;  // occupancy experiments only
+    const size_t lds = (size_t)2 * (BP + 64) * LD * sizeof(float) + lds_pad;
+    if (lds_pad) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gate_kernel_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (v2) hipLaunchKernelGGL(wino_gate_kernel_v2<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
     else hipLaunchKernelGGL(wino_gate_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
   }

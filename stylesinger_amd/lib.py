@@ -11,7 +11,7 @@ import re
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libstylesinger_hip.so")
+LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(HERE, "libstylesinger_hip.so")  # SS_LIB_PATH: debug builds (tools/ablate.sh)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "stylesinger_hip.h")
 
 SS_MAX_TAPS = 16
