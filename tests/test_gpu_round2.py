@@ -193,7 +193,7 @@ def _gemm_bf16(A, Wp, **kw):
     L.gemm_bf16(A, Wp, **kw)
 
 
-@pytest.mark.parametrize("T,K", [(200, 256), (333, 192)])
+@pytest.mark.parametrize("T,K", [(200, 256), (333, 192), (5600, 256)])   # the last shape takes the 128x128 tile (C4-size path)
 def test_gemm_bf16_kernel_matches_torch_on_bf16_operands(T, K):
     """ss_gemm_bf16 (bf16 operands in HBM, fp32 accumulate) vs torch fp32 math on the SAME bf16-rounded operands: STORE with a
     3-tap dilated conv, GATE with the fp32 addend, RESX with the next layer's bf16 operand. Products of bf16 numbers are exact in
