@@ -129,6 +129,11 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
             L.wino_gate(X, packs[f"w_dil_wino.{l}"], G, dilation=d, **kw)
         else:
             L.conv_gemm(X, packs[f"w_dil.{l}"], G, taps=(-d, 0, d), bf16=bf16, **kw)
+    # the chip clocks to its power budget: have the kernel report the shader clock it really ran at (ss_set_clock_probe; the
+    # probe pointer is a launch parameter, so it is set before the capture below)
+    probe = torch.zeros(2, device=dev, dtype=torch.int64) if wino else None
+    if wino:
+        L.check(L.load().ss_set_clock_probe(probe.data_ptr()), "ss_set_clock_probe")
     for l in range(Lyr):
         launch(l)
     torch.cuda.synchronize()
@@ -143,6 +148,8 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                 launch(l)
         graph.replay()
         st.synchronize()
+        if wino:
+            probe.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         for _ in range(iters):
@@ -150,6 +157,11 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         e1.record(st)
         st.synchronize()
     torch.cuda.current_stream().wait_stream(st)
+    clock_ghz = None
+    if wino:
+        L.check(L.load().ss_set_clock_probe(None), "ss_set_clock_probe")
+        cyc, ticks = (int(v) for v in probe.cpu())
+        clock_ghz = cyc / ticks / 10.0 if ticks > 0 else None   # ticks of the constant 100 MHz counter
     sec = e0.elapsed_time(e1) * 1e-3 / (iters * Lyr)
     flops = 2.0 * B * T * (3 * C) * (2 * C)
     executed = flops * (4.0 / 6.0 if wino else 1.0)
@@ -171,6 +183,9 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     return dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)",
                 achieved=flops / sec / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=flops / sec / peak,
                 executed_mfma_frac=executed / sec / peak, executed_flops_per_launch=executed,
+                # `peak` is the data-sheet figure at 2.4 GHz; under this load the chip sustains `clock_ghz` (measured inside the
+                # kernel: s_memtime cycles / s_memrealtime), so the matrix pipes can deliver peak * clock_ghz / 2.4 at most
+                clock_ghz=clock_ghz, executed_mfma_frac_at_clock=(executed / sec / (peak * clock_ghz / 2.4)) if clock_ghz else None,
                 traffic=traffic, traffic_source=pmc_src, us_per_launch=sec * 1e6, flops_per_launch=flops,
                 launches_per_step=None, algorithmic_bytes_per_launch=(B * T * (2.0 * C + 4.0 * 2 * C + 2.0 * C) + 2.0 * 3 * C * 2 * C) if hbm else
                 (4.0 * B * T * (C + 2 * C + C) + 4.0 * (4 if wino else 3) * C * 2 * C))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 7 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies */
+#define SS_ABI_VERSION 8 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -40,6 +40,11 @@ int ss_struct_sizes(int64_t* out, int n);
 /* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
  * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3) */
 int ss_set_tuning(const char* key, int value);
+/* Measurement aid (bench.py's roofline block): while `dev_u64x2` is non-null, wave 0 of workgroup 0 of every Winograd gate launch
+ * adds its lifetime to dev_u64x2[0] in shader cycles (s_memtime) and to dev_u64x2[1] in ticks of the constant 100 MHz counter
+ * (s_memrealtime): [0] / [1] / 10 = the shader clock in GHz the chip sustained under that load (it clocks to its power budget:
+ * 2.4 GHz nominal, ~2.0 GHz measured in these loops). Pass NULL to switch it off. Results never change. */
+int ss_set_clock_probe(void* dev_u64x2);
 
 /* ------------------------------------------------------------------------------------------
  * Generic fp32-MFMA implicit-GEMM 1-D convolution / linear layer.

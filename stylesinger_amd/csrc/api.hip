@@ -14,7 +14,7 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0};
+SsTuning g_ss_tuning = {0, nullptr};
 
 extern "C" int ss_set_tuning(const char* key, int value) {
   if (!key) {
@@ -27,6 +27,10 @@ extern "C" int ss_set_tuning(const char* key, int value) {
   }
   ss_set_error("ss_set_tuning: unknown key/value %s=%d", key, value);
   return SS_ERR_ARG;
+}
+extern "C" int ss_set_clock_probe(void* dev_u64x2) {
+  g_ss_tuning.clock_probe = static_cast<unsigned long long*>(dev_u64x2);
+  return SS_OK;
 }
 extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
 

@@ -42,7 +42,7 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   wave_prio: 0 = all waves at priority 0; 1 = static s_setprio((blockIdx / 256) % 3); 2 = s_setprio(blockIdx % 3).
 //     The blocks sharing a CU then differ in priority, so the matrix pipe of a SIMD serves them one after the other instead
 //     of round-robin: their non-MFMA phases (staging, barrier) stop coinciding (launch structure).
-struct SsTuning { int wave_prio; };
+struct SsTuning { int wave_prio; unsigned long long* clock_probe; };
 extern SsTuning g_ss_tuning;
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)

@@ -17,6 +17,31 @@
 #include "../../include/stylesinger_hip.h"
 #include <stdlib.h>
 #include <type_traits>
+// SS_TRACE (debug builds only, tools/wave_trace.py): every wave of wino_gate_kernel_v2<1> sums, over its K chunks, the shader-clock
+// time spent in each phase of a chunk and writes the sums at exit.
+#ifdef SS_TRACE
+__device__ unsigned long long* g_wino_trace = nullptr;
+extern "C" int ss_debug_set_wino_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &p, sizeof(p));
+}
+#define SS_CLK(var)                                  \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_waitcnt(0xc07f);              \
+    var = (unsigned)__builtin_readcyclecounter();    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#define SS_CLK_VM(var)                               \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_waitcnt(0x0f70);              \
+    var = (unsigned)__builtin_readcyclecounter();    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#else
+#define SS_CLK(var) do { } while (0)
+#define SS_CLK_VM(var) do { } while (0)
+#endif
 #ifndef SS_ABL
 #define SS_ABL 0
 #endif
@@ -368,9 +393,16 @@ __global__ __launch_bounds__(256) void wino_gate_kernel(const ss_conv_gemm_args 
 // version 1 otherwise.
 template <int TN>
 __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_args a, int p_tiles_per_item, int p_tiles,
-                                                           int n_tiles, int log2d, int prio_mode) {
+                                                           int n_tiles, int log2d, int prio_mode, unsigned long long* clock_probe) {
   constexpr int BN = 64 * TN;
   ss_apply_wave_prio(prio_mode);
+  // ss_set_clock_probe: workgroup 0 reports how many shader cycles and 100 MHz ticks its first wave lived (-> sustained clock)
+  const bool probing = clock_probe != nullptr && blockIdx.x == 0;
+  unsigned long long probe_c0 = 0, probe_r0 = 0;
+  if (probing) {
+    probe_c0 = __builtin_readcyclecounter();
+    probe_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BP][LD]
   float* Bs = smem + 2 * BP * LD;    // [2][BN][LD]
@@ -486,6 +518,11 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
 
+#ifdef SS_TRACE
+  unsigned tr_sum[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long tr_t0 = __builtin_readcyclecounter();
+  const unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz counter
+#endif
   Comp cc = comp_of(0);
   load_a(cc, 0);
   load_b(0);
@@ -532,14 +569,19 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
     const float* Bc = Bs + CUR * BN * LD;
     float4 af0, af1;
     BF bf0, bf1;
+    [[maybe_unused]] unsigned ta, tb, tc, td, te, tf;
+    SS_CLK(ta);
     read_frags(Ac, Bc, 0, af0, bf0);
     read_frags(Ac, Bc, 1, af1, bf1);
+    SS_CLK(tb);
     __builtin_amdgcn_sched_barrier(0);
     mfma4(cacc, af0, bf0);
     read_frags(Ac, Bc, 2, af0, bf0);
     __builtin_amdgcn_sched_barrier(0);
     mfma4(cacc, af1, bf1);
     read_frags(Ac, Bc, 3, af1, bf1);
+    SS_CLK(tc);
+    SS_CLK_VM(td);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (decltype(store_tag)::value) {
 #if SS_ABL != 2
@@ -560,8 +602,13 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
     __builtin_amdgcn_sched_barrier(0);
     mfma4(cacc, af0, bf0);
     mfma4(cacc, af1, bf1);
+    SS_CLK(te);
 #if SS_ABL != 4
     __syncthreads();
+#endif
+    SS_CLK(tf);
+#ifdef SS_TRACE
+    tr_sum[0] += tb - ta; tr_sum[1] += tc - tb; tr_sum[2] += td - tc; tr_sum[3] += te - td; tr_sum[4] += tf - te; tr_sum[5] += 1;
 #endif
   };
   using C0 = std::integral_constant<int, 0>;
@@ -598,6 +645,9 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
     chunk(C0{}, Yes{}, No{}, acc[3], cc, cc, 0, 0);
   }
 
+#ifdef SS_TRACE
+  const unsigned long long tr_t1 = __builtin_readcyclecounter();
+#endif
   // ---- frame index / byte offsets of the accumulator rows this lane owns: row r -> pair (r&3) + 8*(r>>2) + 4*lh of the wave tile
   const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
   const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
@@ -714,6 +764,24 @@ __global__ __launch_bounds__(256) void wino_gate_kernel_v2(const ss_conv_gemm_ar
       Cb[(int64_t)t * a.ldc + oc] = g;
     }
   }
+  if (probing && threadIdx.x == 0) {
+    atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
+    atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
+  }
+#ifdef SS_TRACE
+  if (g_wino_trace && lane == 0) {
+    unsigned long long* o = g_wino_trace + ((size_t)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[q] = tr_sum[q];
+    o[6] = tr_t0;
+    o[7] = tr_t1;
+    o[8] = __builtin_readcyclecounter();
+    o[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    o[11] = tr_r0;
+    o[12] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // g0 = w0, g1 = (w0+w1+w2)/2, g2 = (w0-w1+w2)/2, g3 = w2   (src [rows][3] -> dst [rows][4], rows = Cout*Cin)
@@ -772,7 +840,7 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
     const int n_tiles = a.Np / 128;
     const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
     const size_t lds = (size_t)2 * (BP + 128) * LD * sizeof(float);
-    if (v2) hipLaunchKernelGGL(wino_gate_kernel_v2<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
+    if (v2) hipLaunchKernelGGL(wino_gate_kernel_v2<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio, g_ss_tuning.clock_probe);
     else hipLaunchKernelGGL(wino_gate_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
   } else {
     const int n_tiles = a.Np / 64;
@@ -782,7 +850,7 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
     if (lds_pad) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gate_kernel_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (v2) hipLaunchKernelGGL(wino_gate_kernel_v2<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
+    if (v2) hipLaunchKernelGGL(wino_gate_kernel_v2<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio, g_ss_tuning.clock_probe);
     else hipLaunchKernelGGL(wino_gate_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, p_tiles_per_item, p_tiles, n_tiles, log2d, g_ss_tuning.wave_prio);
   }
   SS_CHECK_LAUNCH("ss_wino_gate");

@@ -366,3 +366,34 @@ def test_conv_gemm_bf16_operands_gate_and_resskip(C):
                 accumulate=True, mask_rows=False, bf16=True)
     assert (xd.cpu() - x_ref).abs().max().item() < 2e-5
     assert (sd_.cpu() - s_ref).abs().max().item() < 2e-5
+
+
+def test_clock_probe_reports_a_plausible_shader_clock_and_changes_nothing():
+    """ss_set_clock_probe: the Winograd gate kernel's first wave reports shader cycles and 100 MHz ticks; their ratio is the
+    sustained clock (nominal 2.4 GHz, lower under load). The gate output must not depend on the probe."""
+    dv = dev()
+    B, T, C = 4, 512, 256
+    x = _rand(B, T, C, seed=91).to(dv)
+    w = _rand(2 * C, C, 3, seed=92, scale=1 / math.sqrt(3 * C)).to(dv)
+    Wt = L.pack_conv_weight(L.wino_weight(w), interleave_half=C)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dv)
+    kw = dict(dilation=2, B=B, T=T, Cin=C, N=C, Np=Wt.shape[0], Kp=C, lens=lens, ldc=C)
+    g0 = torch.empty(B, T, C, device=dv)
+    L.wino_gate(x, Wt, g0, **kw)
+    probe = torch.zeros(2, dtype=torch.int64, device=dv)
+    lib = L.load()
+    L.check(lib.ss_set_clock_probe(probe.data_ptr()), "ss_set_clock_probe")
+    try:
+        g1 = torch.empty(B, T, C, device=dv)
+        for _ in range(8):
+            L.wino_gate(x, Wt, g1, **kw)
+        torch.cuda.synchronize()
+    finally:
+        L.check(lib.ss_set_clock_probe(None), "ss_set_clock_probe")
+    cyc, ticks = (int(v) for v in probe.cpu())
+    assert ticks > 0 and 0.5 < cyc / ticks / 10.0 < 2.6, (cyc, ticks)
+    assert torch.equal(g0, g1)
+    before = probe.clone()
+    L.wino_gate(x, Wt, g1, **kw)  # probe off again: nothing is written
+    torch.cuda.synchronize()
+    assert torch.equal(before, probe)

@@ -16,7 +16,7 @@ def test_library_loads_and_exports_header_symbols():
     assert len(names) >= 30
     for n in names:
         assert hasattr(l, n), n
-    assert l.ss_abi_version() == lib.ABI_VERSION == 7
+    assert l.ss_abi_version() == lib.ABI_VERSION == 8
     assert l.ss_last_error() is not None
 
 
