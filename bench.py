@@ -111,6 +111,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     packs = net["packs"][0]
     dstep = packs["dstep"]
     wino = infer.model.use_wino and not bf16
+    wino_m = getattr(infer.model, "wino_m", 2) if wino else 0
 
     hbm = bf16 and getattr(infer.model, "bf16_hbm", False)
     if hbm:  # bf16 operands in HBM (ss_gemm_bf16): the operand X + dstep is already rounded by the producing epilogue
@@ -126,7 +127,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         kw = dict(B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=dstep[0, l], epi=L.EPI_GATE, E=E[:, :, l * 2 * C:],
                   lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
         if wino:
-            L.wino_gate(X, packs[f"w_dil_wino.{l}"], G, dilation=d, **kw)
+            (L.wino43_gate if wino_m == 4 else L.wino_gate)(X, packs[f"w_dil_wino.{l}"], G, dilation=d, **kw)
         else:
             L.conv_gemm(X, packs[f"w_dil.{l}"], G, taps=(-d, 0, d), bf16=bf16, **kw)
     # the chip clocks to its power budget: have the kernel report the shader clock it really ran at (ss_set_clock_probe; the
@@ -164,9 +165,9 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         clock_ghz = cyc / ticks / 10.0 if ticks > 0 else None   # ticks of the constant 100 MHz counter
     sec = e0.elapsed_time(e1) * 1e-3 / (iters * Lyr)
     flops = 2.0 * B * T * (3 * C) * (2 * C)
-    executed = flops * (4.0 / 6.0 if wino else 1.0)
+    executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
-    name = ("wino_gate_kernel_v2 (Winograd F(2,3)" if wino else "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct" if hbm else
+    name = ("wino43_gate_kernel (Winograd F(4,3)" if wino_m == 4 else "wino_gate_kernel_v2 (Winograd F(2,3)" if wino else "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct" if hbm else
             "conv_gemm_kernel<64,128,2,2,GATE" + (",bf16> (direct" if bf16 else "> (direct"))
     # HBM traffic of this launch from the round's PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs,
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
@@ -176,7 +177,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     if os.path.exists(pj):
         try:
             rec = json.load(open(pj))
-            if rec.get("rows") == B * T and rec.get("kernel_form") == ("wino" if wino else ("bf16" if bf16 else "direct")):
+            if rec.get("rows") == B * T and rec.get("kernel_form") == ("wino43" if wino_m == 4 else "wino" if wino else ("bf16" if bf16 else "direct")):
                 traffic, pmc_src = rec.get("hbm_bytes_per_launch"), "profiles/r02_pmc_gate.json"
         except (ValueError, OSError):
             pass
@@ -188,7 +189,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                 clock_ghz=clock_ghz, executed_mfma_frac_at_clock=(executed / sec / (peak * clock_ghz / 2.4)) if clock_ghz else None,
                 traffic=traffic, traffic_source=pmc_src, us_per_launch=sec * 1e6, flops_per_launch=flops,
                 launches_per_step=None, algorithmic_bytes_per_launch=(B * T * (2.0 * C + 4.0 * 2 * C + 2.0 * C) + 2.0 * 3 * C * 2 * C) if hbm else
-                (4.0 * B * T * (C + 2 * C + C) + 4.0 * (4 if wino else 3) * C * 2 * C))
+                (4.0 * B * T * (C + 2 * C + C) + 4.0 * (6 if wino_m == 4 else 4 if wino else 3) * C * 2 * C))
 
 
 def cpu_baseline(hp_over, extra_threads):

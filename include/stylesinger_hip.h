@@ -138,6 +138,14 @@ int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
 int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* stream);
 /* src [Cout][Cin][3] -> dst [Cout][Cin][4]: g0=w0, g1=(w0+w1+w2)/2, g2=(w0-w1+w2)/2, g3=w2 */
 int ss_wino_weight_transform(const float* src, float* dst, int Cout, int Cin, void* stream);
+/* Winograd F(4,3) form of the same layer: four frames (t, t+d, t+2d, t+3d) from 6 products instead of 12 (2x fewer matrix ops
+ * than the direct form). W is the transformed weight packed as a 6-"tap" tensor (ss_wino43_weight_transform then
+ * ss_pack_conv_weight(k=6, interleave_half=C)). Needs Cin % 32 == 0 and Kp == Cin. Same argument use as ss_wino_gate; results
+ * equal the direct form to fp32 rounding (single-layer error about 2x that of F(2,3); tests/test_gpu_kernels.py). */
+int ss_wino43_gate(const ss_conv_gemm_args* args, int dilation, void* stream);
+/* src [Cout][Cin][3] -> dst [Cout][Cin][6]: g0=w0/4, g1=-(w0+w1+w2)/6, g2=-(w0-w1+w2)/6, g3=w0/24+w1/12+w2/6,
+ * g4=w0/24-w1/12+w2/6, g5=w2 */
+int ss_wino43_weight_transform(const float* src, float* dst, int Cout, int Cin, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16-operand GEMM/conv for the denoisers' hidden layers (BASELINE config 4): A and W are bf16 IN HBM (rounded once where
@@ -308,7 +316,8 @@ typedef struct ss_wavenet {
   /* paired nets (n_groups = 2): every weight pointer above is net 0's; net g's tensor lives gs_* floats further.
    * Both nets must share shapes and schedules (the two DDiffNets of stylesinger.py:69-73 do). */
   int32_t n_groups;
-  /* optional Winograd-transformed dilated-conv weights (packed [2C][4*Kp], gate-interleaved); NULL -> direct conv */
+  /* optional Winograd-transformed dilated-conv weights, gate-interleaved; NULL -> direct conv. Packed [2C][4*Kp] for F(2,3)
+   * (wino_m = 0 or 2) or [2C][6*Kp] for F(4,3) (wino_m = 4, below) */
   const float* w_dil_wino[SS_MAX_LAYERS];
   int64_t gs_w_dil_wino;
   int64_t gs_w_in, gs_b_in, gs_uv_embed, gs_dstep, gs_w_dil, gs_w_out, gs_b_out, gs_w_cond, gs_b_cond, gs_w_skip, gs_b_skip,
@@ -317,7 +326,7 @@ typedef struct ss_wavenet {
    * bf16 operands (ss_conv_gemm_args.mfma_bf16); the input and final projections, which touch the diffusion state, the
    * sampler update and all accumulations stay fp32. Winograd weights are ignored in this mode. */
   int32_t mfma_bf16;
-  int32_t reserved0;
+  int32_t wino_m; /* output tile of the Winograd weights in w_dil_wino: 0 or 2 = F(2,3), 4 = F(4,3) */
   /* optional deferred-skip form: w_skipall = the skip halves of all output projections side by side, packed
    * [round_up32(C)][L*C] (column l*C + ci = output_projection_l.weight[C + n][ci]); b_skipall[n] = sum_l bias_l[C + n].
    * When set, the per-layer output projection only computes the residual half and the skip sum is one GEMM per step. */

@@ -264,7 +264,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     if (net->w_dil_wino[l] && !net->mfma_bf16) {  // Winograd F(2,3): pairs of frames (t, t+d) from 4 products instead of 6
       a.W = net->w_dil_wino[l];
       a.w_group_stride = net->gs_w_dil_wino;
-      SS_PROPAGATE(ss_wino_gate(&a, d, stream));
+      SS_PROPAGATE(net->wino_m == 4 ? ss_wino43_gate(&a, d, stream) : ss_wino_gate(&a, d, stream));
     } else {
       SS_PROPAGATE(ss_conv_gemm(&a, stream));
     }

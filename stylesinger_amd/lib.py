@@ -62,7 +62,7 @@ class WaveNet(C.Structure):
         ("n_groups", C.c_int32), ("w_dil_wino", _vp * SS_MAX_LAYERS), ("gs_w_dil_wino", C.c_int64),
     ] + [(n, C.c_int64) for n in ("gs_w_in", "gs_b_in", "gs_uv_embed", "gs_dstep", "gs_w_dil", "gs_w_out", "gs_b_out", "gs_w_cond",
                                   "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")] \
-        + [("mfma_bf16", C.c_int32), ("reserved0", C.c_int32), ("w_skipall", _vp), ("b_skipall", _vp),
+        + [("mfma_bf16", C.c_int32), ("wino_m", C.c_int32), ("w_skipall", _vp), ("b_skipall", _vp),
            ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("reserved1", C.c_int32),
            ("w_dil_h", _vp * SS_MAX_LAYERS), ("w_out_h", _vp * SS_MAX_LAYERS), ("w_skipall_h", _vp), ("w_cond_h", _vp),
            ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64)]
@@ -230,6 +230,21 @@ def wino_gate(A, Wt, out, *, dilation, **kw):
     kw.setdefault("epi", EPI_GATE)
     a = _fill_args(A, Wt, out, **kw)
     check(load().ss_wino_gate(C.byref(a), int(dilation), stream_ptr()), "ss_wino_gate")
+
+
+def wino43_gate(A, Wt, out, *, dilation, **kw):
+    """Winograd F(4,3) dilated conv + gate (ss_wino43_gate); Wt = packed transformed weights (6 'taps')."""
+    kw.setdefault("epi", EPI_GATE)
+    a = _fill_args(A, Wt, out, **kw)
+    check(load().ss_wino43_gate(C.byref(a), int(dilation), stream_ptr()), "ss_wino43_gate")
+
+
+def wino43_weight(w):
+    """conv weight [Cout][Cin][3] (device) -> F(4,3)-transformed [Cout][Cin][6]."""
+    w = w.contiguous().float()
+    out = torch.empty(w.shape[0], w.shape[1], 6, device=w.device, dtype=torch.float32)
+    check(load().ss_wino43_weight_transform(ptr(w), ptr(out), w.shape[0], w.shape[1], stream_ptr()), "ss_wino43_weight_transform")
+    return out
 
 
 def wino_weight(w):

@@ -146,6 +146,9 @@ class StyleSingerHIP(torch.nn.Module):
         self.use_graphs = os.environ.get("SS_GRAPHS", "auto")
         # Winograd F(2,3) for the denoisers' 3-tap dilated convs (1.5x fewer matrix ops, fp32-rounding-equal results)
         self.use_wino = os.environ.get("SS_WINO", "1") not in ("0", "off", "false")
+        # Winograd output tile of the dilated conv: 4 = F(4,3) (6 products per 4 frames), 2 = F(2,3) (4 per 2); direct form = 6 per 2
+        self.wino_m = int(os.environ.get("SS_WINO_M", "4"))
+        assert self.wino_m in (2, 4), "SS_WINO_M must be 2 or 4"
         # per-layer output projection = residual half only; skip sum of all layers as one K = L*C GEMM per step
         self.defer_skip = os.environ.get("SS_DEFER_SKIP", "1") not in ("0", "off", "false")
         self.bf16 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16"
@@ -252,8 +255,7 @@ class StyleSingerHIP(torch.nn.Module):
             t[f"w_dil.{l}"], t[f"w_out.{l}"], t[f"b_out.{l}"] = dil.W, out.W, out.bias
             if self.use_wino:
                 wsrc = self.p(p + ".dilated_conv.weight").contiguous()
-                wt = torch.empty(2 * C, C, 4, device=dev)
-                L.check(L.load().ss_wino_weight_transform(L.ptr(wsrc), L.ptr(wt), 2 * C, C, L.stream_ptr()), "wino transform")
+                wt = L.wino43_weight(wsrc) if self.wino_m == 4 and C % 32 == 0 else L.wino_weight(wsrc)
                 t[f"w_dil_wino.{l}"] = L.pack_conv_weight(wt, interleave_half=C)
             if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
                 t[f"w_dil_h.{l}"] = L.to_bf16(dil.W)
@@ -317,6 +319,7 @@ class StyleSingerHIP(torch.nn.Module):
                 ptr_, gs = place(f"w_dil_wino.{l}")
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
+                net.wino_m = 4 if self.wino_m == 4 and C % 32 == 0 else 2
             if self.bf16_hbm:
                 for key, arr in (("w_dil_h", net.w_dil_h), ("w_out_h", net.w_out_h)):
                     ptr_, gs = place(f"{key}.{l}")

@@ -269,6 +269,48 @@ def test_winograd_gate_equals_direct_conv(C, d, T, B, tile):
     assert err < 5e-6, err
 
 
+@pytest.mark.parametrize("C,d,T,B", [(256, 1, 150, 2), (256, 2, 203, 1), (256, 8, 97, 2), (192, 4, 260, 2), (256, 4, 1536, 3), (64, 1, 5, 1)])
+def test_winograd_f43_gate_equals_direct_conv(C, d, T, B):
+    """ss_wino43_gate (Winograd F(4,3): 6 products per 4 frames) vs a plain torch statement of conv(x + bias) + E -> sigmoid*tanh,
+    with ragged lens, T not a multiple of the 4d frame group, every dilation of the cycle and a tile-spanning length."""
+    dv = dev()
+    x = _rand(B, T, C, seed=171)
+    ab = _rand(C, seed=172)
+    w = _rand(2 * C, C, 3, seed=173, scale=1 / math.sqrt(3 * C))
+    bias = _rand(2 * C, seed=175, scale=0.3)
+    Lyr = 3
+    e = _rand(B, T, Lyr * 2 * C, seed=174)
+    lens = torch.tensor([max(1, T - 11 * i) for i in range(B)], dtype=torch.int32)
+    ref = torch.zeros(B, T, C)
+    for i in range(B):
+        n = int(lens[i])
+        y = (x[i:i + 1, :n] + ab).transpose(1, 2)
+        z = F.conv1d(y.double(), w.double(), bias.double(), padding=d, dilation=d).transpose(1, 2)[0] + e[i, :n, 2 * C:4 * C].double()
+        ref[i, :n] = (torch.sigmoid(z[:, :C]) * torch.tanh(z[:, C:])).float()
+    Wt = L.pack_conv_weight(L.wino43_weight(w.to(dv)), interleave_half=C)
+    Np = Wt.shape[0]
+    assert Wt.shape[1] == 6 * C
+    Cp = Np // 2
+    def packed(v):  # [..., 2C] -> packed column order [..., Np]: 32 first-operand channels, then the 32 second-operand ones
+        out = torch.zeros(*v.shape[:-1], Np)
+        for p in range(Cp // 32):
+            n = min(32, C - p * 32)
+            out[..., (2 * p) * 32:(2 * p) * 32 + n] = v[..., p * 32:p * 32 + n]
+            out[..., (2 * p + 1) * 32:(2 * p + 1) * 32 + n] = v[..., C + p * 32:C + p * 32 + n]
+        return out
+    ep = torch.zeros(B, T, Lyr * Np)
+    ep[..., Np:2 * Np] = packed(e[..., 2 * C:4 * C])
+    epd = ep.to(dv)
+    g = torch.full((B, T, C), 5.0, device=dv)
+    L.wino43_gate(x.to(dv), Wt, g, dilation=d, B=B, T=T, Cin=C, N=C, Np=Np, Kp=C, lens=lens.to(dv), a_bias=ab.to(dv),
+                  bias=packed(bias).to(dv), E=epd[:, :, Np:], lde=Lyr * Np, e_bs=T * Lyr * Np, ldc=C, mask_rows=True)
+    err = (g.cpu() - ref).abs().max().item()
+    assert err < 1e-5, err
+    # rows past an item's length are written as zeros (mask_rows), never left stale
+    for i in range(B):
+        assert torch.all(g[i, int(lens[i]):] == 0)
+
+
 def test_grouped_launch_uses_per_item_weight_sets():
     dv = dev()
     B, T, C = 4, 70, 64

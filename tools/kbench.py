@@ -95,6 +95,15 @@ def main():
             s = timeit(fw, a.iters)
             fl = 2.0 * B * T * 3 * C * 2 * C
             res.append((f"{name} WINO gate K={3 * C} N={2 * C} (algorithmic flops)", s, fl))
+        if a.which in ("wino43", "all"):
+            Wt4 = L.pack_conv_weight(L.wino43_weight(w), interleave_half=C)
+            def fw4():
+                layer[0] = (layer[0] + 1) % Lyr
+                L.wino43_gate(X, Wt4, G, dilation=2, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=ab,
+                              E=E[:, :, layer[0] * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C)
+            s = timeit(fw4, a.iters)
+            fl = 2.0 * B * T * 3 * C * 2 * C
+            res.append((f"{name} WINO F(4,3) gate K={3 * C} N={2 * C} (algorithmic flops)", s, fl))
         if a.which in ("resskip", "all"):
             f = lambda: L.conv_gemm(G, Wo, X, B=B, T=T, Cin=C, N=2 * C, Np=2 * C, Kp=C, lens=lens, epi=L.EPI_RESSKIP, bias=bop, Nh=C,
                                     R=X, ldr=C, ldc=C, post_scale=0.7071, C2=S, ldc2=C, c2_bs=T * C, accumulate=True, tile=a.tile)
@@ -115,7 +124,7 @@ def main():
             s = timeit(f, max(3, a.iters // 5))
             res.append((f"voc C={C} rows={rows} k={k}", s, 2.0 * B * rows * C * C * k))
     for name, s, fl in res:
-        print(f"{name:34s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.2f} TF/s  ({fl / s / 157.3e12 * 100:5.1f}% of fp32 MFMA peak)")
+        print(f"{name:52s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.2f} TF/s  ({fl / s / 157.3e12 * 100:5.1f}% of fp32 MFMA peak)")
 
 
 if __name__ == "__main__":
