@@ -404,9 +404,10 @@ def main():
     # what the kernels are handed: the step-invariant conditioner projections are hoisted out of the loops (SURVEY.md §8d "report both")
     flop_hoisted = (MEL_FLOP_PER_FRAME_STEP - MEL_COND_FLOP) * S_mel + 2 * (F0_FLOP_PER_FRAME_STEP - F0_COND_FLOP) * S_f0 \
         + MEL_COND_FLOP + 2 * F0_COND_FLOP + VOC_FLOP_PER_FRAME + REST_FLOP_PER_FRAME
-    # what the matrix pipe really executes: the 3-tap dilated convs run as Winograd F(2,3) (4 of 6 products) in fp32 mode
+    # what the matrix pipe really executes: in fp32 mode the 3-tap dilated convs run as Winograd F(4,3) (6 of 12 products; F(2,3): 4 of 6)
     wino = infer.model.use_wino and not bf16
-    flop_exec = flop_hoisted - ((MEL_GATE_FLOP * S_mel + 2 * F0_GATE_FLOP * S_f0) / 3.0 if wino else 0.0)
+    wino_saved = 0.5 if getattr(infer.model, "wino_m", 2) == 4 else 1.0 / 3.0
+    flop_exec = flop_hoisted - ((MEL_GATE_FLOP * S_mel + 2 * F0_GATE_FLOP * S_f0) * wino_saved if wino else 0.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
     per_gpu = value / world
 

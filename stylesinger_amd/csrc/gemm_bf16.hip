@@ -37,6 +37,12 @@ __device__ __forceinline__ uint16_t f2bf(float x) {  // RNE, like torch's .bfloa
   return __builtin_bit_cast(uint16_t, (__bf16)x);
 }
 
+// SS_HABL (debug builds only, tools/ablate_h.sh): timing ablations. 1 = no global fetches in the loop, 2 = no MFMAs,
+// 3 = no addend loads in the epilogue, 4 = no epilogue stores. Results are wrong by design.
+#ifndef SS_HABL
+#define SS_HABL 0
+#endif
+
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
   constexpr int WM = 2, WN = 2;
@@ -102,6 +108,9 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     constexpr int ST = decltype(st_tag)::value;
     // a negative tap shift must stay in the VGPR offset (the range check has to see the row): one v_add per load, only for taps
     const int so = a_soff(c);
+#if SS_HABL == 1
+    if (c > 1) return;
+#endif
 #pragma unroll
     for (int i = 0; i < AP; ++i) ra[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[i] + so) | dead, 0, 0);
 #pragma unroll
@@ -142,7 +151,13 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #pragma unroll
       for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < TN; ++n) {
+#if SS_HABL == 2
+          asm volatile("" ::"v"(af[m]), "v"(bf[n]));
+#else
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+#endif
+        }
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -170,18 +185,54 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     body(I0{}, c);
     body(I1{}, c + 1);
   }
+  // GATE: the conditioner addend (fp32, one HBM miss per element) is fetched under the last two chunks' MFMAs, into the registers the
+  // fetch stages no longer need; with the loads in the epilogue every workgroup of a round stalled on them (tools/ablate_h.sh: 56 of 276 us).
+  const int row_base = t0 + wm * 32 * TM + 4 * lh;
+  const int col_base = n0 + wn * 32 * TN;
+  [[maybe_unused]] float pe0[TM][TN / 2 > 0 ? TN / 2 : 1][16], pe1[TM][TN / 2 > 0 ? TN / 2 : 1][16];
+  [[maybe_unused]] auto prefetch_e = [&](int m) {
+    if constexpr (EPI == SS_HEPI_GATE) {
+      const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+      const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(Eb ? (const void*)Eb : (const void*)a.W), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+      const int lde4 = a.lde * 4;
+#pragma unroll
+      for (int n = 0; n < TN; n += 2) {
+        const int pc0 = col_base + n * 32 + l31;
+        const int oc = (pc0 >> 6) * 32 + l31;
+        const int dead = oc < a.N ? 0 : (int)0x80000000;
+        const int eoff = ((row_base + m * 32) * a.lde + pc0) * 4 | dead;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = ((r & 3) + 8 * (r >> 2)) * lde4;
+#if SS_HABL == 3
+          pe0[m][n / 2][r] = (float)ro;
+          pe1[m][n / 2][r] = (float)eoff;
+#else
+          pe0[m][n / 2][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff + ro, 0, 0));
+          pe1[m][n / 2][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff + ro, 128, 0));
+#endif
+        }
+      }
+    }
+  };
   if (c + 1 < nchunks) {  // one body left (nchunks even): chunk c is in buffer 0, chunk c+1 in stage 1
+    prefetch_e(0);
+    __builtin_amdgcn_sched_barrier(0);
     compute(I0{});
     stage(I1{}, I1{});
     __syncthreads();
+    if constexpr (TM > 1) prefetch_e(1);
+    __builtin_amdgcn_sched_barrier(0);
     compute(I1{});
   } else {
+    prefetch_e(0);
+    if constexpr (TM > 1) prefetch_e(1);
+    __builtin_amdgcn_sched_barrier(0);
     compute(I0{});  // nchunks odd: the last chunk sits in buffer 0
   }
 
   // ---------------------------------------------------------------- epilogue (C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*lh)
-  const int row_base = t0 + wm * 32 * TM + 4 * lh;
-  const int col_base = n0 + wn * 32 * TN;
   const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
   if constexpr (EPI == SS_HEPI_STORE) {
     float* Cb = (float*)a.C + (int64_t)b * a.c_batch_stride;
@@ -203,11 +254,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
         }
     }
   } else if constexpr (EPI == SS_HEPI_GATE) {
-    // two-phase per 32-row block (all addend loads of the block first, then compute + store: a load issued after a store to a
-    // possibly aliasing buffer would otherwise wait for a full round trip per element), 32-bit buffer addressing throughout
-    const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
-    const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(Eb ? (const void*)Eb : (const void*)a.W), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+    // addend already in registers (prefetch_e above); 32-bit buffer addressing for the bf16 stores
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr((uint16_t*)a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 2)), 0x00020000);
     const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
@@ -215,7 +262,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     const float m0 = sig_first ? -1.0f : -2.0f, s0 = sig_first ? 1.0f : 2.0f, h0 = sig_first ? 0.0f : -1.0f;
     const float m1 = sig_first ? -2.0f : -1.0f, s1 = sig_first ? 2.0f : 1.0f, h1 = sig_first ? -1.0f : 0.0f;
     auto act = [](float x, float mul, float sc, float sh) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(x * mul)), sc, sh); };
-    const int lde4 = a.lde * 4, ldc2 = a.ldc * 2;
+    const int ldc2 = a.ldc * 2;
 #pragma unroll
     for (int n = 0; n < TN; n += 2) {
       const int pc0 = col_base + n * 32 + l31;  // packed column of the first operand; the second sits 32 further
@@ -225,20 +272,15 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
         const int row0 = row_base + m * 32;
-        const int eoff = (row0 * a.lde + pc0) * 4 | dead;
         const int coff = (row0 * a.ldc + oc) * 2 | dead;
-        float e0[16], e1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = ((r & 3) + 8 * (r >> 2)) * lde4;
-          e0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff + ro, 0, 0));
-          e1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff + ro, 128, 0));
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
-          float g = act(acc[m][n][r] + b0 + e0[r], m0, s0, h0) * act(acc[m][n + 1][r] + b1 + e1[r], m1, s1, h1);
+          float g = act(acc[m][n][r] + b0 + pe0[m][n / 2][r], m0, s0, h0) * act(acc[m][n + 1][r] + b1 + pe1[m][n / 2][r], m1, s1, h1);
           if (row0 + rr >= row_lim) g = 0.f;
+#if SS_HABL == 4
+          if (g == 12345.678f)
+#endif
           __builtin_amdgcn_raw_buffer_store_b16(f2bf(g), rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
         }
       }

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--T", type=int, default=1500)
     ap.add_argument("--prio", type=int, default=-1, help="ss_set_tuning('wave_prio', N)")
+    ap.add_argument("--e-layout", default="row", help="conditioner addend: 'row' = [B][T][L*2C] (one row holds all layers), 'layer' = [L][B][T][2C]")
     a = ap.parse_args()
     if a.prio >= 0:
         L.check(L.load().ss_set_tuning(b"wave_prio", a.prio), "ss_set_tuning")
@@ -70,6 +71,8 @@ def main():
         G = torch.randn(B, T, C, device=d)
         S = torch.zeros(B, T, C, device=d)
         E = torch.randn(B, T, Lyr * 2 * C, device=d)
+        if a.e_layout == "layer":
+            El = torch.randn(Lyr, B, T, 2 * C, device=d)
         layer = [0]
         w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
         wo = torch.randn(2 * C, C, 1, device=d) / math.sqrt(C)
@@ -99,6 +102,10 @@ def main():
             Wt4 = L.pack_conv_weight(L.wino43_weight(w), interleave_half=C)
             def fw4():
                 layer[0] = (layer[0] + 1) % Lyr
+                if a.e_layout == "layer":
+                    L.wino43_gate(X, Wt4, G, dilation=2, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=ab,
+                                  E=El[layer[0]], lde=2 * C, e_bs=T * 2 * C, ldc=C)
+                    return
                 L.wino43_gate(X, Wt4, G, dilation=2, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=ab,
                               E=E[:, :, layer[0] * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C)
             s = timeit(fw4, a.iters)
