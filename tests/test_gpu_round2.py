@@ -89,6 +89,32 @@ def test_c2_batch_item_matches_oracle_at_full_size_and_100_steps():
         assert l1 <= 1e-5 and mx <= 1e-3
 
 
+def test_winograd_f43_f23_and_direct_forms_agree_through_the_whole_path(monkeypatch):
+    """The dilated conv of both denoisers as Winograd F(4,3) (default), F(2,3) (SS_WINO_M=2) and direct (SS_WINO=0): same noise
+    tape, 30 + 2x30 steps, ragged batch. Integer outputs equal; mel within 1e-5 L1 of each other."""
+    S = 30
+    hp = config.make_hparams(dict(timesteps=S, K_step=S, f0_timesteps=S))
+    B, T = 3, 200
+    batch = {k: v.cuda() for k, v in synth.synth_batch(B, T, 8, 120, hp, 4321).items()}
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(5), B, T, S, S)
+    outs = {}
+    for name, env in (("f43", {"SS_WINO_M": "4"}), ("f23", {"SS_WINO_M": "2"}), ("direct", {"SS_WINO": "0"})):
+        for k in ("SS_WINO_M", "SS_WINO"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = _model(hp, 99)
+        assert m.use_wino == (name != "direct") and (name == "direct" or m.wino_m == int(env["SS_WINO_M"]))
+        outs[name] = _fwd(m, batch, noise=noise)
+        torch.cuda.synchronize()
+    for name in ("f23", "direct"):
+        assert torch.equal(outs["f43"]["rq_codes"], outs[name]["rq_codes"])
+        assert torch.equal(outs["f43"]["uv_a"], outs[name]["uv_a"]) and torch.equal(outs["f43"]["uv_b"], outs[name]["uv_b"])
+        l1 = (outs["f43"]["mel_out"] - outs[name]["mel_out"]).abs().mean().item()
+        print(f"mel L1 F(4,3) vs {name}: {l1:.3e}")
+        assert l1 <= 1e-5, (name, l1)
+
+
 def test_bucketed_graph_cache_20_random_lengths():
     """20 utterance lengths through forward(): frames are padded to the 64-frame bucket, so only 4 plans exist; a shape is
     captured on its SECOND use (<= 4 captures per loop); every result equals the un-bucketed, eager run bit for bit."""
