@@ -12,6 +12,7 @@
 //   * gate (sigmoid*tanh), residual/sqrt(2), skip accumulation and the DDPM posterior step are GEMM epilogues.
 // Nothing here allocates or synchronises: the whole loop is hipGraph-capturable.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/stylesinger_hip.h"
 
 namespace {
@@ -276,7 +277,10 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     o.Cin = C;
     o.W = net->w_out[l];
     o.N = defer ? C : 2 * C;  // deferred skip: only the residual half (the first C packed rows) runs per layer
-    if (defer) o.tile = SS_TILE_64x64;
+    if (defer) {
+      static const int env_tile = getenv("SS_RES_TILE") ? atoi(getenv("SS_RES_TILE")) : 0;  // experiments (tools/r2_session28.sh)
+      o.tile = env_tile > 0 ? env_tile : SS_TILE_64x64;
+    }
     o.Np = 2 * C;
     o.Kp = round_up32(C);
     o.epi = SS_EPI_RESSKIP;
@@ -316,7 +320,8 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     k.C = w.S;
     k.ldc = C;
     k.c_batch_stride = (int64_t)T * C;
-    k.tile = SS_TILE_64x64;
+    static const int env_skip_tile = getenv("SS_SKIP_TILE") ? atoi(getenv("SS_SKIP_TILE")) : 0;  // experiments
+    k.tile = env_skip_tile > 0 ? env_skip_tile : SS_TILE_64x64;
     k.mfma_bf16 = net->mfma_bf16;
     if (net->n_groups > 1) {
       k.group_size = B / net->n_groups;
