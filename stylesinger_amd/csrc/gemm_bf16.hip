@@ -17,6 +17,7 @@
 // Arithmetic contract = oracle/restatement.py with set_matmul_rounding("bf16"): RNE rounding of both matmul operands, exact
 // products, fp32 accumulation; everything outside the matmuls fp32.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/stylesinger_hip.h"
 #include <type_traits>
 
@@ -345,6 +346,9 @@ template <int EPI>
 int launch_tiles(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const int n_cols = (EPI == SS_HEPI_GATE) ? a.Np : a.N;
   const long big = (long)ss_cdiv(a.T, 128) * a.B * ss_cdiv(n_cols, 128);
+  static const int env_tile = getenv("SS_HTILE") ? atoi(getenv("SS_HTILE")) : 0;  // experiments: 64 / 128 force the row tile
+  if (env_tile == 64) return launch_h<64, 128, EPI>(a, stream);
+  if (env_tile == 128) return launch_h<128, 128, EPI>(a, stream);
   if (big >= 512) return launch_h<128, 128, EPI>(a, stream);
   return launch_h<64, 128, EPI>(a, stream);
 }
