@@ -269,7 +269,8 @@ def test_winograd_gate_equals_direct_conv(C, d, T, B, tile):
     assert err < 5e-6, err
 
 
-@pytest.mark.parametrize("C,d,T,B", [(256, 1, 150, 2), (256, 2, 203, 1), (256, 8, 97, 2), (192, 4, 260, 2), (256, 4, 1536, 3), (64, 1, 5, 1)])
+@pytest.mark.parametrize("C,d,T,B", [(256, 1, 150, 2), (256, 2, 203, 1), (256, 8, 97, 2), (192, 4, 260, 2), (256, 4, 1536, 3), (64, 1, 5, 1),
+                                      (64, 8, 5, 2), (96, 16, 300, 2), (32, 2, 1, 1)])
 def test_winograd_f43_gate_equals_direct_conv(C, d, T, B):
     """ss_wino43_gate (Winograd F(4,3): 6 products per 4 frames) vs a plain torch statement of conv(x + bias) + E -> sigmoid*tanh,
     with ragged lens, T not a multiple of the 4d frame group, every dilation of the cycle and a tile-spanning length."""
