@@ -144,7 +144,7 @@ class StyleSingerHIP(torch.nn.Module):
         self.n_streams = int(os.environ.get("SS_STREAMS", "1"))  # 2 = split the mel batch over two streams (slower at C2: half-size launches balance worse)
         # hipGraph capture of the diffusion loops: "auto"/"on" = capture per (B, T) on first use, "off" = eager launches
         self.use_graphs = os.environ.get("SS_GRAPHS", "auto")
-        # Winograd F(2,3) for the denoisers' 3-tap dilated convs (1.5x fewer matrix ops, fp32-rounding-equal results)
+        # Winograd form of the denoisers' 3-tap dilated convs (fewer matrix ops, fp32-rounding-equal results); SS_WINO=0: direct conv
         self.use_wino = os.environ.get("SS_WINO", "1") not in ("0", "off", "false")
         # Winograd output tile of the dilated conv: 4 = F(4,3) (6 products per 4 frames), 2 = F(2,3) (4 per 2); direct form = 6 per 2
         self.wino_m = int(os.environ.get("SS_WINO_M", "4"))

@@ -4,6 +4,7 @@ deterministic, and the product refuses to run without a GPU instead of falling b
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -250,6 +251,36 @@ def test_sampler_schedules_and_mode_flags():
     ts = m.ddim_timesteps(50)
     assert ts[0] == 99 and ts[-1] == 0 and len(ts) == 50 and all(a > b for a, b in zip(ts, ts[1:]))
     assert m.ddim_timesteps(1000) == list(range(99, -1, -1)) and m.ddim_timesteps(1) == [0]
-    assert not m.bf16 and m.use_wino and m.defer_skip and m.fold_skip
+    assert not m.bf16 and m.use_wino and m.wino_m == 4 and m.defer_skip and m.fold_skip
     mb = StyleSingerHIP(None, hparams=config.make_hparams(dict(mfma_precision="bf16")))
     assert mb.bf16 and not mb.use_wino and mb.defer_skip and not mb.fold_skip
+
+
+def test_winograd_form_is_selected_by_the_environment(monkeypatch):
+    from stylesinger_amd.model import StyleSingerHIP
+    hp = config.make_hparams({})
+    monkeypatch.setenv("SS_WINO_M", "2")
+    assert StyleSingerHIP(None, hparams=hp).wino_m == 2
+    monkeypatch.setenv("SS_WINO_M", "3")
+    with pytest.raises(AssertionError):
+        StyleSingerHIP(None, hparams=hp)
+    monkeypatch.delenv("SS_WINO_M")
+    monkeypatch.setenv("SS_WINO", "0")
+    assert not StyleSingerHIP(None, hparams=hp).use_wino
+
+
+def test_f43_transform_matrices_reproduce_the_three_tap_conv():
+    """The F(4,3) constants written in csrc/wino43_gate.hip (input rows, weight transform, output combination), restated with numpy:
+    four outputs of a 3-tap correlation from six products, for random inputs, to fp64 rounding."""
+    rng = np.random.default_rng(0)
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], float)
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], float)
+    for _ in range(20):
+        r, w = rng.standard_normal(6), rng.standard_normal(3)
+        m = (BT @ r) * (G @ w)
+        z = np.array([m[0] + m[1] + m[2] + m[3] + m[4], (m[1] - m[2]) + 2 * (m[3] - m[4]), (m[1] + m[2]) + 4 * (m[3] + m[4]),
+                      (m[1] - m[2]) + 8 * (m[3] - m[4]) + m[5]])
+        ref = np.array([w @ r[o:o + 3] for o in range(4)])
+        assert np.abs(z - ref).max() < 1e-12
+    # dstep enters component j with the sum of its coefficients over the valid rows; for interior quads: (0, -6, 0, 0, 0, 0)
+    assert np.allclose(BT.sum(1), [0, -6, 0, 0, 0, 0])
