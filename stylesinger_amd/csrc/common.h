@@ -121,3 +121,25 @@ __device__ __forceinline__ void ss_boxmuller(uint32_t a, uint32_t b, float& z0, 
   z0 = r * c;
   z1 = r * s;
 }
+
+// SS_TRACE (debug builds only, tools/wave_trace.py): phase stamps on the shader clock. SS_CLK waits for the LDS/scalar queue (lgkmcnt 0),
+// SS_CLK_VM for the vector-memory queue (vmcnt 0) before reading s_memtime; both pin the schedule around them.
+#ifdef SS_TRACE
+#define SS_CLK(var)                                  \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_waitcnt(0xc07f);              \
+    var = (unsigned)__builtin_readcyclecounter();    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#define SS_CLK_VM(var)                               \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_waitcnt(0x0f70);              \
+    var = (unsigned)__builtin_readcyclecounter();    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#else
+#define SS_CLK(var) do { } while (0)
+#define SS_CLK_VM(var) do { } while (0)
+#endif

@@ -30,6 +30,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// SS_TRACE (debug builds only, tools/wave_trace.py --kernel wino43): every wave sums, over its chunks, the shader-clock time of the
+// phases of a chunk and writes the sums + its entry/exit stamps at exit (same record layout as wino_gate_kernel_v2).
+#ifdef SS_TRACE
+__device__ unsigned long long* g_wino43_trace = nullptr;
+extern "C" int ss_debug_set_wino43_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino43_trace), &p, sizeof(p));
+}
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -59,6 +68,11 @@ __global__ __launch_bounds__(256, 2) void wino43_gate_kernel(const ss_conv_gemm_
     probe_c0 = __builtin_readcyclecounter();
     probe_r0 = __builtin_amdgcn_s_memrealtime();
   }
+#ifdef SS_TRACE
+  unsigned tr_sum[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long tr_t0 = __builtin_readcyclecounter();
+  const unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BQ][LD]
   float* Bs = smem + 2 * BQ * LD;    // [2][BN][LD]
@@ -227,14 +241,19 @@ __global__ __launch_bounds__(256, 2) void wino43_gate_kernel(const ss_conv_gemm_
     const float* Ac = As + CUR * BQ * LD;
     const float* Bc = Bs + CUR * BN * LD;
     float4 af0, af1, bf0, bf1;
+    [[maybe_unused]] unsigned ta, tb, tc, td, te, tf;
+    SS_CLK(ta);
     read_frags(Ac, Bc, 0, af0, bf0);
     read_frags(Ac, Bc, 1, af1, bf1);
+    SS_CLK(tb);
     __builtin_amdgcn_sched_barrier(0);
     mfma4(acc[J], af0, bf0);
     read_frags(Ac, Bc, 2, af0, bf0);
     __builtin_amdgcn_sched_barrier(0);
     mfma4(acc[J], af1, bf1);
     read_frags(Ac, Bc, 3, af1, bf1);
+    SS_CLK(tc);
+    SS_CLK_VM(td);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (decltype(stage_tag)::value) {
       store_a(As + (CUR ^ 1) * BQ * LD, jn_tag);
@@ -246,7 +265,12 @@ __global__ __launch_bounds__(256, 2) void wino43_gate_kernel(const ss_conv_gemm_
     __builtin_amdgcn_sched_barrier(0);
     mfma4(acc[J], af0, bf0);
     mfma4(acc[J], af1, bf1);
+    SS_CLK(te);
     __syncthreads();
+    SS_CLK(tf);
+#ifdef SS_TRACE
+    tr_sum[0] += tb - ta; tr_sum[1] += tc - tb; tr_sum[2] += td - tc; tr_sum[3] += te - td; tr_sum[4] += tf - te; tr_sum[5] += 1;
+#endif
   };
   using Yes = std::true_type;
   using No = std::false_type;
@@ -267,6 +291,9 @@ __global__ __launch_bounds__(256, 2) void wino43_gate_kernel(const ss_conv_gemm_
     chunk(J3{}, J4{}, Yes{}, Yes{}, No{}, 5 * kb + kc, 0);
     chunk(J4{}, J5{}, Yes{}, No{}, No{}, 0, 0);
   }
+#ifdef SS_TRACE
+  const unsigned long long tr_t1 = __builtin_readcyclecounter();
+#endif
   {  // last chunk (component 5, buffer 1)
     const float* Ac = As + BQ * LD;
     const float* Bc = Bs + BN * LD;
@@ -367,6 +394,20 @@ __global__ __launch_bounds__(256, 2) void wino43_gate_kernel(const ss_conv_gemm_
     atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
     atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
   }
+#ifdef SS_TRACE
+  if (g_wino43_trace && lane == 0) {
+    unsigned long long* o = g_wino43_trace + ((size_t)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[q] = tr_sum[q];
+    o[6] = tr_t0;
+    o[7] = tr_t1;
+    o[8] = __builtin_readcyclecounter();
+    o[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    o[11] = tr_r0;
+    o[12] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // src [rows][3] -> dst [rows][6] (rows = Cout*Cin): the G matrix of F(4,3)

@@ -24,23 +24,6 @@ __device__ unsigned long long* g_wino_trace = nullptr;
 extern "C" int ss_debug_set_wino_trace(void* p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &p, sizeof(p));
 }
-#define SS_CLK(var)                                  \
-  do {                                               \
-    __builtin_amdgcn_sched_barrier(0);               \
-    __builtin_amdgcn_s_waitcnt(0xc07f);              \
-    var = (unsigned)__builtin_readcyclecounter();    \
-    __builtin_amdgcn_sched_barrier(0);               \
-  } while (0)
-#define SS_CLK_VM(var)                               \
-  do {                                               \
-    __builtin_amdgcn_sched_barrier(0);               \
-    __builtin_amdgcn_s_waitcnt(0x0f70);              \
-    var = (unsigned)__builtin_readcyclecounter();    \
-    __builtin_amdgcn_sched_barrier(0);               \
-  } while (0)
-#else
-#define SS_CLK(var) do { } while (0)
-#define SS_CLK_VM(var) do { } while (0)
 #endif
 #ifndef SS_ABL
 #define SS_ABL 0

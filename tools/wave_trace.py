@@ -1,9 +1,11 @@
-"""Per-wave phase timing of the Winograd gate kernel (debug build with -DSS_TRACE; see csrc/wino_gate.hip).
+"""Per-wave phase timing of the Winograd gate kernels (debug build with -DSS_TRACE; see csrc/wino_gate.hip, csrc/wino43_gate.hip).
 
 Build in the container:
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSS_TRACE stylesinger_amd/csrc/*.hip -o stylesinger_amd/_abl/libss_trace.so
 Run on the GPU box:
-    SS_LIB_PATH=stylesinger_amd/_abl/libss_trace.so python tools/wave_trace.py [--B 8] [--T 1500]
+    SS_LIB_PATH=stylesinger_amd/_abl/libss_trace.so python tools/wave_trace.py [--kernel wino|wino43] [--B 8] [--T 1500]
+(`--kernel wino43`, the F(4,3) kernel, was instrumented after the round's GPU budget was spent: its product build is bit-identical to
+the un-instrumented one, the traced build has not run yet.)
 
 Every wave sums the shader-clock time of five phases over its K chunks:
     reads  : barrier release -> first two LDS fragment pairs arrived
@@ -31,9 +33,11 @@ def main():
     ap.add_argument("--T", type=int, default=1500)
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--dil", type=int, default=2)
+    ap.add_argument("--kernel", default="wino", help="wino = F(2,3) wino_gate_kernel_v2, wino43 = F(4,3) wino43_gate_kernel")
     a = ap.parse_args()
     lib = L.load()
-    fn = lib.ss_debug_set_wino_trace  # only in -DSS_TRACE builds
+    f43 = a.kernel == "wino43"
+    fn = lib.ss_debug_set_wino43_trace if f43 else lib.ss_debug_set_wino_trace  # only in -DSS_TRACE builds
     d = torch.device("cuda:0")
     B, T, C, Lyr = a.B, a.T, a.C, 20
     lens = torch.full((B,), T, device=d, dtype=torch.int32)
@@ -42,7 +46,7 @@ def main():
     E = torch.randn(B, T, Lyr * 2 * C, device=d)
     w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
     ab = torch.randn(C, device=d)
-    Wt = L.pack_conv_weight(L.wino_weight(w), interleave_half=C)
+    Wt = L.pack_conv_weight(L.wino43_weight(w) if f43 else L.wino_weight(w), interleave_half=C)
     nblk = 8192
     tr = torch.zeros(nblk * 4 * 16, device=d, dtype=torch.int64)
     fn.argtypes = [ctypes.c_void_p]
@@ -50,8 +54,8 @@ def main():
     assert fn(ctypes.c_void_p(tr.data_ptr())) == 0
 
     def run(layer):
-        L.wino_gate(X, Wt, G, dilation=a.dil, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=ab,
-                    E=E[:, :, layer * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, tile=0)
+        (L.wino43_gate if f43 else L.wino_gate)(X, Wt, G, dilation=a.dil, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=ab,
+                                                E=E[:, :, layer * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, tile=0)
     for i in range(5):
         run(i)
     torch.cuda.synchronize()
