@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 8 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies */
+#define SS_ABI_VERSION 9 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16 */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -456,6 +456,17 @@ int ss_clip(const float* x, float* y, int64_t n, float lo, float hi, void* strea
  * element-wise steps between and after them: |X| from the (re | im) column blocks, and log10(max(eps, .)). */
 int ss_spec_magnitude(const float* S, float* P, int64_t rows, int lds, int ldp, int nbins, int sin_off, void* stream);
 int ss_log10_floor(const float* x, float* y, int64_t n, float eps, void* stream);
+/* power spectrum re^2 + im^2 from the same (re | im) layout: librosa.feature.melspectrogram(power=2.0) as the emotion encoder's
+ * 40-mel front end uses it (data_gen/tts/emotion/audio.py:43-55) */
+int ss_spec_power(const float* S, float* P, int64_t rows, int lds, int ldp, int nbins, int sin_off, void* stream);
+/* y[b][i] = x[b][reflect(i - pad)], i < lens[b] + 2*pad, 0 beyond: numpy.pad(mode="reflect"), the centre padding of librosa.stft
+ * (pad_mode="reflect", librosa 0.8.0 default) per item of a ragged batch. x [B][Lx], y [B][Ly], lens NULL = Lx. */
+int ss_reflect_pad(const float* x, const int32_t* lens, float* y, int B, int Lx, int Ly, int pad, void* stream);
+/* Reference-f0 conditioning (utils/pitch_utils.py:34-62 norm_f0 + norm_interp_f0 with pitch_norm='log', use_uv; called at
+ * inference/StyleSinger.py:152): f0_hz [B][T] (0 = unvoiced) -> out [B][T] = log2(f0 + 1e-8) on voiced frames, np.interp
+ * between voiced neighbours on unvoiced ones (flat beyond the first/last voiced frame, 0 when nothing is voiced);
+ * uv [B][T] = 1.0 on unvoiced frames. Frames >= lens[b] (NULL = T) are written as 0. Inputs and outputs must not alias. */
+int ss_norm_interp_f0(const float* f0_hz, const int32_t* lens, float* out, float* uv, int B, int T, void* stream);
 
 /* Emotion encoder (input producer; data_gen/tts/emotion/model.py:11-78 = nn.LSTM(40, 256, 3) + Linear, inference.py:39-53,
  * 139-151). One LSTM layer's recurrence as a persistent launch (one workgroup per sequence):

@@ -169,6 +169,32 @@ def run_emotion_case(name, n_partials, seed=1234):
     print(f"[gen_golden] {name}: partial {tuple(partial.shape)}")
 
 
+def run_pitch_case(name="norm_interp_f0", seed=1234):
+    """The reference's own `norm_interp_f0` (utils/pitch_utils.py:47-62, called by inference/StyleSinger.py:152) on tracker-like
+    contours: float64 (parselmouth) and float32 inputs, leading / trailing / interior unvoiced runs, all voiced, all unvoiced."""
+    R = refimport.load()
+    from utils.pitch_utils import norm_interp_f0
+    hp = dict(R["hparams"])
+    cases = {}
+    def add(key, hz):
+        f0, uv = norm_interp_f0(hz.numpy().copy(), hp)
+        cases[key] = dict(hz=hz.clone(), f0=f0.clone(), uv=uv.clone())
+    add("t300_f64", synth.synth_f0_hz(0, 300, seed))
+    add("t1500_f64", synth.synth_f0_hz(1, 1500, seed))
+    add("t1500_f32", synth.synth_f0_hz(1, 1500, seed).float())
+    h = synth.synth_f0_hz(2, 700, seed).float()
+    h[:37] = 0.0
+    h[-51:] = 0.0
+    add("t700_edges_f32", h)
+    add("t64_all_voiced_f32", synth.synth_f0_hz(3, 64, seed, unvoiced=0.0).float().clamp_min(100.0))
+    add("t40_all_unvoiced_f32", torch.zeros(40))
+    z = torch.zeros(50)
+    z[17] = 220.0
+    add("t50_one_voiced_f32", z)
+    torch.save(dict(meta=dict(seed=seed, pitch_norm=hp["pitch_norm"], use_uv=hp["use_uv"]), cases=cases), os.path.join(GOLD, name + ".pt"))
+    print(f"[gen_golden] {name}: {sorted(cases)}")
+
+
 def dump_extra_param_specs():
     """Pin the ProDiff-decoder and emotion-encoder state_dict contracts (names + shapes) next to the main ones."""
     import json
@@ -197,6 +223,10 @@ def round2_cases():
     dump_extra_param_specs()
 
 
+def round3_cases():
+    run_pitch_case("norm_interp_f0")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--only-plms" in sys.argv:
@@ -205,6 +235,9 @@ def main():
         return
     if "--round2" in sys.argv:
         round2_cases()
+        return
+    if "--round3" in sys.argv:
+        round3_cases()
         return
     if "--emotion" in sys.argv:
         run_emotion_case("emotion_p5", n_partials=5)
@@ -219,6 +252,7 @@ def main():
     run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)
     run_plms_case("plms_t24_k12_i4", T=24, steps_mel=12, interval=4)
     round2_cases()
+    round3_cases()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,173 @@
+// Input-producer kernels of `preprocess_input` that run on the device: the f0 conditioning of
+// utils/pitch_utils.py:34-62 and the small element-wise steps of the emotion encoder's 40-mel front end
+// (data_gen/tts/emotion/audio.py:43-55). All HBM-bound, off the hot path; the GEMM-shaped steps reuse ss_conv_gemm.
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+#include <limits.h>
+
+namespace {
+
+// inclusive max-scan (dir = +1) / min-scan (dir = -1 means "suffix minimum") helpers over one 256-thread block
+__device__ __forceinline__ int wave_scan_max(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(v, o);
+    if (lane >= o) v = max(v, n);
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_scan_min_down(int v, int lane) {  // suffix minimum inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_down(v, o);
+    if (lane + o < 64) v = min(v, n);
+  }
+  return v;
+}
+
+// One workgroup per utterance. Pass A: prev[t] = last voiced frame <= t (or -1); pass B: next[t] = first voiced frame >= t (or
+// INT_MAX); both kept as integer bit patterns in the two output rows. Pass C: the value.
+//   voiced:            log2(f0 + 1e-8)
+//   no voiced frame:   0
+//   unvoiced:          np.interp(t, voiced_idx, voiced_val): slope * (t - xp[j]) + fp[j] in double (multiply, then add), flat beyond
+//                      the first / last voiced frame.
+__global__ __launch_bounds__(256) void norm_interp_f0_kernel(const float* __restrict__ f0, const int32_t* __restrict__ lens,
+                                                             float* __restrict__ out, float* __restrict__ uv, int T) {
+  const int b = blockIdx.x;
+  const int n = lens ? min(max(lens[b], 0), T) : T;
+  const float* x = f0 + (int64_t)b * T;
+  int* prev = reinterpret_cast<int*>(out + (int64_t)b * T);
+  int* next = reinterpret_cast<int*>(uv + (int64_t)b * T);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int part[4];
+  __shared__ int carry_s;
+  if (tid == 0) carry_s = -1;
+  __syncthreads();
+  for (int base = 0; base < n; base += 256) {
+    const int t = base + tid;
+    int v = (t < n && x[t] != 0.0f) ? t : -1;
+    v = wave_scan_max(v, lane);
+    if (lane == 63) part[wave] = v;
+    __syncthreads();
+    int pre = carry_s;
+    for (int w = 0; w < wave; ++w) pre = max(pre, part[w]);
+    v = max(v, pre);
+    if (t < n) prev[t] = v;
+    __syncthreads();
+    if (tid == 255) carry_s = v;
+    __syncthreads();
+  }
+  if (tid == 0) carry_s = INT_MAX;
+  __syncthreads();
+  const int nchunks = (n + 255) / 256;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int t = c * 256 + tid;
+    int v = (t < n && x[t] != 0.0f) ? t : INT_MAX;
+    v = wave_scan_min_down(v, lane);
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    int post = carry_s;
+    for (int w = wave + 1; w < 4; ++w) post = min(post, part[w]);
+    v = min(v, post);
+    if (t < n) next[t] = v;
+    __syncthreads();
+    if (tid == 0) carry_s = v;
+    __syncthreads();
+  }
+  for (int t = tid; t < T; t += 256) {
+    float y = 0.f, u = 0.f;
+    if (t < n) {
+      const int p = prev[t], q = next[t];
+      if (p == t) {
+        y = (float)log2((double)x[t] + 1e-8);
+      } else {
+        u = 1.f;
+        if (p < 0 && q == INT_MAX) {
+          y = 0.f;
+        } else if (p < 0) {
+          y = (float)log2((double)x[q] + 1e-8);
+        } else if (q == INT_MAX) {
+          y = (float)log2((double)x[p] + 1e-8);
+        } else {
+          // numpy keeps the contour in the input's dtype (fp32 here): fp = float32(log2(.)); np.interp then works in double
+          const double fp0 = (double)(float)log2((double)x[p] + 1e-8), fp1 = (double)(float)log2((double)x[q] + 1e-8);
+          const double slope = __ddiv_rn(__dsub_rn(fp1, fp0), (double)(q - p));
+          y = (float)__dadd_rn(__dmul_rn(slope, (double)(t - p)), fp0);
+        }
+      }
+    }
+    out[(int64_t)b * T + t] = y;
+    uv[(int64_t)b * T + t] = u;
+  }
+}
+
+// power spectrum of a DFT stored as two column blocks (as ss_spec_magnitude): P[r][f] = re^2 + im^2, K padding written as 0
+__global__ void spec_power_kernel(const float* __restrict__ S, float* __restrict__ P, int64_t rows, int lds, int ldp, int nbins,
+                                  int sin_off) {
+  const int64_t n = rows * ldp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ldp;
+    const int f = (int)(i - r * ldp);
+    float v = 0.f;
+    if (f < nbins) {
+      const float re = S[r * lds + f], im = S[r * lds + sin_off + f];
+      v = fmaf(re, re, im * im);
+    }
+    P[i] = v;
+  }
+}
+
+// y[b][i] = x[b][reflect(i - pad)] for i in [0, n[b] + 2 pad), 0 beyond: numpy.pad(mode="reflect") of each item's first n[b] samples
+__global__ void reflect_pad_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens, float* __restrict__ y, int B,
+                                   int Lx, int Ly, int pad) {
+  const int64_t total = (int64_t)B * Ly;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / Ly);
+    const int j = (int)(i - (int64_t)b * Ly);
+    const int n = lens ? min(lens[b], Lx) : Lx;
+    float v = 0.f;
+    if (n > 0 && j < n + 2 * pad) {
+      int s = j - pad;
+      // reflect without repeating the edge sample, period 2(n-1)
+      if (n == 1) {
+        s = 0;
+      } else {
+        const int period = 2 * (n - 1);
+        s %= period;
+        if (s < 0) s += period;
+        if (s >= n) s = period - s;
+      }
+      v = x[(int64_t)b * Lx + s];
+    }
+    y[i] = v;
+  }
+}
+
+inline int fe_grid(int64_t work, int cap = 8192) {
+  const int64_t g = (work + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int ss_norm_interp_f0(const float* f0_hz, const int32_t* lens, float* out, float* uv, int B, int T, void* stream) {
+  SS_CHECK_ARG(f0_hz && out && uv && B > 0 && T > 0, "ss_norm_interp_f0: bad args");
+  SS_CHECK_ARG(f0_hz != out && f0_hz != uv && out != uv, "ss_norm_interp_f0: input and outputs must not alias");
+  hipLaunchKernelGGL(norm_interp_f0_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f0_hz, lens, out, uv, T);
+  SS_CHECK_LAUNCH("ss_norm_interp_f0");
+  return SS_OK;
+}
+
+extern "C" int ss_spec_power(const float* S, float* P, int64_t rows, int lds, int ldp, int nbins, int sin_off, void* stream) {
+  SS_CHECK_ARG(S && P && rows > 0 && nbins > 0 && nbins <= ldp && sin_off + nbins <= lds, "ss_spec_power: bad args");
+  hipLaunchKernelGGL(spec_power_kernel, dim3(fe_grid(rows * ldp)), dim3(256), 0, (hipStream_t)stream, S, P, rows, lds, ldp, nbins, sin_off);
+  SS_CHECK_LAUNCH("ss_spec_power");
+  return SS_OK;
+}
+
+extern "C" int ss_reflect_pad(const float* x, const int32_t* lens, float* y, int B, int Lx, int Ly, int pad, void* stream) {
+  SS_CHECK_ARG(x && y && B > 0 && Lx > 0 && Ly > 0 && pad >= 0, "ss_reflect_pad: bad args");
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(fe_grid((int64_t)B * Ly)), dim3(256), 0, (hipStream_t)stream, x, lens, y, B, Lx, Ly, pad);
+  SS_CHECK_LAUNCH("ss_reflect_pad");
+  return SS_OK;
+}

@@ -4,8 +4,9 @@
 (inference/StyleSinger.py:41-63: run the model, drop all-zero frames, clip the mel to
 [mel_vmin, mel_vmax], vocode with the predicted f0).  `infer_batch` is the batched, device-resident
 form the benchmark and the data-parallel driver use.  The feature extractors of `preprocess_input`
-(resemblyzer / emotion LSTM / parselmouth / librosa, :94-137) are outside the hot path:
-`inp` must already carry `mel`, `f0`, `spk_embed`, `emo_embed`.
+(:94-137) are wired in as far as their models are vendored: `preprocess_batch` computes the reference mel, the emotion
+embedding and the normalised f0 contour on the device; the speaker embedding (resemblyzer) and the f0
+tracker (parselmouth) are un-vendored third-party models and stay inputs.
 """
 import numpy as np
 import torch
@@ -117,13 +118,16 @@ class StyleSingerInfer:
 
     # ---- the reference's single-utterance surface ---------------------------------------------
     def input_to_batch(self, item):
-        """inference/StyleSinger.py:139-172 (f0 must already be the normalised/interpolated log2 contour)."""
+        """inference/StyleSinger.py:139-172: `item['f0']` is the tracker's contour in Hz (0 = unvoiced) and goes through
+        `norm_interp_f0` (utils/pitch_utils.py:47-62) exactly as there (:152)."""
+        from .pitch import norm_interp_f0
         d = self.device
         t = lambda x, dt: torch.as_tensor(np.asarray(x), dtype=dt)[None].to(d)
+        f0, _uv = norm_interp_f0(np.asarray(item["f0"]), self.hparams)
         return dict(txt_tokens=t(item["ph_token"], torch.long), ref_mels=t(item["mel"], torch.float32),
                     spk_embed=t(item["spk_embed"], torch.float32), emo_embed=t(item["emo_embed"], torch.float32),
                     note=t(item["note"], torch.long), note_dur=t(item["note_dur"], torch.float32),
-                    note_type=t(item["note_type"], torch.long), ref_f0=t(item["f0"], torch.float32),
+                    note_type=t(item["note_type"], torch.long), ref_f0=f0[None].to(d),
                     **({"mel2ph": t(item["mel2ph"], torch.long)} if "mel2ph" in item else {}))
 
     def forward_model(self, inp, noise=None, vocoder_noise=None):

@@ -87,13 +87,37 @@ class _DiffPlan:
             nb = self.bounds[i + 1] - self.bounds[i]
             wsb = lib.ss_wavenet_workspace_bytes(C_byref(pk["mel"]["net"]), nb, T)
             self.ws_mel.append((wsb, torch.empty(wsb, device=dev, dtype=torch.uint8)))
+        self.ws_prodiff = None   # full-batch workspace of the ProDiff decoder when ws_mel is split (allocated on first use, plan-owned)
         self.g_f0 = None
         self.g_mel = None
         self.g_ddim = {}
         self.plms_hist = None
         self.uses = 0   # forwards that asked for this shape (auto mode captures on the second one)
-        self.bytes = sum(t.numel() * t.element_size() for t in vars(self).values() if torch.is_tensor(t)) \
-            + sum(w.numel() for _, w in self.ws_mel)
+        self.recount()
+
+    def recount(self):
+        """Bytes this plan keeps alive, each storage once (cond_a / cond_b / lens / f0[i] / uv[i] are views of the pair buffers)."""
+        seen, total = set(), 0
+
+        def add(t):
+            nonlocal total
+            if not torch.is_tensor(t):
+                return
+            st = t.untyped_storage()
+            if st.data_ptr() not in seen:
+                seen.add(st.data_ptr())
+                total += st.nbytes()
+        for v in vars(self).values():
+            if torch.is_tensor(v):
+                add(v)
+            elif isinstance(v, (list, tuple)):
+                for e in v:
+                    if isinstance(e, (list, tuple)):
+                        for ee in e:
+                            add(ee)
+                    else:
+                        add(e)
+        self.bytes = total
 
 
 def _pad_frames(x, T, dim=-1):
@@ -503,7 +527,11 @@ class StyleSingerHIP(torch.nn.Module):
             pl = _DiffPlan(self, B, T, dev)
             self._plans[key] = pl
             total = sum(p.bytes for p in self._plans.values())
+            synced = False
             while total > self.plan_bytes and len(self._plans) > 1:
+                if not synced:   # another slot's stream may still be replaying the victim's graph into its workspace
+                    torch.cuda.synchronize(dev)
+                    synced = True
                 _, old = self._plans.popitem(last=False)   # least recently used
                 total -= old.bytes
         else:
@@ -568,6 +596,7 @@ class StyleSingerHIP(torch.nn.Module):
         if plms_interval is not None:
             if pl.plms_hist is None:
                 pl.plms_hist = torch.empty(6 * B * T * M, device=pl.xm.device, dtype=torch.float32)
+                pl.recount()
             L.check(lib.ss_meldiff_sample_plms(C_byref(net), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, K, int(plms_interval),
                                                L.hptr(ac), 1, L.ptr(pl.plms_hist), L.ptr(wsp), wsb, L.stream_ptr()), "meldiff plms")
             return
@@ -840,10 +869,16 @@ class StyleSingerHIP(torch.nn.Module):
             S = int(hp["timesteps"])
             pl.cond_mel.copy_(dec_inp)
             sch = pk["prodiff_sched"]
-            wsb, wsp = pl.ws_mel[0] if len(pl.ws_mel) == 1 else (None, None)
-            if wsp is None:
-                wsb = lib.ss_wavenet_workspace_bytes(C_byref(pk["mel"]["net"]), B, T)
-                wsp = torch.empty(wsb, device=dev, dtype=torch.uint8)
+            # the workspace must outlive this call: a captured graph replays into it (a per-call temporary would be freed and its
+            # address reused by the allocator while pl.g_mel still writes there)
+            if len(pl.ws_mel) == 1:
+                wsb, wsp = pl.ws_mel[0]
+            else:
+                if pl.ws_prodiff is None:
+                    wsb = lib.ss_wavenet_workspace_bytes(C_byref(pk["mel"]["net"]), B, T)
+                    pl.ws_prodiff = (wsb, torch.empty(wsb, device=dev, dtype=torch.uint8))
+                    pl.recount()
+                wsb, wsp = pl.ws_prodiff
 
             def run_prodiff(zs=None):
                 if zs is None:

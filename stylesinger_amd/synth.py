@@ -250,6 +250,23 @@ def synth_utterance(idx, T, Tp, Tr, hp=None, seed=1234):
                 ref_f0=ref_f0, spk_embed=spk, emo_embed=emo)
 
 
+def synth_f0_hz(idx, Tr, seed=1234, unvoiced=0.2, dtype=torch.float64):
+    """A tracker-like reference contour in Hz: 100-500 Hz with ~`unvoiced` of the frames in unvoiced runs
+    (value 0), float64 like parselmouth's output - the input `norm_interp_f0` (utils/pitch_utils.py:47-62) expects."""
+    g = _gen(seed, f"f0hz{idx}")
+    tt = torch.arange(Tr, dtype=torch.float64)
+    hz = 250.0 + 120.0 * torch.sin(tt * (2 * math.pi / 180.0) + torch.rand(1, generator=g, dtype=torch.float64) * 6.28) \
+        + 60.0 * torch.sin(tt * (2 * math.pi / 37.0))
+    hz = hz.clamp(100.0, 500.0)
+    t = 0
+    while t < Tr:  # alternate voiced / unvoiced runs
+        run = int(torch.randint(8, 60, (1,), generator=g))
+        if float(torch.rand(1, generator=g)) < unvoiced * 2.0 and run < Tr:
+            hz[t:t + run // 2] = 0.0
+        t += run
+    return hz.to(dtype)
+
+
 def synth_batch(B, T, Tp, Tr, hp=None, seed=1234, first_index=0):
     items = [synth_utterance(first_index + i, T, Tp, Tr, hp, seed) for i in range(B)]
     return {k: torch.stack([it[k] for it in items]) for k in items[0]}

@@ -1,5 +1,7 @@
 """GPU parity of the whole hot path: HIP (through the C-ABI) vs the golden outputs of the REAL reference and
 vs the CPU restatement, with a shared noise tape.  Tolerances are stated next to each check."""
+import os
+
 import pytest
 import torch
 
@@ -210,22 +212,29 @@ def test_long_form_30s_sequence_matches_oracle():
     assert l1 <= MEL_L1_TOL
 
 
-def test_single_utterance_entrypoint_matches_batched_path():
+def test_single_utterance_entrypoint_matches_batched_path(golden_dir):
     """StyleSingerInfer.forward_model (the reference's B=1 numpy surface, inference/StyleSinger.py:41-63) must agree
-    with the batched device path on the same utterance and seed."""
+    with the batched device path on the same utterance and seed. `inp['f0']` is a tracker contour in Hz as at
+    inference/StyleSinger.py:125-136; `input_to_batch` runs it through norm_interp_f0 like :152 - checked against the output of
+    the REAL utils/pitch_utils.py function (tests/golden/norm_interp_f0.pt)."""
     from stylesinger_amd.infer import StyleSingerInfer
     hp = config.make_hparams(dict(timesteps=4, K_step=4, f0_timesteps=4))
     sd = synth.synth_acoustic_state_dict(hp, 11)
     vsd = synth.synth_vocoder_state_dict(None, 11)
     inf = StyleSingerInfer(hp, device="cuda:0", model_state=sd, vocoder_state=vsd)
-    it = synth.synth_utterance(0, 40, 5, 36, hp, 11)
+    pc = torch.load(os.path.join(golden_dir, "norm_interp_f0.pt"), weights_only=False)["cases"]["t300_f64"]
+    Tr = pc["hz"].numel()
+    it = synth.synth_utterance(0, 40, 5, Tr, hp, 11)
     inp = dict(ph_token=it["txt_tokens"].numpy(), mel=it["ref_mels"].numpy(), spk_embed=it["spk_embed"].numpy(),
                emo_embed=it["emo_embed"].numpy(), note=it["note"].numpy(), note_dur=it["note_dur"].numpy(),
-               note_type=it["note_type"].numpy(), f0=it["ref_f0"].numpy(), mel2ph=it["mel2ph"].numpy())
+               note_type=it["note_type"].numpy(), f0=pc["hz"].numpy(), mel2ph=it["mel2ph"].numpy())
+    sample = inf.input_to_batch(inp)
+    assert torch.equal(sample["ref_f0"][0].cpu(), pc["f0"])      # what the reference's input_to_batch would hand the model
     tape = synth.NoiseTape(5)
     noise = synth.draw_acoustic_noise(tape, 1, 40, 4, 4)
     vnoise = synth.draw_vocoder_noise(tape, 1, 40 * 256)
     wav1 = inf.forward_model(inp, noise=noise, vocoder_noise=vnoise)
+    it["ref_f0"] = pc["f0"]
     batch = {k: v[None].cuda() for k, v in it.items()}
     res = inf.infer_batch(batch, noise=noise, vocoder_noise=vnoise)
     assert wav1.shape == (40 * 256,)

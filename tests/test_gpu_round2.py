@@ -16,6 +16,8 @@ from stylesinger_amd import config, synth  # noqa: E402
 from stylesinger_amd.model import StyleSingerHIP  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# mel L1 of the bf16-operand 1000-step chain on `acoustic_t32_mel1000` vs the real fp32 reference, measured on MI355X (profiles/r03_parity.json)
+BF16_CHAIN_L1_MEASURED = float(os.environ.get("SS_BF16_CHAIN_L1", "0.0334"))
 
 
 class ListTape:
@@ -85,8 +87,17 @@ def test_c2_batch_item_matches_oracle_at_full_size_and_100_steps():
           f"f0 max err {f0e:.3e} Hz")
     assert flips == 0
     assert cflips <= 1          # a 1e-3 Hz difference can move one frame across a coarse-pitch bin edge
-    if cflips == 0:
-        assert l1 <= 1e-5 and mx <= 1e-3
+    # always bound the mel: a flipped frame selects another pitch-embedding row, which the decoder's conv-FFN spreads over
+    # +-4 frames per layer -> compare away from +-20 frames around a flip (as test_long_form_30s_sequence_matches_oracle does)
+    keep = torch.ones(T, dtype=torch.bool)
+    for tt in (full["pitch_coarse"][i].cpu() != ref["pitch_coarse"][0]).nonzero().flatten().tolist():
+        keep[max(0, tt - 20):tt + 21] = False
+    dm = (full["mel_out"][i].cpu() - ref["mel_out"][0]).abs()[keep]
+    l1k, mxk = dm.mean().item(), dm.max().item()
+    from conftest import record_measurement
+    record_measurement("c2_item3_t1500_100steps_vs_oracle", mel_l1=l1, mel_max=mx, mel_l1_away_from_flips=l1k, voicing_flips=flips,
+                       coarse_flips=cflips, f0_max_err_hz=f0e)
+    assert l1k <= 1e-5 and mxk <= 1e-3, (l1k, mxk, cflips)
 
 
 def test_winograd_f43_f23_and_direct_forms_agree_through_the_whole_path(monkeypatch):
@@ -330,7 +341,12 @@ def test_bf16_mode_on_the_1000_step_golden_reports_its_distance_to_the_fp32_refe
     print(f"bf16 mode, 1000-step golden: mel chain alone L1 vs the fp32 reference {l1:.3e} (max {mx:.3e}); whole path {l1_full:.3e} "
           f"({flips} voicing decisions differ from the fp32 run)")
     assert torch.isfinite(full["mel_out"]).all() and torch.isfinite(mel_chain).all()
-    assert l1 <= 0.1
+    from conftest import record_measurement
+    record_measurement("c4_bf16_t32_1000steps_vs_fp32_reference", mel_chain_l1=l1, mel_chain_max=mx, whole_path_l1=l1_full,
+                       voicing_decisions_differing=flips, pinned=False)
+    # round-3 measurement on MI355X: see BF16_CHAIN_L1_MEASURED below; the bound is 3x that (a regression guard, NOT parity: this
+    # mode does not meet north_star's 1e-4 against the fp32 reference and cannot by construction)
+    assert l1 <= 3 * BF16_CHAIN_L1_MEASURED, (l1, BF16_CHAIN_L1_MEASURED)
 
 
 def test_from_clean_build_on_this_box_runs(tmp_path):

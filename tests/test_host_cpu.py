@@ -17,7 +17,7 @@ def test_library_loads_and_exports_header_symbols():
     assert len(names) >= 30
     for n in names:
         assert hasattr(l, n), n
-    assert l.ss_abi_version() == lib.ABI_VERSION == 8
+    assert l.ss_abi_version() == lib.ABI_VERSION == 9
     assert l.ss_last_error() is not None
 
 
@@ -284,3 +284,19 @@ def test_f43_transform_matrices_reproduce_the_three_tap_conv():
         assert np.abs(z - ref).max() < 1e-12
     # dstep enters component j with the sum of its coefficients over the valid rows; for interior quads: (0, -6, 0, 0, 0, 0)
     assert np.allclose(BT.sum(1), [0, -6, 0, 0, 0, 0])
+
+
+def test_norm_interp_f0_matches_the_reference_function(golden_dir):
+    """pitch.norm_interp_f0 vs the REAL utils/pitch_utils.py:47-62 on float64 / float32 contours with leading, trailing and
+    interior unvoiced runs, all-voiced, all-unvoiced and single-voiced-frame inputs: bit-exact (same numpy arithmetic)."""
+    from stylesinger_amd import pitch
+    g = torch.load(os.path.join(golden_dir, "norm_interp_f0.pt"), weights_only=False)
+    hp = config.make_hparams()
+    assert hp["pitch_norm"] == g["meta"]["pitch_norm"] and hp["use_uv"] == g["meta"]["use_uv"]
+    for key, c in g["cases"].items():
+        f0, uv = pitch.norm_interp_f0(c["hz"].numpy(), hp)
+        assert f0.dtype == torch.float32 and uv.dtype == torch.float32
+        assert torch.equal(uv, c["uv"]), key
+        assert torch.equal(f0, c["f0"]), (key, (f0 - c["f0"]).abs().max().item())
+        f0t, uvt = pitch.norm_interp_f0(c["hz"], hp)   # torch input, as the reference also accepts
+        assert torch.equal(f0t, c["f0"]) and torch.equal(uvt, c["uv"]), key
