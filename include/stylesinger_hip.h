@@ -38,7 +38,9 @@ int ss_device_info(int dev, int* n_cu, char* arch, int arch_len);
  * lets a binding verify its mirror */
 int ss_struct_sizes(int64_t* out, int n);
 /* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
- * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3) */
+ * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3); "gate16" = 0|1|2|3 tiling of the F(4,3) gate launches inside the
+ * denoiser loops (1 = per-launch pick, default; 0 = 32x32x2 tiles; 2|3 = force 16x16x4 tiles of 16*MT quads); "res_tile" /
+ * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice) */
 int ss_set_tuning(const char* key, int value);
 /* Measurement aid (bench.py's roofline block): while `dev_u64x2` is non-null, wave 0 of workgroup 0 of every Winograd gate launch
  * adds its lifetime to dev_u64x2[0] in shader cycles (s_memtime) and to dev_u64x2[1] in ticks of the constant 100 MHz counter
@@ -143,6 +145,15 @@ int ss_wino_weight_transform(const float* src, float* dst, int Cout, int Cin, vo
  * ss_pack_conv_weight(k=6, interleave_half=C)). Needs Cin % 32 == 0 and Kp == Cin. Same argument use as ss_wino_gate; results
  * equal the direct form to fp32 rounding (single-layer error about 2x that of F(2,3); tests/test_gpu_kernels.py). */
 int ss_wino43_gate(const ss_conv_gemm_args* args, int dilation, void* stream);
+/* The same layer on 16x16x4 fp32 MFMA tiles: a wave tile is 16*mt quads x 16 packed columns (8 channels, both gate operands), a
+ * workgroup 16*mt quads x 64 packed columns; mt = 2 | 3, or 0 = ss_wino43_gate16_pick decides per launch and falls back to
+ * ss_wino43_gate when the 32x32x2 tiles fit better (many rounds of workgroups per launch). For single-round launches: at BASELINE
+ * config 2 the mel launch is 512 workgroups (2 per CU) and the f0-pair launch 768 (3 per CU) instead of 384 / 564 uneven ones.
+ * Same arguments, same weights (ss_wino43_weight_transform + ss_pack_conv_weight(k=6, interleave_half=C)), same arithmetic up to
+ * the summation order over K (tests/test_gpu_round3.py). */
+int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int mt, void* stream);
+/* the tiling ss_wino43_gate16(mt = 0) uses for a launch of B items x T frames x Np packed columns: 2 | 3, or 0 = the 32x32x2 kernel */
+int ss_wino43_gate16_pick(int B, int T, int Np, int dilation);
 /* src [Cout][Cin][3] -> dst [Cout][Cin][6]: g0=w0/4, g1=-(w0+w1+w2)/6, g2=-(w0-w1+w2)/6, g3=w0/24+w1/12+w2/6,
  * g4=w0/24-w1/12+w2/6, g5=w2 */
 int ss_wino43_weight_transform(const float* src, float* dst, int Cout, int Cin, void* stream);

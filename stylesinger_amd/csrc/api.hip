@@ -14,7 +14,7 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0, nullptr};
+SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 0};
 
 extern "C" int ss_set_tuning(const char* key, int value) {
   if (!key) {
@@ -23,6 +23,18 @@ extern "C" int ss_set_tuning(const char* key, int value) {
   }
   if (strcmp(key, "wave_prio") == 0 && value >= 0 && value <= 2) {
     g_ss_tuning.wave_prio = value;
+    return SS_OK;
+  }
+  if (strcmp(key, "gate16_plain_transform") == 0 && (value == 0 || value == 1)) {
+    g_ss_tuning.gate16_plain_transform = value;
+    return SS_OK;
+  }
+  if (strcmp(key, "gate16") == 0 && value >= 0 && value <= 3) {
+    g_ss_tuning.gate16 = value;
+    return SS_OK;
+  }
+  if ((strcmp(key, "res_tile") == 0 || strcmp(key, "skip_tile") == 0) && value >= SS_TILE_AUTO && value <= SS_TILE_128x32) {
+    (key[0] == 'r' ? g_ss_tuning.res_tile : g_ss_tuning.skip_tile) = value;
     return SS_OK;
   }
   ss_set_error("ss_set_tuning: unknown key/value %s=%d", key, value);

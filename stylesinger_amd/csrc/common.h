@@ -42,7 +42,13 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   wave_prio: 0 = all waves at priority 0; 1 = static s_setprio((blockIdx / 256) % 3); 2 = s_setprio(blockIdx % 3).
 //     The blocks sharing a CU then differ in priority, so the matrix pipe of a SIMD serves them one after the other instead
 //     of round-robin: their non-MFMA phases (staging, barrier) stop coinciding (launch structure).
-struct SsTuning { int wave_prio; unsigned long long* clock_probe; };
+//   gate16: tiling of the Winograd F(4,3) gate launch. 1 (default) = pick per launch (ss_wino43_gate16_pick: 16x16x4 tiles of
+//     16*MT quads when that fills the chip better, else the 32x32x2 kernel); 0 = always the 32x32x2 kernel; 2 / 3 = force MT.
+//   res_tile / skip_tile: SS_TILE_* override of the residual-half projection / the K = L*C skip GEMM of the denoiser loops
+//     (0 = the built-in choice); validated by ss_set_tuning.
+//   gate16_plain_transform: 1 = the 16x16 gate kernel builds each Winograd component from the raw rows (28 VALU ops per element);
+//     0 (default) = shared sub-expressions (18). Same values up to fp32 rounding.
+struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int gate16_plain_transform; };
 extern SsTuning g_ss_tuning;
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)

@@ -265,7 +265,12 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     if (net->w_dil_wino[l] && !net->mfma_bf16) {  // Winograd F(2,3): pairs of frames (t, t+d) from 4 products instead of 6
       a.W = net->w_dil_wino[l];
       a.w_group_stride = net->gs_w_dil_wino;
-      SS_PROPAGATE(net->wino_m == 4 ? ss_wino43_gate(&a, d, stream) : ss_wino_gate(&a, d, stream));
+      if (net->wino_m == 4) {
+        const int g16 = g_ss_tuning.gate16;  // 0: 32x32x2 tiles; 1: per-launch pick; 2 / 3: 16x16x4 tiles of 16*MT quads
+        SS_PROPAGATE(g16 == 0 ? ss_wino43_gate(&a, d, stream) : ss_wino43_gate16(&a, d, g16 == 1 ? 0 : g16, stream));
+      } else {
+        SS_PROPAGATE(ss_wino_gate(&a, d, stream));
+      }
     } else {
       SS_PROPAGATE(ss_conv_gemm(&a, stream));
     }
@@ -277,10 +282,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     o.Cin = C;
     o.W = net->w_out[l];
     o.N = defer ? C : 2 * C;  // deferred skip: only the residual half (the first C packed rows) runs per layer
-    if (defer) {
-      static const int env_tile = getenv("SS_RES_TILE") ? atoi(getenv("SS_RES_TILE")) : 0;  // experiments (tools/r2_session28.sh)
-      o.tile = env_tile > 0 ? env_tile : SS_TILE_64x64;
-    }
+    if (defer) o.tile = g_ss_tuning.res_tile > 0 ? g_ss_tuning.res_tile : SS_TILE_64x64;
     o.Np = 2 * C;
     o.Kp = round_up32(C);
     o.epi = SS_EPI_RESSKIP;
@@ -320,8 +322,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     k.C = w.S;
     k.ldc = C;
     k.c_batch_stride = (int64_t)T * C;
-    static const int env_skip_tile = getenv("SS_SKIP_TILE") ? atoi(getenv("SS_SKIP_TILE")) : 0;  // experiments
-    k.tile = env_skip_tile > 0 ? env_skip_tile : SS_TILE_64x64;
+    k.tile = g_ss_tuning.skip_tile > 0 ? g_ss_tuning.skip_tile : SS_TILE_64x64;
     k.mfma_bf16 = net->mfma_bf16;
     if (net->n_groups > 1) {
       k.group_size = B / net->n_groups;

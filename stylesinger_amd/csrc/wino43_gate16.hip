@@ -1,0 +1,435 @@
+// Winograd F(4,3) dilated conv + conditioner addend + gate (modules/diff/net.py:66-73) on 16x16x4 fp32 MFMA tiles: the round-3 form of
+// the dominant kernel for SINGLE-ROUND launches (BASELINE config 2: 12 000 - 24 000 frames per launch on 1024 SIMDs).
+//
+// Why a second tiling of the same arithmetic (wino43_gate.hip has the algebra and the 32x32x2 form): at the C2 shape the 32x32 kernel
+// launches 1504 wave tiles of 32 quads x 32 columns on 1024 SIMDs - a SIMD holds two of them or one, so the launch lasts as long as
+// two tiles while a quarter of the matrix pipes idle (executed MFMA fraction 0.44, profiles/r02_pmc_gate.json). Here a wave tile is
+// 16*MT quads x 16 columns (MT = 3: 48 x 16, 25 % smaller than 32 x 32), a workgroup 16*MT quads x 64 packed columns:
+//   mel  (8 x 1500 frames, 512 columns): MT = 3 -> 8 x 8 x 8 = 512 workgroups = exactly 2 per CU, 2 equal waves per SIMD
+//   f0   (16 x 1500 frames, 384 columns): MT = 3 -> 16 x 8 x 6 = 768 workgroups = exactly 3 per CU
+// Differences from the 32x32 kernel that follow from the 16-column wave tile:
+//   * a wave's 16 MFMA columns are 8 first-operand and 8 second-operand columns of the SAME 8 channels (packed columns
+//     n0 + 8w + c and n0 + 32 + 8w + c), so the gate product is an in-wave DPP exchange (row_ror:8) - no LDS, no barrier in the epilogue;
+//   * every weight element is used by exactly one wave: the B operand goes global -> registers directly (two chunks ahead, 3 register
+//     stages), only the transformed A tile is staged through LDS (2 x 16*MT x 32 floats);
+//   * v_mfma_f32_16x16x4_f32 has a 40-cycle dependent latency at a 32-cycle issue rate: the MT row tiles of a component interleave.
+// Arithmetic (transforms, exact-fp32 products, fp32 accumulation, gate) is the 32x32 kernel's; only the order in which the K products
+// enter an accumulator differs (a 16x16x4 MFMA consumes K = {4h+e, 8+4h+e, 16+4h+e, 24+4h+e} of a chunk), so the two forms agree to
+// fp32 rounding, not bit for bit (tests/test_gpu_round3.py: 2e-6 on gate outputs).
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LD = BK;
+constexpr int BN = 64;
+constexpr int NC = 6;
+
+// 16-byte slot swizzle of a [rows][32] fp32 tile. Reads: lane (r = l & 15, kg = l >> 4) takes slots 2kg, 2kg+1 of row r; with the
+// ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) this map is conflict-free (simulated; SQ_LDS_BANK_CONFLICT = 0).
+__device__ __forceinline__ int swz16(int row) { return ((row >> 1) & 7) ^ ((((row >> 2) ^ (row >> 3)) & 1) << 1); }
+__device__ __forceinline__ int lds_slot16(int row, int slot) { return row * LD + ((slot ^ swz16(row)) << 2); }
+
+template <int J, int Q>
+struct Coef16 {
+  static constexpr float v = (J == 0) ? (Q == 0 ? 4.f : Q == 2 ? -5.f : Q == 4 ? 1.f : 0.f)
+                           : (J == 1) ? (Q == 1 ? -4.f : Q == 2 ? -4.f : Q == 3 ? 1.f : Q == 4 ? 1.f : 0.f)
+                           : (J == 2) ? (Q == 1 ? 4.f : Q == 2 ? -4.f : Q == 3 ? -1.f : Q == 4 ? 1.f : 0.f)
+                           : (J == 3) ? (Q == 1 ? -2.f : Q == 2 ? -1.f : Q == 3 ? 2.f : Q == 4 ? 1.f : 0.f)
+                           : (J == 4) ? (Q == 1 ? 2.f : Q == 2 ? -1.f : Q == 3 ? -2.f : Q == 4 ? 1.f : 0.f)
+                                      : (Q == 1 ? 4.f : Q == 3 ? -5.f : Q == 5 ? 1.f : 0.f);
+};
+
+// elementwise helpers on float4 / float2 (the two staging slot widths)
+__device__ __forceinline__ float4 vfma(float c, const float4& r, const float4& v) {
+  return make_float4(fmaf(c, r.x, v.x), fmaf(c, r.y, v.y), fmaf(c, r.z, v.z), fmaf(c, r.w, v.w));
+}
+__device__ __forceinline__ float2 vfma(float c, const float2& r, const float2& v) { return make_float2(fmaf(c, r.x, v.x), fmaf(c, r.y, v.y)); }
+__device__ __forceinline__ float4 vadd(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float2 vadd(const float2& a, const float2& b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float4 vsub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// SHARED: the input transform with shared sub-expressions (18 instead of 28 VALU ops per element and K chunk - VALU instructions
+// take matrix-pipe time on gfx950):
+//   A = r4 - 4 r2, B = r3 - 4 r1, C = r4 - r2, D = r3 - r1   ->   c1 = A + B, c2 = A - B, c3 = C + 2 D, c4 = C - 2 D
+// each with dstep entering through the sum of its coefficients over the valid rows, as in the plain form.
+template <int MT, bool SHARED>
+__global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gemm_args a, int q_tiles_per_item, int q_tiles, int n_tiles,
+                                                               int log2d, unsigned long long* clock_probe) {
+  constexpr int BQ = 16 * MT;
+  constexpr int NFULL = BQ / 32;             // staging passes of 32 rows x 8 sixteen-byte slots
+  constexpr bool HALF = (BQ % 32) != 0;      // + one pass of 16 rows x 16 eight-byte half slots
+  const bool probing = clock_probe != nullptr && blockIdx.x == 0;
+  unsigned long long probe_c0 = 0, probe_r0 = 0;
+  if (probing) {
+    probe_c0 = __builtin_readcyclecounter();
+    probe_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;  // [2][BQ][LD]
+
+  const int id = blockIdx.x;
+  const int grp = id / (8 * n_tiles);
+  const int rem = id % (8 * n_tiles);
+  const int qt = grp * 8 + (rem & 7);
+  const int nt = rem >> 3;
+  if (qt >= q_tiles) return;
+  const int b = qt / q_tiles_per_item;
+  const int q0 = (qt % q_tiles_per_item) * BQ;
+  const int n0 = nt * BN;
+  const int d = 1 << log2d;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kg = lane >> 4;
+
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+  const float* Wg = a.W + (int64_t)grp_w * a.w_group_stride;
+  const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;
+  const int kchunks = a.Kp / BK;
+  const int ldw = NC * a.Kp;
+
+  auto uniform_ptr = [](const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Wg), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(abiasg ? abiasg : Wg), 0, __builtin_amdgcn_readfirstlane(abiasg ? a.Cin * 4 : 0), 0x00020000);
+
+  // ---- staging roles: thread -> (quad row, K slot) of the raw rows; roff = byte offset of raw row r (frame t + (r-1)d) or out of
+  // range (-> the fetch returns 0) when that frame is outside [0, len); mc = what dstep enters each component with (sum of the
+  // component's coefficients over the VALID rows)
+  const int st_c4 = tid & 7, st_row = tid >> 3;     // full passes: 32 rows x 8 slots of 16 B
+  const int sh_c2 = tid & 15, sh_row = tid >> 4;    // half pass: 16 rows x 16 half slots of 8 B
+  int roff4[NFULL > 0 ? NFULL : 1][6];
+  float mc4[NC][NFULL > 0 ? NFULL : 1];
+  int roffh[6];
+  float mch[NC];
+  auto row_setup = [&](int q, int col_floats, int (&ro)[6], auto&& set_mc) {
+    const int t = q + 3 * (q & ~(d - 1));
+    float v[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int tr = t + (r - 1) * d;
+      const bool ok = (unsigned)tr < (unsigned)len;
+      v[r] = ok ? 1.0f : 0.0f;
+      ro[r] = ok ? (tr * a.lda + col_floats) * 4 : (int)0x80000000;
+    }
+    set_mc(0, 4.f * v[0] - 5.f * v[2] + v[4]);
+    set_mc(5, 4.f * v[1] - 5.f * v[3] + v[5]);
+    if constexpr (SHARED) {  // coefficients of the shared terms A, B, C, D
+      set_mc(1, v[4] - 4.f * v[2]);
+      set_mc(2, v[3] - 4.f * v[1]);
+      set_mc(3, v[4] - v[2]);
+      set_mc(4, v[3] - v[1]);
+    } else {
+      set_mc(1, -4.f * v[1] - 4.f * v[2] + v[3] + v[4]);
+      set_mc(2, 4.f * v[1] - 4.f * v[2] - v[3] + v[4]);
+      set_mc(3, -2.f * v[1] - v[2] + 2.f * v[3] + v[4]);
+      set_mc(4, 2.f * v[1] - v[2] - 2.f * v[3] + v[4]);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NFULL; ++i) row_setup(q0 + st_row + i * 32, st_c4 * 4, roff4[i], [&](int j, float x) { mc4[j][i] = x; });
+  if constexpr (HALF) row_setup(q0 + NFULL * 32 + sh_row, sh_c2 * 2, roffh, [&](int j, float x) { mch[j] = x; });
+
+  // ---- B operand: lane (lc, kg) of wave w owns packed column pc and K floats [8kg, 8kg+8) of every chunk
+  const int c7 = lc & 7, chi = lc >> 3;
+  const int pc = n0 + 8 * wave + c7 + 32 * chi;
+  const int w_voff = (pc * ldw + kg * 8) * 4;
+
+  u32x4 rr4[NFULL > 0 ? NFULL : 1][6];
+  u32x2 rr2[6];
+  float4 rpb4;
+  float2 rpb2;
+  auto load_rows = [&](int ci0b) {  // ci0b = byte offset of the K chunk inside a row (wave-uniform -> SGPR soffset)
+    ci0b = __builtin_amdgcn_readfirstlane(ci0b);
+    if constexpr (NFULL > 0) rpb4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_bias, st_c4 * 16, ci0b, 0));
+    if constexpr (HALF) rpb2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_bias, sh_c2 * 8, ci0b, 0));
+#pragma unroll
+    for (int i = 0; i < NFULL; ++i)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) rr4[i][r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, roff4[i][r], ci0b, 0);
+    if constexpr (HALF) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) rr2[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a, roffh[r], ci0b, 0);
+    }
+  };
+  float4 bst[3][2];
+  auto load_b = [&](auto stag, int cb) {  // cb = byte offset of the weight chunk inside a packed row (wave-uniform)
+    constexpr int S = decltype(stag)::value;
+    cb = __builtin_amdgcn_readfirstlane(cb);
+    bst[S][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, cb, 0));
+    bst[S][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, cb, 0));
+  };
+  int a_wr4[NFULL > 0 ? NFULL : 1];
+#pragma unroll
+  for (int i = 0; i < NFULL; ++i) a_wr4[i] = lds_slot16(st_row + i * 32, st_c4);
+  const int a_wrh = lds_slot16(NFULL * 32 + sh_row, sh_c2 >> 1) + (sh_c2 & 1) * 2;
+  // shared-term temporaries (SHARED): (A, B) live from component 1 to 2, (C, D) from 3 to 4
+  float4 tp4[NFULL > 0 ? NFULL : 1], tq4[NFULL > 0 ? NFULL : 1];
+  float2 tph, tqh;
+  auto component = [&](auto jtag, const auto& pb, float m0, float m1, float m2, float m3, float m4, float m5, const auto& r0, const auto& r1,
+                       const auto& r2, const auto& r3, const auto& r4, const auto& r5, auto& tp, auto& tq) {
+    constexpr int J = decltype(jtag)::value;
+    using V = std::remove_cv_t<std::remove_reference_t<decltype(pb)>>;
+    if constexpr (!SHARED) {
+      const float mj = J == 0 ? m0 : J == 1 ? m1 : J == 2 ? m2 : J == 3 ? m3 : J == 4 ? m4 : m5;
+      V v = vfma(mj, pb, V{});
+      if constexpr (Coef16<J, 0>::v != 0.f) v = vfma(Coef16<J, 0>::v, r0, v);
+      if constexpr (Coef16<J, 1>::v != 0.f) v = vfma(Coef16<J, 1>::v, r1, v);
+      if constexpr (Coef16<J, 2>::v != 0.f) v = vfma(Coef16<J, 2>::v, r2, v);
+      if constexpr (Coef16<J, 3>::v != 0.f) v = vfma(Coef16<J, 3>::v, r3, v);
+      if constexpr (Coef16<J, 4>::v != 0.f) v = vfma(Coef16<J, 4>::v, r4, v);
+      if constexpr (Coef16<J, 5>::v != 0.f) v = vfma(Coef16<J, 5>::v, r5, v);
+      return v;
+    } else {
+      if constexpr (J == 0) return vfma(m0, pb, vfma(-5.f, r2, vfma(4.f, r0, r4)));
+      if constexpr (J == 1) {
+        tp = vfma(m1, pb, vfma(-4.f, r2, r4));
+        tq = vfma(m2, pb, vfma(-4.f, r1, r3));
+        return vadd(tp, tq);
+      }
+      if constexpr (J == 2) return vsub(tp, tq);
+      if constexpr (J == 3) {
+        tp = vfma(m3, pb, vsub(r4, r2));
+        tq = vfma(m4, pb, vsub(r3, r1));
+        return vfma(2.f, tq, tp);
+      }
+      if constexpr (J == 4) return vfma(-2.f, tq, tp);
+      if constexpr (J == 5) return vfma(m5, pb, vfma(-5.f, r3, vfma(4.f, r1, r5)));
+    }
+  };
+  auto store_a = [&](float* Ad, auto jtag) {
+#pragma unroll
+    for (int i = 0; i < NFULL; ++i) {
+      auto R = [&](int q) { return __builtin_bit_cast(float4, rr4[i][q]); };
+      const float4 v = component(jtag, rpb4, mc4[0][i], mc4[1][i], mc4[2][i], mc4[3][i], mc4[4][i], mc4[5][i], R(0), R(1), R(2), R(3), R(4),
+                                 R(5), tp4[i], tq4[i]);
+      *reinterpret_cast<float4*>(Ad + a_wr4[i]) = v;
+    }
+    if constexpr (HALF) {
+      auto R = [&](int q) { return __builtin_bit_cast(float2, rr2[q]); };
+      const float2 v = component(jtag, rpb2, mch[0], mch[1], mch[2], mch[3], mch[4], mch[5], R(0), R(1), R(2), R(3), R(4), R(5), tph, tqh);
+      *reinterpret_cast<float2*>(Ad + a_wrh) = v;
+    }
+  };
+
+  f32x4 acc[NC][MT];
+#pragma unroll
+  for (int j = 0; j < NC; ++j)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][m][r] = 0.f;
+
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
+  using J4 = std::integral_constant<int, 4>;
+  using J5 = std::integral_constant<int, 5>;
+  const int kb = a.Kp * 4;  // bytes of one component in a packed weight row
+  const int cs = BK * 4;    // bytes of one K chunk
+  // chunk (k, j): weights at byte j*kb + k*cs of a packed row; register stage j % 3
+  load_rows(0);
+  load_b(J0{}, 0);
+  load_b(J1{}, kb);
+  store_a(As, J0{});
+  __syncthreads();
+
+  // fragment addresses: row tile m, lane row lc, slots 2kg + h
+  int a_rd[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_rd[m][h] = lds_slot16(16 * m + lc, 2 * kg + h);
+
+  auto mfma_half = [&](auto jtag, const float4 (&af)[MT], const float4& bf) {
+    constexpr int J = decltype(jtag)::value;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[J][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, bf.x, acc[J][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[J][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, bf.y, acc[J][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[J][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, bf.z, acc[J][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[J][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bf.w, acc[J][m], 0, 0, 0);
+  };
+  // chunk (k, J): MFMAs from LDS buffer J&1 and weight stage J%3 into acc[J]. In their shadow the component tile of chunk g+1 is built
+  // from the raw rows in registers and stored to the other buffer; then the weights of chunk g+2 are fetched into stage (J+2)%3 and -
+  // when component JN was the last user of the raw rows (JN = 5) - the raw rows of K chunk k+1.
+  auto chunk = [&](auto jtag, auto jn_tag, auto stage_tag, auto fetch_b_tag, auto fetch_rows_tag, int cb2, int rows_ci0b) {
+    constexpr int J = decltype(jtag)::value;
+    constexpr int CUR = J & 1;
+    constexpr int S = J % 3;
+    const float* Ac = As + CUR * BQ * LD;
+    float4 af0[MT], af1[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af0[m] = *reinterpret_cast<const float4*>(Ac + a_rd[m][0]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af1[m] = *reinterpret_cast<const float4*>(Ac + a_rd[m][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(jtag, af0, bst[S][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (decltype(stage_tag)::value) store_a(As + (CUR ^ 1) * BQ * LD, jn_tag);
+    __builtin_amdgcn_sched_barrier(0);  // stores first, then the fetches into the SAME registers
+    if constexpr (decltype(fetch_b_tag)::value) load_b(std::integral_constant<int, (J + 2) % 3>{}, cb2);
+    if constexpr (decltype(fetch_rows_tag)::value) load_rows(rows_ci0b);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(jtag, af1, bst[S][1]);
+    __syncthreads();
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+  for (int k = 0; k + 1 < kchunks; ++k) {
+    const int kc = k * cs;
+    chunk(J0{}, J1{}, Yes{}, Yes{}, No{}, 2 * kb + kc, 0);        // stage (k,1); fetch weights (k,2)
+    chunk(J1{}, J2{}, Yes{}, Yes{}, No{}, 3 * kb + kc, 0);        // stage (k,2); fetch weights (k,3)
+    chunk(J2{}, J3{}, Yes{}, Yes{}, No{}, 4 * kb + kc, 0);        // stage (k,3); fetch weights (k,4)
+    chunk(J3{}, J4{}, Yes{}, Yes{}, No{}, 5 * kb + kc, 0);        // stage (k,4); fetch weights (k,5)
+    chunk(J4{}, J5{}, Yes{}, Yes{}, Yes{}, kc + cs, kc + cs);     // stage (k,5) = last use of the rows; fetch weights (k+1,0), rows k+1
+    chunk(J5{}, J0{}, Yes{}, Yes{}, No{}, kb + kc + cs, 0);       // stage (k+1,0); fetch weights (k+1,1)
+  }
+  {
+    const int kc = (kchunks - 1) * cs;
+    chunk(J0{}, J1{}, Yes{}, Yes{}, No{}, 2 * kb + kc, 0);
+    chunk(J1{}, J2{}, Yes{}, Yes{}, No{}, 3 * kb + kc, 0);
+    chunk(J2{}, J3{}, Yes{}, Yes{}, No{}, 4 * kb + kc, 0);
+    chunk(J3{}, J4{}, Yes{}, Yes{}, No{}, 5 * kb + kc, 0);
+    chunk(J4{}, J5{}, Yes{}, No{}, No{}, 0, 0);
+    chunk(J5{}, J0{}, No{}, No{}, No{}, 0, 0);
+  }
+
+  // ---- epilogue: output transform, conditioner addend, gate; accumulator (m, r) of this lane = quad 16m + 4kg + r, column lc ----
+  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+  const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(Eb ? Eb : Wg), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+  const int oc = (n0 >> 1) + 8 * wave + c7;  // output channel: both its operands live in this wave (lanes lc and lc ^ 8)
+  const bool col_ok = oc < a.N;
+  const int colb = pc * 4 + (col_ok ? 0 : (int)0x80000000);
+  const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc] : 0.f;
+  const bool use_sig = (chi == 0) == (a.gate_mode == 0);
+  // sigmoid(x) = rcp(1 + exp(-x)); tanh(x) = 2*sigmoid(2x) - 1: one exp + one rcp either way, selected per lane by (mul, scale, shift)
+  const float am = use_sig ? -1.0f : -2.0f, as = use_sig ? 1.0f : 2.0f, ah = use_sig ? 0.0f : -1.0f;
+  auto act = [&](float x) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(x * am)), as, ah); };
+  auto partner = [](float x) {  // the value of lane lc ^ 8 of the same 16-lane row (DPP row_ror:8)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+  };
+  const int lde4 = a.lde * 4;
+  float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+  const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+  const int dl = d * lde4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float pe[4][4];
+    int t0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = q0 + 16 * m + 4 * kg + r;
+      t0[r] = q + 3 * (q & ~(d - 1));
+      const int off = t0[r] * lde4 + colb;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) pe[r][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off + o * dl, 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a0 = acc[0][m][r], a5 = acc[5][m][r];
+      const float s12 = acc[1][m][r] + acc[2][m][r], d12 = acc[1][m][r] - acc[2][m][r];
+      const float s34 = acc[3][m][r] + acc[4][m][r], d34 = acc[3][m][r] - acc[4][m][r];
+      const float z0 = a0 + s12 + s34;
+      const float z1 = fmaf(2.0f, d34, d12);
+      const float z2 = fmaf(4.0f, s34, s12);
+      const float z3 = fmaf(8.0f, d34, d12) + a5;
+      const float u0 = act(z0 + (bs + pe[r][0]));
+      const float u1 = act(z1 + (bs + pe[r][1]));
+      const float u2 = act(z2 + (bs + pe[r][2]));
+      const float u3 = act(z3 + (bs + pe[r][3]));
+      const float g0 = u0 * partner(u0), g1 = u1 * partner(u1), g2 = u2 * partner(u2), g3 = u3 * partner(u3);
+      // lanes holding the first operand write frames t, t+d; their partners write t+2d, t+3d (the products are identical)
+      float ga = chi ? g2 : g0, gb = chi ? g3 : g1;
+      const int ta = t0[r] + (chi ? 2 * d : 0), tb = ta + d;
+      if (ta >= row_lim) ga = 0.f;
+      if (tb >= row_lim) gb = 0.f;
+      if (col_ok && ta < a.T) Cb[(int64_t)ta * a.ldc + oc] = ga;
+      if (col_ok && tb < a.T) Cb[(int64_t)tb * a.ldc + oc] = gb;
+    }
+  }
+  if (probing && threadIdx.x == 0) {
+    atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
+    atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
+  }
+}
+
+template <int MT, bool SHARED>
+int launch16(const ss_conv_gemm_args& a, int dilation, int log2d, hipStream_t stream) {
+  constexpr int BQ = 16 * MT;
+  const int quads_per_item = ss_cdiv(a.T, 4 * dilation) * dilation;
+  const int q_tiles_per_item = ss_cdiv(quads_per_item, BQ);
+  const int q_tiles = q_tiles_per_item * a.B;
+  const int n_tiles = a.Np / BN;
+  const int grid = ss_cdiv(q_tiles, 8) * 8 * n_tiles;
+  const size_t lds = (size_t)2 * BQ * LD * sizeof(float);
+  hipLaunchKernelGGL((wino43_gate16_kernel<MT, SHARED>), dim3(grid), dim3(256), lds, stream, a, q_tiles_per_item, q_tiles, n_tiles, log2d,
+                     g_ss_tuning.clock_probe);
+  return 0;
+}
+
+}  // namespace
+
+// Workgroups a tiling of `quads` rows launches, and the model used to pick one: a launch costs (work per wave tile) x (workgroup
+// layers per CU). MT = 0 in the return value means "the 32x32x2 kernel (wino43_gate.hip) is the better fit".
+extern "C" int ss_wino43_gate16_pick(int B, int T, int Np, int dilation) {
+  const int quads_per_item = ss_cdiv(T, 4 * dilation) * dilation;
+  const int n_tiles = Np / BN;
+  auto layers = [&](int bq) { return ss_cdiv((long)ss_cdiv(quads_per_item, bq) * B * n_tiles, 256); };
+  // many rounds per launch: tile granularity no longer matters and the 32x32 tile moves half the LDS bytes per flop
+  if (layers(64) >= 6) return 0;
+  int best = 0;  // the 64-quad tile of the 32x32x2 kernel
+  long best_cost = 4L * layers(64);
+  for (int mt = 3; mt >= 2; --mt) {
+    const long cost = (long)mt * layers(16 * mt);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = mt;
+    }
+  }
+  return best;
+}
+
+extern "C" int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int mt, void* stream) {
+  SS_CHECK_ARG(args != nullptr, "ss_wino43_gate16: null args");
+  const ss_conv_gemm_args& a = *args;
+  SS_CHECK_ARG(a.A && a.W && a.C, "ss_wino43_gate16: null A/W/C");
+  SS_CHECK_ARG(dilation >= 1 && (dilation & (dilation - 1)) == 0 && dilation <= 64, "ss_wino43_gate16: dilation %d must be a power of two <= 64", dilation);
+  SS_CHECK_ARG((a.Cin % BK) == 0 && a.Kp == a.Cin && (a.lda & 3) == 0, "ss_wino43_gate16: Cin=%d must be a multiple of 32 and Kp == Cin", a.Cin);
+  SS_CHECK_ARG((a.Np % 64) == 0 && 2 * a.N <= a.Np, "ss_wino43_gate16: Np=%d must be a multiple of 64 and >= 2*N", a.Np);
+  SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (!a.E || (int64_t)a.T * a.lde * 4 < (1ll << 31)) &&
+                   (int64_t)a.Np * NC * a.Kp * 4 < (1ll << 31),
+               "ss_wino43_gate16: item too large for 32-bit offsets");
+  SS_CHECK_ARG(mt == 0 || mt == 2 || mt == 3, "ss_wino43_gate16: mt=%d must be 0 (auto), 2 or 3", mt);
+  int log2d = 0;
+  while ((1 << log2d) < dilation) ++log2d;
+  if (mt == 0) {
+    mt = ss_wino43_gate16_pick(a.B, a.T, a.Np, dilation);
+    if (mt == 0) return ss_wino43_gate(args, dilation, stream);
+  }
+  const bool plain = g_ss_tuning.gate16_plain_transform != 0;
+  if (mt == 2) plain ? launch16<2, false>(a, dilation, log2d, (hipStream_t)stream) : launch16<2, true>(a, dilation, log2d, (hipStream_t)stream);
+  else plain ? launch16<3, false>(a, dilation, log2d, (hipStream_t)stream) : launch16<3, true>(a, dilation, log2d, (hipStream_t)stream);
+  SS_CHECK_LAUNCH("ss_wino43_gate16");
+  return SS_OK;
+}

@@ -156,9 +156,10 @@ def load():
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
-    prio = os.environ.get("SS_WAVE_PRIO")
-    if prio is not None:
-        check(lib.ss_set_tuning(b"wave_prio", int(prio)), "ss_set_tuning")
+    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE16_PLAIN", b"gate16_plain_transform"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
+        val = os.environ.get(env)
+        if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
+            check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")
     return lib
 
 
@@ -237,6 +238,13 @@ def wino43_gate(A, Wt, out, *, dilation, **kw):
     kw.setdefault("epi", EPI_GATE)
     a = _fill_args(A, Wt, out, **kw)
     check(load().ss_wino43_gate(C.byref(a), int(dilation), stream_ptr()), "ss_wino43_gate")
+
+
+def wino43_gate16(A, Wt, out, *, dilation, mt=0, **kw):
+    """The F(4,3) gate on 16x16x4 MFMA tiles (ss_wino43_gate16); mt = 0 lets the library pick, 2 / 3 force the row-tile count."""
+    kw.setdefault("epi", EPI_GATE)
+    a = _fill_args(A, Wt, out, **kw)
+    check(load().ss_wino43_gate16(C.byref(a), int(dilation), int(mt), stream_ptr()), "ss_wino43_gate16")
 
 
 def wino43_weight(w):

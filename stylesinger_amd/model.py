@@ -530,7 +530,8 @@ class StyleSingerHIP(torch.nn.Module):
             synced = False
             while total > self.plan_bytes and len(self._plans) > 1:
                 if not synced:   # another slot's stream may still be replaying the victim's graph into its workspace
-                    torch.cuda.synchronize(dev)
+                    if torch.cuda.is_available():
+                        torch.cuda.synchronize(dev)
                     synced = True
                 _, old = self._plans.popitem(last=False)   # least recently used
                 total -= old.bytes

@@ -269,11 +269,13 @@ def test_winograd_gate_equals_direct_conv(C, d, T, B, tile):
     assert err < 5e-6, err
 
 
+@pytest.mark.parametrize("mt", [None, 2, 3, 0])
 @pytest.mark.parametrize("C,d,T,B", [(256, 1, 150, 2), (256, 2, 203, 1), (256, 8, 97, 2), (192, 4, 260, 2), (256, 4, 1536, 3), (64, 1, 5, 1),
                                       (64, 8, 5, 2), (96, 16, 300, 2), (32, 2, 1, 1)])
-def test_winograd_f43_gate_equals_direct_conv(C, d, T, B):
-    """ss_wino43_gate (Winograd F(4,3): 6 products per 4 frames) vs a plain torch statement of conv(x + bias) + E -> sigmoid*tanh,
-    with ragged lens, T not a multiple of the 4d frame group, every dilation of the cycle and a tile-spanning length."""
+def test_winograd_f43_gate_equals_direct_conv(C, d, T, B, mt):
+    """ss_wino43_gate (Winograd F(4,3): 6 products per 4 frames; mt None = 32x32x2 tiles) and ss_wino43_gate16 (16x16x4 tiles of 16*mt
+    quads; mt 0 = the library's pick) vs a plain torch statement of conv(x + bias) + E -> sigmoid*tanh, with ragged lens, T not a
+    multiple of the 4d frame group, every dilation of the cycle and a tile-spanning length."""
     dv = dev()
     x = _rand(B, T, C, seed=171)
     ab = _rand(C, seed=172)
@@ -303,8 +305,12 @@ def test_winograd_f43_gate_equals_direct_conv(C, d, T, B):
     ep[..., Np:2 * Np] = packed(e[..., 2 * C:4 * C])
     epd = ep.to(dv)
     g = torch.full((B, T, C), 5.0, device=dv)
-    L.wino43_gate(x.to(dv), Wt, g, dilation=d, B=B, T=T, Cin=C, N=C, Np=Np, Kp=C, lens=lens.to(dv), a_bias=ab.to(dv),
-                  bias=packed(bias).to(dv), E=epd[:, :, Np:], lde=Lyr * Np, e_bs=T * Lyr * Np, ldc=C, mask_rows=True)
+    kw = dict(dilation=d, B=B, T=T, Cin=C, N=C, Np=Np, Kp=C, lens=lens.to(dv), a_bias=ab.to(dv),
+              bias=packed(bias).to(dv), E=epd[:, :, Np:], lde=Lyr * Np, e_bs=T * Lyr * Np, ldc=C, mask_rows=True)
+    if mt is None:
+        L.wino43_gate(x.to(dv), Wt, g, **kw)
+    else:
+        L.wino43_gate16(x.to(dv), Wt, g, mt=mt, **kw)
     err = (g.cpu() - ref).abs().max().item()
     assert err < 1e-5, err
     # rows past an item's length are written as zeros (mask_rows), never left stale

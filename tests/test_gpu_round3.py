@@ -86,3 +86,37 @@ def test_c4_shape_item_matches_oracle_with_100_step_chains():
     assert flips == 0
     assert cf.float().mean().item() <= 1e-3
     assert l1k <= 1e-5 and mxk <= 1e-3, (l1k, mxk)
+
+
+@pytest.mark.parametrize("mt", [2, 3])
+def test_gate16_grouped_pair_launch_matches_the_32x32_kernel(mt):
+    """The f0-pair form of the launch (C = 192, two weight sets selected by b // group_size, conditioner slab with a layer stride,
+    ragged lens, a gate_mode-1 pass as the RSA uses it) on 16x16x4 tiles vs the round-2 32x32x2 kernel: same arithmetic up to the
+    summation order over K -> 2e-6 on gate outputs in (-1, 1); rows past lens written as 0; the pick model returns a tiling."""
+    import math
+    from stylesinger_amd import lib as L
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    B, T, C, Lyr = 6, 333, 192, 3
+    x = torch.randn(B, T, C, generator=g).to(dv)
+    ws = [torch.randn(2 * C, C, 3, generator=g) / math.sqrt(3 * C) for _ in range(2)]
+    Wt = torch.stack([L.pack_conv_weight(L.wino43_weight(w.to(dv)), interleave_half=C) for w in ws]).contiguous()
+    Np = Wt.shape[1]
+    ab = torch.randn(2, C, generator=g).to(dv)
+    bias = (torch.randn(2, Np, generator=g) * 0.3).to(dv)
+    E = torch.randn(B, T, Lyr * Np, generator=g).to(dv)
+    lens = torch.tensor([T, T - 5, 1, T - 40, 17, T - 1], dtype=torch.int32).to(dv)
+    for d, mode in ((1, 0), (4, 0), (8, 1)):
+        kw = dict(dilation=d, B=B, T=T, Cin=C, N=C, Np=Np, Kp=C, lens=lens, a_bias=ab, bias=bias, E=E[:, :, Np:], lde=Lyr * Np,
+                  e_bs=T * Lyr * Np, ldc=C, mask_rows=True, gate_mode=mode, group_size=3, w_gs=Wt[0].numel(), bias_gs=Np, a_bias_gs=C)
+        want = torch.full((B, T, C), 7.0, device=dv)
+        got = torch.full((B, T, C), 9.0, device=dv)
+        L.wino43_gate(x, Wt, want, **kw)
+        L.wino43_gate16(x, Wt, got, mt=mt, **kw)
+        err = (got - want).abs().max().item()
+        assert err <= 2e-6, (d, mode, err)
+        for i in range(B):
+            assert torch.all(got[i, int(lens[i]):] == 0)
+    lib = L.load()
+    assert lib.ss_wino43_gate16_pick(8, 1500, 512, 2) == 3 and lib.ss_wino43_gate16_pick(16, 1500, 384, 1) == 3
+    assert lib.ss_wino43_gate16_pick(32, 5625, 512, 4) == 0      # many rounds per launch: the 32x32x2 tiles

@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--T", type=int, default=1500)
     ap.add_argument("--prio", type=int, default=-1, help="ss_set_tuning('wave_prio', N)")
+    ap.add_argument("--mt", default="-1,3,2", help="wino43_16: comma list of tilings (-1 = the 32x32x2 kernel, 0 = library pick, 2, 3)")
+    ap.add_argument("--pair", type=int, default=1, help="wino43_16: time the f0 launch with 2B items (both nets), as the loop launches it")
     ap.add_argument("--e-layout", default="row", help="conditioner addend: 'row' = [B][T][L*2C] (one row holds all layers), 'layer' = [L][B][T][2C]")
     a = ap.parse_args()
     if a.prio >= 0:
@@ -111,6 +113,25 @@ def main():
             s = timeit(fw4, a.iters)
             fl = 2.0 * B * T * 3 * C * 2 * C
             res.append((f"{name} WINO F(4,3) gate K={3 * C} N={2 * C} (algorithmic flops)", s, fl))
+        if a.which in ("wino43_16", "all"):
+            Wt4 = L.pack_conv_weight(L.wino43_weight(w), interleave_half=C)
+            Bn = B * (2 if name == "f0" and a.pair else 1)   # the f0 launch of the real loop carries both nets: 2B items
+            Xn = torch.randn(Bn, T, C, device=d)
+            Gn = torch.empty(Bn, T, C, device=d)
+            En = torch.randn(Bn, T, Lyr * 2 * C, device=d)
+            ln = torch.full((Bn,), T, device=d, dtype=torch.int32)
+            for mt in [int(v) for v in a.mt.split(",")]:
+                def fw16():
+                    layer[0] = (layer[0] + 1) % Lyr
+                    kw = dict(dilation=2, B=Bn, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=ln, a_bias=ab,
+                              E=En[:, :, layer[0] * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C)
+                    if mt < 0:
+                        L.wino43_gate(Xn, Wt4, Gn, **kw)
+                    else:
+                        L.wino43_gate16(Xn, Wt4, Gn, mt=mt, **kw)
+                s = timeit(fw16, a.iters)
+                fl = 2.0 * Bn * T * 3 * C * 2 * C
+                res.append((f"{name} F(4,3) gate {'32x32x2 tiles' if mt < 0 else '16x16x4 mt=%d' % mt} rows={Bn * T}", s, fl))
         if a.which in ("resskip", "all"):
             f = lambda: L.conv_gemm(G, Wo, X, B=B, T=T, Cin=C, N=2 * C, Np=2 * C, Kp=C, lens=lens, epi=L.EPI_RESSKIP, bias=bop, Nh=C,
                                     R=X, ldr=C, ldc=C, post_scale=0.7071, C2=S, ldc2=C, c2_bs=T * C, accumulate=True, tile=a.tile)
