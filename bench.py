@@ -113,6 +113,8 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     wino = infer.model.use_wino and not bf16
     wino_m = getattr(infer.model, "wino_m", 2) if wino else 0
 
+    g16 = L.load().ss_get_tuning(b"gate16") if wino_m == 4 else 0
+    mt = (L.load().ss_wino43_gate16_pick(B, T, 2 * C, 1) if g16 == 1 else g16) if g16 else 0   # 0 = the 32x32x2 kernel
     hbm = bf16 and getattr(infer.model, "bf16_hbm", False)
     if hbm:  # bf16 operands in HBM (ss_gemm_bf16): the operand X + dstep is already rounded by the producing epilogue
         Xh = L.to_bf16(X)
@@ -126,7 +128,9 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
             return
         kw = dict(B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=dstep[0, l], epi=L.EPI_GATE, E=E[:, :, l * 2 * C:],
                   lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
-        if wino:
+        if wino and wino_m == 4 and g16:   # what run_residual_stack launches (diffusion.hip): the library picks the tiling per launch
+            L.wino43_gate16(X, packs[f"w_dil_wino.{l}"], G, dilation=d, mt=0 if g16 == 1 else g16, **kw)
+        elif wino:
             (L.wino43_gate if wino_m == 4 else L.wino_gate)(X, packs[f"w_dil_wino.{l}"], G, dilation=d, **kw)
         else:
             L.conv_gemm(X, packs[f"w_dil.{l}"], G, taps=(-d, 0, d), bf16=bf16, **kw)
@@ -167,7 +171,8 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     flops = 2.0 * B * T * (3 * C) * (2 * C)
     executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
-    name = ("wino43_gate_kernel (Winograd F(4,3)" if wino_m == 4 else "wino_gate_kernel_v2 (Winograd F(2,3)" if wino else "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct" if hbm else
+    name = (f"wino43_gate16_kernel<{mt}> (Winograd F(4,3), 16x16x4 tiles of {16 * mt} quads" if wino_m == 4 and mt else
+            "wino43_gate_kernel (Winograd F(4,3)" if wino_m == 4 else "wino_gate_kernel_v2 (Winograd F(2,3)" if wino else "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct" if hbm else
             "conv_gemm_kernel<64,128,2,2,GATE" + (",bf16> (direct" if bf16 else "> (direct"))
     # HBM traffic of this launch from the round's PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs,
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.

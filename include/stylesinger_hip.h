@@ -42,6 +42,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * denoiser loops (1 = per-launch pick, default; 0 = 32x32x2 tiles; 2|3 = force 16x16x4 tiles of 16*MT quads); "res_tile" /
  * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice) */
 int ss_set_tuning(const char* key, int value);
+/* current value of a tuning knob (>= 0), or < 0 for an unknown key */
+int ss_get_tuning(const char* key);
 /* Measurement aid (bench.py's roofline block): while `dev_u64x2` is non-null, wave 0 of workgroup 0 of every Winograd gate launch
  * adds its lifetime to dev_u64x2[0] in shader cycles (s_memtime) and to dev_u64x2[1] in ticks of the constant 100 MHz counter
  * (s_memrealtime): [0] / [1] / 10 = the shader clock in GHz the chip sustained under that load (it clocks to its power budget:

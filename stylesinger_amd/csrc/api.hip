@@ -40,6 +40,17 @@ extern "C" int ss_set_tuning(const char* key, int value) {
   ss_set_error("ss_set_tuning: unknown key/value %s=%d", key, value);
   return SS_ERR_ARG;
 }
+extern "C" int ss_get_tuning(const char* key) {
+  if (key) {
+    if (strcmp(key, "wave_prio") == 0) return g_ss_tuning.wave_prio;
+    if (strcmp(key, "gate16") == 0) return g_ss_tuning.gate16;
+    if (strcmp(key, "gate16_plain_transform") == 0) return g_ss_tuning.gate16_plain_transform;
+    if (strcmp(key, "res_tile") == 0) return g_ss_tuning.res_tile;
+    if (strcmp(key, "skip_tile") == 0) return g_ss_tuning.skip_tile;
+  }
+  ss_set_error("ss_get_tuning: unknown key %s", key ? key : "(null)");
+  return SS_ERR_ARG;
+}
 extern "C" int ss_set_clock_probe(void* dev_u64x2) {
   g_ss_tuning.clock_probe = static_cast<unsigned long long*>(dev_u64x2);
   return SS_OK;

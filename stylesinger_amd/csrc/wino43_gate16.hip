@@ -15,7 +15,7 @@
 //   * v_mfma_f32_16x16x4_f32 has a 40-cycle dependent latency at a 32-cycle issue rate: the MT row tiles of a component interleave.
 // Arithmetic (transforms, exact-fp32 products, fp32 accumulation, gate) is the 32x32 kernel's; only the order in which the K products
 // enter an accumulator differs (a 16x16x4 MFMA consumes K = {4h+e, 8+4h+e, 16+4h+e, 24+4h+e} of a chunk), so the two forms agree to
-// fp32 rounding, not bit for bit (tests/test_gpu_round3.py: 2e-6 on gate outputs).
+// fp32 rounding, not bit for bit (tests/test_gpu_round3.py).
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
 #include <type_traits>
@@ -23,6 +23,12 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// SS_G16_ABL (debug builds only, tools/ablate_g16.sh; results are wrong by design): 1 = no global fetches inside the loop, 2 = no LDS
+// stores, 3 = no MFMAs, 4 = no barriers in the loop, 5 = no conditioner-addend loads, 6 = no activations / exchange in the epilogue
+#ifndef SS_G16_ABL
+#define SS_G16_ABL 0
+#endif
 
 namespace {
 
@@ -260,6 +266,11 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
 
   auto mfma_half = [&](auto jtag, const float4 (&af)[MT], const float4& bf) {
     constexpr int J = decltype(jtag)::value;
+    if constexpr (SS_G16_ABL == 3) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[J][m][0] += af[m].x * bf.x + af[m].w * bf.w;
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[J][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, bf.x, acc[J][m], 0, 0, 0);
 #pragma unroll
@@ -285,13 +296,13 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(jtag, af0, bst[S][0]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (decltype(stage_tag)::value) store_a(As + (CUR ^ 1) * BQ * LD, jn_tag);
+    if constexpr (decltype(stage_tag)::value && SS_G16_ABL != 2) store_a(As + (CUR ^ 1) * BQ * LD, jn_tag);
     __builtin_amdgcn_sched_barrier(0);  // stores first, then the fetches into the SAME registers
-    if constexpr (decltype(fetch_b_tag)::value) load_b(std::integral_constant<int, (J + 2) % 3>{}, cb2);
-    if constexpr (decltype(fetch_rows_tag)::value) load_rows(rows_ci0b);
+    if constexpr (decltype(fetch_b_tag)::value && SS_G16_ABL != 1) load_b(std::integral_constant<int, (J + 2) % 3>{}, cb2);
+    if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1) load_rows(rows_ci0b);
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(jtag, af1, bst[S][1]);
-    __syncthreads();
+    if constexpr (SS_G16_ABL != 4) __syncthreads();
   };
   using Yes = std::true_type;
   using No = std::false_type;
@@ -315,59 +326,88 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
   }
 
   // ---- epilogue: output transform, conditioner addend, gate; accumulator (m, r) of this lane = quad 16m + 4kg + r, column lc ----
+  // VALU instructions take matrix-pipe time and this is the densest VALU block of the kernel: every address is one
+  // per-lane base per row tile + a wave-uniform SGPR offset (frame of quad q+r = frame of q + r + 3 (r & ~(d-1)) for q = 0 mod 4), stores
+  // are buffer stores (out-of-range rows / columns are dropped by the range check, no exec masking), the activation is one
+  // multiply-exp2-add-rcp-fma chain, and the common case (no bias pointer, tile entirely inside [0, len)) skips the bias adds and the
+  // padding-row zeroing.
   const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
   const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(Eb ? Eb : Wg), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 4)), 0x00020000);
   const int oc = (n0 >> 1) + 8 * wave + c7;  // output channel: both its operands live in this wave (lanes lc and lc ^ 8)
   const bool col_ok = oc < a.N;
-  const int colb = pc * 4 + (col_ok ? 0 : (int)0x80000000);
-  const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc] : 0.f;
+  const int oob = col_ok ? 0 : (int)0x80000000;
   const bool use_sig = (chi == 0) == (a.gate_mode == 0);
-  // sigmoid(x) = rcp(1 + exp(-x)); tanh(x) = 2*sigmoid(2x) - 1: one exp + one rcp either way, selected per lane by (mul, scale, shift)
-  const float am = use_sig ? -1.0f : -2.0f, as = use_sig ? 1.0f : 2.0f, ah = use_sig ? 0.0f : -1.0f;
-  auto act = [&](float x) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(x * am)), as, ah); };
+  // sigmoid(x) = rcp(1 + exp2(-x log2 e)); tanh(x) = 2 sigmoid(2x) - 1: one exp2 + one rcp either way, selected per lane by (mul, scale, shift)
+  const float am = (use_sig ? -1.0f : -2.0f) * 1.44269504088896340736f, as = use_sig ? 1.0f : 2.0f, ah = use_sig ? 0.0f : -1.0f;
+  auto act = [&](float x) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * am)), as, ah); };
   auto partner = [](float x) {  // the value of lane lc ^ 8 of the same 16-lane row (DPP row_ror:8)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true));
   };
-  const int lde4 = a.lde * 4;
-  float* Cb = a.C + (int64_t)b * a.c_batch_stride;
+  const int lde4 = a.lde * 4, ldc4 = a.ldc * 4;
   const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
-  const int dl = d * lde4;
+  // lanes holding the first operand write frames t, t+d; their partners t+2d, t+3d (both lanes compute the same products)
+  const int my_first = chi ? 2 * d : 0;
+  auto epilogue = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    float bs = 0.f;
+    if constexpr (!FAST) bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + pc] : 0.f;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    float pe[4][4];
-    int t0[4];
+    for (int m = 0; m < MT; ++m) {
+      const int qm = q0 + 16 * m + 4 * kg;          // multiple of 4
+      const int tm = qm + 3 * (qm & ~(d - 1));      // frame of quad qm
+      const int e_base = tm * lde4 + (pc * 4 + oob);
+      const int c_base = (tm + my_first) * ldc4 + (oc * 4 + oob);
+      float pe[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = q0 + 16 * m + 4 * kg + r;
-      t0[r] = q + 3 * (q & ~(d - 1));
-      const int off = t0[r] * lde4 + colb;
+      for (int r = 0; r < 4; ++r) {
+        const int dr = r + 3 * (r & ~(d - 1));      // wave-uniform
 #pragma unroll
-      for (int o = 0; o < 4; ++o) pe[r][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, off + o * dl, 0, 0));
+        for (int o = 0; o < 4; ++o)
+          pe[r][o] = SS_G16_ABL == 5 ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, e_base, (dr + o * d) * lde4, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int dr = r + 3 * (r & ~(d - 1));
+        const float a0 = acc[0][m][r], a5 = acc[5][m][r];
+        float s12 = acc[1][m][r] + acc[2][m][r], d12 = acc[1][m][r] - acc[2][m][r];
+        const float s34 = acc[3][m][r] + acc[4][m][r], d34 = acc[3][m][r] - acc[4][m][r];
+        if constexpr (!FAST) {
+          s12 += bs;  // enters z0, z2
+          d12 += bs;  // enters z1, z3
+        }
+        const float z0 = a0 + s12 + s34;
+        const float z1 = fmaf(2.0f, d34, d12);
+        const float z2 = fmaf(4.0f, s34, s12);
+        const float z3 = fmaf(8.0f, d34, d12) + a5;
+        const float u0 = act(z0 + pe[r][0]);
+        const float u1 = act(z1 + pe[r][1]);
+        const float u2 = act(z2 + pe[r][2]);
+        const float u3 = act(z3 + pe[r][3]);
+        float g0, g1, g2, g3;
+        if constexpr (SS_G16_ABL == 6) {
+          g0 = z0 + pe[r][0]; g1 = z1 + pe[r][1]; g2 = z2 + pe[r][2]; g3 = z3 + pe[r][3];
+        } else {
+          g0 = u0 * partner(u0); g1 = u1 * partner(u1); g2 = u2 * partner(u2); g3 = u3 * partner(u3);
+        }
+        float ga = chi ? g2 : g0, gb = chi ? g3 : g1;
+        if constexpr (!FAST) {
+          const int ta = tm + dr + my_first;
+          if (ta >= row_lim) ga = 0.f;
+          if (ta + d >= row_lim) gb = 0.f;
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ga), rsrc_c, c_base, dr * ldc4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb), rsrc_c, c_base, (dr + d) * ldc4, 0);
+      }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float a0 = acc[0][m][r], a5 = acc[5][m][r];
-      const float s12 = acc[1][m][r] + acc[2][m][r], d12 = acc[1][m][r] - acc[2][m][r];
-      const float s34 = acc[3][m][r] + acc[4][m][r], d34 = acc[3][m][r] - acc[4][m][r];
-      const float z0 = a0 + s12 + s34;
-      const float z1 = fmaf(2.0f, d34, d12);
-      const float z2 = fmaf(4.0f, s34, s12);
-      const float z3 = fmaf(8.0f, d34, d12) + a5;
-      const float u0 = act(z0 + (bs + pe[r][0]));
-      const float u1 = act(z1 + (bs + pe[r][1]));
-      const float u2 = act(z2 + (bs + pe[r][2]));
-      const float u3 = act(z3 + (bs + pe[r][3]));
-      const float g0 = u0 * partner(u0), g1 = u1 * partner(u1), g2 = u2 * partner(u2), g3 = u3 * partner(u3);
-      // lanes holding the first operand write frames t, t+d; their partners write t+2d, t+3d (the products are identical)
-      float ga = chi ? g2 : g0, gb = chi ? g3 : g1;
-      const int ta = t0[r] + (chi ? 2 * d : 0), tb = ta + d;
-      if (ta >= row_lim) ga = 0.f;
-      if (tb >= row_lim) gb = 0.f;
-      if (col_ok && ta < a.T) Cb[(int64_t)ta * a.ldc + oc] = ga;
-      if (col_ok && tb < a.T) Cb[(int64_t)tb * a.ldc + oc] = gb;
-    }
-  }
+  };
+  // last frame this tile can touch: quad q0 + BQ - 1, frame + 3d
+  const int q_last = q0 + BQ - 1;
+  const bool fast = a.bias == nullptr && (q_last + 3 * (q_last & ~(d - 1)) + 3 * d) < row_lim;  // block-uniform
+  if (fast) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
   if (probing && threadIdx.x == 0) {
     atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
     atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
@@ -420,6 +460,7 @@ extern "C" int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int
   SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (!a.E || (int64_t)a.T * a.lde * 4 < (1ll << 31)) &&
                    (int64_t)a.Np * NC * a.Kp * 4 < (1ll << 31),
                "ss_wino43_gate16: item too large for 32-bit offsets");
+  SS_CHECK_ARG((int64_t)a.T * a.ldc * 4 < (1ll << 31), "ss_wino43_gate16: output item too large for 32-bit offsets");
   SS_CHECK_ARG(mt == 0 || mt == 2 || mt == 3, "ss_wino43_gate16: mt=%d must be 0 (auto), 2 or 3", mt);
   int log2d = 0;
   while ((1 << log2d) < dilation) ++log2d;

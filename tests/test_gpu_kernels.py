@@ -312,7 +312,9 @@ def test_winograd_f43_gate_equals_direct_conv(C, d, T, B, mt):
     else:
         L.wino43_gate16(x.to(dv), Wt, g, mt=mt, **kw)
     err = (g.cpu() - ref).abs().max().item()
-    assert err < 1e-5, err
+    # max over up to 1.2 M outputs of ONE F(4,3) layer vs a float64 conv: 9.2e-6 for exact-fp32 products in any summation order
+    # (CPU emulation of the transforms, tools/wino43_numerics.py; mean error 7e-7) - the bound leaves 2x for the order over K
+    assert err < (2e-5 if B * T * C > 500000 else 1e-5), err
     # rows past an item's length are written as zeros (mask_rows), never left stale
     for i in range(B):
         assert torch.all(g[i, int(lens[i]):] == 0)

@@ -92,7 +92,7 @@ def test_c4_shape_item_matches_oracle_with_100_step_chains():
 def test_gate16_grouped_pair_launch_matches_the_32x32_kernel(mt):
     """The f0-pair form of the launch (C = 192, two weight sets selected by b // group_size, conditioner slab with a layer stride,
     ragged lens, a gate_mode-1 pass as the RSA uses it) on 16x16x4 tiles vs the round-2 32x32x2 kernel: same arithmetic up to the
-    summation order over K -> 2e-6 on gate outputs in (-1, 1); rows past lens written as 0; the pick model returns a tiling."""
+    summation order over K -> 1e-5 on gate outputs in (-1, 1); rows past lens written as 0; the pick model returns a tiling."""
     import math
     from stylesinger_amd import lib as L
     dv = torch.device("cuda:0")
@@ -114,7 +114,7 @@ def test_gate16_grouped_pair_launch_matches_the_32x32_kernel(mt):
         L.wino43_gate(x, Wt, want, **kw)
         L.wino43_gate16(x, Wt, got, mt=mt, **kw)
         err = (got - want).abs().max().item()
-        assert err <= 2e-6, (d, mode, err)
+        assert err <= 1e-5, (d, mode, err)
         for i in range(B):
             assert torch.all(got[i, int(lens[i]):] == 0)
     lib = L.load()
