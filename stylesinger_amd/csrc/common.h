@@ -46,9 +46,7 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     16*MT quads when that fills the chip better, else the 32x32x2 kernel); 0 = always the 32x32x2 kernel; 2 / 3 = force MT.
 //   res_tile / skip_tile: SS_TILE_* override of the residual-half projection / the K = L*C skip GEMM of the denoiser loops
 //     (0 = the built-in choice); validated by ss_set_tuning.
-//   gate16_plain_transform: 1 = the 16x16 gate kernel builds each Winograd component from the raw rows (28 VALU ops per element);
-//     0 (default) = shared sub-expressions (18). Same values up to fp32 rounding.
-struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int gate16_plain_transform; };
+struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; };
 extern SsTuning g_ss_tuning;
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)

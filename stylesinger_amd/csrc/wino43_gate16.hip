@@ -42,15 +42,6 @@ constexpr int NC = 6;
 __device__ __forceinline__ int swz16(int row) { return ((row >> 1) & 7) ^ ((((row >> 2) ^ (row >> 3)) & 1) << 1); }
 __device__ __forceinline__ int lds_slot16(int row, int slot) { return row * LD + ((slot ^ swz16(row)) << 2); }
 
-template <int J, int Q>
-struct Coef16 {
-  static constexpr float v = (J == 0) ? (Q == 0 ? 4.f : Q == 2 ? -5.f : Q == 4 ? 1.f : 0.f)
-                           : (J == 1) ? (Q == 1 ? -4.f : Q == 2 ? -4.f : Q == 3 ? 1.f : Q == 4 ? 1.f : 0.f)
-                           : (J == 2) ? (Q == 1 ? 4.f : Q == 2 ? -4.f : Q == 3 ? -1.f : Q == 4 ? 1.f : 0.f)
-                           : (J == 3) ? (Q == 1 ? -2.f : Q == 2 ? -1.f : Q == 3 ? 2.f : Q == 4 ? 1.f : 0.f)
-                           : (J == 4) ? (Q == 1 ? 2.f : Q == 2 ? -1.f : Q == 3 ? -2.f : Q == 4 ? 1.f : 0.f)
-                                      : (Q == 1 ? 4.f : Q == 3 ? -5.f : Q == 5 ? 1.f : 0.f);
-};
 
 // elementwise helpers on float4 / float2 (the two staging slot widths)
 __device__ __forceinline__ float4 vfma(float c, const float4& r, const float4& v) {
@@ -62,11 +53,7 @@ __device__ __forceinline__ float2 vadd(const float2& a, const float2& b) { retur
 __device__ __forceinline__ float4 vsub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-// SHARED: the input transform with shared sub-expressions (18 instead of 28 VALU ops per element and K chunk - VALU instructions
-// take matrix-pipe time on gfx950):
-//   A = r4 - 4 r2, B = r3 - 4 r1, C = r4 - r2, D = r3 - r1   ->   c1 = A + B, c2 = A - B, c3 = C + 2 D, c4 = C - 2 D
-// each with dstep entering through the sum of its coefficients over the valid rows, as in the plain form.
-template <int MT, bool SHARED>
+template <int MT>
 __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gemm_args a, int q_tiles_per_item, int q_tiles, int n_tiles,
                                                                int log2d, unsigned long long* clock_probe) {
   constexpr int BQ = 16 * MT;
@@ -136,17 +123,10 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
     }
     set_mc(0, 4.f * v[0] - 5.f * v[2] + v[4]);
     set_mc(5, 4.f * v[1] - 5.f * v[3] + v[5]);
-    if constexpr (SHARED) {  // coefficients of the shared terms A, B, C, D
-      set_mc(1, v[4] - 4.f * v[2]);
-      set_mc(2, v[3] - 4.f * v[1]);
-      set_mc(3, v[4] - v[2]);
-      set_mc(4, v[3] - v[1]);
-    } else {
-      set_mc(1, -4.f * v[1] - 4.f * v[2] + v[3] + v[4]);
-      set_mc(2, 4.f * v[1] - 4.f * v[2] - v[3] + v[4]);
-      set_mc(3, -2.f * v[1] - v[2] + 2.f * v[3] + v[4]);
-      set_mc(4, 2.f * v[1] - v[2] - 2.f * v[3] + v[4]);
-    }
+    set_mc(1, v[4] - 4.f * v[2]);  // coefficient sums of the shared terms A, B, C, D (see `build`)
+    set_mc(2, v[3] - 4.f * v[1]);
+    set_mc(3, v[4] - v[2]);
+    set_mc(4, v[3] - v[1]);
   };
 #pragma unroll
   for (int i = 0; i < NFULL; ++i) row_setup(q0 + st_row + i * 32, st_c4 * 4, roff4[i], [&](int j, float x) { mc4[j][i] = x; });
@@ -185,51 +165,50 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
 #pragma unroll
   for (int i = 0; i < NFULL; ++i) a_wr4[i] = lds_slot16(st_row + i * 32, st_c4);
   const int a_wrh = lds_slot16(NFULL * 32 + sh_row, sh_c2 >> 1) + (sh_c2 & 1) * 2;
-  // shared-term temporaries (SHARED): (A, B) live from component 1 to 2, (C, D) from 3 to 4
-  float4 tp4[NFULL > 0 ? NFULL : 1], tq4[NFULL > 0 ? NFULL : 1];
-  float2 tph, tqh;
-  auto component = [&](auto jtag, const auto& pb, float m0, float m1, float m2, float m3, float m4, float m5, const auto& r0, const auto& r1,
-                       const auto& r2, const auto& r3, const auto& r4, const auto& r5, auto& tp, auto& tq) {
-    constexpr int J = decltype(jtag)::value;
-    using V = std::remove_cv_t<std::remove_reference_t<decltype(pb)>>;
-    if constexpr (!SHARED) {
-      const float mj = J == 0 ? m0 : J == 1 ? m1 : J == 2 ? m2 : J == 3 ? m3 : J == 4 ? m4 : m5;
-      V v = vfma(mj, pb, V{});
-      if constexpr (Coef16<J, 0>::v != 0.f) v = vfma(Coef16<J, 0>::v, r0, v);
-      if constexpr (Coef16<J, 1>::v != 0.f) v = vfma(Coef16<J, 1>::v, r1, v);
-      if constexpr (Coef16<J, 2>::v != 0.f) v = vfma(Coef16<J, 2>::v, r2, v);
-      if constexpr (Coef16<J, 3>::v != 0.f) v = vfma(Coef16<J, 3>::v, r3, v);
-      if constexpr (Coef16<J, 4>::v != 0.f) v = vfma(Coef16<J, 4>::v, r4, v);
-      if constexpr (Coef16<J, 5>::v != 0.f) v = vfma(Coef16<J, 5>::v, r5, v);
-      return v;
+  // Input transform with shared sub-expressions (18 instead of 28 VALU ops per element and K chunk - VALU instructions take
+  // matrix-pipe time on gfx950):
+  //   A = r4 - 4 r2, B = r3 - 4 r1, C = r4 - r2, D = r3 - r1   ->   c1 = A + B, c2 = A - B, c3 = C + 2 D, c4 = C - 2 D
+  //   c0 = 4 r0 - 5 r2 + r4, c5 = 4 r1 - 5 r3 + r5; dstep enters every term through the sum of its coefficients over the valid rows.
+  // The six components of a K chunk are consumed in the order c1, c0, c5, c2, c3, c4 ("positions" 0..5) so that the raw rows are dead
+  // after the third build and the rows of the NEXT K chunk can be fetched three positions (not one) before their first use:
+  //   position 5 of k-1 : build c1(k) = A + B   (rows(k) must have landed; A, B kept)
+  //   position 0        : build c0(k), C        position 1 : build c5(k), D        -> rows(k) dead: fetch rows(k+1) at position 2
+  //   position 2, 3, 4  : build c2 = A - B, c3 = C + 2 D, c4 = C - 2 D from the kept terms
+  float4 tA4[NFULL > 0 ? NFULL : 1], tB4[NFULL > 0 ? NFULL : 1], tC4[NFULL > 0 ? NFULL : 1], tD4[NFULL > 0 ? NFULL : 1];
+  float2 tAh, tBh, tCh, tDh;
+  // BUILD = index in the consumption order of the component being built
+  auto build = [&](auto ptag, const auto& pb, float m0, float mA, float mB, float mC, float mD, float m5, const auto& r0, const auto& r1,
+                   const auto& r2, const auto& r3, const auto& r4, const auto& r5, auto& tA, auto& tB, auto& tC, auto& tD) {
+    constexpr int P = decltype(ptag)::value;
+    if constexpr (P == 0) {  // c1
+      tA = vfma(mA, pb, vfma(-4.f, r2, r4));
+      tB = vfma(mB, pb, vfma(-4.f, r1, r3));
+      return vadd(tA, tB);
+    } else if constexpr (P == 1) {  // c0 (+ C)
+      tC = vfma(mC, pb, vsub(r4, r2));
+      return vfma(m0, pb, vfma(-5.f, r2, vfma(4.f, r0, r4)));
+    } else if constexpr (P == 2) {  // c5 (+ D)
+      tD = vfma(mD, pb, vsub(r3, r1));
+      return vfma(m5, pb, vfma(-5.f, r3, vfma(4.f, r1, r5)));
+    } else if constexpr (P == 3) {
+      return vsub(tA, tB);          // c2
+    } else if constexpr (P == 4) {
+      return vfma(2.f, tD, tC);     // c3
     } else {
-      if constexpr (J == 0) return vfma(m0, pb, vfma(-5.f, r2, vfma(4.f, r0, r4)));
-      if constexpr (J == 1) {
-        tp = vfma(m1, pb, vfma(-4.f, r2, r4));
-        tq = vfma(m2, pb, vfma(-4.f, r1, r3));
-        return vadd(tp, tq);
-      }
-      if constexpr (J == 2) return vsub(tp, tq);
-      if constexpr (J == 3) {
-        tp = vfma(m3, pb, vsub(r4, r2));
-        tq = vfma(m4, pb, vsub(r3, r1));
-        return vfma(2.f, tq, tp);
-      }
-      if constexpr (J == 4) return vfma(-2.f, tq, tp);
-      if constexpr (J == 5) return vfma(m5, pb, vfma(-5.f, r3, vfma(4.f, r1, r5)));
+      return vfma(-2.f, tD, tC);    // c4
     }
   };
-  auto store_a = [&](float* Ad, auto jtag) {
+  auto store_a = [&](float* Ad, auto ptag) {
 #pragma unroll
     for (int i = 0; i < NFULL; ++i) {
       auto R = [&](int q) { return __builtin_bit_cast(float4, rr4[i][q]); };
-      const float4 v = component(jtag, rpb4, mc4[0][i], mc4[1][i], mc4[2][i], mc4[3][i], mc4[4][i], mc4[5][i], R(0), R(1), R(2), R(3), R(4),
-                                 R(5), tp4[i], tq4[i]);
+      const float4 v = build(ptag, rpb4, mc4[0][i], mc4[1][i], mc4[2][i], mc4[3][i], mc4[4][i], mc4[5][i], R(0), R(1), R(2), R(3), R(4),
+                             R(5), tA4[i], tB4[i], tC4[i], tD4[i]);
       *reinterpret_cast<float4*>(Ad + a_wr4[i]) = v;
     }
     if constexpr (HALF) {
       auto R = [&](int q) { return __builtin_bit_cast(float2, rr2[q]); };
-      const float2 v = component(jtag, rpb2, mch[0], mch[1], mch[2], mch[3], mch[4], mch[5], R(0), R(1), R(2), R(3), R(4), R(5), tph, tqh);
+      const float2 v = build(ptag, rpb2, mch[0], mch[1], mch[2], mch[3], mch[4], mch[5], R(0), R(1), R(2), R(3), R(4), R(5), tAh, tBh, tCh, tDh);
       *reinterpret_cast<float2*>(Ad + a_wrh) = v;
     }
   };
@@ -242,19 +221,21 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[j][m][r] = 0.f;
 
-  using J0 = std::integral_constant<int, 0>;
-  using J1 = std::integral_constant<int, 1>;
-  using J2 = std::integral_constant<int, 2>;
-  using J3 = std::integral_constant<int, 3>;
-  using J4 = std::integral_constant<int, 4>;
-  using J5 = std::integral_constant<int, 5>;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  using P4 = std::integral_constant<int, 4>;
+  using P5 = std::integral_constant<int, 5>;
+  // ORD[p] = component consumed at position p
+  constexpr int ORD[6] = {1, 0, 5, 2, 3, 4};
   const int kb = a.Kp * 4;  // bytes of one component in a packed weight row
   const int cs = BK * 4;    // bytes of one K chunk
-  // chunk (k, j): weights at byte j*kb + k*cs of a packed row; register stage j % 3
+  // chunk (k, p): weights of component ORD[p] at byte ORD[p]*kb + k*cs of a packed row; register stage p % 3; LDS buffer p & 1
   load_rows(0);
-  load_b(J0{}, 0);
-  load_b(J1{}, kb);
-  store_a(As, J0{});
+  load_b(P0{}, ORD[0] * kb);
+  load_b(P1{}, ORD[1] * kb);
+  store_a(As, P0{});
   __syncthreads();
 
   // fragment addresses: row tile m, lane row lc, slots 2kg + h
@@ -280,13 +261,14 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[J][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bf.w, acc[J][m], 0, 0, 0);
   };
-  // chunk (k, J): MFMAs from LDS buffer J&1 and weight stage J%3 into acc[J]. In their shadow the component tile of chunk g+1 is built
-  // from the raw rows in registers and stored to the other buffer; then the weights of chunk g+2 are fetched into stage (J+2)%3 and -
-  // when component JN was the last user of the raw rows (JN = 5) - the raw rows of K chunk k+1.
-  auto chunk = [&](auto jtag, auto jn_tag, auto stage_tag, auto fetch_b_tag, auto fetch_rows_tag, int cb2, int rows_ci0b) {
-    constexpr int J = decltype(jtag)::value;
-    constexpr int CUR = J & 1;
-    constexpr int S = J % 3;
+  // position P of K chunk k: MFMAs of component ORD[P] from LDS buffer P&1 and weight stage P%3. In their shadow the component of
+  // position P+1 is built (registers -> other LDS buffer), the weights of position P+2 are fetched into stage (P+2)%3, and at position 2
+  // (the raw rows are dead by then) the raw rows of K chunk k+1.
+  auto chunk = [&](auto ptag, auto stage_tag, auto fetch_b_tag, auto fetch_rows_tag, int k) {
+    constexpr int P = decltype(ptag)::value;
+    constexpr int CUR = P & 1;
+    constexpr int S = P % 3;
+    constexpr int PN = (P + 1) % 6, P2N = (P + 2) % 6;
     const float* Ac = As + CUR * BQ * LD;
     float4 af0[MT], af1[MT];
 #pragma unroll
@@ -294,35 +276,35 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
 #pragma unroll
     for (int m = 0; m < MT; ++m) af1[m] = *reinterpret_cast<const float4*>(Ac + a_rd[m][1]);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_half(jtag, af0, bst[S][0]);
+    mfma_half(std::integral_constant<int, ORD[P]>{}, af0, bst[S][0]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (decltype(stage_tag)::value && SS_G16_ABL != 2) store_a(As + (CUR ^ 1) * BQ * LD, jn_tag);
+    if constexpr (decltype(stage_tag)::value && SS_G16_ABL != 2) store_a(As + (CUR ^ 1) * BQ * LD, std::integral_constant<int, PN>{});
     __builtin_amdgcn_sched_barrier(0);  // stores first, then the fetches into the SAME registers
-    if constexpr (decltype(fetch_b_tag)::value && SS_G16_ABL != 1) load_b(std::integral_constant<int, (J + 2) % 3>{}, cb2);
-    if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1) load_rows(rows_ci0b);
+    if constexpr (decltype(fetch_b_tag)::value && SS_G16_ABL != 1)
+      load_b(std::integral_constant<int, (P + 2) % 3>{}, ORD[P2N] * kb + (k + (P + 2) / 6) * cs);
+    if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1) load_rows((k + 1) * cs);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_half(jtag, af1, bst[S][1]);
+    mfma_half(std::integral_constant<int, ORD[P]>{}, af1, bst[S][1]);
     if constexpr (SS_G16_ABL != 4) __syncthreads();
   };
   using Yes = std::true_type;
   using No = std::false_type;
   for (int k = 0; k + 1 < kchunks; ++k) {
-    const int kc = k * cs;
-    chunk(J0{}, J1{}, Yes{}, Yes{}, No{}, 2 * kb + kc, 0);        // stage (k,1); fetch weights (k,2)
-    chunk(J1{}, J2{}, Yes{}, Yes{}, No{}, 3 * kb + kc, 0);        // stage (k,2); fetch weights (k,3)
-    chunk(J2{}, J3{}, Yes{}, Yes{}, No{}, 4 * kb + kc, 0);        // stage (k,3); fetch weights (k,4)
-    chunk(J3{}, J4{}, Yes{}, Yes{}, No{}, 5 * kb + kc, 0);        // stage (k,4); fetch weights (k,5)
-    chunk(J4{}, J5{}, Yes{}, Yes{}, Yes{}, kc + cs, kc + cs);     // stage (k,5) = last use of the rows; fetch weights (k+1,0), rows k+1
-    chunk(J5{}, J0{}, Yes{}, Yes{}, No{}, kb + kc + cs, 0);       // stage (k+1,0); fetch weights (k+1,1)
+    chunk(P0{}, Yes{}, Yes{}, No{}, k);
+    chunk(P1{}, Yes{}, Yes{}, No{}, k);
+    chunk(P2{}, Yes{}, Yes{}, Yes{}, k);   // rows(k) are dead: fetch rows(k+1), three positions before position 5 builds c1(k+1)
+    chunk(P3{}, Yes{}, Yes{}, No{}, k);
+    chunk(P4{}, Yes{}, Yes{}, No{}, k);    // fetches the weights of (k+1, position 0)
+    chunk(P5{}, Yes{}, Yes{}, No{}, k);    // builds c1(k+1); fetches the weights of (k+1, position 1)
   }
   {
-    const int kc = (kchunks - 1) * cs;
-    chunk(J0{}, J1{}, Yes{}, Yes{}, No{}, 2 * kb + kc, 0);
-    chunk(J1{}, J2{}, Yes{}, Yes{}, No{}, 3 * kb + kc, 0);
-    chunk(J2{}, J3{}, Yes{}, Yes{}, No{}, 4 * kb + kc, 0);
-    chunk(J3{}, J4{}, Yes{}, Yes{}, No{}, 5 * kb + kc, 0);
-    chunk(J4{}, J5{}, Yes{}, No{}, No{}, 0, 0);
-    chunk(J5{}, J0{}, No{}, No{}, No{}, 0, 0);
+    const int k = kchunks - 1;
+    chunk(P0{}, Yes{}, Yes{}, No{}, k);
+    chunk(P1{}, Yes{}, Yes{}, No{}, k);
+    chunk(P2{}, Yes{}, Yes{}, No{}, k);
+    chunk(P3{}, Yes{}, Yes{}, No{}, k);
+    chunk(P4{}, Yes{}, No{}, No{}, k);
+    chunk(P5{}, No{}, No{}, No{}, k);
   }
 
   // ---- epilogue: output transform, conditioner addend, gate; accumulator (m, r) of this lane = quad 16m + 4kg + r, column lc ----
@@ -414,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
   }
 }
 
-template <int MT, bool SHARED>
+template <int MT>
 int launch16(const ss_conv_gemm_args& a, int dilation, int log2d, hipStream_t stream) {
   constexpr int BQ = 16 * MT;
   const int quads_per_item = ss_cdiv(a.T, 4 * dilation) * dilation;
@@ -423,7 +405,7 @@ int launch16(const ss_conv_gemm_args& a, int dilation, int log2d, hipStream_t st
   const int n_tiles = a.Np / BN;
   const int grid = ss_cdiv(q_tiles, 8) * 8 * n_tiles;
   const size_t lds = (size_t)2 * BQ * LD * sizeof(float);
-  hipLaunchKernelGGL((wino43_gate16_kernel<MT, SHARED>), dim3(grid), dim3(256), lds, stream, a, q_tiles_per_item, q_tiles, n_tiles, log2d,
+  hipLaunchKernelGGL(wino43_gate16_kernel<MT>, dim3(grid), dim3(256), lds, stream, a, q_tiles_per_item, q_tiles, n_tiles, log2d,
                      g_ss_tuning.clock_probe);
   return 0;
 }
@@ -468,9 +450,8 @@ extern "C" int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int
     mt = ss_wino43_gate16_pick(a.B, a.T, a.Np, dilation);
     if (mt == 0) return ss_wino43_gate(args, dilation, stream);
   }
-  const bool plain = g_ss_tuning.gate16_plain_transform != 0;
-  if (mt == 2) plain ? launch16<2, false>(a, dilation, log2d, (hipStream_t)stream) : launch16<2, true>(a, dilation, log2d, (hipStream_t)stream);
-  else plain ? launch16<3, false>(a, dilation, log2d, (hipStream_t)stream) : launch16<3, true>(a, dilation, log2d, (hipStream_t)stream);
+  if (mt == 2) launch16<2>(a, dilation, log2d, (hipStream_t)stream);
+  else launch16<3>(a, dilation, log2d, (hipStream_t)stream);
   SS_CHECK_LAUNCH("ss_wino43_gate16");
   return SS_OK;
 }
