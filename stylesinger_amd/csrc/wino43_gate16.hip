@@ -25,7 +25,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // SS_G16_ABL (debug builds only, tools/ablate_g16.sh; results are wrong by design): 1 = no global fetches inside the loop, 2 = no LDS
-// stores, 3 = no MFMAs, 4 = no barriers in the loop, 5 = no conditioner-addend loads, 6 = no activations / exchange in the epilogue
+// stores, 3 = no MFMAs, 4 = no barriers in the loop, 5 = no conditioner-addend loads, 6 = no activations / exchange in the epilogue,
+// 7 = no weight fetches inside the loop, 8 = no raw-row fetches inside the loop
 #ifndef SS_G16_ABL
 #define SS_G16_ABL 0
 #endif
@@ -280,9 +281,9 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (decltype(stage_tag)::value && SS_G16_ABL != 2) store_a(As + (CUR ^ 1) * BQ * LD, std::integral_constant<int, PN>{});
     __builtin_amdgcn_sched_barrier(0);  // stores first, then the fetches into the SAME registers
-    if constexpr (decltype(fetch_b_tag)::value && SS_G16_ABL != 1)
+    if constexpr (decltype(fetch_b_tag)::value && SS_G16_ABL != 1 && SS_G16_ABL != 7)
       load_b(std::integral_constant<int, (P + 2) % 3>{}, ORD[P2N] * kb + (k + (P + 2) / 6) * cs);
-    if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1) load_rows((k + 1) * cs);
+    if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1 && SS_G16_ABL != 8) load_rows((k + 1) * cs);
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(std::integral_constant<int, ORD[P]>{}, af1, bst[S][1]);
     if constexpr (SS_G16_ABL != 4) __syncthreads();

@@ -113,3 +113,74 @@ class MelFrontendHIP:
         L.check(lib.ss_log10_floor(L.ptr(mel), L.ptr(mel), mel.numel(), self.eps, L.stream_ptr()), "log10")
         mel.masked_fill_((torch.arange(T, device=self.device)[None, :] >= frames[:, None])[:, :, None], 0.0)
         return mel, frames
+
+
+class EmotionMelFrontendHIP:
+    """The emotion encoder's own front end on the device: `data_gen/tts/emotion/audio.py:43-55 wav_to_mel_spectrogram` =
+    librosa.feature.melspectrogram(y, 16000, n_fft=400, hop_length=160, n_mels=40), i.e. a centred STFT with REFLECT padding, a
+    periodic Hann window of 400, |X|^2, a Slaney 40-mel basis 0-8 kHz, no log; plus `normalize_volume` (:109-115) as
+    `preprocess_wav` applies it. (`trim_long_silences` needs webrtcvad - un-vendored - and stays with the caller.)
+
+    MI355X mapping: hop (160) does not divide the frame (400), so the frame is padded to 3 rows of the waveform viewed as
+    [L/160][160] (the window is zero beyond sample 400): the windowed real DFT is a 3-tap `ss_conv_gemm` (K = 480, N = 2 x 224
+    cos|sin columns, exact-fp32 MFMA) over the reflect-padded waveform (`ss_reflect_pad`, per-item lengths), then
+    `ss_spec_power` and the mel projection as a second GEMM (K = 201 -> 224, N = 40)."""
+    SR, N_FFT, HOP, N_MELS = 16000, 400, 160, 40
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.StyleSingerHipError("EmotionMelFrontendHIP needs a GPU: there is no CPU path")
+        n_fft, hop = self.N_FFT, self.HOP
+        self.taps = (n_fft + hop - 1) // hop           # 3 rows of 160 samples cover the 400-sample frame
+        self.nbins = n_fft // 2 + 1                    # 201
+        self.nb_pad = L.round_up(self.nbins, 32)       # 224
+        k = np.arange(n_fft, dtype=np.float64)
+        win = 0.5 - 0.5 * np.cos(2 * np.pi * k / n_fft)
+        ang = 2 * np.pi * np.outer(np.arange(self.nbins, dtype=np.float64), k) / n_fft
+        basis = np.zeros((2 * self.nb_pad, self.taps * hop), dtype=np.float64)
+        basis[:self.nbins, :n_fft] = np.cos(ang) * win
+        basis[self.nb_pad:self.nb_pad + self.nbins, :n_fft] = -np.sin(ang) * win
+        w = torch.from_numpy(basis.astype(np.float32)).reshape(2 * self.nb_pad, self.taps, hop).permute(0, 2, 1).contiguous()
+        self.W_dft = L.pack_conv_weight(w.to(self.device))
+        fb = np.zeros((self.N_MELS, self.nb_pad), dtype=np.float32)
+        fb[:, :self.nbins] = mel_filterbank(self.SR, n_fft, self.N_MELS, 0.0, self.SR / 2.0)
+        self.W_mel = L.pack_conv_weight(torch.from_numpy(fb)[:, :, None].contiguous().to(self.device))
+
+    @torch.no_grad()
+    def normalize_volume(self, wav, lens, target_dbfs=-30.0):
+        """audio.normalize_volume(increase_only=True) per item of a zero-padded batch [B, L]: scale by 10^(change/20) when
+        change = target - 10 log10(mean(wav^2)) >= 0 (mean over the item's own samples), else leave untouched."""
+        n = lens.to(self.device).to(torch.float32).clamp_min(1.0)
+        ms = (wav.float() ** 2).sum(dim=1) / n
+        change = target_dbfs - 10.0 * torch.log10(ms)
+        gain = torch.where(change < 0, torch.ones_like(change), 10.0 ** (change / 20.0))
+        return wav * gain[:, None]
+
+    @torch.no_grad()
+    def wav2mel(self, wav, lens=None):
+        """wav fp32 [B, L] on the device, zero beyond lens[b] (host ints / CPU tensor, default L) -> (frames [B, T, 40] fp32 power
+        mel, n_frames list): T = 1 + max(lens) // 160; rows past an item's own 1 + lens[b] // 160 frames are not meaningful."""
+        wav = wav.to(self.device).float().contiguous()
+        B, Lx = wav.shape
+        hop, n_fft, taps = self.HOP, self.N_FFT, self.taps
+        lens_h = [int(Lx)] * B if lens is None else [int(v) for v in lens]
+        if min(lens_h) <= n_fft // 2:
+            raise ValueError(f"EmotionMelFrontendHIP: reflect padding needs more than {n_fft // 2} samples per item")
+        lens_d = torch.tensor(lens_h, device=self.device, dtype=torch.int32)
+        T = 1 + max(lens_h) // hop
+        rows = T + taps - 1
+        Ly = rows * hop
+        lib = L.load()
+        yp = torch.empty(B, Ly, device=self.device, dtype=torch.float32)
+        L.check(lib.ss_reflect_pad(L.ptr(wav), L.ptr(lens_d), L.ptr(yp), B, Lx, Ly, n_fft // 2, L.stream_ptr()), "ss_reflect_pad")
+        S = torch.empty(B, T, 2 * self.nb_pad, device=self.device, dtype=torch.float32)
+        L.conv_gemm(yp, self.W_dft, S, B=B, T=T, Cin=hop, N=2 * self.nb_pad, Np=self.W_dft.shape[0], Kp=self.W_dft.shape[1] // taps,
+                    lda=hop, a_bs=Ly, taps=tuple(range(taps)), lens=torch.full((B,), rows, device=self.device, dtype=torch.int32),
+                    mask_rows=False)
+        P = torch.empty(B, T, self.nb_pad, device=self.device, dtype=torch.float32)
+        L.check(lib.ss_spec_power(L.ptr(S), L.ptr(P), B * T, 2 * self.nb_pad, self.nb_pad, self.nbins, self.nb_pad, L.stream_ptr()), "ss_spec_power")
+        mel = torch.empty(B, T, self.N_MELS, device=self.device, dtype=torch.float32)
+        L.conv_gemm(P, self.W_mel, mel, B=B, T=T, Cin=self.nb_pad, N=self.N_MELS, Np=self.W_mel.shape[0], Kp=self.W_mel.shape[1],
+                    mask_rows=False)
+        return mel, [1 + n // hop for n in lens_h]

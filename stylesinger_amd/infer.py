@@ -18,8 +18,12 @@ from .vocoder import get_vocoder_cls
 
 
 class StyleSingerInfer:
-    def __init__(self, hparams=None, device=None, model_state=None, vocoder_state=None, vocoder_config=None, dictionary=None):
+    def __init__(self, hparams=None, device=None, model_state=None, vocoder_state=None, vocoder_config=None, dictionary=None,
+                 emotion_state=None):
+        """`emotion_state`: state_dict of the reference's emotion encoder checkpoint (`EmotionEncoder.load_model`,
+        inference/StyleSinger.py:101) - enables the emotion branch of `preprocess_batch`."""
         self.hparams = make_hparams(hparams)
+        self._front_hparams = hparams
         if device is None:
             if not torch.cuda.is_available():
                 raise L.StyleSingerHipError("StyleSingerInfer (HIP) needs a GPU: there is no CPU path")
@@ -33,6 +37,12 @@ class StyleSingerInfer:
             vcfg["mfma_precision"] = self.hparams.get("mfma_precision", "fp32")
         self.vocoder = get_vocoder_cls(self.hparams)(config=vcfg, state_dict=vocoder_state,
                                                      device=self.device, hparams=self.hparams)
+        self._mel_frontend = None
+        self._emo_frontend = None
+        self.emotion_encoder = None
+        if emotion_state is not None:
+            from .emotion import EmotionEncoderHIP
+            self.emotion_encoder = EmotionEncoderHIP(emotion_state, device=self.device)
 
     @classmethod
     def from_checkpoints(cls, hparams, exp_dir, vocoder_dir, device=None, dictionary=None):
@@ -115,6 +125,98 @@ class StyleSingerInfer:
         pcm = wav_to_pcm16(res["wav"], res["lens"], hop, norm=bool(self.hparams.get("out_wav_norm", False)))
         writer.submit_batch(names, pcm, res["lens"], hop)
         return res
+
+    # ---- input producers on the device ------------------------------------------
+    @staticmethod
+    def align_f0_to_mel(f0, n_mel, hop_size=256):
+        """The tracker-output alignment of preprocess_input (inference/StyleSinger.py:120-136): left pad 2 * pad_size frames, right
+        pad to the mel length, repeat the last value / crop when still off (|delta| <= 8 asserted there). numpy in, numpy out."""
+        pad_size = {128: 4, 256: 2}[hop_size]
+        f0 = np.asarray(f0)
+        lpad = pad_size * 2
+        rpad = n_mel - len(f0) - lpad
+        f0 = np.pad(f0, [[lpad, max(rpad, 0)]], mode="constant") if rpad >= 0 else np.pad(f0, [[lpad, 0]], mode="constant")
+        delta = n_mel - len(f0)
+        assert abs(delta) <= 8, delta
+        if delta > 0:
+            f0 = np.concatenate([f0, [f0[-1]] * delta], 0)
+        return f0[:n_mel]
+
+    @torch.no_grad()
+    def embed_emotion_batch(self, wavs, lens):
+        """`Embed_utterance(wav, using_partials=True)` (data_gen/tts/emotion/inference.py:111-151) for a batch of PREPROCESSED
+        waveforms (`preprocess_wav` output, zero beyond lens[b]; lens are host ints): per item zero-pad to the last partial's end,
+        40-mel power spectrogram (EmotionMelFrontendHIP), the partial windows of ALL items through the LSTM in one pass, mean + L2
+        norm per item. -> [B, 256] on the device."""
+        from .emotion import compute_partial_slices
+        from .frontend import EmotionMelFrontendHIP
+        if self.emotion_encoder is None:
+            raise L.StyleSingerHipError("embed_emotion_batch: construct StyleSingerInfer(..., emotion_state=<emotion encoder state_dict>)")
+        if self._emo_frontend is None:
+            self._emo_frontend = EmotionMelFrontendHIP(self.device)
+        lens = [int(v) for v in lens]
+        B = len(lens)
+        slices = [compute_partial_slices(n) for n in lens]
+        need = [max(n, ws[-1].stop) for n, (ws, _) in zip(lens, slices)]   # `if max_wave_length >= len(wav): pad` (:129-131)
+        buf = torch.zeros(B, max(need), device=self.device, dtype=torch.float32)
+        buf[:, :wavs.shape[1]] = wavs.to(self.device).float()[:, :max(need)]
+        mel40, _ = self._emo_frontend.wav2mel(buf, need)
+        idx_b, idx_t = [], []
+        counts = []
+        for b, (_, ms) in enumerate(slices):
+            counts.append(len(ms))
+            for sl in ms:
+                idx_b.append(torch.full((sl.stop - sl.start,), b, dtype=torch.long))
+                idx_t.append(torch.arange(sl.start, sl.stop, dtype=torch.long))
+        ib = torch.cat(idx_b).to(self.device)
+        it = torch.cat(idx_t).to(self.device)
+        frames = mel40[ib, it].reshape(sum(counts), 160, mel40.shape[-1]).contiguous()
+        part = self.emotion_encoder.embed_frames_batch(frames)
+        out = torch.empty(B, part.shape[1], device=self.device, dtype=torch.float32)
+        lib, o = L.load(), 0
+        for b, c in enumerate(counts):
+            L.check(lib.ss_mean_l2norm(L.ptr(part[o:o + c]), L.ptr(out[b]), c, part.shape[1], L.stream_ptr()), "ss_mean_l2norm")
+            o += c
+        return out
+
+    @torch.no_grad()
+    def preprocess_batch(self, ref_wavs, ref_lens, spk_embed, f0_hz, txt_tokens, note, note_dur, note_type, mel2ph=None,
+                         emo_embed=None, emo_wavs=None, emo_lens=None):
+        """Batched device form of `preprocess_input` + `input_to_batch` (inference/StyleSinger.py:94-172): from reference audio to
+        the dict `infer_batch` takes, with no host round trip of the data.
+          ref_wavs [B, L] fp32 48 kHz reference audio (zero beyond ref_lens[b]; ref_lens host ints)   -> ref_mels  (process_audio, :106-118)
+          f0_hz    [B, Tr] tracker contour in Hz aligned to the mel frames (align_f0_to_mel), 0 = unvoiced -> ref_f0 (norm_interp_f0, :152)
+          emo_wavs [B, Le] `preprocess_wav` output for the emotion encoder (zero beyond emo_lens[b])  -> emo_embed (Embed_utterance, :104)
+                   default: the reference audio itself, volume-normalised on the device; `trim_long_silences` needs the un-vendored
+                   webrtcvad and is the caller's step. Pass `emo_embed` [B, 256] instead to skip this branch.
+          spk_embed [B, 256] stays an input: its model (resemblyzer VoiceEncoder, :100-103) is un-vendored, as is the f0 tracker
+                   (parselmouth, :125-127)."""
+        from .frontend import MelFrontendHIP
+        from .pitch import norm_interp_f0_device
+        d = self.device
+        if self._mel_frontend is None:
+            self._mel_frontend = MelFrontendHIP(self._front_hparams, device=d)
+        ref_lens_h = [int(v) for v in ref_lens]
+        ref_wavs = ref_wavs.to(d).float()
+        ref_mels, frames = self._mel_frontend.wav2mel(ref_wavs, torch.tensor(ref_lens_h, dtype=torch.int64))
+        Tr = ref_mels.shape[1]
+        f0_hz = f0_hz.to(d).float()
+        if f0_hz.shape[1] != Tr:
+            raise ValueError(f"preprocess_batch: f0_hz has {f0_hz.shape[1]} frames, the reference mel {Tr} (use align_f0_to_mel)")
+        ref_f0, _uv = norm_interp_f0_device(f0_hz, frames, self.hparams)
+        if emo_embed is None:
+            if emo_wavs is None:
+                if self._emo_frontend is None:
+                    from .frontend import EmotionMelFrontendHIP
+                    self._emo_frontend = EmotionMelFrontendHIP(d)
+                emo_wavs = self._emo_frontend.normalize_volume(ref_wavs, torch.tensor(ref_lens_h))
+                emo_lens = ref_lens_h
+            emo_embed = self.embed_emotion_batch(emo_wavs, emo_lens)
+        batch = dict(txt_tokens=txt_tokens.to(d), note=note.to(d), note_dur=note_dur.to(d).float(), note_type=note_type.to(d),
+                     spk_embed=spk_embed.to(d).float(), emo_embed=emo_embed.to(d).float(), ref_mels=ref_mels, ref_f0=ref_f0)
+        if mel2ph is not None:
+            batch["mel2ph"] = mel2ph.to(d)
+        return batch
 
     # ---- the reference's single-utterance surface ---------------------------------------------
     def input_to_batch(self, item):

@@ -120,3 +120,79 @@ def test_gate16_grouped_pair_launch_matches_the_32x32_kernel(mt):
     lib = L.load()
     assert lib.ss_wino43_gate16_pick(8, 1500, 512, 2) == 3 and lib.ss_wino43_gate16_pick(16, 1500, 384, 1) == 3
     assert lib.ss_wino43_gate16_pick(32, 5625, 512, 4) == 0      # many rounds per launch: the 32x32x2 tiles
+
+
+def test_preprocess_batch_feeds_infer_batch_from_device_buffers(golden_dir):
+    """`StyleSingerInfer.preprocess_batch` (reference audio -> ref mel, emotion embedding, normalised f0) (a) equals the
+    batch assembled by hand from the stand-alone producers bit for bit, tensors and the mel `infer_batch` makes of them; (b) every
+    producer agrees with its oracle: librosa-restated mels (oracle/frontend.py), the emotion LSTM restatement on the oracle's 40-mel
+    partials, and the REAL reference's norm_interp_f0 (host mirror, pinned bit-exactly by tests/golden/norm_interp_f0.pt)."""
+    from oracle import frontend as OF
+    from stylesinger_amd import pitch
+    from stylesinger_amd.emotion import EmotionEncoderHIP, compute_partial_slices
+    from stylesinger_amd.frontend import EmotionMelFrontendHIP, MelFrontendHIP
+    from stylesinger_amd.infer import StyleSingerInfer
+    dev = torch.device("cuda:0")
+    hp = config.make_hparams(dict(timesteps=3, K_step=3, f0_timesteps=3))
+    esd = synth.synth_emotion_state_dict(5)
+    inf = StyleSingerInfer(hp, device=dev, model_state=synth.synth_acoustic_state_dict(hp, 5), vocoder_state=synth.synth_vocoder_state_dict(None, 5),
+                           emotion_state=esd)
+    g = torch.Generator().manual_seed(11)
+    lens = [43200, 33711]                      # 0.9 s and 0.7 s of "48 kHz" audio, the second not a multiple of the hop
+    B, Lmax = len(lens), max(lens)
+    wav = torch.zeros(B, Lmax)
+    for b, n in enumerate(lens):
+        t = torch.arange(n) / 48000.0
+        wav[b, :n] = (0.05 * torch.sin(2 * np.pi * (180.0 + 40 * b) * t) + 0.02 * torch.sin(2 * np.pi * 1234.0 * t) + 0.01 * torch.randn(n, generator=g)) * (0.2 if b == 0 else 1.0)   # item 0 is below -30 dBFS: normalize_volume raises it
+    Tr = 1 + Lmax // 256
+    frames = [1 + n // 256 for n in lens]
+    f0 = torch.zeros(B, Tr, dtype=torch.float64)
+    for b in range(B):
+        f0[b, :frames[b]] = synth.synth_f0_hz(b, frames[b], 5)
+    T, Tp = 48, 6
+    it = synth.synth_batch(B, T, Tp, 8, hp, 5)
+    args = dict(txt_tokens=it["txt_tokens"], note=it["note"], note_dur=it["note_dur"], note_type=it["note_type"], mel2ph=it["mel2ph"])
+    batch = inf.preprocess_batch(wav.to(dev), lens, it["spk_embed"], f0.float(), **args)
+    # (a) hand-assembled from the stand-alone producers
+    mf, ef, enc = MelFrontendHIP(hp, device=dev), EmotionMelFrontendHIP(dev), EmotionEncoderHIP(esd, device=dev)
+    mel_h, fr_h = mf.wav2mel(wav.to(dev), torch.tensor(lens))
+    f0_h, _ = pitch.norm_interp_f0_device(f0.float().to(dev), fr_h, hp)
+    ew = ef.normalize_volume(wav.to(dev), torch.tensor(lens))
+    emo_h = []
+    for b, n in enumerate(lens):
+        ws, ms = compute_partial_slices(n)
+        need = max(n, ws[-1].stop)
+        one = torch.zeros(1, need, device=dev)
+        one[0, :n] = ew[b, :n]
+        m40, _ = ef.wav2mel(one, [need])
+        emo_h.append(enc.embed_utterance_frames(m40[0].cpu(), n_samples=n))
+    emo_h = torch.stack(emo_h)
+    assert torch.equal(batch["ref_mels"], mel_h) and torch.equal(batch["ref_f0"], f0_h)
+    assert torch.equal(batch["emo_embed"], emo_h.to(dev)), (batch["emo_embed"] - emo_h.to(dev)).abs().max().item()
+    hand = dict(batch, ref_mels=mel_h, ref_f0=f0_h, emo_embed=emo_h.to(dev))
+    r1 = inf.infer_batch(batch, seed=3, vocode=False)
+    r2 = inf.infer_batch(hand, seed=3, vocode=False)
+    assert torch.equal(r1["mel"], r2["mel"]) and torch.isfinite(r1["mel"]).all()
+    # (b) against the oracles
+    worst = dict(mel=0.0, f0=0.0, mel40=0.0, emo=0.0)
+    for b, n in enumerate(lens):
+        ref_mel = torch.from_numpy(OF.wav2mel(wav[b, :n].numpy()))
+        assert ref_mel.shape[0] == frames[b]
+        worst["mel"] = max(worst["mel"], (batch["ref_mels"][b, :frames[b]].cpu() - ref_mel).abs().max().item())
+        assert (batch["ref_mels"][b, frames[b]:] == 0).all()
+        f0_ref, _ = pitch.norm_interp_f0(f0[b, :frames[b]].numpy(), hp)
+        worst["f0"] = max(worst["f0"], (batch["ref_f0"][b, :frames[b]].cpu() - f0_ref).abs().max().item())
+        ew_ref = OF.normalize_volume(wav[b, :n].numpy())
+        fr_ref = torch.from_numpy(OF.embed_utterance_frames(ew_ref))
+        ws, ms = compute_partial_slices(n)
+        need = max(n, ws[-1].stop)
+        one = torch.zeros(1, need, device=dev)
+        one[0, :n] = ew[b, :n]
+        m40 = ef.wav2mel(one, [need])[0][0].cpu()
+        got_fr = torch.stack([m40[s] for s in ms])
+        worst["mel40"] = max(worst["mel40"], ((got_fr - fr_ref).abs().max() / fr_ref.abs().max()).item())
+        emo_ref, _ = R.emotion_embed(esd, fr_ref)
+        worst["emo"] = max(worst["emo"], (batch["emo_embed"][b].cpu() - emo_ref).abs().max().item())
+    print("preprocess_batch vs oracles:", worst)
+    record_measurement("preprocess_batch_vs_oracles", **worst)
+    assert worst["mel"] <= 5e-5 and worst["f0"] <= 2e-6 and worst["mel40"] <= 1e-5 and worst["emo"] <= 2e-5, worst
