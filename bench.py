@@ -341,8 +341,11 @@ def main():
     n_emul = max(1, args.emulate_ranks)
     assert n_emul == 1 or world == 1
 
+    n_shards = world * n_emul
+
     def make_batch(r):
-        b = synth.synth_batch(B, T, Tp, Tr, hp, 1234, first_index=r * B)
+        # the reference's sharding rule x[rank::num_replicas] (tasks/tts/tts_base.py:132): shard r holds utterances r, r + W, ...
+        b = synth.synth_batch(B, T, Tp, Tr, hp, 1234, indices=ssd.shard_indices(B * n_shards, r, n_shards))
         return {k: v.to(dev) for k, v in b.items()}
     batches = {r: make_batch(r) for r in ([rank] if n_emul == 1 else range(n_emul))}
     if sweep_mode:
@@ -377,7 +380,7 @@ def main():
         mel, f0, lens = ssd.gather_mels(res["mel"], res["f0"], res["lens"])   # the ONE collective of the data path
         e1.record()
         gather_events.append((e0, e1))
-        own = slice(r * B, (r + 1) * B) if world > 1 else slice(None)
+        own = slice(r * B, (r + 1) * B) if world > 1 else slice(None)   # the gathered buffer is rank-major: rows of shard r
         last["mel"], last["r"] = mel, r
         if voc_stream is None:
             return infer.vocode(mel[own], f0[own], lens[own], seed=4321 + i)

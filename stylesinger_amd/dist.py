@@ -26,10 +26,25 @@ def _is_dist(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+_comm_streams = {}
+
+
+def comm_stream(device):
+    """The ONE stream of this process on which the data path's collectives are issued. Steps may run on several HIP streams
+    (batches in flight), but every rank calls gather_mels in the same host order, and issuing them all from one stream keeps
+    that order on the device too: in-flight batches can never interleave their collectives differently on different ranks."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _comm_streams:
+        _comm_streams[key] = torch.cuda.Stream(device=key)
+    return _comm_streams[key]
+
+
 def gather_mels(mel, f0, lens, group=None):
     """mel [B_local,T,M], f0 [B_local,T], lens int32 [B_local] -> (mel_all [W*B_local,T,M], f0_all, lens_all int32).
     Equal-shaped buffers on every rank (pad T to the global max and B_local to shard_slots() before calling).
-    The lengths ride in the same buffer bit-cast to fp32 (a collective moves bits), so they come back exact."""
+    The lengths ride in the same buffer bit-cast to fp32 (a collective moves bits), so they come back exact.
+    The collective runs on the dedicated communication stream: it waits (event) for the calling stream's producers, and the
+    calling stream waits (event) for it - callers on different step streams stay asynchronous to each other."""
     if not _is_dist(group):
         return mel, f0, lens
     W = dist.get_world_size(group)
@@ -38,15 +53,30 @@ def gather_mels(mel, f0, lens, group=None):
     payload[:, :, :M] = mel
     payload[:, :, M] = f0
     payload[:, :, M + 1] = lens.to(torch.int32).view(torch.float32)[:, None]
-    if dist.get_backend(group) == "gloo" and payload.is_cuda:
-        # orchestration tests on one device run over gloo, whose collectives take host buffers; RCCL (backend "nccl") gathers
-        # the device buffer directly over xGMI
-        host = torch.empty(W * Bl, T, M + 2, dtype=torch.float32)
-        dist.all_gather_into_tensor(host, payload.cpu(), group=group)
-        out = host.to(mel.device)
-    else:
-        out = torch.empty(W * Bl, T, M + 2, device=mel.device, dtype=torch.float32)
+    if not payload.is_cuda:
+        out = torch.empty(W * Bl, T, M + 2, dtype=torch.float32)
         dist.all_gather_into_tensor(out, payload, group=group)
+        return out[:, :, :M].contiguous(), out[:, :, M].contiguous(), out[:, 0, M + 1].contiguous().view(torch.int32)
+    cur = torch.cuda.current_stream(mel.device)
+    cs = comm_stream(mel.device)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    out = torch.empty(W * Bl, T, M + 2, device=mel.device, dtype=torch.float32)
+    with torch.cuda.stream(cs):
+        cs.wait_event(ready)
+        if dist.get_backend(group) == "gloo":
+            # orchestration tests on one device run over gloo, whose collectives take host buffers (the copy synchronises the
+            # communication stream only); RCCL (backend "nccl") gathers the device buffer directly over xGMI
+            host = torch.empty(W * Bl, T, M + 2, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, payload.cpu(), group=group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, payload, group=group)
+        done = torch.cuda.Event()
+        done.record(cs)
+    payload.record_stream(cs)
+    out.record_stream(cur)
+    cur.wait_event(done)
     return out[:, :, :M].contiguous(), out[:, :, M].contiguous(), out[:, 0, M + 1].contiguous().view(torch.int32)
 
 

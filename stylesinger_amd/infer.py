@@ -92,7 +92,16 @@ class StyleSingerInfer:
         def finish(entry):
             res, strm = entry
             main.wait_stream(strm)
+            # the results were allocated from the side stream's pool and are handed to the caller's stream: tell the allocator, or
+            # the next batch on that side stream could reuse the memory while `main` still reads it
+            for v in list(res.values()) + list(res.get("model_out", {}).values()):
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
             return res
+        batches = list(batches)
+        if batches:   # lazily built shared state is created here, on the caller's stream, not inside a forward on a side stream
+            longest = max(int(b["mel2ph"].shape[1]) if b.get("mel2ph") is not None else 0 for b in batches)
+            self.model.warm_caches(max(longest, max(int(b["ref_mels"].shape[1]) for b in batches), 2048), self.device)
         for i, batch in enumerate(batches):
             strm = self._flight_streams[i % in_flight]
             strm.wait_stream(main)   # the batch's inputs were produced on the caller's stream

@@ -246,7 +246,12 @@ class StyleSingerHIP(torch.nn.Module):
         bias = L.pack_bias(self.p(prefix + ".bias"), interleave_half=half)
         return _Packed(W, bias, Cout, Cin, k, half)
 
-    def _pack_wavenet_tensors(self, prefix, C, Lyr, steps, f0):
+    def _wino_form(self, C, cycle):
+        """Which Winograd form a denoiser's dilated convs take, decided ONCE at pack time from what the kernels accept: F(4,3)
+        (ss_wino43_gate / ss_wino43_gate16) needs C % 32 == 0 and dilations 2^(l % cycle) <= 64; otherwise F(2,3)."""
+        return 4 if (self.wino_m == 4 and C % 32 == 0 and (1 << (max(int(cycle), 1) - 1)) <= 64) else 2
+
+    def _pack_wavenet_tensors(self, prefix, C, Lyr, steps, f0, cycle=4):
         """Packed device tensors of one denoiser (DiffNet / DDiffNet), keyed like the ss_wavenet fields."""
         dev = self.p(prefix + ".mlp.0.weight").device
         t = {}
@@ -279,7 +284,7 @@ class StyleSingerHIP(torch.nn.Module):
             t[f"w_dil.{l}"], t[f"w_out.{l}"], t[f"b_out.{l}"] = dil.W, out.W, out.bias
             if self.use_wino:
                 wsrc = self.p(p + ".dilated_conv.weight").contiguous()
-                wt = L.wino43_weight(wsrc) if self.wino_m == 4 and C % 32 == 0 else L.wino_weight(wsrc)
+                wt = L.wino43_weight(wsrc) if self._wino_form(C, cycle) == 4 else L.wino_weight(wsrc)
                 t[f"w_dil_wino.{l}"] = L.pack_conv_weight(wt, interleave_half=C)
             if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
                 t[f"w_dil_h.{l}"] = L.to_bf16(dil.W)
@@ -313,7 +318,7 @@ class StyleSingerHIP(torch.nn.Module):
         """Build the ss_wavenet descriptor of one net, or of a PAIR of same-shaped nets (grouped launches: every
         weight tensor is stacked [2][...] so that net g sits gs_* floats after net 0)."""
         hp = self.hp
-        packs = [self._pack_wavenet_tensors(pf, C, Lyr, steps, f0) for pf in prefixes]
+        packs = [self._pack_wavenet_tensors(pf, C, Lyr, steps, f0, cycle) for pf in prefixes]
         keep = []
         net = L.WaveNet()
         net.C, net.L, net.cond_dim, net.dil_cycle, net.in_dim, net.out_dim, net.steps = C, Lyr, hp["hidden_size"], cycle, in_dim, out_dim, steps
@@ -343,7 +348,7 @@ class StyleSingerHIP(torch.nn.Module):
                 ptr_, gs = place(f"w_dil_wino.{l}")
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
-                net.wino_m = 4 if self.wino_m == 4 and C % 32 == 0 else 2
+                net.wino_m = self._wino_form(C, cycle)
             if self.bf16_hbm:
                 for key, arr in (("w_dil_h", net.w_dil_h), ("w_out_h", net.w_out_h)):
                     ptr_, gs = place(f"{key}.{l}")
@@ -477,8 +482,19 @@ class StyleSingerHIP(torch.nn.Module):
 
     def _pos(self, n, dev):
         if self._pos_table is None or self._pos_table.shape[0] < n:
+            # a blocking host->device copy (pageable source): complete on return, whichever stream built it, so forwards running
+            # on other streams may read it without an event. A table that is being REPLACED may still be read by a forward in flight
+            # on another stream: keep the old one alive until the device is idle.
+            old = self._pos_table
             self._pos_table = _sin_table(max(n, 2048), self.hp["hidden_size"]).to(dev)
+            if old is not None and old.is_cuda:
+                torch.cuda.synchronize(dev)
         return self._pos_table
+
+    def warm_caches(self, max_frames, device):
+        """Build the lazily created shared state (packed weights, sinusoidal table) BEFORE forwards fork onto side streams."""
+        self._ensure_packed()
+        self._pos(int(max_frames) + 2, torch.device(device))
 
     # ---- op helpers -----------------------------------------------------------------------------
     def _gemm(self, x, pk, out, B, T, *, taps=None, lens=None, act=L.ACT_NONE, pre_scale=1.0, R=None, mask_rows=True,

@@ -267,8 +267,11 @@ def synth_f0_hz(idx, Tr, seed=1234, unvoiced=0.2, dtype=torch.float64):
     return hz.to(dtype)
 
 
-def synth_batch(B, T, Tp, Tr, hp=None, seed=1234, first_index=0):
-    items = [synth_utterance(first_index + i, T, Tp, Tr, hp, seed) for i in range(B)]
+def synth_batch(B, T, Tp, Tr, hp=None, seed=1234, first_index=0, indices=None):
+    """`indices`: explicit utterance indices (e.g. a rank's shard rank, rank + W, ...); default first_index .. first_index + B - 1."""
+    idx = list(indices) if indices is not None else [first_index + i for i in range(B)]
+    assert len(idx) == B
+    items = [synth_utterance(i, T, Tp, Tr, hp, seed) for i in idx]
     return {k: torch.stack([it[k] for it in items]) for k in items[0]}
 
 

@@ -223,6 +223,14 @@ def test_bench_two_ranks_on_one_device_matches_single_process():
     one = _run_bench(["--gpus", "1", "--emulate-ranks", "2"] + small)
     assert one["n_gpus"] == 1 and len(one["checksum"]["mel_items"]) == 4
     assert two["checksum"]["mel_items"] == one["checksum"]["mel_items"], (two["checksum"], one["checksum"])
+    # three batches in flight on three HIP streams, four steps: the collectives of in-flight batches are issued from ONE
+    # communication stream (dist.comm_stream), so both ranks see them in the same order and the gathered batch is unchanged
+    multi = ["--steps", "4", "--warmup", "0", "--streams", "3", "--batch", "2", "--frames", "192", "--diff-steps", "4", "--no-cpu-baseline",
+             "--no-roofline", "--checksum"]
+    two3 = _run_bench(["--gpus", "2"] + multi, {"SS_BENCH_ONE_DEVICE": "1"})
+    one3 = _run_bench(["--gpus", "1", "--emulate-ranks", "2"] + multi)
+    assert two3["n_gpus"] == 2 and "3 HIP streams" in two3["config"]["step_overlap"]
+    assert two3["checksum"]["mel_items"] == one3["checksum"]["mel_items"], (two3["checksum"], one3["checksum"])
 
 
 def _gemm_bf16(A, Wp, **kw):

@@ -1,0 +1,46 @@
+#!/bin/bash
+# How every measured number and profile in this repo is produced. Run ON THE GPU BOX from the repo root:
+#     /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/reproduce.sh <section> [args]'
+# Output goes to gpurun_out/ (scratch, merged back by gpurun); what is quoted in DESIGN.md / README.md is copied to profiles/.
+# Sections:
+#   tests            python -m pytest tests -m gpu            (the parity tests proper; measured distances -> parity_measurements.jsonl)
+#   bench [args]     python bench.py [args]                   (the driver's line; default = c2 + cpu_baseline + secondary c5 / c4)
+#   profile [args]   rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary [args]`
+#   pmc-gate         PMC passes on the dominant kernel launch (one counter block per pass, --kernel-trace --pmc only)
+#   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs)
+#   ablate-gate16    timing ablations of the 16x16-tile gate kernel (debug builds: tools/ablate_g16.sh build, in the container)
+#   ubench           micro-benchmarks behind DESIGN.md §3.0 (VALU beside fp32 MFMA, 16x16x4 issue rate, DPP / LDS-DMA probes)
+cd ${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+R=$PWD
+mkdir -p gpurun_out
+sec=$1; shift
+case "$sec" in
+  tests)
+    python -m pytest tests -x -q -m gpu -s 2>&1 | tail -60 | tee gpurun_out/tests.log ;;
+  bench)
+    python bench.py "$@" 2>&1 | tail -3 | tee gpurun_out/bench.json ;;
+  profile)
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- \
+       python $R/bench.py --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $R/gpurun_out/prof_bench.log 2>&1)
+    grep -E "^\{" gpurun_out/prof_bench.log | cut -c1-600
+    head -30 "$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)" | cut -c1-220 ;;
+  pmc-gate)
+    K="python $R/tools/kbench.py --which wino43_16 --net mel --iters 20 --mt ${1:-3}"
+    bash tools/pmc.sh g16_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -- $K
+    bash tools/pmc.sh g16_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS -- $K
+    bash tools/pmc.sh g16_grbm GRBM_GUI_ACTIVE -- $K
+    bash tools/pmc.sh g16_fetch FETCH_SIZE -- $K
+    bash tools/pmc.sh g16_write WRITE_SIZE -- $K
+    bash tools/pmc.sh g16_tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -- $K ;;
+  kbench)
+    python tools/kbench.py --which wino43_16 --iters 60 --mt=-1,3,2
+    python tools/kbench.py --which resskip --iters 60 --tile 3
+    python tools/kbench.py --which voc --iters 30 ;;
+  ablate-gate16)
+    bash tools/ablate_g16.sh run ;;
+  ubench)
+    for f in mfma_valu mfma16 glds_probe; do
+      hipcc --offload-arch=gfx950 -O3 tools/ubench/$f.hip -o /tmp/$f 2>/dev/null && /tmp/$f
+    done ;;
+  *) echo "unknown section '$sec'"; sed -n 2,15p $0; exit 2 ;;
+esac
