@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 9 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16 */
+#define SS_ABI_VERSION 9 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -40,7 +40,8 @@ int ss_struct_sizes(int64_t* out, int n);
 /* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
  * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3); "gate16" = 0|1|2|3 tiling of the F(4,3) gate launches inside the
  * denoiser loops (1 = per-launch pick, default; 0 = 32x32x2 tiles; 2|3 = force 16x16x4 tiles of 16*MT quads); "res_tile" /
- * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice) */
+ * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice); "res16" = 0|1|4|6|8
+ * residual-half projection on ss_gemm16_res (1 = on, row tile picked per launch, default; 0 = ss_conv_gemm; 4|6|8 = force 16*mt rows) */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -133,6 +134,14 @@ typedef struct ss_conv_gemm_args {
 } ss_conv_gemm_args;
 
 int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
+
+/* Small-K GEMM on 16x16x4 fp32 MFMA tiles for the residual half of the denoisers' output projection (net.py:75-77, deferred-skip
+ * form):  C = (R + A . W^T + bias) * post_scale,  K = Cin = Kp in {192, 256}, one tap. A workgroup is 16*mt rows x 64 columns
+ * (mt = 4 | 6 | 8, 0 = ss_gemm16_pick); the wave's whole weight slice is register-resident, the A tile arrives by LDS-DMA.
+ * Uses A, lda, Cin, Kp, lens, B, T, W, N, Np, bias, R, ldr, C, ldc, post_scale, mask_rows, batch strides and the group fields of
+ * ss_conv_gemm_args; C may alias R (in-place residual update). Same result as ss_conv_gemm(epi STORE + R) up to the K order. */
+int ss_gemm16_res(const ss_conv_gemm_args* args, int mt, void* stream);
+int ss_gemm16_pick(int B, int T, int N);
 
 /* Winograd F(2,3) form of the 3-tap dilated conv + SS_EPI_GATE epilogue (net.py:66-73): same arguments as the
  * direct call except that W is the TRANSFORMED weight packed as a 4-"tap" tensor (ss_wino_weight_transform then

@@ -46,7 +46,9 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     16*MT quads when that fills the chip better, else the 32x32x2 kernel); 0 = always the 32x32x2 kernel; 2 / 3 = force MT.
 //   res_tile / skip_tile: SS_TILE_* override of the residual-half projection / the K = L*C skip GEMM of the denoiser loops
 //     (0 = the built-in choice); validated by ss_set_tuning.
-struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; };
+//   res16: 1 (default) = the residual-half projection of the deferred-skip loops runs on ss_gemm16_res (16x16x4 tiles, LDS-DMA);
+//     0 = ss_conv_gemm; 4 / 6 / 8 = force the row tile.
+struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; };
 extern SsTuning g_ss_tuning;
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)

@@ -305,7 +305,12 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       o.w_group_stride = net->gs_w_out;
       o.bias_group_stride = net->gs_b_out;
     }
-    SS_PROPAGATE(ss_conv_gemm(&o, stream));
+    const int r16 = g_ss_tuning.res16;
+    if (defer && r16 != 0 && !net->mfma_bf16 && (C == 192 || C == 256)) {
+      SS_PROPAGATE(ss_gemm16_res(&o, r16 == 1 ? 0 : r16, stream));   // 16x16x4 tiles, balanced single round (gemm16.hip)
+    } else {
+      SS_PROPAGATE(ss_conv_gemm(&o, stream));
+    }
   }
   if (net->w_skipall && !hmode(net)) {  // S = sum_l skip_l = [g_0 | g_1 | ... | g_{L-1}] . [W_skip_0 ; ... ; W_skip_{L-1}]^T + sum_l b_skip_l
     ss_conv_gemm_args k = base_args(B, T, lens);

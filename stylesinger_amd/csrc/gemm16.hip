@@ -1,0 +1,248 @@
+// Small-K fp32 GEMM on 16x16x4 MFMA tiles for the SINGLE-ROUND launches of the denoiser loops: the residual half of the output
+// projection  x <- (x + g . W_res^T + b) / sqrt(2)  (modules/diff/net.py:75-77, deferred-skip form: N = C columns), 3000 launches per
+// BASELINE-config-2 step with K = N = 256 (mel) or 192 (f0 pair).
+//
+// Why not the generic conv_gemm_kernel<64,64> it replaces there (round 2: 22.6 us per launch for 10 us of matrix time):
+//   * tile count: 64-row tiles give 768 workgroups for the mel launch and 1152 for the f0 pair - on 768 resident slots the f0 launch
+//     runs 1.5 rounds. Here a workgroup is 16*MT rows x 64 columns (4 waves x 16 columns); MT = 6 (96 rows) makes an 8 s utterance
+//     exactly 16 row tiles: mel 512 workgroups (2 per CU), f0 pair 768 (3 per CU), one balanced round each.
+//   * K is small, so the WHOLE weight slice of a wave (16 columns x K) is fetched once into registers before the loop (48 / 64 VGPRs):
+//     the loop issues no weight loads and needs no LDS for B.
+//   * the A tile goes global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs, no ds_write, no VALU): each DMA instruction
+//     moves 8 rows x 128 B (full lines); the LDS image is lane-linear, so the XOR slot swizzle is applied on the SOURCE address.
+//     A ring of 3 K chunks is in flight with counted s_waitcnt vmcnt + a raw s_barrier per chunk (a __syncthreads() would drain the
+//     DMA queue: cdna_hip_programming.md "Pipelining across barriers").
+//   * epilogue operands (the residual stream tile) are fetched at kernel entry, addresses are one VGPR base + SGPR offsets, stores are
+//     buffer stores (rows >= T dropped by the range check).
+// Arithmetic: exact fp32 products, fp32 accumulation; the K order inside an accumulator differs from the 32x32x2 kernel
+// (tests/test_gpu_round3.py compares with torch fp32 and with ss_conv_gemm).
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LD = BK;
+constexpr int BN = 64;
+constexpr int NBUF = 3;
+
+// same 16-byte slot swizzle as the 16x16 gate kernel (conflict-free ds_read_b128 for lanes (row = l & 15, slots 2(l>>4), 2(l>>4)+1))
+__device__ __forceinline__ int swz16(int row) { return ((row >> 1) & 7) ^ ((((row >> 2) ^ (row >> 3)) & 1) << 1); }
+
+// s_waitcnt vmcnt(N), other counters untouched (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4, expcnt imm[6:4], lgkmcnt imm[11:8])
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+template <int MT, int KCH>
+__global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
+  constexpr int BM = 16 * MT;
+  constexpr int GROUPS = BM / 8;                 // DMA instructions per chunk (8 rows x 128 B each)
+  constexpr int DPW = (GROUPS + 3) / 4;          // ... per wave
+  static_assert(GROUPS % 4 == 0, "row groups must split evenly over the 4 waves");
+  __shared__ __attribute__((aligned(16))) float As0[BM * LD];
+  __shared__ __attribute__((aligned(16))) float As1[BM * LD];
+  __shared__ __attribute__((aligned(16))) float As2[BM * LD];
+
+  const int id = blockIdx.x;
+  const int grp = id / (8 * n_tiles);
+  const int rem = id % (8 * n_tiles);
+  const int mt = grp * 8 + (rem & 7);
+  const int nt = rem >> 3;
+  if (mt >= m_tiles) return;
+  const int b = mt / m_tiles_per_item;
+  const int t0 = (mt % m_tiles_per_item) * BM;
+  const int n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kg = lane >> 4;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+
+  auto uniform_ptr = [](const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.W + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane(a.Np * a.Kp * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<float*>(a.R) + (int64_t)b * a.r_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldr * 4)),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 4)), 0x00020000);
+
+  // ---- the wave's weight slice: column n0 + 16 w + lc, K floats [32 j + 8 kg, +8) of every chunk j -> registers, once
+  const int col = n0 + 16 * wave + lc;
+  const int w_voff = (col * a.Kp + kg * 8) * 4;
+  float4 bw[KCH][2];
+#pragma unroll
+  for (int j = 0; j < KCH; ++j) {
+    bw[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, j * (BK * 4), 0));
+    bw[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, j * (BK * 4), 0));
+  }
+  // ---- epilogue operands: residual-stream tile (rows 16 m + 4 kg + r, column col) and the bias
+  const bool col_ok = col < a.N;
+  const int oob = col_ok ? 0 : (int)0x80000000;
+  const int r_base = ((t0 + 4 * kg) * a.ldr + col) * 4 + oob;
+  float rv[MT][4];   // fetched inside the loop (chunk KCH-3), into the registers the consumed weight chunks have freed
+  const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + col] : 0.f;
+
+  // ---- A tile by LDS-DMA. DMA instruction (wave w, j): rows 8 (w + 4 j) .. +8 of the tile; lane i lands at byte 16 i of that 1-KiB
+  // piece = (row i >> 3, physical slot i & 7), so it FETCHES logical slot (i & 7) ^ swz16(row).
+  int a_voff[DPW];
+#pragma unroll
+  for (int j = 0; j < DPW; ++j) {
+    const int row = 8 * (wave + 4 * j) + (lane >> 3);
+    a_voff[j] = ((t0 + row) * a.lda + (((lane & 7) ^ swz16(row)) << 2)) * 4;   // rows >= len are out of range: the DMA writes zeros
+  }
+  auto dma = [&](float* buf, int c) {
+#pragma unroll
+    for (int j = 0; j < DPW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(buf + (wave + 4 * j) * 8 * LD), 16, a_voff[j],
+                                               c * (BK * 4), 0, 0);
+  };
+  int a_rd[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_rd[m][h] = (16 * m + lc) * LD + (((2 * kg + h) ^ swz16(16 * m + lc)) << 2);
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+
+  float* const bufs[NBUF] = {As0, As1, As2};
+  __builtin_amdgcn_sched_barrier(0);   // the counted waits below rely on the DMA pieces being issued in chunk order
+  dma(bufs[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (KCH > 1) dma(bufs[1], 1);
+  __builtin_amdgcn_sched_barrier(0);
+  // chunk c: wait for MY pieces of chunk c (the DPW instructions of chunk c+1 may stay in flight), barrier (everyone's pieces of chunk c
+  // have landed; everyone is done reading chunk c-1), refill the slot chunk c-1 used with chunk c+2, fragments, MFMAs.
+  auto chunk = [&](auto ctag) {
+    constexpr int c = decltype(ctag)::value;
+    // outstanding VMEM ops younger than my pieces of chunk c: the DPW pieces of chunk c+1, plus - in chunk RC+1 - the 4 MT residual loads
+    constexpr int RC = KCH >= 3 ? KCH - 3 : 0;   // the chunk that issues the residual-stream loads (before its DMA)
+    if constexpr (c + 1 >= KCH) wait_vmcnt<0>();
+    else if constexpr (c == RC + 1 && KCH >= 3) wait_vmcnt<DPW + 4 * MT>();
+    else wait_vmcnt<DPW>();
+    __builtin_amdgcn_s_barrier();
+    const float* Ac = bufs[c % NBUF];
+    float4 af[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      af[m][0] = *reinterpret_cast<const float4*>(Ac + a_rd[m][0]);
+      af[m][1] = *reinterpret_cast<const float4*>(Ac + a_rd[m][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all fragment reads of the chunk are in flight before anything else issues
+    if constexpr (c == RC) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, r_base, (16 * m + r) * a.ldr * 4, 0));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (c + 2 < KCH) dma(bufs[(c + 2) % NBUF], c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    // MT independent accumulators per K step: consecutive MFMAs never touch the same one (40-cycle dependent latency, 32-cycle issue)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 bf = bw[c][h];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].x, bf.x, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].y, bf.y, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].z, bf.z, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].w, bf.w, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto run = [&](auto... cs) { (chunk(cs), ...); };
+  if constexpr (KCH == 6)
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
+        std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+  else
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
+        std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{});
+
+  // ---- epilogue: x <- (x + v + bias) * post_scale, rows >= len written as 0 (mask_rows), rows >= T dropped by the range check
+  const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+  const int c_base = ((t0 + 4 * kg) * a.ldc + col) * 4 + oob;
+  const bool interior = t0 + BM <= row_lim;   // block-uniform
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float o = (rv[m][r] + (acc[m][r] + bs)) * a.post_scale;
+      if (!interior && t0 + 16 * m + 4 * kg + r >= row_lim) o = 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsrc_c, c_base, (16 * m + r) * a.ldc * 4, 0);
+    }
+}
+
+template <int MT, int KCH>
+int launch_res(const ss_conv_gemm_args& a, hipStream_t stream) {
+  constexpr int BM = 16 * MT;
+  const int m_tiles_per_item = ss_cdiv(a.T, BM);
+  const int m_tiles = m_tiles_per_item * a.B;
+  const int n_tiles = ss_cdiv(a.N, BN);
+  const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
+  hipLaunchKernelGGL((gemm16_res_kernel<MT, KCH>), dim3(grid), dim3(256), 0, stream, a, m_tiles_per_item, m_tiles, n_tiles);
+  return 0;
+}
+
+}  // namespace
+
+// row-tile count (16*mt rows per workgroup) for a launch of B items x T rows x N columns: fewest workgroup layers per CU x rows per tile
+extern "C" int ss_gemm16_pick(int B, int T, int N) {
+  const int n_tiles = ss_cdiv(N, BN);
+  int best = 4;
+  long best_cost = -1;
+  for (int mt = 8; mt >= 4; mt -= 2) {   // 128, 96, 64 rows
+    const long wgs = (long)ss_cdiv(T, 16 * mt) * B * n_tiles;
+    const long cost = (long)mt * ss_cdiv(wgs, 256);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = mt;
+    }
+  }
+  return best;
+}
+
+extern "C" int ss_gemm16_res(const ss_conv_gemm_args* args, int mt, void* stream) {
+  SS_CHECK_ARG(args != nullptr, "ss_gemm16_res: null args");
+  const ss_conv_gemm_args& a = *args;
+  SS_CHECK_ARG(a.A && a.W && a.C && a.R, "ss_gemm16_res: null A/W/C/R");
+  SS_CHECK_ARG(a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm16_res: one tap at offset 0 only");
+  SS_CHECK_ARG(a.Kp == a.Cin && (a.Kp == 192 || a.Kp == 256) && (a.lda & 3) == 0, "ss_gemm16_res: K=%d must be 192 or 256 (= Kp), lda %% 4 == 0", a.Cin);
+  SS_CHECK_ARG(a.N > 0 && a.N <= a.Np && (a.Np & 15) == 0, "ss_gemm16_res: bad N=%d Np=%d", a.N, a.Np);
+  SS_CHECK_ARG(a.a_scale == 1.0f && a.a_lrelu == 1.0f && a.a_bias == nullptr && a.mfma_bf16 == 0, "ss_gemm16_res: no A prologue, fp32 only");
+  SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (int64_t)a.T * a.ldr * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 4 < (1ll << 31) &&
+                   (int64_t)a.Np * a.Kp * 4 < (1ll << 31), "ss_gemm16_res: item too large for 32-bit offsets");
+  SS_CHECK_ARG(mt == 0 || mt == 4 || mt == 6 || mt == 8, "ss_gemm16_res: mt=%d must be 0 (auto), 4, 6 or 8", mt);
+  if (mt == 0) mt = ss_gemm16_pick(a.B, a.T, a.N);
+  hipStream_t s = (hipStream_t)stream;
+  const bool k6 = a.Kp == 192;
+  switch (mt) {
+    case 4: k6 ? launch_res<4, 6>(a, s) : launch_res<4, 8>(a, s); break;
+    case 6: k6 ? launch_res<6, 6>(a, s) : launch_res<6, 8>(a, s); break;
+    default: k6 ? launch_res<8, 6>(a, s) : launch_res<8, 8>(a, s); break;
+  }
+  SS_CHECK_LAUNCH("ss_gemm16_res");
+  return SS_OK;
+}

@@ -156,7 +156,7 @@ def load():
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
-    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
+    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_RES16", b"res16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")
@@ -245,6 +245,12 @@ def wino43_gate16(A, Wt, out, *, dilation, mt=0, **kw):
     kw.setdefault("epi", EPI_GATE)
     a = _fill_args(A, Wt, out, **kw)
     check(load().ss_wino43_gate16(C.byref(a), int(dilation), int(mt), stream_ptr()), "ss_wino43_gate16")
+
+
+def gemm16_res(A, W, out, *, mt=0, **kw):
+    """Residual projection C = (R + A.W^T + bias) * post_scale on 16x16x4 tiles (ss_gemm16_res); same keyword arguments as conv_gemm."""
+    a = _fill_args(A, W, out, **kw)
+    check(load().ss_gemm16_res(C.byref(a), int(mt), stream_ptr()), "ss_gemm16_res")
 
 
 def wino43_weight(w):

@@ -196,3 +196,42 @@ def test_preprocess_batch_feeds_infer_batch_from_device_buffers(golden_dir):
     print("preprocess_batch vs oracles:", worst)
     record_measurement("preprocess_batch_vs_oracles", **worst)
     assert worst["mel"] <= 5e-5 and worst["f0"] <= 2e-6 and worst["mel40"] <= 1e-5 and worst["emo"] <= 2e-5, worst
+
+
+@pytest.mark.parametrize("mt", [0, 4, 6, 8])
+@pytest.mark.parametrize("C,B,T,groups", [(256, 3, 333, 1), (192, 4, 200, 2), (256, 1, 1536, 1), (192, 2, 97, 1)])
+def test_gemm16_res_matches_torch_and_the_generic_kernel(C, B, T, groups, mt):
+    """ss_gemm16_res (16x16x4 tiles, LDS-DMA A ring, register-resident weights): x <- (x + g . W_res^T + b) / sqrt(2) in place, ragged
+    lens (rows past lens written as 0, the DMA zero-fills rows past lens), grouped weight sets, only the first C of the 2C packed rows
+    used - vs torch float64 and vs ss_conv_gemm's RESSKIP epilogue."""
+    import math
+    from stylesinger_amd import lib as L
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + T + mt)
+    Lyr = 3
+    ga = torch.randn(B, T, Lyr * C, generator=g)           # gate outputs of all layers: the operand is a column slice (lda = L*C)
+    x = torch.randn(B, T, C, generator=g)
+    ws = [torch.randn(2 * C, C, 1, generator=g) / math.sqrt(C) for _ in range(groups)]
+    bs = [torch.randn(2 * C, generator=g) * 0.1 for _ in range(groups)]
+    lens = torch.tensor([max(1, T - 13 * i) for i in range(B)], dtype=torch.int32)
+    s = 1.0 / math.sqrt(2.0)
+    ref = torch.zeros(B, T, C)
+    for i in range(B):
+        n, gi = int(lens[i]), i * groups // B
+        v = ga[i, :n, C:2 * C].double() @ ws[gi][:C, :, 0].double().t() + bs[gi][:C].double()
+        ref[i, :n] = ((x[i, :n].double() + v) * s).float()
+    Wp = torch.stack([L.pack_conv_weight(w.to(dv)) for w in ws]).contiguous()
+    bp = torch.stack([L.pack_bias(b_.to(dv)) for b_ in bs]).contiguous()
+    kw = dict(B=B, T=T, Cin=C, N=C, Np=Wp.shape[1], Kp=Wp.shape[2], lda=Lyr * C, a_bs=T * Lyr * C, lens=lens.to(dv), bias=bp, ldr=C, ldc=C,
+              post_scale=s, mask_rows=True, group_size=(B // groups if groups > 1 else 0), w_gs=Wp[0].numel(), bias_gs=bp[0].numel())
+    A = ga.to(dv)[:, :, C:]
+    x1 = x.to(dv).clone()
+    L.gemm16_res(A, Wp, x1, mt=mt, R=x1, **kw)
+    err = (x1.cpu() - ref).abs().max().item()
+    assert err <= 2e-5, err
+    for i in range(B):
+        assert torch.all(x1[i, int(lens[i]):] == 0)
+    x2 = x.to(dv).clone()
+    S = torch.zeros(B, T, C, device=dv)
+    L.conv_gemm(A, Wp, x2, epi=L.EPI_RESSKIP, R=x2, Nh=C, C2=S, ldc2=C, c2_bs=T * C, tile=3, **kw)
+    assert (x1 - x2).abs().max().item() <= 1e-5

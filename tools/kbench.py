@@ -132,6 +132,24 @@ def main():
                 s = timeit(fw16, a.iters)
                 fl = 2.0 * Bn * T * 3 * C * 2 * C
                 res.append((f"{name} F(4,3) gate {'32x32x2 tiles' if mt < 0 else '16x16x4 mt=%d' % mt} rows={Bn * T}", s, fl))
+        if a.which in ("res16", "all"):
+            Bn = B * (2 if name == "f0" and a.pair else 1)
+            GAn = torch.randn(Bn, T, Lyr * C, device=d)
+            Xn = torch.randn(Bn, T, C, device=d)
+            Sn = torch.zeros(Bn, T, C, device=d)
+            ln = torch.full((Bn,), T, device=d, dtype=torch.int32)
+            kwr = dict(B=Bn, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lda=Lyr * C, a_bs=T * Lyr * C, lens=ln, bias=bop, ldr=C, ldc=C, post_scale=0.7071)
+            for mt in [int(v) for v in a.mt.split(",")]:
+                def fr():
+                    layer[0] = (layer[0] + 1) % Lyr
+                    Al = GAn[:, :, layer[0] * C:]
+                    if mt < 0:
+                        L.conv_gemm(Al, Wo, Xn, epi=L.EPI_RESSKIP, R=Xn, Nh=C, C2=Sn, ldc2=C, c2_bs=T * C, tile=3, **kwr)
+                    else:
+                        L.gemm16_res(Al, Wo, Xn, mt=mt, R=Xn, **kwr)
+                s = timeit(fr, a.iters)
+                fl = 2.0 * Bn * T * C * C
+                res.append((f"{name} residual projection {'conv_gemm 64x64' if mt < 0 else 'gemm16 mt=%d' % mt} rows={Bn * T} K=N={C}", s, fl))
         if a.which in ("resskip", "all"):
             f = lambda: L.conv_gemm(G, Wo, X, B=B, T=T, Cin=C, N=2 * C, Np=2 * C, Kp=C, lens=lens, epi=L.EPI_RESSKIP, bias=bop, Nh=C,
                                     R=X, ldr=C, ldc=C, post_scale=0.7071, C2=S, ldc2=C, c2_bs=T * C, accumulate=True, tile=a.tile)
