@@ -91,6 +91,10 @@ def build(verbose=True, jobs=None):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-6000:])
+    # a shared library links with undefined symbols; make sure this one resolves when it is loaded (e.g. a kernel whose host launch
+    # stub the compiler dropped shows up only here)
+    import ctypes
+    ctypes.CDLL(LIB)
     if verbose:
         print("[stylesinger_amd.build] %d sources, %d recompiled -> %s" % (len(srcs), len(rebuilt), LIB))
     return LIB

@@ -38,6 +38,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
+// LDS-DMA of 64 x 16 bytes: lane i's 16 bytes land at lds_dst + 16 i (wave-uniform destination, per-lane source offset).
+// (A __device__ helper on purpose: with the builtin written directly inside the templated __global__ body, the host pass of hipcc
+//  (ROCm 7.2) silently drops the kernel's launch stub and the library no longer links.)
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+
 template <int MT, int KCH>
 __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
   constexpr int BM = 16 * MT;
@@ -106,8 +113,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
   auto dma = [&](float* buf, int c) {
 #pragma unroll
     for (int j = 0; j < DPW; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(buf + (wave + 4 * j) * 8 * LD), 16, a_voff[j],
-                                               c * (BK * 4), 0, 0);
+      glds16(rsrc_a, buf + (wave + 4 * j) * 8 * LD, a_voff[j], c * (BK * 4));
   };
   int a_rd[MT][2];
 #pragma unroll
