@@ -40,8 +40,9 @@ int ss_struct_sizes(int64_t* out, int n);
 /* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
  * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3); "gate16" = 0|1|2|3 tiling of the F(4,3) gate launches inside the
  * denoiser loops (1 = per-launch pick, default; 0 = 32x32x2 tiles; 2|3 = force 16x16x4 tiles of 16*MT quads); "res_tile" /
- * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice); "res16" = 0|1|4|6|8
- * residual-half projection on ss_gemm16_res (1 = on, row tile picked per launch, default; 0 = ss_conv_gemm; 4|6|8 = force 16*mt rows) */
+ * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice); "res16" / "skip16" = 0|1|4|6|8
+ * residual-half projection on ss_gemm16_res / skip GEMM on ss_gemm16_store (1 = on, row tile picked per launch, default; 0 =
+ * ss_conv_gemm; 4|6|8 = force 16*mt rows) */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -142,6 +143,10 @@ int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
  * ss_conv_gemm_args; C may alias R (in-place residual update). Same result as ss_conv_gemm(epi STORE + R) up to the K order. */
 int ss_gemm16_res(const ss_conv_gemm_args* args, int mt, void* stream);
 int ss_gemm16_pick(int B, int T, int N);
+/* Streaming form for large K (the K = L*C skip GEMM of the deferred-skip loops): C = act(A . W^T + bias), act none | relu, rows >=
+ * lens[b] written as 0 when mask_rows. Both operands arrive by LDS-DMA (shared A ring, per-wave B ring), no VALU work in the loop.
+ * K = Cin = Kp multiple of 32, one tap; same 16*mt x 64 tiles as ss_gemm16_res. */
+int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream);
 
 /* Winograd F(2,3) form of the 3-tap dilated conv + SS_EPI_GATE epilogue (net.py:66-73): same arguments as the
  * direct call except that W is the TRANSFORMED weight packed as a 4-"tap" tensor (ss_wino_weight_transform then

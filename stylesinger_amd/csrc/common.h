@@ -48,7 +48,8 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     (0 = the built-in choice); validated by ss_set_tuning.
 //   res16: 1 (default) = the residual-half projection of the deferred-skip loops runs on ss_gemm16_res (16x16x4 tiles, LDS-DMA);
 //     0 = ss_conv_gemm; 4 / 6 / 8 = force the row tile.
-struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; };
+//   skip16: the same switch for the K = L*C skip GEMM (ss_gemm16_store).
+struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; };
 extern SsTuning g_ss_tuning;
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)

@@ -334,12 +334,14 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       k.w_group_stride = net->gs_w_skipall;
       k.bias_group_stride = net->gs_b_skipall;
     }
+    const int s16 = g_ss_tuning.skip16;
+    const bool use16 = s16 != 0 && !net->mfma_bf16 && k.Kp == k.Cin;   // 16x16x4 tiles, both operands by LDS-DMA (gemm16.hip)
     if (net->skipall_folded) {  // w_skipall already carries skip_projection / sqrt(L): this GEMM + ReLU is the stack's output
       k.act = SS_ACT_RELU;
       k.C = w.G;
-      return ss_conv_gemm(&k, stream);
+      return use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream);
     }
-    SS_PROPAGATE(ss_conv_gemm(&k, stream));
+    SS_PROPAGATE(use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream));
   }
   // x = relu(skip_projection(sum(skip) / sqrt(L)))   (net.py:124-127)
   ss_conv_gemm_args s = base_args(B, T, lens);

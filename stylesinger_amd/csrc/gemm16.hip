@@ -201,6 +201,145 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Streaming form for large K (the K = L*C skip GEMM of the deferred-skip loops: 5120 / 1920): C = act(A . W^T + bias).
+// Both operands arrive by LDS-DMA, nothing is staged through VGPRs and the loop has no VALU work at all:
+//   A ring: 2 buffers of [16 MT rows][32 floats], filled by all four waves (the tile is shared);
+//   B ring: 2 buffers of [16 columns][32 floats] PER WAVE (a wave only ever reads its own 16 columns, so its pieces need no barrier).
+// Chunk c: wait for my pieces of chunk c (vmcnt 0: nothing younger is in flight), barrier, issue the DMA of chunk c+1 into the buffers
+// chunk c-1 used, read the fragments of chunk c, 8 MT MFMAs. One chunk of MFMA time (x the waves sharing the SIMD) covers the DMA latency.
+template <int MT>
+__global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
+  constexpr int BM = 16 * MT;
+  constexpr int GROUPS = BM / 8;
+  constexpr int DPW = GROUPS / 4;
+  static_assert(GROUPS % 4 == 0, "row groups must split evenly over the 4 waves");
+  __shared__ __attribute__((aligned(16))) float A0[BM * LD];
+  __shared__ __attribute__((aligned(16))) float A1[BM * LD];
+  __shared__ __attribute__((aligned(16))) float B0[4 * 16 * LD];
+  __shared__ __attribute__((aligned(16))) float B1[4 * 16 * LD];
+
+  const int id = blockIdx.x;
+  const int grp = id / (8 * n_tiles);
+  const int rem = id % (8 * n_tiles);
+  const int mt = grp * 8 + (rem & 7);
+  const int nt = rem >> 3;
+  if (mt >= m_tiles) return;
+  const int b = mt / m_tiles_per_item;
+  const int t0 = (mt % m_tiles_per_item) * BM;
+  const int n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kg = lane >> 4;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+  const int kchunks = a.Kp / BK;
+
+  auto uniform_ptr = [](const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.W + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane(a.Np * a.Kp * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 4)), 0x00020000);
+
+  int a_voff[DPW], b_voff[2];
+#pragma unroll
+  for (int j = 0; j < DPW; ++j) {
+    const int row = 8 * (wave + 4 * j) + (lane >> 3);
+    a_voff[j] = ((t0 + row) * a.lda + (((lane & 7) ^ swz16(row)) << 2)) * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {   // the wave's 16 weight rows (= output columns) in two pieces of 8 rows x 128 B; rows >= Np read 0
+    const int row = 8 * j + (lane >> 3);
+    b_voff[j] = ((n0 + 16 * wave + row) * a.Kp + (((lane & 7) ^ swz16(row)) << 2)) * 4;
+  }
+  auto dma = [&](float* Abuf, float* Bbuf, int c) {
+    const int so = c * (BK * 4);
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) glds16(rsrc_a, Abuf + (wave + 4 * j) * 8 * LD, a_voff[j], so);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(rsrc_w, Bbuf + (wave * 16 + 8 * j) * LD, b_voff[j], so);
+  };
+  const int rd0 = lc * LD + (((2 * kg) ^ swz16(lc)) << 2), rd1 = lc * LD + (((2 * kg + 1) ^ swz16(lc)) << 2);
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+
+  auto chunk = [&](const float* Ac, const float* Bc, float* An, float* Bn, int c, bool more) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    float4 af[MT][2], bf[2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      af[m][0] = *reinterpret_cast<const float4*>(Ac + 16 * m * LD + rd0);
+      af[m][1] = *reinterpret_cast<const float4*>(Ac + 16 * m * LD + rd1);
+    }
+    bf[0] = *reinterpret_cast<const float4*>(Bc + wave * 16 * LD + rd0);
+    bf[1] = *reinterpret_cast<const float4*>(Bc + wave * 16 * LD + rd1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) dma(An, Bn, c + 1);   // wave-uniform branch
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].x, bf[h].x, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].y, bf[h].y, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].z, bf[h].z, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].w, bf[h].w, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  dma(A0, B0, 0);
+  int c = 0;
+  for (; c + 2 <= kchunks; c += 2) {
+    chunk(A0, B0, A1, B1, c, true);
+    chunk(A1, B1, A0, B0, c + 1, c + 2 < kchunks);
+  }
+  if (c < kchunks) chunk(A0, B0, A1, B1, c, false);
+
+  const int col = n0 + 16 * wave + lc;
+  const bool col_ok = col < a.N;
+  const int oob = col_ok ? 0 : (int)0x80000000;
+  const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + col] : 0.f;
+  const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+  const int c_base = ((t0 + 4 * kg) * a.ldc + col) * 4 + oob;
+  const bool relu = a.act == SS_ACT_RELU;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float o = acc[m][r] + bs;
+      if (relu) o = fmaxf(o, 0.f);
+      if (t0 + 16 * m + 4 * kg + r >= row_lim) o = 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsrc_c, c_base, (16 * m + r) * a.ldc * 4, 0);
+    }
+}
+
+template <int MT>
+int launch_store(const ss_conv_gemm_args& a, hipStream_t stream) {
+  constexpr int BM = 16 * MT;
+  const int m_tiles_per_item = ss_cdiv(a.T, BM);
+  const int m_tiles = m_tiles_per_item * a.B;
+  const int n_tiles = ss_cdiv(a.N, BN);
+  const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
+  hipLaunchKernelGGL(gemm16_store_kernel<MT>, dim3(grid), dim3(256), 0, stream, a, m_tiles_per_item, m_tiles, n_tiles);
+  return 0;
+}
+
 template <int MT, int KCH>
 int launch_res(const ss_conv_gemm_args& a, hipStream_t stream) {
   constexpr int BM = 16 * MT;
@@ -250,5 +389,29 @@ extern "C" int ss_gemm16_res(const ss_conv_gemm_args* args, int mt, void* stream
     default: k6 ? launch_res<8, 6>(a, s) : launch_res<8, 8>(a, s); break;
   }
   SS_CHECK_LAUNCH("ss_gemm16_res");
+  return SS_OK;
+}
+
+extern "C" int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream) {
+  SS_CHECK_ARG(args != nullptr, "ss_gemm16_store: null args");
+  const ss_conv_gemm_args& a = *args;
+  SS_CHECK_ARG(a.A && a.W && a.C, "ss_gemm16_store: null A/W/C");
+  SS_CHECK_ARG(a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm16_store: one tap at offset 0 only");
+  SS_CHECK_ARG(a.Kp == a.Cin && (a.Kp % BK) == 0 && (a.lda & 3) == 0, "ss_gemm16_store: K=%d must equal Kp and be a multiple of 32, lda %% 4 == 0", a.Cin);
+  SS_CHECK_ARG(a.N > 0 && a.N <= a.Np, "ss_gemm16_store: bad N=%d Np=%d", a.N, a.Np);
+  SS_CHECK_ARG(a.a_scale == 1.0f && a.a_lrelu == 1.0f && a.a_bias == nullptr && a.mfma_bf16 == 0 && a.pre_scale == 1.0f && a.post_scale == 1.0f &&
+                   a.R == nullptr && !a.accumulate && (a.act == SS_ACT_NONE || a.act == SS_ACT_RELU),
+               "ss_gemm16_store: plain C = act(A.W^T + bias) only (act none | relu), fp32");
+  SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 4 < (1ll << 31) && (int64_t)a.Np * a.Kp * 4 < (1ll << 31),
+               "ss_gemm16_store: item too large for 32-bit offsets");
+  SS_CHECK_ARG(mt == 0 || mt == 4 || mt == 6 || mt == 8, "ss_gemm16_store: mt=%d must be 0 (auto), 4, 6 or 8", mt);
+  if (mt == 0) mt = ss_gemm16_pick(a.B, a.T, a.N);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mt) {
+    case 4: launch_store<4>(a, s); break;
+    case 6: launch_store<6>(a, s); break;
+    default: launch_store<8>(a, s); break;
+  }
+  SS_CHECK_LAUNCH("ss_gemm16_store");
   return SS_OK;
 }

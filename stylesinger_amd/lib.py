@@ -156,7 +156,7 @@ def load():
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
-    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_RES16", b"res16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
+    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")
@@ -251,6 +251,12 @@ def gemm16_res(A, W, out, *, mt=0, **kw):
     """Residual projection C = (R + A.W^T + bias) * post_scale on 16x16x4 tiles (ss_gemm16_res); same keyword arguments as conv_gemm."""
     a = _fill_args(A, W, out, **kw)
     check(load().ss_gemm16_res(C.byref(a), int(mt), stream_ptr()), "ss_gemm16_res")
+
+
+def gemm16_store(A, W, out, *, mt=0, **kw):
+    """C = act(A.W^T + bias) on 16x16x4 tiles with both operands streamed by LDS-DMA (ss_gemm16_store)."""
+    a = _fill_args(A, W, out, **kw)
+    check(load().ss_gemm16_store(C.byref(a), int(mt), stream_ptr()), "ss_gemm16_store")
 
 
 def wino43_weight(w):

@@ -235,3 +235,33 @@ def test_gemm16_res_matches_torch_and_the_generic_kernel(C, B, T, groups, mt):
     S = torch.zeros(B, T, C, device=dv)
     L.conv_gemm(A, Wp, x2, epi=L.EPI_RESSKIP, R=x2, Nh=C, C2=S, ldc2=C, c2_bs=T * C, tile=3, **kw)
     assert (x1 - x2).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("mt", [0, 4, 6, 8])
+@pytest.mark.parametrize("K,N,B,T,groups,relu", [(1920, 192, 4, 150, 2, True), (5120, 256, 2, 333, 1, True), (96, 80, 1, 70, 1, False), (32, 64, 3, 17, 1, False)])
+def test_gemm16_store_matches_torch(K, N, B, T, groups, relu, mt):
+    """ss_gemm16_store (both operands streamed by LDS-DMA): C = act(A . W^T + bias) for the skip-GEMM shapes (K = L*C), odd and even
+    chunk counts (K = 96 -> 3 chunks, 32 -> 1), N not a multiple of 64, ragged lens, grouped weights - vs torch float64."""
+    import math
+    from stylesinger_amd import lib as L
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(K + N + mt)
+    A = torch.randn(B, T, K, generator=g)
+    ws = [torch.randn(N, K, 1, generator=g) / math.sqrt(K) for _ in range(groups)]
+    bs = [torch.randn(N, generator=g) * 0.1 for _ in range(groups)]
+    lens = torch.tensor([max(1, T - 9 * i) for i in range(B)], dtype=torch.int32)
+    ref = torch.zeros(B, T, N)
+    for i in range(B):
+        n, gi = int(lens[i]), i * groups // B
+        v = A[i, :n].double() @ ws[gi][:, :, 0].double().t() + bs[gi].double()
+        ref[i, :n] = (v.clamp_min(0) if relu else v).float()
+    Wp = torch.stack([L.pack_conv_weight(w.to(dv)) for w in ws]).contiguous()
+    bp = torch.stack([L.pack_bias(b_.to(dv)) for b_ in bs]).contiguous()
+    out = torch.full((B, T, N), 3.0, device=dv)
+    L.gemm16_store(A.to(dv), Wp, out, mt=mt, B=B, T=T, Cin=K, N=N, Np=Wp.shape[1], Kp=Wp.shape[2], lens=lens.to(dv), bias=bp,
+                   act=L.ACT_RELU if relu else L.ACT_NONE, mask_rows=True, group_size=(B // groups if groups > 1 else 0), w_gs=Wp[0].numel(),
+                   bias_gs=bp[0].numel())
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 3e-5, err
+    for i in range(B):
+        assert torch.all(out[i, int(lens[i]):] == 0)

@@ -33,3 +33,9 @@ for (name, B, T, C, Lyr) in (("mel", 8, 1500, 256, 20), ("f0", 16, 1500, 192, 10
         s = timeit(g, 20)
         fl = 2.0 * B * T * Lyr * C * C
         print(f"{name} skip GEMM K={Lyr * C} N={C} tile {tile}: {s * 1e6:7.1f} us = {s * 1e6 / Lyr:6.1f} us/layer  {fl / s / 1e12:6.1f} TF/s")
+    for mt in (6, 4, 8):
+        def g16():
+            L.gemm16_store(Gall, Ws, S, mt=mt, B=B, T=T, Cin=Lyr * C, N=C, Np=Ws.shape[0], Kp=Ws.shape[1], lens=lens, bias=bo, act=L.ACT_RELU)
+        s = timeit(g16, 20)
+        fl = 2.0 * B * T * Lyr * C * C
+        print(f"{name} skip GEMM K={Lyr * C} N={C} gemm16_store mt={mt}: {s * 1e6:7.1f} us  {fl / s / 1e12:6.1f} TF/s ({fl / s / 157.3e12 * 100:.1f} % of peak)")
