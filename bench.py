@@ -180,12 +180,16 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
     traffic = None
     pmc_src = None
-    pj = os.path.join(ROOT, "profiles", "r02_pmc_gate.json")
-    if os.path.exists(pj):
+    form = (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("bf16" if bf16 else "direct"))
+    for fn in ("r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
+        pj = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(pj):
+            continue
         try:
             rec = json.load(open(pj))
-            if rec.get("rows") == B * T and rec.get("kernel_form") == ("wino43" if wino_m == 4 else "wino" if wino else ("bf16" if bf16 else "direct")):
-                traffic, pmc_src = rec.get("hbm_bytes_per_launch"), "profiles/r02_pmc_gate.json"
+            if rec.get("rows") == B * T and rec.get("kernel_form") == form:
+                traffic, pmc_src = rec.get("hbm_bytes_per_launch"), "profiles/" + fn
+                break
         except (ValueError, OSError):
             pass
     return dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)",

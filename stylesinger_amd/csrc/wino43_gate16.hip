@@ -55,7 +55,7 @@ __device__ __forceinline__ float4 vsub(const float4& a, const float4& b) { retur
 __device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { return make_float2(a.x - b.x, a.y - b.y); }
 
 template <int MT>
-__global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gemm_args a, int q_tiles_per_item, int q_tiles, int n_tiles,
+__global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, int q_tiles_per_item, int q_tiles, int n_tiles,
                                                                int log2d, unsigned long long* clock_probe) {
   constexpr int BQ = 16 * MT;
   constexpr int NFULL = BQ / 32;             // staging passes of 32 rows x 8 sixteen-byte slots
@@ -298,11 +298,40 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
     chunk(P4{}, Yes{}, Yes{}, No{}, k);    // fetches the weights of (k+1, position 0)
     chunk(P5{}, Yes{}, Yes{}, No{}, k);    // builds c1(k+1); fetches the weights of (k+1, position 1)
   }
+  // The conditioner addend of the epilogue (48 values per lane at MT = 3; a 40 KB row stride, i.e. one HBM / L2 miss per element) is
+  // fetched under the last three chunks, into the registers the raw rows and the shared terms no longer need: in a single-round launch
+  // every workgroup reaches its epilogue at the same time, so loads issued there are fully exposed (ablation: 4.4 of 59 us).
+  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+  const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(Eb ? Eb : Wg), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+  const int oc = (n0 >> 1) + 8 * wave + c7;  // output channel: both its operands live in this wave (lanes lc and lc ^ 8)
+  const bool col_ok = oc < a.N;
+  const int oob = col_ok ? 0 : (int)0x80000000;
+  const int lde4 = a.lde * 4, ldc4 = a.ldc * 4;
+  float pe[MT][4][4];
+  auto fetch_addend = [&]() {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int qm = q0 + 16 * m + 4 * kg;          // multiple of 4
+      const int tm = qm + 3 * (qm & ~(d - 1));      // frame of quad qm
+      const int e_base = tm * lde4 + (pc * 4 + oob);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int dr = r + 3 * (r & ~(d - 1));      // wave-uniform: frame of quad qm + r = tm + dr
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          pe[m][r][o] = SS_G16_ABL == 5 ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, e_base, (dr + o * d) * lde4, 0));
+      }
+    }
+  };
   {
     const int k = kchunks - 1;
     chunk(P0{}, Yes{}, Yes{}, No{}, k);
     chunk(P1{}, Yes{}, Yes{}, No{}, k);
-    chunk(P2{}, Yes{}, Yes{}, No{}, k);
+    chunk(P2{}, Yes{}, Yes{}, No{}, k);   // the last build that reads the raw rows happened in P1; P2 built c2 from (A, B)
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_addend();
+    __builtin_amdgcn_sched_barrier(0);
     chunk(P3{}, Yes{}, Yes{}, No{}, k);
     chunk(P4{}, Yes{}, No{}, No{}, k);
     chunk(P5{}, No{}, No{}, No{}, k);
@@ -314,14 +343,8 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
   // are buffer stores (out-of-range rows / columns are dropped by the range check, no exec masking), the activation is one
   // multiply-exp2-add-rcp-fma chain, and the common case (no bias pointer, tile entirely inside [0, len)) skips the bias adds and the
   // padding-row zeroing.
-  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
-  const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(Eb ? Eb : Wg), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 4)), 0x00020000);
-  const int oc = (n0 >> 1) + 8 * wave + c7;  // output channel: both its operands live in this wave (lanes lc and lc ^ 8)
-  const bool col_ok = oc < a.N;
-  const int oob = col_ok ? 0 : (int)0x80000000;
   const bool use_sig = (chi == 0) == (a.gate_mode == 0);
   // sigmoid(x) = rcp(1 + exp2(-x log2 e)); tanh(x) = 2 sigmoid(2x) - 1: one exp2 + one rcp either way, selected per lane by (mul, scale, shift)
   const float am = (use_sig ? -1.0f : -2.0f) * 1.44269504088896340736f, as = use_sig ? 1.0f : 2.0f, ah = use_sig ? 0.0f : -1.0f;
@@ -329,7 +352,6 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
   auto partner = [](float x) {  // the value of lane lc ^ 8 of the same 16-lane row (DPP row_ror:8)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true));
   };
-  const int lde4 = a.lde * 4, ldc4 = a.ldc * 4;
   const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
   // lanes holding the first operand write frames t, t+d; their partners t+2d, t+3d (both lanes compute the same products)
   const int my_first = chi ? 2 * d : 0;
@@ -341,16 +363,7 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
     for (int m = 0; m < MT; ++m) {
       const int qm = q0 + 16 * m + 4 * kg;          // multiple of 4
       const int tm = qm + 3 * (qm & ~(d - 1));      // frame of quad qm
-      const int e_base = tm * lde4 + (pc * 4 + oob);
       const int c_base = (tm + my_first) * ldc4 + (oc * 4 + oob);
-      float pe[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int dr = r + 3 * (r & ~(d - 1));      // wave-uniform
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-          pe[r][o] = SS_G16_ABL == 5 ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, e_base, (dr + o * d) * lde4, 0));
-      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int dr = r + 3 * (r & ~(d - 1));
@@ -365,13 +378,13 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16_kernel(const ss_conv_gem
         const float z1 = fmaf(2.0f, d34, d12);
         const float z2 = fmaf(4.0f, s34, s12);
         const float z3 = fmaf(8.0f, d34, d12) + a5;
-        const float u0 = act(z0 + pe[r][0]);
-        const float u1 = act(z1 + pe[r][1]);
-        const float u2 = act(z2 + pe[r][2]);
-        const float u3 = act(z3 + pe[r][3]);
+        const float u0 = act(z0 + pe[m][r][0]);
+        const float u1 = act(z1 + pe[m][r][1]);
+        const float u2 = act(z2 + pe[m][r][2]);
+        const float u3 = act(z3 + pe[m][r][3]);
         float g0, g1, g2, g3;
         if constexpr (SS_G16_ABL == 6) {
-          g0 = z0 + pe[r][0]; g1 = z1 + pe[r][1]; g2 = z2 + pe[r][2]; g3 = z3 + pe[r][3];
+          g0 = z0 + pe[m][r][0]; g1 = z1 + pe[m][r][1]; g2 = z2 + pe[m][r][2]; g3 = z3 + pe[m][r][3];
         } else {
           g0 = u0 * partner(u0); g1 = u1 * partner(u1); g2 = u2 * partner(u2); g3 = u3 * partner(u3);
         }
@@ -425,7 +438,9 @@ extern "C" int ss_wino43_gate16_pick(int B, int T, int Np, int dilation) {
   long best_cost = 4L * layers(64);
   for (int mt = 3; mt >= 2; --mt) {
     const long cost = (long)mt * layers(16 * mt);
-    if (cost < best_cost) {
+    // ties go to the smaller tile: MT = 2 fits three workgroups per CU (168 registers; MT = 3: 252 -> two) and measured 1 % faster where
+    // both fill the chip evenly (BASELINE config 2: mel 768 workgroups of MT = 2 vs 512 of MT = 3)
+    if (cost < best_cost || (cost == best_cost && best != 0)) {
       best_cost = cost;
       best = mt;
     }
