@@ -40,7 +40,8 @@ int ss_struct_sizes(int64_t* out, int n);
 /* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
  * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3); "gate16" = 0|1|2|3 tiling of the F(4,3) gate launches inside the
  * denoiser loops (1 = per-launch pick, default; 0 = 32x32x2 tiles; 2|3 = force 16x16x4 tiles of 16*MT quads); "res_tile" /
- * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice); "res16" / "skip16" = 0|1|4|6|8
+ * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice); "gate256" = 0|1 bf16 GATE launches on the 256x256 LDS-DMA kernel when they
+ * qualify (default 1); "res16" / "skip16" = 0|1|4|6|8
  * residual-half projection on ss_gemm16_res / skip GEMM on ss_gemm16_store (1 = on, row tile picked per launch, default; 0 =
  * ss_conv_gemm; 4|6|8 = force 16*mt rows) */
 int ss_set_tuning(const char* key, int value);
@@ -221,6 +222,12 @@ typedef struct ss_gemm_bf16_args {
   int32_t group_size;
 } ss_gemm_bf16_args;
 int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
+/* The SS_HEPI_GATE form of ss_gemm_bf16 for many-round launches (BASELINE config 4): three taps (-d, 0, d) with d <= 8, K = 192 | 256,
+ * Np a multiple of 256. 256 rows x 256 packed columns per workgroup, 8 waves, both operands by LDS-DMA, the A tile staged once per
+ * channel chunk with its dilation halo. ss_gemm_bf16 dispatches here when ss_gemm_bf16_gate256_ok(args) (and the "gate256" tuning knob)
+ * say so; same arithmetic contract, results equal up to the K summation order. */
+int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream);
+int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* args);
 /* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,

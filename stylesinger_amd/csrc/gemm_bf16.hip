@@ -393,6 +393,8 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
       return launch_tiles<SS_HEPI_STORE>(a, stream);
     case SS_HEPI_GATE:
       SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: GATE needs C");
+      // many-round launches of the 3-tap dilated conv (BASELINE config 4) go to the 256x256 / 8-wave / LDS-DMA kernel
+      if (g_ss_tuning.gate256 && ss_gemm_bf16_gate256_ok(&a)) return ss_gemm_bf16_gate256(&a, stream_);
       return launch_tiles<SS_HEPI_GATE>(a, stream);
     case SS_HEPI_RESX:
       SS_CHECK_ARG(a.X != nullptr, "ss_gemm_bf16: RESX needs X");

@@ -156,7 +156,7 @@ def load():
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
-    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
+    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE256", b"gate256"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")
@@ -332,7 +332,7 @@ def to_bf16(x, bias=None, lens=None):
 
 
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
-              next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0):
+              next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -351,6 +351,9 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.C = ptr(out); a.ldc = ldc if ldc is not None else (out.shape[-1] if out is not None else 0)
     a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
     a.mask_rows = int(mask_rows)
+    if gate256:   # the 256x256 LDS-DMA kernel directly (ss_gemm_bf16 picks it by itself for many-round launches)
+        check(load().ss_gemm_bf16_gate256(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate256")
+        return
     check(load().ss_gemm_bf16(C.byref(a), stream_ptr()), "ss_gemm_bf16")
 
 

@@ -265,3 +265,39 @@ def test_gemm16_store_matches_torch(K, N, B, T, groups, relu, mt):
     assert err <= 3e-5, err
     for i in range(B):
         assert torch.all(out[i, int(lens[i]):] == 0)
+
+
+@pytest.mark.parametrize("C,d,T,B", [(256, 1, 300, 2), (256, 2, 777, 3), (256, 4, 256, 1), (256, 8, 1100, 2), (192, 8, 530, 2)])
+def test_bf16_gate256_kernel_matches_the_generic_bf16_kernel(C, d, T, B):
+    """ss_gemm_bf16_gate256 (256x256 tiles, 8 waves, LDS-DMA, A staged once with its dilation halo) vs ss_gemm_bf16's generic GATE kernel on
+    the same bf16 operands: ragged lens (zero padding by the DMA's range check, also for NEGATIVE rows of the halo), T not a multiple
+    of 256, every dilation of the cycle, C = 192 (3 channel chunks, Np = 384 -> not a multiple of 256: rejected) - outputs are bf16
+    gate values in (-1, 1): equal up to one bf16 ulp of the K-order difference (4e-3 abs), rows past lens exactly 0."""
+    import math
+    from stylesinger_amd import lib as L
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + d + T)
+    x = torch.randn(B, T, C, generator=g).to(dv)
+    lens = torch.tensor([max(1, T - 41 * i) for i in range(B)], dtype=torch.int32).to(dv)
+    for b in range(B):
+        x[b, int(lens[b]):] = 0
+    xh = L.to_bf16(x)
+    w = (torch.randn(2 * C, C, 3, generator=g) / math.sqrt(3 * C)).to(dv)
+    Wh = L.to_bf16(L.pack_conv_weight(w, interleave_half=C))
+    Np = Wh.shape[0]
+    E = (torch.randn(B, T, 2 * Np, generator=g) * 0.5).to(dv)
+    bias = (torch.randn(Np, generator=g) * 0.2).to(dv)
+    kw = dict(B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=Np, epi=L.HEPI_GATE, lens=lens, E=E[:, :, Np:], lde=2 * Np, e_bs=T * 2 * Np, bias=bias)
+    want = torch.full((B, T, C), 3.0, device=dv, dtype=torch.bfloat16)
+    L.gemm_bf16(xh, Wh, out=want, **kw)
+    if Np % 256 != 0:
+        with pytest.raises(L.StyleSingerHipError):
+            L.gemm_bf16(xh, Wh, out=torch.empty_like(want), gate256=True, **kw)
+        return
+    got = torch.full((B, T, C), 5.0, device=dv, dtype=torch.bfloat16)
+    L.gemm_bf16(xh, Wh, out=got, gate256=True, **kw)
+    err = (got.float() - want.float()).abs().max().item()
+    assert err <= 4e-3, err
+    assert (got.float() - want.float()).abs().mean().item() <= 2e-4
+    for b in range(B):
+        assert torch.all(got[b, int(lens[b]):] == 0)
