@@ -19,6 +19,12 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// SS_G256_ABL (debug builds only; results wrong by design): 1 = no DMA inside the loop, 2 = no MFMAs, 3 = no barriers, 4 = no epilogue
+// loads/stores except one store per lane
+#ifndef SS_G256_ABL
+#define SS_G256_ABL 0
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BKH = 64;
@@ -40,10 +46,15 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ds
 template <int CCS>
 __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem_g256[];   // 144 KB: one workgroup per CU
+  // [A0 40 K][B0 32 K][A1 40 K][B1 32 K]: the operands of the LAST step live in A1 / B1, so the first 72 KB are free while it runs
   char* const A0 = smem_g256;
-  char* const A1 = A0 + AROWS * ROWB;
-  char* const B0 = A1 + AROWS * ROWB;
-  char* const B1 = B0 + BN * ROWB;
+  char* const B0 = A0 + AROWS * ROWB;
+  char* const A1 = B0 + BN * ROWB;
+  char* const B1 = A1 + AROWS * ROWB;
+  // epilogue view of the same memory: two 64-KB addend quarters and a 16-KB output staging tile
+  char* const EQ0 = smem_g256;
+  char* const EQ1 = smem_g256 + 64 * 1024;
+  char* const OUT = smem_g256 + 128 * 1024;
 
   // consecutive workgroups walk row tiles of the SAME column tile (ids = mod 8 -> one XCD): the 3 x 256-column weight slice stays in
   // that XCD's L2 while the activations stream through
@@ -78,29 +89,23 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   // ---- DMA roles. A: 40 pieces of 8 rows x 128 B (rows t0 - 8 + r, r < 320; r >= 272 forced out of range); wave w issues pieces
   // w, w + 8, ..., w + 32. B: 32 pieces; wave w issues w, w + 8, w + 16, w + 24. Lane i of a piece lands at (row i >> 3, physical slot
   // i & 7) and therefore fetches logical slot (i & 7) ^ ((row >> 1) & 7).
-  int a_voff[5], b_voff[4];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int r = 8 * (wave + 8 * j) + (lane >> 3);
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);
-    const int grow = t0 - HALO + r;   // may be negative: the byte offset is then >= 2^31 as unsigned -> out of range -> zeros
-    a_voff[j] = (r < BM + 2 * HALO) ? (grow * a.lda + slot * 8) * 2 : (int)0x80000000;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = 8 * (wave + 8 * j) + (lane >> 3);
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);
-    b_voff[j] = ((n0 + r) * ldw + slot * 8) * 2;
-  }
-  // `dead` = 0x80000000 turns a DMA into out-of-range reads (zeros written, no memory traffic): the pieces past the last step are
-  // still issued - into buffers nobody reads any more - so that every step has the same instruction stream and the same counted waits
+  // (piece w + 8 j starts 64 j rows after piece w and ((r >> 1) & 7) does not depend on j: ONE per-lane offset per operand)
+  const int r0 = 8 * wave + (lane >> 3);
+  const int slot0 = (lane & 7) ^ ((r0 >> 1) & 7);
+  const int a_voff = ((t0 - HALO + r0) * a.lda + slot0 * 8) * 2;   // may be negative: >= 2^31 as unsigned -> out of range -> zeros
+  const int b_voff = ((n0 + r0) * ldw + slot0 * 8) * 2;
+  const int a_tail_dead = wave < 2 ? 0 : (int)0x80000000;          // piece w + 32 = rows 256 + 8 w ..: only rows < 272 exist
   auto dma_a = [&](char* buf, int cc, int dead) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, a_voff[j] | dead, cc * (BKH * 2));
+    for (int j = 0; j < 5; ++j)
+      // the row offset of piece j goes into the VGPR offset (one add), NOT the SGPR offset: for the rows before the item (t0 - 8 + r < 0)
+      // the per-lane offset is negative, i.e. >= 2^31 as unsigned, and the hardware adds the SGPR offset without wrapping - a positive
+      // SGPR part would leave valid rows of later pieces out of range
+      glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | dead | (j == 4 ? a_tail_dead : 0), cc * (BKH * 2));
   };
   auto dma_b = [&](char* buf, int cc, int tap, int dead) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(rsrc_w, buf + (wave + 8 * j) * 8 * ROWB, b_voff[j] | dead, (tap * a.K + cc * BKH) * 2);
+    for (int j = 0; j < 4; ++j) glds16(rsrc_w, buf + (wave + 8 * j) * 8 * ROWB, b_voff | dead, (tap * a.K + cc * BKH) * 2 + 64 * j * ldw * 2);
   };
 
   // ---- fragment addresses. A, tap j: row = HALO + (j - 1) d + 128 wm + 32 m + l31; k-step ks reads slot (2 ks + lh) ^ swz(row).
@@ -115,6 +120,18 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   }
   const int b_base = (64 * wn + l31) * ROWB;
   const int b_swz = (((64 * wn + l31) >> 1) & 7) ^ lh;
+
+  // conditioner addend: fp32 [rows][lde], the tile's 256 packed columns are 1 KB contiguous per row -> one row per DMA instruction.
+  // Quarter q = tile rows 128 h + 32 q + (0..31), h = 0, 1 -> 64 pieces; wave w issues pieces w, w + 8, ..., w + 56.
+  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
+  const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(Eb ? (const void*)Eb : (const void*)a.W), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
+  const int e_voff = ((t0 + wave) * a.lde + n0) * 4 + lane * 16;   // piece w + 8 j: 8 j rows further (j < 4), 128 + 8 (j - 4) for j >= 4
+  auto dma_e = [&](char* buf, int q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      glds16(rsrc_e, buf + (wave + 8 * j) * 1024, e_voff, (q * 32 + (j < 4 ? 8 * j : 128 + 8 * (j - 4))) * a.lde * 4);
+  };
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -137,27 +154,41 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
     const char* Bc = (S & 1) ? B1 : B0;
     char* Bn = (S & 1) ? B0 : B1;
     char* An = (CC & 1) ? A0 : A1;
-    if constexpr (TAP == 2) wait_vmcnt<5>();
+    // (no DMA is ever issued past the last step: the epilogue's addend quarters reuse this memory and must not race with zero fills)
+    if constexpr (TAP == 2 && CC + 1 < CCS) wait_vmcnt<5>();   // the 5 pieces of A chunk cc+1, issued last step after its weight pieces
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    dma_b(Bn, (S + 1) / 3, (S + 1) % 3, LAST ? (int)0x80000000 : 0);
+    if constexpr (SS_G256_ABL != 3) __builtin_amdgcn_s_barrier();
+    if constexpr (SS_G256_ABL != 1 && !LAST) dma_b(Bn, (S + 1) / 3, (S + 1) % 3, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TAP == 1) dma_a(An, CC + 1, CC + 1 >= CCS ? (int)0x80000000 : 0);
+    if constexpr (TAP == 1 && SS_G256_ABL != 1 && CC + 1 < CCS) dma_a(An, CC + 1, 0);
+    if constexpr (LAST) {   // the first addend quarter flies under the last step (into A0 / B0, which that step does not read)
+      __builtin_amdgcn_sched_barrier(0);
+      dma_e(EQ0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {   // one k-step at a time: 6 fragment reads (24 registers) feed 8 MFMAs; the partner wave of the SIMD
-      bf16x8 af[4], bf[2];             // covers the LDS latency with its own MFMAs
+    // fragments of k-step ks+1 are read before the MFMAs of k-step ks issue (two register sets of 6 x 16 B): the two waves of a SIMD
+    // belong to the same workgroup and leave every barrier in lockstep, so a partner's MFMAs do NOT cover this wave's LDS latency
+    bf16x8 af[2][4], bf[2][2];
+    auto read_frags = [&](int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
       const int ao = a_base[TAP] + (((2 * ks) ^ a_swz[TAP]) << 4);
       const int bo = b_base + (((2 * ks) ^ b_swz) << 4);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8*>(Ac + ao + m * 32 * ROWB);
+      for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(Ac + ao + m * 32 * ROWB);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(Bc + bo + n * 32 * ROWB);
+      for (int n = 0; n < 2; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(Bc + bo + n * 32 * ROWB);
+    };
+    read_frags(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) read_frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) {
+          if constexpr (SS_G256_ABL == 2) acc[m][n][0] += (float)af[ks & 1][m][0] * (float)bf[ks & 1][n][0];
+          else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][m], bf[ks & 1][n], acc[m][n], 0, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -170,44 +201,63 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{},
       integral_constant<int, 4>{}, integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{},
       integral_constant<int, 8>{});
-  if constexpr (CCS == 4) run(integral_constant<int, 9>{}, integral_constant<int, 10>{}, integral_constant<int, 11>{});
+  static_assert(CCS == 4, "the epilogue's LDS plan assumes the last step reads A1 / B1");
+  run(integral_constant<int, 9>{}, integral_constant<int, 10>{}, integral_constant<int, 11>{});
 
-  // ---- epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 lh): addend, gate, bf16 store; per row block of 32
-  const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
-  const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(Eb ? (const void*)Eb : (const void*)a.W), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr((uint16_t*)a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 2)), 0x00020000);
+  // ---- epilogue. A single workgroup per CU has nobody to overlap its epilogue with, so nothing here may wait on HBM or issue narrow
+  // stores (ablation: with plain per-lane addend loads and 2-byte stores the epilogue took 2/3 of the launch):
+  //   * the fp32 addend tile (256 rows x 1 KB) arrives by LDS-DMA in four quarters of 64 rows (one row per DMA instruction), double
+  //     buffered: quarter 0 was issued inside the last MFMA step into the 72 KB that step no longer uses, quarter q+1 flies while q is used;
+  //   * the bf16 gate outputs of a quarter are staged in LDS and leave as 16-byte stores of row-contiguous runs (256 B per row).
+  // Pass q handles accumulator block m = q of every wave: tile rows 128 wm + 32 q + (0..31), LDS row k = 32 wm + (0..31).
   const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
-  const int pc0 = n0 + 64 * wn + l31;            // packed column of the first operand; the second sits 32 further
-  const int oc = (pc0 >> 6) * 32 + l31;          // output channel
-  const int dead = oc < a.N ? 0 : (int)0x80000000;
-  const float b0 = (biasg && !dead) ? biasg[pc0] : 0.f, b1 = (biasg && !dead) ? biasg[pc0 + 32] : 0.f;
+  const int pcl = 64 * wn + l31;                 // packed column inside the tile (first operand; the second sits 32 further)
+  const int ocl = 32 * wn + l31;                 // output channel inside the tile
+  const bool ch_ok = (n0 >> 1) + ocl < a.N;
+  const float b0 = (biasg && ch_ok) ? biasg[n0 + pcl] : 0.f, b1 = (biasg && ch_ok) ? biasg[n0 + pcl + 32] : 0.f;
   const bool sig_first = a.gate_mode == 0;
   const float L2E = 1.44269504088896340736f;
   const float m0 = (sig_first ? -1.0f : -2.0f) * L2E, s0 = sig_first ? 1.0f : 2.0f, h0 = sig_first ? 0.0f : -1.0f;
   const float m1 = (sig_first ? -2.0f : -1.0f) * L2E, s1 = sig_first ? 2.0f : 1.0f, h1 = sig_first ? -1.0f : 0.0f;
   auto act = [](float x, float mul, float sc, float sh) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * mul)), sc, sh); };
   const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
-  const int lde4 = a.lde * 4, ldc2 = a.ldc * 2;
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr((uint16_t*)a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 2)), 0x00020000);
+  __builtin_amdgcn_s_barrier();   // everyone is done with A1 / B1: the second quarter and the staging tile may overwrite them
+  dma_e(EQ1, 1);
+  const int e_rd = (32 * wm + 4 * lh) * 1024 + pcl * 4;        // + rr * 1024 (+ 128 for the second operand)
+  const int o_wr = (32 * wm + 4 * lh) * 256 + ocl * 2;         // + rr * 256
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int row0 = t0 + 128 * wm + 32 * m + 4 * lh;
-    const int eoff = (row0 * a.lde + pc0) * 4 | dead;
-    const int coff = (row0 * a.ldc + oc) * 2 | dead;
-    float e0[16], e1[16];
+  for (int q = 0; q < 4; ++q) {
+    const char* Eq = (q & 1) ? EQ1 : EQ0;
+    // my pieces of quarter q have landed; younger operations that may still fly, in issue order
+    //   E0 | E1 | pass 0: E2, 2 stores | pass 1: E3, 2 stores | pass 2: 2 stores | pass 3: 2 stores
+    if (q == 0) wait_vmcnt<8>();
+    else if (q == 1) wait_vmcnt<10>();
+    else if (q == 2) wait_vmcnt<12>();
+    else wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone finished reading the staging tile of quarter q-1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2);
-      e0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff, rr * lde4, 0));
-      e1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, eoff, rr * lde4 + 128, 0));
+      const float e0 = *reinterpret_cast<const float*>(Eq + e_rd + rr * 1024);
+      const float e1 = *reinterpret_cast<const float*>(Eq + e_rd + rr * 1024 + 128);
+      float g = act(acc[q][0][r] + b0 + e0, m0, s0, h0) * act(acc[q][1][r] + b1 + e1, m1, s1, h1);
+      if (t0 + 128 * wm + 32 * q + 4 * lh + rr >= row_lim) g = 0.f;
+      *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * 256) = f2bf(g);
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my staging writes are done
+    __builtin_amdgcn_s_barrier();         // the staging tile is complete; everyone finished reading addend quarter q
+    if (q + 2 < 4) dma_e((q & 1) ? EQ1 : EQ0, q + 2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = (r & 3) + 8 * (r >> 2);
-      float g = act(acc[m][0][r] + b0 + e0[r], m0, s0, h0) * act(acc[m][1][r] + b1 + e1[r], m1, s1, h1);
-      if (row0 + rr >= row_lim) g = 0.f;
-      __builtin_amdgcn_raw_buffer_store_b16(f2bf(g), rsrc_c, coff, rr * ldc2, 0);   // rows >= T: out of range, dropped
+    for (int j = 0; j < 2; ++j) {   // 64 rows x 256 B = 1024 pieces of 16 B, two per thread: piece p = (row p >> 4, 8 channels p & 15)
+      const int p = tid + 512 * j;
+      const int k = p >> 4, c8 = p & 15;
+      const int grow = t0 + 128 * (k >> 5) + 32 * q + (k & 31);
+      const uint4 v = *reinterpret_cast<const uint4*>(OUT + p * 16);
+      const bool ok = (n0 >> 1) + 8 * c8 < a.N;   // N is a multiple of 8 (checked by the launcher)
+      const int off = ok ? (grow * a.ldc + (n0 >> 1) + 8 * c8) * 2 : (int)0x80000000;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_c, off, 0, 0);   // rows >= T dropped
     }
   }
 }
@@ -220,7 +270,7 @@ extern "C" int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* a) {
   if (!a || a->epi != SS_HEPI_GATE || a->ntaps != 3) return 0;
   const int d = a->tap_off[2];
   if (d < 1 || d > HALO || a->tap_off[0] != -d || a->tap_off[1] != 0) return 0;
-  if ((a->K != 256 && a->K != 192) || (a->Np % BN) != 0 || (a->lda % 8) != 0) return 0;
+  if (a->K != 256 || (a->Np % BN) != 0 || (a->lda % 8) != 0 || (a->N % 8) != 0) return 0;
   const long tiles = (long)ss_cdiv(a->T, BM) * a->B * (a->Np / BN);
   return tiles >= 1024 ? 1 : 0;
 }
@@ -231,7 +281,8 @@ extern "C" int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream)
   SS_CHECK_ARG(a.A && a.W && a.C, "ss_gemm_bf16_gate256: null A/W/C");
   SS_CHECK_ARG(a.epi == SS_HEPI_GATE && a.ntaps == 3 && a.tap_off[1] == 0 && a.tap_off[0] == -a.tap_off[2] && a.tap_off[2] >= 1 &&
                    a.tap_off[2] <= HALO, "ss_gemm_bf16_gate256: GATE with taps (-d, 0, d), 1 <= d <= 8 only");
-  SS_CHECK_ARG((a.K == 256 || a.K == 192) && (a.Np % BN) == 0 && 2 * a.N <= a.Np && (a.lda % 8) == 0, "ss_gemm_bf16_gate256: K 192 | 256, Np %% 256, lda %% 8");
+  SS_CHECK_ARG(a.K == 256 && (a.Np % BN) == 0 && 2 * a.N <= a.Np && (a.lda % 8) == 0 && (a.N % 8) == 0 && (a.ldc % 8) == 0,
+               "ss_gemm_bf16_gate256: K = 256, Np %% 256, lda %% 8, N %% 8, ldc %% 8");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 2 < (1ll << 31) &&
                    (int64_t)a.Np * 3 * a.K * 2 < (1ll << 31), "ss_gemm_bf16_gate256: item too large for 32-bit offsets");
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
@@ -247,8 +298,7 @@ extern "C" int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream)
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, n_tiles, a.tap_off[2]);
   };
-  if (a.K == 256) go(&gate256_kernel<4>);
-  else go(&gate256_kernel<3>);
+  go(&gate256_kernel<4>);   // 12 steps: the last one reads A1 / B1, which is what the epilogue's LDS plan relies on
   SS_CHECK_LAUNCH("ss_gemm_bf16_gate256");
   return SS_OK;
 }

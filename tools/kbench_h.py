@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--T", type=int, default=5625)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--which", default="all")
+    ap.add_argument("--no-e", action="store_true", help="gate without the conditioner addend (what-if: how much of the launch is the addend?)")
     ap.add_argument("--e-layout", default="row", help="'row' = [B][T][L*2C], 'layer' = [L][B][T][2C]")
     a = ap.parse_args()
     d = torch.device("cuda:0")
@@ -43,6 +44,9 @@ def main():
             if a.e_layout == "layer":
                 L.gemm_bf16(Xh, Wh, B=B, T=T, K=C, taps=(-2, 0, 2), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
                             E=El[layer[0]], lde=2 * C, e_bs=T * 2 * C, out=Gh)
+                return
+            if a.no_e:
+                L.gemm_bf16(Xh, Wh, B=B, T=T, K=C, taps=(-2, 0, 2), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, out=Gh)
                 return
             L.gemm_bf16(Xh, Wh, B=B, T=T, K=C, taps=(-2, 0, 2), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
                         E=E[:, :, layer[0] * 2 * C:], lde=4 * 2 * C, e_bs=T * 4 * 2 * C, out=Gh)
