@@ -173,8 +173,12 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     flops = 2.0 * B * T * (3 * C) * (2 * C)
     executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
+    # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
+    g256 = hbm and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
+    hbm_name = ("gate256_kernel (bf16 operands in HBM, 256x256 tiles by LDS-DMA, direct" if g256 else
+                "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct")
     name = (f"wino43_gate16_kernel<{mt}> (Winograd F(4,3), 16x16x4 tiles of {16 * mt} quads" if wino_m == 4 and mt else
-            "wino43_gate_kernel (Winograd F(4,3)" if wino_m == 4 else "wino_gate_kernel_v2 (Winograd F(2,3)" if wino else "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct" if hbm else
+            "wino43_gate_kernel (Winograd F(4,3)" if wino_m == 4 else "wino_gate_kernel_v2 (Winograd F(2,3)" if wino else hbm_name if hbm else
             "conv_gemm_kernel<64,128,2,2,GATE" + (",bf16> (direct" if bf16 else "> (direct"))
     # HBM traffic of this launch from the round's PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs,
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
@@ -464,6 +468,10 @@ def main():
     wino_saved = 0.5 if getattr(infer.model, "wino_m", 2) == 4 else 1.0 / 3.0
     flop_exec = flop_hoisted - ((MEL_GATE_FLOP * S_mel + 2 * F0_GATE_FLOP * S_f0) * wino_saved if wino else 0.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
+    # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
+    g256 = hbm and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
+    hbm_name = ("gate256_kernel (bf16 operands in HBM, 256x256 tiles by LDS-DMA, direct" if g256 else
+                "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct")
     per_gpu = value / world
 
     if rank == 0:

@@ -17,7 +17,7 @@ from stylesinger_amd.model import StyleSingerHIP  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # mel L1 of the bf16-operand 1000-step chain on `acoustic_t32_mel1000` vs the real fp32 reference, measured on MI355X (profiles/r03_parity.json)
-BF16_CHAIN_L1_MEASURED = float(os.environ.get("SS_BF16_CHAIN_L1", "0.0334"))
+BF16_CHAIN_L1_MEASURED = float(os.environ.get("SS_BF16_CHAIN_L1", "2.5e-3"))
 
 
 class ListTape:
