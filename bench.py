@@ -468,10 +468,6 @@ def main():
     wino_saved = 0.5 if getattr(infer.model, "wino_m", 2) == 4 else 1.0 / 3.0
     flop_exec = flop_hoisted - ((MEL_GATE_FLOP * S_mel + 2 * F0_GATE_FLOP * S_f0) * wino_saved if wino else 0.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
-    # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
-    g256 = hbm and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
-    hbm_name = ("gate256_kernel (bf16 operands in HBM, 256x256 tiles by LDS-DMA, direct" if g256 else
-                "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct")
     per_gpu = value / world
 
     if rank == 0:

@@ -39,7 +39,8 @@ int ss_device_info(int dev, int* n_cu, char* arch, int arch_len);
 int ss_struct_sizes(int64_t* out, int n);
 /* process-wide performance knobs (results never change): "wave_prio" = 0|1|2 static per-workgroup wave priority in the MFMA
  * kernels (0 = none, 1 = (blockIdx/256)%3, 2 = blockIdx%3); "gate16" = 0|1|2|3 tiling of the F(4,3) gate launches inside the
- * denoiser loops (1 = per-launch pick, default; 0 = 32x32x2 tiles; 2|3 = force 16x16x4 tiles of 16*MT quads); "res_tile" /
+ * denoiser loops (1 = per-launch pick, default; 0 = 32x32x2 tiles; 2|3 = force 16x16x4 tiles of 16*MT quads); "gate16_ks" = 0|1
+ * the 16x16x4 gate kernel stages one Winograd component per barrier (0) or all six of a K chunk at once (1, default); "res_tile" /
  * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice); "gate256" = 0|1 bf16 GATE launches on the 256x256 LDS-DMA kernel when they
  * qualify (default 1); "res16" / "skip16" = 0|1|4|6|8
  * residual-half projection on ss_gemm16_res / skip GEMM on ss_gemm16_store (1 = on, row tile picked per launch, default; 0 =

@@ -14,7 +14,7 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1};
+SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1};
 
 extern "C" int ss_set_tuning(const char* key, int value) {
   if (!key) {
@@ -33,6 +33,10 @@ extern "C" int ss_set_tuning(const char* key, int value) {
     g_ss_tuning.gate256 = value;
     return SS_OK;
   }
+  if (strcmp(key, "gate16_ks") == 0 && (value == 0 || value == 1)) {
+    g_ss_tuning.gate16_ks = value;
+    return SS_OK;
+  }
   if (strcmp(key, "gate16") == 0 && value >= 0 && value <= 3) {
     g_ss_tuning.gate16 = value;
     return SS_OK;
@@ -49,6 +53,7 @@ extern "C" int ss_get_tuning(const char* key) {
     if (strcmp(key, "wave_prio") == 0) return g_ss_tuning.wave_prio;
     if (strcmp(key, "gate16") == 0) return g_ss_tuning.gate16;
     if (strcmp(key, "gate256") == 0) return g_ss_tuning.gate256;
+    if (strcmp(key, "gate16_ks") == 0) return g_ss_tuning.gate16_ks;
     if (strcmp(key, "res16") == 0) return g_ss_tuning.res16;
     if (strcmp(key, "skip16") == 0) return g_ss_tuning.skip16;
     if (strcmp(key, "res_tile") == 0) return g_ss_tuning.res_tile;

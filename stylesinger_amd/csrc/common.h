@@ -49,9 +49,11 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   res16: 1 (default) = the residual-half projection of the deferred-skip loops runs on ss_gemm16_res (16x16x4 tiles, LDS-DMA);
 //     0 = ss_conv_gemm; 4 / 6 / 8 = force the row tile.
 //   skip16: the same switch for the K = L*C skip GEMM (ss_gemm16_store).
+//   gate16_ks: 1 (default) = the 16x16x4 gate kernel stages all six Winograd components of a K chunk at once (one barrier per K chunk, 48 / 72 KB
+//     of LDS); 0 = one component per barrier (8 / 12 KB).
 //   gate256: 1 (default) = bf16 GATE launches that qualify (ss_gemm_bf16_gate256_ok) run on the 256x256 LDS-DMA kernel; 0 = always the
 //     generic bf16 kernel.
-struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; };
+struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks; };
 extern SsTuning g_ss_tuning;
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)

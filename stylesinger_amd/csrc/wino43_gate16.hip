@@ -54,7 +54,7 @@ __device__ __forceinline__ float2 vadd(const float2& a, const float2& b) { retur
 __device__ __forceinline__ float4 vsub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-template <int MT>
+template <int MT, bool KS>
 __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, int q_tiles_per_item, int q_tiles, int n_tiles,
                                                                int log2d, unsigned long long* clock_probe) {
   constexpr int BQ = 16 * MT;
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
     probe_r0 = __builtin_amdgcn_s_memrealtime();
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;  // [2][BQ][LD]
+  float* As = smem;  // [2][BQ][LD]; KS: [2][6][BQ][LD] (all six components of a K chunk staged at once)
+  constexpr int SZC = BQ * LD;  // floats of one staged component
 
   const int id = blockIdx.x;
   const int grp = id / (8 * n_tiles);
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   int a_wr4[NFULL > 0 ? NFULL : 1];
 #pragma unroll
   for (int i = 0; i < NFULL; ++i) a_wr4[i] = lds_slot16(st_row + i * 32, st_c4);
-  const int a_wrh = lds_slot16(NFULL * 32 + sh_row, sh_c2 >> 1) + (sh_c2 & 1) * 2;
+  int a_wrh = lds_slot16(NFULL * 32 + sh_row, sh_c2 >> 1) + (sh_c2 & 1) * 2;
   // Input transform with shared sub-expressions (18 instead of 28 VALU ops per element and K chunk - VALU instructions take
   // matrix-pipe time on gfx950):
   //   A = r4 - 4 r2, B = r3 - 4 r1, C = r4 - r2, D = r3 - r1   ->   c1 = A + B, c2 = A - B, c3 = C + 2 D, c4 = C - 2 D
@@ -237,6 +238,20 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   load_b(P0{}, ORD[0] * kb);
   load_b(P1{}, ORD[1] * kb);
   store_a(As, P0{});
+  if constexpr (KS) {
+    // K-staged form: the six components of chunk k+1 are built during chunk k (one per position, into the OTHER half of the LDS), so a
+    // K chunk needs ONE barrier instead of six; chunk 0 is built here, then the raw rows of chunk 1 are fetched.
+    store_a(As + 1 * SZC, P1{});
+    store_a(As + 2 * SZC, P2{});
+    store_a(As + 3 * SZC, P3{});
+    store_a(As + 4 * SZC, P4{});
+    store_a(As + 5 * SZC, P5{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(cs);
+#pragma unroll
+    for (int i = 0; i < NFULL; ++i) a_wr4[i] += 6 * SZC;
+    a_wrh += 6 * SZC;
+  }
   __syncthreads();
 
   // fragment addresses: row tile m, lane row lc, slots 2kg + h
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
 #pragma unroll
     for (int h = 0; h < 2; ++h) a_rd[m][h] = lds_slot16(16 * m + lc, 2 * kg + h);
 
+  int ks_delta = 6 * SZC;
   auto mfma_half = [&](auto jtag, const float4 (&af)[MT], const float4& bf) {
     constexpr int J = decltype(jtag)::value;
     if constexpr (SS_G16_ABL == 3) {
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
     constexpr int CUR = P & 1;
     constexpr int S = P % 3;
     constexpr int PN = (P + 1) % 6, P2N = (P + 2) % 6;
-    const float* Ac = As + CUR * BQ * LD;
+    const float* Ac = As + (KS ? P : CUR) * SZC;   // KS: a_rd / a_wr carry the half of the LDS this K chunk reads / writes
     float4 af0[MT], af1[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) af0[m] = *reinterpret_cast<const float4*>(Ac + a_rd[m][0]);
@@ -279,24 +295,60 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(std::integral_constant<int, ORD[P]>{}, af0, bst[S][0]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (decltype(stage_tag)::value && SS_G16_ABL != 2) store_a(As + (CUR ^ 1) * BQ * LD, std::integral_constant<int, PN>{});
+    if constexpr (decltype(stage_tag)::value && SS_G16_ABL != 2) {
+      if constexpr (KS) store_a(As + P * SZC, ptag);   // component of the same position, NEXT K chunk
+      else store_a(As + (CUR ^ 1) * SZC, std::integral_constant<int, PN>{});
+    }
     __builtin_amdgcn_sched_barrier(0);  // stores first, then the fetches into the SAME registers
     if constexpr (decltype(fetch_b_tag)::value && SS_G16_ABL != 1 && SS_G16_ABL != 7)
       load_b(std::integral_constant<int, (P + 2) % 3>{}, ORD[P2N] * kb + (k + (P + 2) / 6) * cs);
-    if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1 && SS_G16_ABL != 8) load_rows((k + 1) * cs);
+    if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1 && SS_G16_ABL != 8) load_rows((k + (KS ? 2 : 1)) * cs);
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(std::integral_constant<int, ORD[P]>{}, af1, bst[S][1]);
-    if constexpr (SS_G16_ABL != 4) __syncthreads();
+    if constexpr (!KS) {
+      if constexpr (SS_G16_ABL != 4) __syncthreads();
+    } else if constexpr (P == 5 && decltype(stage_tag)::value) {
+      if constexpr (SS_G16_ABL != 4) __syncthreads();
+      // swap the halves: what was written becomes what is read
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        a_rd[m][0] += ks_delta;
+        a_rd[m][1] += ks_delta;
+      }
+#pragma unroll
+      for (int i = 0; i < NFULL; ++i) a_wr4[i] -= ks_delta;
+      a_wrh -= ks_delta;
+      ks_delta = -ks_delta;
+    }
   };
   using Yes = std::true_type;
   using No = std::false_type;
-  for (int k = 0; k + 1 < kchunks; ++k) {
+  if constexpr (KS) {
+    // chunk k builds chunk k+1 from rows(k+1); rows(k+2) are fetched at position 2, after the last build that reads the raw rows
+    for (int k = 0; k + 2 < kchunks; ++k) {
+      chunk(P0{}, Yes{}, Yes{}, No{}, k);
+      chunk(P1{}, Yes{}, Yes{}, No{}, k);
+      chunk(P2{}, Yes{}, Yes{}, Yes{}, k);
+      chunk(P3{}, Yes{}, Yes{}, No{}, k);
+      chunk(P4{}, Yes{}, Yes{}, No{}, k);
+      chunk(P5{}, Yes{}, Yes{}, No{}, k);
+    }
+    const int k = kchunks - 2;   // builds the last chunk, fetches no rows
     chunk(P0{}, Yes{}, Yes{}, No{}, k);
     chunk(P1{}, Yes{}, Yes{}, No{}, k);
-    chunk(P2{}, Yes{}, Yes{}, Yes{}, k);   // rows(k) are dead: fetch rows(k+1), three positions before position 5 builds c1(k+1)
+    chunk(P2{}, Yes{}, Yes{}, No{}, k);
     chunk(P3{}, Yes{}, Yes{}, No{}, k);
-    chunk(P4{}, Yes{}, Yes{}, No{}, k);    // fetches the weights of (k+1, position 0)
-    chunk(P5{}, Yes{}, Yes{}, No{}, k);    // builds c1(k+1); fetches the weights of (k+1, position 1)
+    chunk(P4{}, Yes{}, Yes{}, No{}, k);
+    chunk(P5{}, Yes{}, Yes{}, No{}, k);
+  } else {
+    for (int k = 0; k + 1 < kchunks; ++k) {
+      chunk(P0{}, Yes{}, Yes{}, No{}, k);
+      chunk(P1{}, Yes{}, Yes{}, No{}, k);
+      chunk(P2{}, Yes{}, Yes{}, Yes{}, k);   // rows(k) are dead: fetch rows(k+1), three positions before position 5 builds c1(k+1)
+      chunk(P3{}, Yes{}, Yes{}, No{}, k);
+      chunk(P4{}, Yes{}, Yes{}, No{}, k);    // fetches the weights of (k+1, position 0)
+      chunk(P5{}, Yes{}, Yes{}, No{}, k);    // builds c1(k+1); fetches the weights of (k+1, position 1)
+    }
   }
   // The conditioner addend of the epilogue (48 values per lane at MT = 3; a 40 KB row stride, i.e. one HBM / L2 miss per element) is
   // fetched under the last three chunks, into the registers the raw rows and the shared terms no longer need: in a single-round launch
@@ -326,14 +378,15 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   };
   {
     const int k = kchunks - 1;
-    chunk(P0{}, Yes{}, Yes{}, No{}, k);
-    chunk(P1{}, Yes{}, Yes{}, No{}, k);
-    chunk(P2{}, Yes{}, Yes{}, No{}, k);   // the last build that reads the raw rows happened in P1; P2 built c2 from (A, B)
+    using St = std::integral_constant<bool, !KS>;   // KS: everything this chunk reads was built during the previous one
+    chunk(P0{}, St{}, Yes{}, No{}, k);
+    chunk(P1{}, St{}, Yes{}, No{}, k);
+    chunk(P2{}, St{}, Yes{}, No{}, k);   // the last build that reads the raw rows happened in P1; P2 built c2 from (A, B)
     __builtin_amdgcn_sched_barrier(0);
     fetch_addend();
     __builtin_amdgcn_sched_barrier(0);
-    chunk(P3{}, Yes{}, Yes{}, No{}, k);
-    chunk(P4{}, Yes{}, No{}, No{}, k);
+    chunk(P3{}, St{}, Yes{}, No{}, k);
+    chunk(P4{}, St{}, No{}, No{}, k);
     chunk(P5{}, No{}, No{}, No{}, k);
   }
 
@@ -410,7 +463,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   }
 }
 
-template <int MT>
+template <int MT, bool KS>
 int launch16(const ss_conv_gemm_args& a, int dilation, int log2d, hipStream_t stream) {
   constexpr int BQ = 16 * MT;
   const int quads_per_item = ss_cdiv(a.T, 4 * dilation) * dilation;
@@ -418,8 +471,13 @@ int launch16(const ss_conv_gemm_args& a, int dilation, int log2d, hipStream_t st
   const int q_tiles = q_tiles_per_item * a.B;
   const int n_tiles = a.Np / BN;
   const int grid = ss_cdiv(q_tiles, 8) * 8 * n_tiles;
-  const size_t lds = (size_t)2 * BQ * LD * sizeof(float);
-  hipLaunchKernelGGL(wino43_gate16_kernel<MT>, dim3(grid), dim3(256), lds, stream, a, q_tiles_per_item, q_tiles, n_tiles, log2d,
+  const size_t lds = (size_t)(KS ? 12 : 2) * BQ * LD * sizeof(float);
+  if constexpr (KS && MT == 3) {   // 72 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino43_gate16_kernel<MT, KS>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+  }
+  hipLaunchKernelGGL((wino43_gate16_kernel<MT, KS>), dim3(grid), dim3(256), lds, stream, a, q_tiles_per_item, q_tiles, n_tiles, log2d,
                      g_ss_tuning.clock_probe);
   return 0;
 }
@@ -466,8 +524,12 @@ extern "C" int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int
     mt = ss_wino43_gate16_pick(a.B, a.T, a.Np, dilation);
     if (mt == 0) return ss_wino43_gate(args, dilation, stream);
   }
-  if (mt == 2) launch16<2>(a, dilation, log2d, (hipStream_t)stream);
-  else launch16<3>(a, dilation, log2d, (hipStream_t)stream);
+  // K-staged form (one barrier per K chunk, six components staged at once): needs at least two K chunks
+  const bool ks = g_ss_tuning.gate16_ks != 0 && a.Kp >= 2 * BK;
+  int rc = 0;
+  if (mt == 2) rc = ks ? launch16<2, true>(a, dilation, log2d, (hipStream_t)stream) : launch16<2, false>(a, dilation, log2d, (hipStream_t)stream);
+  else rc = ks ? launch16<3, true>(a, dilation, log2d, (hipStream_t)stream) : launch16<3, false>(a, dilation, log2d, (hipStream_t)stream);
+  SS_CHECK_ARG(rc == 0, "ss_wino43_gate16: hipFuncSetAttribute failed (%d)", rc);
   SS_CHECK_LAUNCH("ss_wino43_gate16");
   return SS_OK;
 }

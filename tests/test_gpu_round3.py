@@ -122,6 +122,45 @@ def test_gate16_grouped_pair_launch_matches_the_32x32_kernel(mt):
     assert lib.ss_wino43_gate16_pick(32, 5625, 512, 4) == 0      # many rounds per launch: the 32x32x2 tiles
 
 
+@pytest.mark.parametrize("mt", [2, 3])
+def test_gate16_k_staged_form_is_bit_identical(mt):
+    """`gate16_ks` (all six Winograd components of a K chunk staged at once, one barrier per K chunk) only changes WHEN a component
+    is built, not the arithmetic or the order the products enter an accumulator: outputs equal the one-component-per-barrier form bit
+    for bit - mel shape (C = 256, 8 K chunks), f0-pair shape (C = 192, 6, grouped weights, bias), C = 64 (2 chunks: no steady-state
+    loop), ragged lens, every dilation of the cycle."""
+    import math
+    from stylesinger_amd import lib as L
+    dv = torch.device("cuda:0")
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    before = lib.ss_get_tuning(b"gate16_ks")
+    try:
+        for (B, T, C, grouped) in ((3, 700, 256, False), (4, 333, 192, True), (2, 95, 64, False)):
+            x = torch.randn(B, T, C, generator=g).to(dv)
+            nw = 2 if grouped else 1
+            ws = [torch.randn(2 * C, C, 3, generator=g) / math.sqrt(3 * C) for _ in range(nw)]
+            Wt = torch.stack([L.pack_conv_weight(L.wino43_weight(w.to(dv)), interleave_half=C) for w in ws]).contiguous()
+            Np = Wt.shape[1]
+            ab = torch.randn(nw, C, generator=g).to(dv)
+            bias = (torch.randn(nw, Np, generator=g) * 0.3).to(dv) if grouped else None
+            E = torch.randn(B, T, 2 * Np, generator=g).to(dv)
+            lens = torch.tensor([T, T - 7, 5, T - 1][:B], dtype=torch.int32).to(dv)
+            for d in (1, 2, 4, 8):
+                kw = dict(dilation=d, B=B, T=T, Cin=C, N=C, Np=Np, Kp=C, lens=lens, a_bias=ab, bias=bias, E=E[:, :, Np:], lde=2 * Np,
+                          e_bs=T * 2 * Np, ldc=C, mask_rows=True)
+                if grouped:
+                    kw.update(group_size=2, w_gs=Wt[0].numel(), bias_gs=Np, a_bias_gs=C)
+                outs = []
+                for ks in (0, 1):
+                    L.check(lib.ss_set_tuning(b"gate16_ks", ks), "ss_set_tuning")
+                    o = torch.full((B, T, C), 9.0, device=dv)
+                    L.wino43_gate16(x, Wt if grouped else Wt[0], o, mt=mt, **kw)
+                    outs.append(o)
+                assert torch.equal(outs[0], outs[1]), (B, T, C, d, (outs[0] - outs[1]).abs().max().item())
+    finally:
+        L.check(lib.ss_set_tuning(b"gate16_ks", before), "ss_set_tuning")
+
+
 def test_preprocess_batch_feeds_infer_batch_from_device_buffers(golden_dir):
     """`StyleSingerInfer.preprocess_batch` (reference audio -> ref mel, emotion embedding, normalised f0) (a) equals the
     batch assembled by hand from the stand-alone producers bit for bit, tensors and the mel `infer_batch` makes of them; (b) every
