@@ -67,6 +67,13 @@ __device__ __forceinline__ void ss_apply_wave_prio(int mode) {
 // ----------------------------------------------------------------------------------------------
 // Device math. Activations follow the torch CPU definitions the reference relies on.
 // ----------------------------------------------------------------------------------------------
+// lens[b] for a block-uniform b as a SCALAR load (constant address space): left to the compiler it may become a vector load whose
+// s_waitcnt vmcnt(0) sits in front of the kernel's first operand fetch - one full memory round trip per launch.
+__device__ __forceinline__ int ss_uniform_len(const int* lens, int b, int T) {
+  if (!lens) return T;
+  const auto* p = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(lens));
+  return p[__builtin_amdgcn_readfirstlane(b)];
+}
 __device__ __forceinline__ float ss_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Gate nonlinearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error
 // <= ~3e-7 on outputs in [-1,1], far inside the 1e-4 mel budget, and ~10x fewer VALU ops than ocml tanhf/expf.

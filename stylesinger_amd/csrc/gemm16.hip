@@ -6,8 +6,9 @@
 //   * tile count: 64-row tiles give 768 workgroups for the mel launch and 1152 for the f0 pair - on 768 resident slots the f0 launch
 //     runs 1.5 rounds. Here a workgroup is 16*MT rows x 64 columns (4 waves x 16 columns); MT = 6 (96 rows) makes an 8 s utterance
 //     exactly 16 row tiles: mel 512 workgroups (2 per CU), f0 pair 768 (3 per CU), one balanced round each.
-//   * K is small, so the WHOLE weight slice of a wave (16 columns x K) is fetched once into registers before the loop (48 / 64 VGPRs):
-//     the loop issues no weight loads and needs no LDS for B.
+//   * a wave's weight slice (16 columns x K) goes global -> registers directly, two chunks ahead through 3 register stages, issued
+//     right behind the A pieces of the same chunk (the VMEM counter retires in order: fetched up front they all had to land before
+//     the first MFMA - 3.3 of 22 us in the ablation); no LDS for B.
 //   * the A tile goes global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs, no ds_write, no VALU): each DMA instruction
 //     moves 8 rows x 128 B (full lines); the LDS image is lane-linear, so the XOR slot swizzle is applied on the SOURCE address.
 //     A ring of 3 K chunks is in flight with counted s_waitcnt vmcnt + a raw s_barrier per chunk (a __syncthreads() would drain the
@@ -21,6 +22,12 @@
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// SS_R16_ABL (debug builds only, tools/ablate_r16.sh; results are wrong by design), gemm16_res_kernel: 1 = no weight preload, 2 = no A
+// DMA after the first two chunks, 3 = no MFMAs, 4 = no residual-stream loads, 5 = no output stores, 6 = no barriers in the loop
+#ifndef SS_R16_ABL
+#define SS_R16_ABL 0
+#endif
 
 namespace {
 
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kg = lane >> 4;
-  const int len = a.lens ? a.lens[b] : a.T;
+  const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
 
   auto uniform_ptr = [](const float* p) {
@@ -89,18 +96,30 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
   // ---- the wave's weight slice: column n0 + 16 w + lc, K floats [32 j + 8 kg, +8) of every chunk j -> registers, once
   const int col = n0 + 16 * wave + lc;
   const int w_voff = (col * a.Kp + kg * 8) * 4;
-  float4 bw[KCH][2];
-#pragma unroll
-  for (int j = 0; j < KCH; ++j) {
-    bw[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, j * (BK * 4), 0));
-    bw[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, j * (BK * 4), 0));
-  }
+  // streamed two chunks ahead through a ring of 3 register stages, issued right after the A pieces of the same chunk: the VMEM
+  // counter retires in order, so weights fetched up front would all have to land before the first MFMA (ablation: 3.3 of 22 us)
+  float4 bw[3][2];
+  auto load_w = [&](auto jtag) {
+    constexpr int j = decltype(jtag)::value;
+    if constexpr (SS_R16_ABL == 1) {
+      bw[j % 3][0] = make_float4(0.01f * lane, 0.02f, 0.03f * j, 0.04f);
+      bw[j % 3][1] = make_float4(0.05f, 0.06f * lane, 0.07f, 0.08f * j);
+    } else {
+      bw[j % 3][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, j * (BK * 4), 0));
+      bw[j % 3][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, j * (BK * 4), 0));
+    }
+  };
+  constexpr int WL = SS_R16_ABL == 1 ? 0 : 2;   // VMEM instructions of one weight stage
   // ---- epilogue operands: residual-stream tile (rows 16 m + 4 kg + r, column col) and the bias
   const bool col_ok = col < a.N;
   const int oob = col_ok ? 0 : (int)0x80000000;
   const int r_base = ((t0 + 4 * kg) * a.ldr + col) * 4 + oob;
-  float rv[MT][4];   // fetched inside the loop (chunk KCH-3), into the registers the consumed weight chunks have freed
-  const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + col] : 0.f;
+  float rv[MT][4];   // fetched inside the loop (chunk KCH-3)
+  // the bias travels with them (a buffer load with an empty range when there is none): fetched through a pointer at kernel entry it
+  // put a full memory round trip in front of the first A piece
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : a.W), 0, __builtin_amdgcn_readfirstlane(a.bias ? a.N * 4 : 0), 0x00020000);
+  float bs = 0.f;
 
   // ---- A tile by LDS-DMA. DMA instruction (wave w, j): rows 8 (w + 4 j) .. +8 of the tile; lane i lands at byte 16 i of that 1-KiB
   // piece = (row i >> 3, physical slot i & 7), so it FETCHES logical slot (i & 7) ^ swz16(row).
@@ -130,19 +149,24 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
   float* const bufs[NBUF] = {As0, As1, As2};
   __builtin_amdgcn_sched_barrier(0);   // the counted waits below rely on the DMA pieces being issued in chunk order
   dma(bufs[0], 0);
+  load_w(std::integral_constant<int, 0>{});
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (KCH > 1) dma(bufs[1], 1);
+  if constexpr (KCH > 1) {
+    dma(bufs[1], 1);
+    load_w(std::integral_constant<int, 1>{});
+  }
   __builtin_amdgcn_sched_barrier(0);
   // chunk c: wait for MY pieces of chunk c (the DPW instructions of chunk c+1 may stay in flight), barrier (everyone's pieces of chunk c
   // have landed; everyone is done reading chunk c-1), refill the slot chunk c-1 used with chunk c+2, fragments, MFMAs.
   auto chunk = [&](auto ctag) {
     constexpr int c = decltype(ctag)::value;
-    // outstanding VMEM ops younger than my pieces of chunk c: the DPW pieces of chunk c+1, plus - in chunk RC+1 - the 4 MT residual loads
+    // outstanding VMEM ops younger than my pieces and weights of chunk c: the DPW pieces + WL weight loads of chunk c+1, plus - in chunk
+    // RC+1 - the 4 MT residual loads and the bias load
     constexpr int RC = KCH >= 3 ? KCH - 3 : 0;   // the chunk that issues the residual-stream loads (before its DMA)
     if constexpr (c + 1 >= KCH) wait_vmcnt<0>();
-    else if constexpr (c == RC + 1 && KCH >= 3) wait_vmcnt<DPW + 4 * MT>();
-    else wait_vmcnt<DPW>();
-    __builtin_amdgcn_s_barrier();
+    else if constexpr (c == RC + 1 && KCH >= 3) wait_vmcnt<DPW + WL + 1 + (SS_R16_ABL == 4 ? 0 : 4 * MT)>();
+    else wait_vmcnt<DPW + WL>();
+    if constexpr (SS_R16_ABL != 6) __builtin_amdgcn_s_barrier();
     const float* Ac = bufs[c % NBUF];
     float4 af[MT][2];
 #pragma unroll
@@ -156,15 +180,24 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          rv[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, r_base, (16 * m + r) * a.ldr * 4, 0));
+          rv[m][r] = SS_R16_ABL == 4 ? 0.5f * r : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, r_base, (16 * m + r) * a.ldr * 4, 0));
+      bs = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, col * 4, 0, 0));   // col >= N: out of range -> 0
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (c + 2 < KCH) dma(bufs[(c + 2) % NBUF], c + 2);
+    if constexpr (c + 2 < KCH) {
+      if constexpr (SS_R16_ABL != 2) dma(bufs[(c + 2) % NBUF], c + 2);
+      load_w(std::integral_constant<int, c + 2>{});
+    }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SS_R16_ABL == 3) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][0] += af[m][0].x * bw[c % 3][0].x + af[m][1].w * bw[c % 3][1].w;
+      return;
+    }
     // MT independent accumulators per K step: consecutive MFMAs never touch the same one (40-cycle dependent latency, 32-cycle issue)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float4 bf = bw[c][h];
+      const float4 bf = bw[c % 3][h];
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h].x, bf.x, acc[m], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -197,6 +230,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
     for (int r = 0; r < 4; ++r) {
       float o = (rv[m][r] + (acc[m][r] + bs)) * a.post_scale;
       if (!interior && t0 + 16 * m + 4 * kg + r >= row_lim) o = 0.f;
+      if (SS_R16_ABL == 5 && o != 123456.789f) continue;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsrc_c, c_base, (16 * m + r) * a.ldc * 4, 0);
     }
 }
@@ -230,7 +264,7 @@ __global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm
   const int n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kg = lane >> 4;
-  const int len = a.lens ? a.lens[b] : a.T;
+  const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const int kchunks = a.Kp / BK;
 

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int len = a.lens ? a.lens[b] : a.T;
+  const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const int nchunks_tap = a.K / BKH;
   const int nchunks = a.ntaps * nchunks_tap;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int len = a.lens ? a.lens[b] : a.T;
+  const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const int ldw = 3 * a.K;            // bf16 per packed weight row (3 taps)
 

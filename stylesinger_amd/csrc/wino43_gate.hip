@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void wino43_gate_kernel(const ss_conv_gemm_
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int len = a.lens ? a.lens[b] : a.T;
+  const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const float* Wg = a.W + (int64_t)grp_w * a.w_group_stride;
   const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;

@@ -76,15 +76,17 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   const int qt = grp * 8 + (rem & 7);
   const int nt = rem >> 3;
   if (qt >= q_tiles) return;
-  const int b = qt / q_tiles_per_item;
-  const int q0 = (qt % q_tiles_per_item) * BQ;
+  // block-uniform by construction; telling the compiler so makes lens[b] a scalar load instead of a vector load + vmcnt(0) in front of
+  // the first row fetch
+  const int b = __builtin_amdgcn_readfirstlane(qt / q_tiles_per_item);
+  const int q0 = __builtin_amdgcn_readfirstlane((qt % q_tiles_per_item) * BQ);
   const int n0 = nt * BN;
   const int d = 1 << log2d;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kg = lane >> 4;
 
-  const int len = a.lens ? a.lens[b] : a.T;
+  const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const float* Wg = a.W + (int64_t)grp_w * a.w_group_stride;
   const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;
