@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 9 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res */
+#define SS_ABI_VERSION 10 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -150,6 +150,13 @@ int ss_gemm16_pick(int B, int T, int N);
  * K = Cin = Kp multiple of 32, one tap; same 16*mt x 64 tiles as ss_gemm16_res. */
 int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream);
 
+/* Grouped Winograd F(4,3) form of a k-tap (3 | 7 | 11) dilated (1 | 3 | 5) C -> C conv with the SS_EPI_STORE epilogue (act none | leaky-relu,
+ * bias, residual R, post_scale, accumulate, row mask) and the input leaky-relu of the HiFi-GAN ResBlocks (hifigan_nsf.py:54-61 /
+ * hifigan.py ResBlock1): the taps are split into ceil(k/3) groups of three, each an F(4,3) product, six accumulators over all groups.
+ * args as for ss_conv_gemm with W = ss_pack_conv_weight of the transformed taps [C][C][6*ceil(k/3)] (ss_wino43_weight_transform per
+ * group, zero-padded last group), Kp == Np == N == Cin == C (multiple of 64), fp32 only. ss_wino43_conv_ok: 1 if (C, k, dilation) is covered. */
+int ss_wino43_conv(const ss_conv_gemm_args* args, int k, int dilation, void* stream);
+int ss_wino43_conv_ok(int C, int k, int dilation);
 /* Winograd F(2,3) form of the 3-tap dilated conv + SS_EPI_GATE epilogue (net.py:66-73): same arguments as the
  * direct call except that W is the TRANSFORMED weight packed as a 4-"tap" tensor (ss_wino_weight_transform then
  * ss_pack_conv_weight(k=4, interleave_half=C)) and the dilation is passed explicitly (power of two). 1.5x fewer
@@ -470,7 +477,12 @@ typedef struct ss_hifigan {
   const float* src_b; /* [1] */
   /* 1 = bf16-operand MFMA for conv_pre, the transposed convs and the residual blocks (conv_post and the NSF source stay fp32) */
   int32_t mfma_bf16;
-  int32_t reserved0;
+  /* 1 = ResBlock convs with a Winograd pack below run as grouped F(4,3) (ss_wino43_conv; fp32 mode, C a multiple of 64, k in {3,7,11},
+   * dilation in {1,3,5}); 0 / NULL pack = direct ss_conv_gemm. Same results to fp32 rounding (wav max error 1.3e-7 vs 0.9e-7 on the
+   * reference's golden cases, oracle/wino_vocoder_numerics.py) */
+  int32_t wino;
+  const float* w_rb1_wino[SS_HG_MAX_UPS][SS_HG_MAX_KERNELS][3]; /* ss_pack_conv_weight of the [C][C][6*ceil(k/3)] transformed taps */
+  const float* w_rb2_wino[SS_HG_MAX_UPS][SS_HG_MAX_KERNELS][3];
 } ss_hifigan;
 
 int64_t ss_hifigan_workspace_bytes(const ss_hifigan* hg, int B, int T);

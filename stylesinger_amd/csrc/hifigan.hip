@@ -354,8 +354,10 @@ inline ss_conv_gemm_args base_args(int B, int T, const int32_t* lens) {
   return a;
 }
 
-int conv_same(const float* A, int B, int Trows, int C, const int32_t* lens, const float* W, const float* bias, int k, int d,
-              float lrelu, const float* R, float post_scale, int accumulate, float* out, int bf16, hipStream_t stream) {
+// W_wino != NULL: the grouped Winograd F(4,3) kernel (fp32 mode; the caller checked ss_wino43_conv_ok). act_out = 1: leaky-relu(0.1)
+// of the OUTPUT in the epilogue - the value is only ever read through the next conv's input leaky-relu, which then passes lrelu = 1.
+int conv_same(const float* A, int B, int Trows, int C, const int32_t* lens, const float* W, const float* W_wino, const float* bias, int k,
+              int d, float lrelu, int act_out, const float* R, float post_scale, int accumulate, float* out, int bf16, hipStream_t stream) {
   ss_conv_gemm_args a = base_args(B, Trows, lens);
   a.mfma_bf16 = bf16;
   a.A = A;
@@ -379,6 +381,14 @@ int conv_same(const float* A, int B, int Trows, int C, const int32_t* lens, cons
   a.C = out;
   a.ldc = C;
   a.c_batch_stride = (int64_t)Trows * C;
+  if (act_out) {
+    a.act = SS_ACT_LRELU_;
+    a.act_slope = 0.1f;
+  }
+  if (W_wino) {
+    a.W = W_wino;
+    return ss_wino43_conv(&a, k, d, stream);
+  }
   return ss_conv_gemm(&a, stream);
 }
 
@@ -509,15 +519,19 @@ extern "C" int ss_hifigan_forward(const ss_hifigan* hg, const float* mel, const 
       const float* xin = w.x;
       for (int m = 0; m < 3; ++m) {
         const int d = hg->rb_d[j][m];
-        SS_PROPAGATE(conv_same(xin, B, rows_out, cout, lens_out, hg->w_rb1[i][j][m], hg->b_rb1[i][j][m], k, d, 0.1f,
-                               nullptr, 1.0f, 0, w.ta, hg->mfma_bf16, stream));
+        const bool wino = hg->wino && !hg->mfma_bf16;
+        const float* ww1 = wino && ss_wino43_conv_ok(cout, k, d) ? hg->w_rb1_wino[i][j][m] : nullptr;
+        const float* ww2 = wino && ss_wino43_conv_ok(cout, k, 1) ? hg->w_rb2_wino[i][j][m] : nullptr;
+        // xt = c1(lrelu(x)) is only read as lrelu(xt): the first conv stores lrelu(xt), the second needs no input activation
+        SS_PROPAGATE(conv_same(xin, B, rows_out, cout, lens_out, hg->w_rb1[i][j][m], ww1, hg->b_rb1[i][j][m], k, d, 0.1f, 1, nullptr, 1.0f,
+                               0, w.ta, hg->mfma_bf16, stream));
         if (m < 2) {
-          SS_PROPAGATE(conv_same(w.ta, B, rows_out, cout, lens_out, hg->w_rb2[i][j][m], hg->b_rb2[i][j][m], k, 1, 0.1f, xin,
-                                 1.0f, 0, w.tb, hg->mfma_bf16, stream));
+          SS_PROPAGATE(conv_same(w.ta, B, rows_out, cout, lens_out, hg->w_rb2[i][j][m], ww2, hg->b_rb2[i][j][m], k, 1, 1.0f, 0, xin, 1.0f,
+                                 0, w.tb, hg->mfma_bf16, stream));
           xin = w.tb;
         } else {
-          SS_PROPAGATE(conv_same(w.ta, B, rows_out, cout, lens_out, hg->w_rb2[i][j][m], hg->b_rb2[i][j][m], k, 1, 0.1f, xin,
-                                 inv, j > 0, w.xs, hg->mfma_bf16, stream));
+          SS_PROPAGATE(conv_same(w.ta, B, rows_out, cout, lens_out, hg->w_rb2[i][j][m], ww2, hg->b_rb2[i][j][m], k, 1, 1.0f, 0, xin, inv,
+                                 j > 0, w.xs, hg->mfma_bf16, stream));
         }
       }
     }

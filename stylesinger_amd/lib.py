@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 9  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 10  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -92,7 +92,8 @@ class HifiGan(C.Structure):
         ("w_noise", _vp * SS_HG_MAX_UPS), ("b_noise", _vp * SS_HG_MAX_UPS),
         ("w_rb1", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS), ("b_rb1", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS),
         ("w_rb2", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS), ("b_rb2", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS),
-        ("w_post", _vp), ("b_post", _vp), ("src_w", _vp), ("src_b", _vp), ("mfma_bf16", C.c_int32), ("reserved0", C.c_int32),
+        ("w_post", _vp), ("b_post", _vp), ("src_w", _vp), ("src_b", _vp), ("mfma_bf16", C.c_int32), ("wino", C.c_int32),
+        ("w_rb1_wino", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS), ("w_rb2_wino", ((_vp * 3) * SS_HG_MAX_KERNELS) * SS_HG_MAX_UPS),
     ]
 
 
@@ -264,6 +265,25 @@ def wino43_weight(w):
     w = w.contiguous().float()
     out = torch.empty(w.shape[0], w.shape[1], 6, device=w.device, dtype=torch.float32)
     check(load().ss_wino43_weight_transform(ptr(w), ptr(out), w.shape[0], w.shape[1], stream_ptr()), "ss_wino43_weight_transform")
+    return out
+
+
+def wino43_group_weight(w):
+    """conv weight [Cout][Cin][k] (device, k odd) -> [Cout][Cin][6 * ceil(k/3)]: the taps in groups of three (zero padded), every group
+    F(4,3)-transformed - the B operand of ss_wino43_conv after ss_pack_conv_weight."""
+    w = w.contiguous().float()
+    Cout, Cin, k = w.shape
+    G = (k + 2) // 3
+    wp = torch.zeros(Cout, Cin, 3 * G, device=w.device, dtype=torch.float32)
+    wp[..., :k] = w
+    return torch.cat([wino43_weight(wp[..., 3 * g:3 * g + 3]) for g in range(G)], dim=-1).contiguous()
+
+
+def wino43_conv(A, W, out, *, k, dilation, **kw):
+    """Grouped Winograd F(4,3) conv (ss_wino43_conv); keyword arguments as conv_gemm (taps are implied by k and dilation)."""
+    taps = [(j - (k - 1) // 2) * dilation for j in range(k)]
+    a = _fill_args(A, W, out, taps=taps, **kw)
+    check(load().ss_wino43_conv(C.byref(a), k, dilation, stream_ptr()), "ss_wino43_conv")
     return out
 
 

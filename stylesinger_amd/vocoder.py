@@ -82,6 +82,9 @@ class HifiGanGeneratorHIP(torch.nn.Module):
         hg.sr, hg.harmonics = h["audio_sample_rate"], h["harmonic_num"]
         import os
         hg.mfma_bf16 = 1 if os.environ.get("SS_PRECISION", h.get("mfma_precision", "fp32")) == "bf16" else 0
+        # grouped Winograd F(4,3) ResBlock convs (fp32 mode; SS_VOC_WINO=0 keeps the direct convs)
+        hg.wino = 1 if (not hg.mfma_bf16 and os.environ.get("SS_VOC_WINO", str(h.get("vocoder_wino", 1))) != "0") else 0
+        lib = L.load()
         for i, (u, k) in enumerate(zip(rates, ks)):
             hg.up_rate[i], hg.up_k[i] = u, k
         for i in range(len(rates), L.SS_HG_MAX_UPS):
@@ -109,12 +112,18 @@ class HifiGanGeneratorHIP(torch.nn.Module):
             for j in range(nk):
                 for m in range(3):
                     pfx = f"resblocks.{i * nk + j}"
+                    k, d = h["resblock_kernel_sizes"][j], h["resblock_dilation_sizes"][j][m]
+                    cout = hg.c0 >> (i + 1)
                     v, s0 = self._wn(f"{pfx}.convs1.{m}")
                     hg.w_rb1[i][j][m] = hold(L.pack_conv_weight(v, scale0=s0))
                     hg.b_rb1[i][j][m] = hold(L.pack_bias(self.p(f"{pfx}.convs1.{m}.bias")))
+                    if hg.wino and lib.ss_wino43_conv_ok(cout, k, d):   # grouped F(4,3) pack of the folded weight
+                        hg.w_rb1_wino[i][j][m] = hold(L.pack_conv_weight(L.wino43_group_weight(v * s0.view(-1, 1, 1))))
                     v, s0 = self._wn(f"{pfx}.convs2.{m}")
                     hg.w_rb2[i][j][m] = hold(L.pack_conv_weight(v, scale0=s0))
                     hg.b_rb2[i][j][m] = hold(L.pack_bias(self.p(f"{pfx}.convs2.{m}.bias")))
+                    if hg.wino and lib.ss_wino43_conv_ok(cout, k, 1):
+                        hg.w_rb2_wino[i][j][m] = hold(L.pack_conv_weight(L.wino43_group_weight(v * s0.view(-1, 1, 1))))
         v, s0 = self._wn("conv_post")
         hg.w_post = hold((v * s0.view(-1, 1, 1)).contiguous())  # 1 x c_last x 7 filter, consumed raw by conv_post_kernel
         hg.b_post = hold(self.p("conv_post.bias").contiguous())

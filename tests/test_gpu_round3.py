@@ -340,3 +340,73 @@ def test_bf16_gate256_kernel_matches_the_generic_bf16_kernel(C, d, T, B):
     assert (got.float() - want.float()).abs().mean().item() <= 2e-4
     for b in range(B):
         assert torch.all(got[b, int(lens[b]):] == 0)
+
+
+@pytest.mark.parametrize("C,k,d", [(64, 3, 1), (64, 7, 3), (64, 11, 5), (128, 3, 5), (128, 11, 1), (256, 7, 1), (256, 3, 3)])
+def test_wino43_conv_matches_torch_conv1d_and_the_direct_kernel(C, k, d):
+    """ss_wino43_conv (grouped Winograd F(4,3): ceil(k/3) tap groups, six accumulators over all of them) vs torch fp32 conv1d on the same
+    leaky-relu'd input and vs ss_conv_gemm: ragged lens (frames >= len read as zero padding and are written as 0), input leaky-relu,
+    bias, in-place residual, post_scale + accumulate, leaky-relu of the output. Tolerance 5e-5 abs on O(1) outputs that are sums of up to
+    11 x 256 products (measured: <= 2.1e-5 vs torch, the same as the direct kernel's distance; emulation in
+    oracle/wino_vocoder_numerics.py: 2.7e-6 vs float64 at C = 32)."""
+    import math
+    import torch.nn.functional as F
+    from stylesinger_amd import lib as L
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 * C + 10 * k + d)
+    B, T = 3, 777
+    lens_l = [T, T - 123, 41]
+    x = torch.randn(B, T, C, generator=g)
+    for b, n in enumerate(lens_l):
+        x[b, n:] = 0
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    bias = torch.randn(C, generator=g) * 0.3
+    res = torch.randn(B, T, C, generator=g)
+    prev = torch.randn(B, T, C, generator=g)
+    lens = torch.tensor(lens_l, dtype=torch.int32).to(dv)
+    Ww = L.pack_conv_weight(L.wino43_group_weight(w.to(dv)))
+    Wd = L.pack_conv_weight(w.to(dv))
+    bp = L.pack_bias(bias.to(dv))
+    xd = x.to(dv)
+    kw = dict(B=B, T=T, Cin=C, N=C, Np=C, Kp=C, lens=lens, bias=bp, ldc=C, mask_rows=True)
+    taps = [(j - (k - 1) // 2) * d for j in range(k)]
+
+    def ref(slope_in, act_out, R, post, acc):
+        outs = []
+        for b, n in enumerate(lens_l):
+            xi = F.leaky_relu(x[b:b + 1, :n], slope_in) if slope_in != 1.0 else x[b:b + 1, :n]
+            y = F.conv1d(xi.transpose(1, 2), w, bias, padding=(k - 1) // 2 * d, dilation=d).transpose(1, 2)
+            if act_out:
+                y = F.leaky_relu(y, 0.1)
+            if R is not None:
+                y = y + R[b:b + 1, :n]
+            y = y * post
+            if acc is not None:
+                y = y + acc[b:b + 1, :n]
+            outs.append(F.pad(y, (0, 0, 0, T - n)))
+        return torch.cat(outs)
+
+    # (1) first conv of a ResBlock pair: input leaky-relu, output leaky-relu, no residual
+    want = ref(0.1, True, None, 1.0, None)
+    got = torch.full((B, T, C), 9.0, device=dv)
+    L.wino43_conv(xd, Ww, got, k=k, dilation=d, a_lrelu=0.1, act=L.ACT_LRELU, act_slope=0.1, **kw)
+    direct = torch.full((B, T, C), 7.0, device=dv)
+    L.conv_gemm(xd, Wd, direct, taps=taps, a_lrelu=0.1, act=L.ACT_LRELU, act_slope=0.1, **kw)
+    e1, e1d = (got.cpu() - want).abs().max().item(), (got - direct).abs().max().item()
+    assert e1 <= 5e-5 and e1d <= 5e-5, (e1, e1d)
+    for b, n in enumerate(lens_l):
+        assert torch.all(got[b, n:] == 0)
+    # (2) second conv: no input activation, residual IN PLACE (R == C), then (3) the accumulating form with post_scale
+    want = ref(1.0, False, res, 1.0, None)
+    buf = res.to(dv).clone()
+    L.wino43_conv(xd, Ww, buf, k=k, dilation=d, R=buf, ldr=C, **kw)
+    e2 = (buf.cpu() - want).abs().max().item()
+    assert e2 <= 5e-5, e2
+    want = ref(1.0, False, res, 1.0 / 3.0, prev)
+    for b, n in enumerate(lens_l):
+        want[b, n:] = 0
+    acc = prev.to(dv).clone()
+    L.wino43_conv(xd, Ww, acc, k=k, dilation=d, R=res.to(dv), ldr=C, post_scale=1.0 / 3.0, accumulate=True, **kw)
+    e3 = (acc.cpu() - want).abs().max().item()
+    assert e3 <= 5e-5, e3
+    record_measurement(f"wino43_conv_C{C}_k{k}_d{d}", max_err_vs_torch=max(e1, e2, e3), max_err_vs_direct_kernel=e1d)

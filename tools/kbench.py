@@ -169,6 +169,12 @@ def main():
                                     taps=[(j - k // 2) * 3 for j in range(k)], lens=ln, a_lrelu=0.1, bias=bias, R=X, ldr=C, tile=a.tile)
             s = timeit(f, max(3, a.iters // 5))
             res.append((f"voc C={C} rows={rows} k={k}", s, 2.0 * B * rows * C * C * k))
+            if L.load().ss_wino43_conv_ok(C, k, 3):   # the same conv as grouped Winograd F(4,3) (algorithmic flops of the direct form)
+                Ww = L.pack_conv_weight(L.wino43_group_weight(w))
+                fw = lambda: L.wino43_conv(X, Ww, Y, k=k, dilation=3, B=B, T=rows, Cin=C, N=C, Np=C, Kp=C, lens=ln, a_lrelu=0.1, bias=bias,
+                                           R=X, ldr=C)
+                s = timeit(fw, max(3, a.iters // 5))
+                res.append((f"voc C={C} rows={rows} k={k} grouped F(4,3)", s, 2.0 * B * rows * C * C * k))
     for name, s, fl in res:
         print(f"{name:52s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.2f} TF/s  ({fl / s / 157.3e12 * 100:5.1f}% of fp32 MFMA peak)")
 
