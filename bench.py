@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 MEL_FLOP_PER_FRAME_STEP = 26.43e6   # SURVEY.md §8(d), algorithmic (cond-proj counted)
 F0_FLOP_PER_FRAME_STEP = 7.94e6     # per network
 VOC_FLOP_PER_FRAME = 614.6e6
+# ResBlock convs of the stages with C = 256 / 128 / 64 (rows per frame 8 / 64 / 128): 2 * rows * C^2 * (3 + 7 + 11) taps * 6 convs
+VOC_RESBLOCK_C64UP_FLOP_PER_FRAME = 252.0 * (8 * 256 ** 2 + 64 * 128 ** 2 + 128 * 64 ** 2)
 REST_FLOP_PER_FRAME = 45e6
 MEL_COND_FLOP = 5.24e6              # step-invariant conditioner projections (hoisted: executed once, not per step)
 F0_COND_FLOP = 1.97e6
@@ -196,7 +198,23 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                 break
         except (ValueError, OSError):
             pass
-    return dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)",
+    # the same kernel INSIDE the graph-replayed loop, from this round's committed rocprofv3 --kernel-trace --stats summary (the dense replay
+    # above runs the kernel back to back, where the chip clocks down; in the loop it alternates with the projections): average duration of
+    # the C2 launches and the executed-MFMA fraction that follows from it. null when no such profile exists for this kernel / shape.
+    in_loop = None
+    csv_path = os.path.join(ROOT, "profiles", "r03_bench_c2_1stream_kernel_stats.csv")
+    if wino_m == 4 and mt and B * T == 12000 and os.path.exists(csv_path):
+        try:
+            import csv
+            for row in csv.DictReader(open(csv_path)):
+                if f"wino43_gate16_kernel<{mt}" in row["Name"]:
+                    us = float(row["AverageNs"]) * 1e-3
+                    in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak,
+                               "source": "profiles/r03_bench_c2_1stream_kernel_stats.csv"}
+                    break
+        except (KeyError, ValueError, OSError):
+            in_loop = None
+    return dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)", in_loop_from_profile=in_loop,
                 achieved=flops / sec / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=flops / sec / peak,
                 executed_mfma_frac=executed / sec / peak, executed_flops_per_launch=executed,
                 # `peak` is the data-sheet figure at 2.4 GHz; under this load the chip sustains `clock_ghz` (measured inside the
@@ -467,6 +485,10 @@ def main():
     wino = infer.model.use_wino and not bf16
     wino_saved = 0.5 if getattr(infer.model, "wino_m", 2) == 4 else 1.0 / 3.0
     flop_exec = flop_hoisted - ((MEL_GATE_FLOP * S_mel + 2 * F0_GATE_FLOP * S_f0) * wino_saved if wino else 0.0)
+    # HiFi-GAN ResBlock convs of the C >= 64 stages as grouped F(4,3) (fp32 mode, default): 1.5 * ceil(k/3) instead of k products per
+    # output and tap group -> 12 / 21 of the direct form's flops for k = 3, 7, 11
+    if not bf16 and getattr(infer.vocoder.model, "_pk", None) and infer.vocoder.model._pk["hg"].wino:
+        flop_exec -= VOC_RESBLOCK_C64UP_FLOP_PER_FRAME * (1.0 - 12.0 / 21.0)
     peak = PEAK_BF16_MFMA if bf16 else PEAK_FP32_MFMA
     per_gpu = value / world
 
