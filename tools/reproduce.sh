@@ -7,8 +7,9 @@
 #   bench [args]     python bench.py [args]                   (the driver's line; default = c2 + cpu_baseline + secondary c5 / c4)
 #   profile [args]   rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary [args]`
 #   pmc-gate         PMC passes on the dominant kernel launch (one counter block per pass, --kernel-trace --pmc only)
-#   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs)
+#   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs direct vs grouped F(4,3))
 #   ablate-gate16    timing ablations of the 16x16-tile gate kernel (debug builds: tools/ablate_g16.sh build, in the container)
+#   ablate-res16     the same for the residual-projection kernel (tools/ablate_r16.sh build, in the container)
 #   ubench           micro-benchmarks behind DESIGN.md §3.0 (VALU beside fp32 MFMA, 16x16x4 issue rate, DPP / LDS-DMA probes)
 cd ${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 R=$PWD
@@ -34,12 +35,14 @@ case "$sec" in
     bash tools/pmc.sh g16_tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -- $K ;;
   kbench)
     python tools/kbench.py --which wino43_16 --iters 60 --mt=-1,3,2
-    python tools/kbench.py --which resskip --iters 60 --tile 3
+    python tools/kbench.py --which res16 --iters 60 --mt 6
     python tools/kbench.py --which voc --iters 30 ;;
   ablate-gate16)
     bash tools/ablate_g16.sh run ;;
+  ablate-res16)
+    bash tools/ablate_r16.sh run ;;
   ubench)
-    for f in mfma_valu mfma16 glds_probe; do
+    for f in mfma_valu mfma16 glds_probe l2bw soffset_probe; do
       hipcc --offload-arch=gfx950 -O3 tools/ubench/$f.hip -o /tmp/$f 2>/dev/null && /tmp/$f
     done ;;
   *) echo "unknown section '$sec'"; sed -n 2,15p $0; exit 2 ;;
