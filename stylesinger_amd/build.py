@@ -87,14 +87,20 @@ def build(verbose=True, jobs=None):
     objs = [o for o, _ in res]
     rebuilt = [o for o, r in res if r]
     if rebuilt or not os.path.exists(LIB):
+        if os.path.exists(LIB + ".ok"):
+            os.remove(LIB + ".ok")
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-6000:])
     # a shared library links with undefined symbols; make sure this one resolves when it is loaded (e.g. a kernel whose host launch
-    # stub the compiler dropped shows up only here)
-    import ctypes
-    ctypes.CDLL(LIB)
+    # stub the compiler dropped shows up only here). In a CHILD process: loading it here, before torch, would bring the system HIP runtime
+    # into this process ahead of the one torch ships, and a later torch.cuda in the same process then finds no device.
+    if not os.path.exists(LIB + ".ok"):
+        r = subprocess.run([sys.executable, "-c", "import ctypes, sys; ctypes.CDLL(sys.argv[1])", LIB], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("libstylesinger_hip.so does not load:\n" + (r.stderr or r.stdout)[-4000:])
+        open(LIB + ".ok", "w").close()
     if verbose:
         print("[stylesinger_amd.build] %d sources, %d recompiled -> %s" % (len(srcs), len(rebuilt), LIB))
     return LIB

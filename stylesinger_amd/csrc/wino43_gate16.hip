@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   const int n0 = nt * BN;
   const int d = 1 << log2d;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lc = lane & 15, kg = lane >> 4;
 
   const int len = ss_uniform_len(a.lens, b, a.T);
@@ -352,9 +352,16 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
       chunk(P5{}, Yes{}, Yes{}, No{}, k);    // builds c1(k+1); fetches the weights of (k+1, position 1)
     }
   }
+  {
   // The conditioner addend of the epilogue (48 values per lane at MT = 3; a 40 KB row stride, i.e. one HBM / L2 miss per element) is
   // fetched under the last three chunks, into the registers the raw rows and the shared terms no longer need: in a single-round launch
   // every workgroup reaches its epilogue at the same time, so loads issued there are fully exposed (ablation: 4.4 of 59 us).
+  // From here on the lane coordinates are derived afresh (two mbcnt instructions): nothing lane-dependent of the prologue has to stay
+  // in a register across the K loop for the epilogue's sake (the K-staged MT = 2 form otherwise spills 7 registers to scratch).
+  const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int lc = lane_e & 15, kg = lane_e >> 4;
+  const int c7 = lc & 7, chi = lc >> 3;
+  const int pc = n0 + 8 * wave + c7 + 32 * chi;
   const float* Eb = a.E ? a.E + (int64_t)b * a.e_batch_stride : nullptr;
   const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(Eb ? Eb : Wg), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
@@ -459,7 +466,8 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   const bool fast = a.bias == nullptr && (q_last + 3 * (q_last & ~(d - 1)) + 3 * d) < row_lim;  // block-uniform
   if (fast) epilogue(std::true_type{});
   else epilogue(std::false_type{});
-  if (probing && threadIdx.x == 0) {
+  }
+  if (probing && wave == 0 && __builtin_amdgcn_mbcnt_lo(~0u, 0u) == 0 && __builtin_amdgcn_mbcnt_hi(~0u, 0u) == 0) {   // thread 0, without keeping threadIdx alive
     atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
     atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
   }
