@@ -88,6 +88,14 @@ __device__ __forceinline__ float ss_mish(float x) {
   return x * tanhf(sp);
 }
 __device__ __forceinline__ float ss_lrelu(float x, float slope) { return x >= 0.0f ? x : x * slope; }
+// The same value for 0 < slope < 1 from the product sx = slope * x in ONE instruction: max(x, sx). fmaxf(x, sx) - and fmed3(x, sx, inf), which
+// the compiler folds back into it - costs two on this target (IEEE mode: a possibly signalling x is quieted by v_max x, x before the v_max),
+// and VALU instructions take matrix time; the asm is the bare v_max_f32.
+__device__ __forceinline__ float ss_lrelu_max(float x, float sx) {
+  float o;
+  asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(sx));
+  return o;
+}
 
 enum SsAct { SS_ACT_NONE = 0, SS_ACT_RELU = 1, SS_ACT_GELU = 2, SS_ACT_MISH = 3, SS_ACT_TANH = 4, SS_ACT_LRELU = 5 };
 

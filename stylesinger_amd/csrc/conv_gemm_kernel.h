@@ -175,8 +175,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         float4 v = __builtin_bit_cast(float4, ra[i]);
-        v.x = fmaxf(v.x, pro_slope * v.x); v.y = fmaxf(v.y, pro_slope * v.y);
-        v.z = fmaxf(v.z, pro_slope * v.z); v.w = fmaxf(v.w, pro_slope * v.w);
+        v.x = ss_lrelu_max(v.x, pro_slope * v.x); v.y = ss_lrelu_max(v.y, pro_slope * v.y);
+        v.z = ss_lrelu_max(v.z, pro_slope * v.z); v.w = ss_lrelu_max(v.w, pro_slope * v.w);
         *reinterpret_cast<float4*>(Ad + lds_slot(st_row + i * RP, st_c4)) = v;
       }
       return;

@@ -16,13 +16,15 @@
 // c4 with the shared terms of wino43_gate16.hip (18 VALU per element instead of 28; the raw rows are dead after the third build, so the
 // rows of the next step are fetched three components ahead). Rows outside [0, len) are out of the buffer range -> read 0: the row offset
 // lives in a VGPR (negative = out of range), the K-chunk offset in an SGPR; moving to the next tap group adds 3 d rows to the VGPRs.
-// The leaky-relu of the input is applied ONCE per fetched row register (max(x, slope x) == x >= 0 ? x : slope x for 0 < slope < 1).
+// The leaky-relu of the input is applied ONCE per fetched row register (max(x, slope x) == x >= 0 ? x : slope x for 0 < slope < 1): one
+// packed multiply per two elements + one bare v_max_f32 per element (ss_lrelu_max).
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -119,12 +121,14 @@ __global__ __launch_bounds__(256, 2) void wino43_conv_kernel(const ss_conv_gemm_
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          float4 v = __builtin_bit_cast(float4, rr[i][r]);
-          v.x = fmaxf(v.x, v.x * slope);
-          v.y = fmaxf(v.y, v.y * slope);
-          v.z = fmaxf(v.z, v.z * slope);
-          v.w = fmaxf(v.w, v.w * slope);
-          rr[i][r] = __builtin_bit_cast(u32x4, v);
+          const f32x4 v = __builtin_bit_cast(f32x4, rr[i][r]);
+          const f32x4 sv = v * slope;   // two v_pk_mul_f32
+          f32x4 o;
+          o.x = ss_lrelu_max(v.x, sv.x);
+          o.y = ss_lrelu_max(v.y, sv.y);
+          o.z = ss_lrelu_max(v.z, sv.z);
+          o.w = ss_lrelu_max(v.w, sv.w);
+          rr[i][r] = __builtin_bit_cast(u32x4, o);
         }
     }
   };
