@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 10 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan */
+#define SS_ABI_VERSION 11 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3) */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -150,6 +150,13 @@ int ss_gemm16_pick(int B, int T, int N);
  * K = Cin = Kp multiple of 32, one tap; same 16*mt x 64 tiles as ss_gemm16_res. */
 int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream);
 
+/* "bf16x3" form of ss_wino43_gate16 (opt-in precision mode): the same F(4,3) gate with every fp32 product computed on the BF16 matrix cores
+ * from operands split into three bf16 terms (a = hi + mid + lo, round-to-nearest each; six partial products hi.hi, hi.mid, mid.hi, hi.lo,
+ * lo.hi, mid.mid accumulated in fp32, smallest first). Wx = ss_split3_weights of the packed F(4,3) weights ([Np][6][3][Kp] bf16; with
+ * grouped launches args->w_group_stride counts bf16 elements); args->W is ignored. mt as ss_wino43_gate16.
+ * ss_split3_weights: [rows][cols] fp32 -> [rows][3][cols] bf16 (call with rows = Np * 6, cols = Kp on a packed F(4,3) weight). */
+int ss_wino43_gate16x(const ss_conv_gemm_args* args, const void* Wx, int dilation, int mt, void* stream);
+int ss_split3_weights(const float* src, void* dst, int64_t rows, int cols, void* stream);
 /* Grouped Winograd F(4,3) form of a k-tap (3 | 7 | 11) dilated (1 | 3 | 5) C -> C conv with the SS_EPI_STORE epilogue (act none | leaky-relu,
  * bias, residual R, post_scale, accumulate, row mask) and the input leaky-relu of the HiFi-GAN ResBlocks (hifigan_nsf.py:54-61 /
  * hifigan.py ResBlock1): the taps are split into ceil(k/3) groups of three, each an F(4,3) product, six accumulators over all groups.
@@ -379,7 +386,10 @@ typedef struct ss_wavenet {
    * and skip_projection, net.py:124-126): the K = L*C GEMM + ReLU then IS the stack output and the skip_projection
    * launch disappears. */
   int32_t skipall_folded;
-  int32_t reserved1;
+  /* 1 = "bf16x3" precision mode (opt-in): layers with a w_dil_x3 pack run the F(4,3) gate on the BF16 matrix cores from split operands
+   * (ss_wino43_gate16x: three bf16 terms per operand, six exact products, fp32 accumulation - fp32-grade results at 6/16 of the fp32
+   * matrix time); everything else of the loop is unchanged */
+  int32_t mfma_x3;
   /* optional bf16 copies of the hidden-layer weights (same packed layouts, ss_to_bf16). When w_dil_h[0] is set and mfma_bf16 = 1
    * the residual stack runs on ss_gemm_bf16: activations travel between the layers as bf16 (y = x + dstep, gate outputs) and
    * the workspace carries the bf16 planes. w_out_h = residual half only ([C][C]); needs the deferred-skip form (w_skipall_h). */
@@ -388,6 +398,9 @@ typedef struct ss_wavenet {
   const uint16_t* w_skipall_h;
   const uint16_t* w_cond_h;
   int64_t gs_w_dil_h, gs_w_out_h, gs_w_skipall_h, gs_w_cond_h;
+  /* optional split copies of the F(4,3) gate weights: ss_split3_weights of w_dil_wino ([2C][6][3][Kp] bf16); gs in bf16 elements */
+  const uint16_t* w_dil_x3[SS_MAX_LAYERS];
+  int64_t gs_w_dil_x3;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -265,7 +265,10 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     if (net->w_dil_wino[l] && !net->mfma_bf16) {  // Winograd F(2,3): pairs of frames (t, t+d) from 4 products instead of 6
       a.W = net->w_dil_wino[l];
       a.w_group_stride = net->gs_w_dil_wino;
-      if (net->wino_m == 4) {
+      if (net->wino_m == 4 && net->mfma_x3 && net->w_dil_x3[l]) {   // opt-in "bf16x3" mode: split operands on the bf16 matrix cores
+        a.w_group_stride = net->gs_w_dil_x3;
+        SS_PROPAGATE(ss_wino43_gate16x(&a, net->w_dil_x3[l], d, 0, stream));
+      } else if (net->wino_m == 4) {
         const int g16 = g_ss_tuning.gate16;  // 0: 32x32x2 tiles; 1: per-launch pick; 2 / 3: 16x16x4 tiles of 16*MT quads
         SS_PROPAGATE(g16 == 0 ? ss_wino43_gate(&a, d, stream) : ss_wino43_gate16(&a, d, g16 == 1 ? 0 : g16, stream));
       } else {

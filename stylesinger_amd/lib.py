@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 10  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 11  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -63,9 +63,10 @@ class WaveNet(C.Structure):
     ] + [(n, C.c_int64) for n in ("gs_w_in", "gs_b_in", "gs_uv_embed", "gs_dstep", "gs_w_dil", "gs_w_out", "gs_b_out", "gs_w_cond",
                                   "gs_b_cond", "gs_w_skip", "gs_b_skip", "gs_w_final", "gs_b_final")] \
         + [("mfma_bf16", C.c_int32), ("wino_m", C.c_int32), ("w_skipall", _vp), ("b_skipall", _vp),
-           ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("reserved1", C.c_int32),
+           ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("mfma_x3", C.c_int32),
            ("w_dil_h", _vp * SS_MAX_LAYERS), ("w_out_h", _vp * SS_MAX_LAYERS), ("w_skipall_h", _vp), ("w_cond_h", _vp),
-           ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64)]
+           ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64),
+           ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64)]
 
 
 class GemmBf16Args(C.Structure):
@@ -284,6 +285,24 @@ def wino43_conv(A, W, out, *, k, dilation, **kw):
     taps = [(j - (k - 1) // 2) * dilation for j in range(k)]
     a = _fill_args(A, W, out, taps=taps, **kw)
     check(load().ss_wino43_conv(C.byref(a), k, dilation, stream_ptr()), "ss_wino43_conv")
+    return out
+
+
+def split3_weights(Wp, Kp):
+    """packed F(4,3) weights [Np][6 * Kp] fp32 -> [Np][6][3][Kp] bf16: every element as its three bf16 terms."""
+    Wp = Wp.contiguous().float()
+    rows = Wp.numel() // Kp
+    out = torch.empty(Wp.shape[0], 3 * Wp.shape[1], device=Wp.device, dtype=torch.bfloat16)
+    check(load().ss_split3_weights(ptr(Wp), ptr(out), rows, Kp, stream_ptr()), "ss_split3_weights")
+    return out
+
+
+def wino43_gate16x(A, Wx, out, *, dilation, mt=0, **kw):
+    """bf16x3 form of the F(4,3) gate (ss_wino43_gate16x); Wx = split3_weights(packed F(4,3) weight); keyword arguments as wino43_gate16
+    (w_gs, if given, in bf16 elements)."""
+    kw.setdefault("epi", EPI_GATE)
+    a = _fill_args(A, Wx, out, **kw)
+    check(load().ss_wino43_gate16x(C.byref(a), ptr(Wx), dilation, mt, stream_ptr()), "ss_wino43_gate16x")
     return out
 
 

@@ -176,6 +176,9 @@ class StyleSingerHIP(torch.nn.Module):
         # per-layer output projection = residual half only; skip sum of all layers as one K = L*C GEMM per step
         self.defer_skip = os.environ.get("SS_DEFER_SKIP", "1") not in ("0", "off", "false")
         self.bf16 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16"
+        # opt-in "bf16x3": fp32 products of the F(4,3) gate from operands split into three bf16 terms on the bf16 matrix cores
+        # (ss_wino43_gate16x; fp32-grade results, oracle/bf16x3_numerics.py); everything else as the fp32 mode
+        self.x3 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16x3"
         # fold skip_projection / sqrt(L) into the skip-all weights (fp32 mode only: in bf16 mode the operand rounding of the
         # two separate GEMMs is part of the stated arithmetic)
         self.fold_skip = self.defer_skip and not self.bf16 and os.environ.get("SS_FOLD_SKIP", "1") not in ("0", "off", "false")
@@ -286,6 +289,8 @@ class StyleSingerHIP(torch.nn.Module):
                 wsrc = self.p(p + ".dilated_conv.weight").contiguous()
                 wt = L.wino43_weight(wsrc) if self._wino_form(C, cycle) == 4 else L.wino_weight(wsrc)
                 t[f"w_dil_wino.{l}"] = L.pack_conv_weight(wt, interleave_half=C)
+                if self.x3 and self._wino_form(C, cycle) == 4:
+                    t[f"w_dil_x3.{l}"] = L.split3_weights(t[f"w_dil_wino.{l}"], dil.Kp)
             if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
                 t[f"w_dil_h.{l}"] = L.to_bf16(dil.W)
                 t[f"w_out_h.{l}"] = L.to_bf16(out.W)
@@ -349,6 +354,11 @@ class StyleSingerHIP(torch.nn.Module):
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
                 net.wino_m = self._wino_form(C, cycle)
+                if self.x3 and f"w_dil_x3.{l}" in packs[0]:
+                    ptr_, gs = place(f"w_dil_x3.{l}")
+                    net.w_dil_x3[l] = ptr_
+                    net.gs_w_dil_x3 = gs
+                    net.mfma_x3 = 1
             if self.bf16_hbm:
                 for key, arr in (("w_dil_h", net.w_dil_h), ("w_out_h", net.w_out_h)):
                     ptr_, gs = place(f"{key}.{l}")
