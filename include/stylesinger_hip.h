@@ -152,11 +152,12 @@ int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream);
 
 /* "bf16x3" form of ss_wino43_gate16 (opt-in precision mode): the same F(4,3) gate with every fp32 product computed on the BF16 matrix cores
  * from operands split into three bf16 terms (a = hi + mid + lo, round-to-nearest each; six partial products hi.hi, hi.mid, mid.hi, hi.lo,
- * lo.hi, mid.mid accumulated in fp32, smallest first). Wx = ss_split3_weights of the packed F(4,3) weights ([Np][6][3][Kp] bf16; with
+ * lo.hi, mid.mid accumulated in fp32, smallest first). Wx = ss_split3_weights of the packed F(4,3) weights (Np * 18 * Kp bf16; with
  * grouped launches args->w_group_stride counts bf16 elements); args->W is ignored. mt as ss_wino43_gate16.
- * ss_split3_weights: [rows][cols] fp32 -> [rows][3][cols] bf16 (call with rows = Np * 6, cols = Kp on a packed F(4,3) weight). */
+ * ss_split3_weights: packed F(4,3) weights [Np][6 * Kp] fp32 -> the three bf16 terms of every element in the kernel's fetch order
+ * [n tile][wave][K chunk][component][plane][lane][8] (Np % 64 == 0, Kp % 32 == 0). */
 int ss_wino43_gate16x(const ss_conv_gemm_args* args, const void* Wx, int dilation, int mt, void* stream);
-int ss_split3_weights(const float* src, void* dst, int64_t rows, int cols, void* stream);
+int ss_split3_weights(const float* src, void* dst, int Np, int Kp, void* stream);
 /* Grouped Winograd F(4,3) form of a k-tap (3 | 7 | 11) dilated (1 | 3 | 5) C -> C conv with the SS_EPI_STORE epilogue (act none | leaky-relu,
  * bias, residual R, post_scale, accumulate, row mask) and the input leaky-relu of the HiFi-GAN ResBlocks (hifigan_nsf.py:54-61 /
  * hifigan.py ResBlock1): the taps are split into ceil(k/3) groups of three, each an F(4,3) product, six accumulators over all groups.
@@ -398,7 +399,7 @@ typedef struct ss_wavenet {
   const uint16_t* w_skipall_h;
   const uint16_t* w_cond_h;
   int64_t gs_w_dil_h, gs_w_out_h, gs_w_skipall_h, gs_w_cond_h;
-  /* optional split copies of the F(4,3) gate weights: ss_split3_weights of w_dil_wino ([2C][6][3][Kp] bf16); gs in bf16 elements */
+  /* optional split copies of the F(4,3) gate weights: ss_split3_weights of w_dil_wino (2C * 18 * Kp bf16, fetch order of the kernel); gs in bf16 elements */
   const uint16_t* w_dil_x3[SS_MAX_LAYERS];
   int64_t gs_w_dil_x3;
 } ss_wavenet;

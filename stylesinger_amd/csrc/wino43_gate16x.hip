@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16x_kernel(const ss_conv_ge
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;
   const int kchunks = a.Kp / BK;
-  const int ldw = NC * 3 * a.Kp;   // bf16 per packed weight row: [component][plane][Kp]
+  // weights: [n tile][wave][K chunk][component][plane][lane][8 bf16] (ss_split3_weights): one fetch instruction of a wave = 1 KB contiguous
+  const int wtile = NC * 3 * a.Kp * BN;   // bf16 of one 64-column tile
 
   auto uniform_ptr = [](const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16x_kernel(const ss_conv_ge
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(Wx + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 2), 0x00020000);
+      uniform_ptr(Wx + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane((a.Np / BN) * wtile * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(abiasg ? (const void*)abiasg : (const void*)Wx), 0, __builtin_amdgcn_readfirstlane(abiasg ? a.Cin * 4 : 0), 0x00020000);
 
@@ -210,8 +211,7 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16x_kernel(const ss_conv_ge
   {
     const int lane = tid & 63;
     const int lc = lane & 15, kg = lane >> 4;
-    const int pc = n0 + 8 * wave + (lc & 7) + 32 * (lc >> 3);
-    w_voff = (pc * ldw + kg * 8) * 2;
+    w_voff = (nt * wtile + wave * (wtile / 4)) * 2 + lane * 16;
     a_rd = lc * ROWB + ((kg ^ swz64(lc)) << 4);
   }   // + (j * 3 + p) * PLANE + m * 16 * ROWB (16 m rows leave row & 8 unchanged)
   // weights: one register slot per component (3 planes x 16 B). The slots of a half are refilled while the OTHER half is on the matrix
@@ -219,10 +219,10 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16x_kernel(const ss_conv_ge
   bf16x8 bst[NC][3];
   auto load_b = [&](auto jtag, int k) {
     constexpr int J = decltype(jtag)::value;
-    const int cb = __builtin_amdgcn_readfirstlane(((J * 3) * a.Kp + k * BK) * 2);
+    const int cb = __builtin_amdgcn_readfirstlane(((k * NC + J) * 3) * 1024);   // 1 KB per (K chunk, component, plane) and wave
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      bst[J][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, cb + p * a.Kp * 2, 0));
+      bst[J][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, cb + p * 1024, 0));
   };
   f32x4 acc[NC][MT];
 #pragma unroll
@@ -308,10 +308,6 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16x_kernel(const ss_conv_ge
     __syncthreads();
   }
   first_half(kchunks - 1, false);
-  comp(J3{}, []() {});
-  comp(J4{}, []() {});
-  comp(J5{}, []() {});
-
   // ---- epilogue (wino43_gate16.hip): output transform, conditioner addend, gate; accumulator (m, r) = quad 16 m + 4 kg + r, column lc
   // (lane coordinates derived afresh: nothing lane-dependent of the prologue has to stay in a register across the K loop for this)
   {
@@ -326,6 +322,26 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16x_kernel(const ss_conv_ge
   const bool col_ok = oc < a.N;
   const int oob = col_ok ? 0 : (int)0x80000000;
   const int lde4 = a.lde * 4, ldc4 = a.ldc * 4;
+  // the conditioner addend (16 MT values per lane, a 40 KB row stride: one L2 / HBM miss per element) is fetched under the last half step,
+  // into the registers the raw rows no longer need
+  float pe[MT][4][4];
+  comp(J3{}, [&]() {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int qm = q0 + 16 * m + 4 * kg;
+      const int tm = qm + 3 * (qm & ~(d - 1));
+      const int e_base = tm * lde4 + (pc * 4 + oob);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int dr = r + 3 * (r & ~(d - 1));
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          pe[m][r][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, e_base, (dr + o * d) * lde4, 0));
+      }
+    }
+  });
+  comp(J4{}, []() {});
+  comp(J5{}, []() {});
   const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(a.C + (int64_t)b * a.c_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 4)), 0x00020000);
   const bool use_sig = (chi == 0) == (a.gate_mode == 0);
@@ -341,26 +357,17 @@ __global__ __launch_bounds__(256, 2) void wino43_gate16x_kernel(const ss_conv_ge
   for (int m = 0; m < MT; ++m) {
     const int qm = q0 + 16 * m + 4 * kg;
     const int tm = qm + 3 * (qm & ~(d - 1));
-    const int e_base = tm * lde4 + (pc * 4 + oob);
     const int c_base = (tm + my_first) * ldc4 + (oc * 4 + oob);
-    float pe[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int dr = r + 3 * (r & ~(d - 1));
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-        pe[r][o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, e_base, (dr + o * d) * lde4, 0));
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int dr = r + 3 * (r & ~(d - 1));
       const float a0 = acc[0][m][r], a5 = acc[5][m][r];
       const float s12 = acc[1][m][r] + acc[2][m][r] + bs, d12 = acc[1][m][r] - acc[2][m][r] + bs;
       const float s34 = acc[3][m][r] + acc[4][m][r], d34 = acc[3][m][r] - acc[4][m][r];
-      const float u0 = act(a0 + s12 + s34 + pe[r][0]);
-      const float u1 = act(fmaf(2.0f, d34, d12) + pe[r][1]);
-      const float u2 = act(fmaf(4.0f, s34, s12) + pe[r][2]);
-      const float u3 = act(fmaf(8.0f, d34, d12) + a5 + pe[r][3]);
+      const float u0 = act(a0 + s12 + s34 + pe[m][r][0]);
+      const float u1 = act(fmaf(2.0f, d34, d12) + pe[m][r][1]);
+      const float u2 = act(fmaf(4.0f, s34, s12) + pe[m][r][2]);
+      const float u3 = act(fmaf(8.0f, d34, d12) + a5 + pe[m][r][3]);
       const float g0 = u0 * partner(u0), g1 = u1 * partner(u1), g2 = u2 * partner(u2), g3 = u3 * partner(u3);
       float ga = chi ? g2 : g0, gb = chi ? g3 : g1;
       const int ta = tm + dr + my_first;
@@ -385,29 +392,38 @@ void launch16x(const ss_conv_gemm_args& a, const uint16_t* Wx, int dilation, int
   hipLaunchKernelGGL(wino43_gate16x_kernel<MT>, dim3(grid), dim3(256), lds, stream, a, Wx, q_tiles_per_item, q_tiles, n_tiles, log2d);
 }
 
-// [rows][cols] fp32 -> [rows][3][cols] bf16: the three terms of every element (round-to-nearest-even each)
-__global__ void split3_rows_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t rows, int cols) {
-  const int64_t n = rows * cols;
+// packed F(4,3) weights [Np][6][Kp] fp32 -> the three bf16 terms of every element in the order the kernel fetches them:
+// [n tile (64 columns)][wave][K chunk][component][plane][lane][8 bf16], lane = kg * 16 + chi * 8 + c7 holding column 64 nt + 8 w + c7 + 32 chi,
+// K elements 32 k + 8 kg + (0..7)
+__global__ void split3_pack_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int Np, int Kp) {
+  const int64_t n = (int64_t)Np * NC * Kp;
+  const int kchunks = Kp / BK;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / cols;
-    const int c = (int)(i % cols);
+    const int kk = (int)(i % Kp);
+    const int j = (int)((i / Kp) % NC);
+    const int col = (int)(i / ((int64_t)Kp * NC));
+    const int nt = col / BN, cl = col % BN;
+    const int chi = cl / 32, w = (cl % 32) / 8, c7 = cl % 8;
+    const int k = kk / BK, kg = (kk % BK) / 8, e = kk % 8;
     uint32_t h, m, l;
     split3(src[i], 0.f, h, m, l);
-    uint16_t* o = dst + r * 3 * cols + c;
-    o[0] = (uint16_t)h;
-    o[cols] = (uint16_t)m;
-    o[2 * cols] = (uint16_t)l;
+    const int lane = kg * 16 + chi * 8 + c7;
+    const int64_t base = ((((int64_t)(nt * 4 + w) * kchunks + k) * NC + j) * 3) * 512 + lane * 8 + e;
+    dst[base] = (uint16_t)h;
+    dst[base + 512] = (uint16_t)m;
+    dst[base + 1024] = (uint16_t)l;
   }
 }
 
 }  // namespace
 
-// packed F(4,3) weights [Np][6 * Kp] fp32 (ss_pack_conv_weight of the transformed taps) -> [Np][6][3][Kp] bf16
-extern "C" int ss_split3_weights(const float* src, void* dst, int64_t rows, int cols, void* stream) {
-  SS_CHECK_ARG(src && dst && rows > 0 && cols > 0, "ss_split3_weights: bad args");
-  const int64_t n = rows * cols;
+// packed F(4,3) weights [Np][6 * Kp] fp32 (ss_pack_conv_weight of the transformed taps) -> [Np * 18 * Kp] bf16 in the fetch order of
+// wino43_gate16x_kernel (Np a multiple of 64, Kp a multiple of 32)
+extern "C" int ss_split3_weights(const float* src, void* dst, int Np, int Kp, void* stream) {
+  SS_CHECK_ARG(src && dst && Np > 0 && (Np % BN) == 0 && Kp > 0 && (Kp % BK) == 0, "ss_split3_weights: Np %% 64, Kp %% 32");
+  const int64_t n = (int64_t)Np * NC * Kp;
   const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-  hipLaunchKernelGGL(split3_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, rows, cols);
+  hipLaunchKernelGGL(split3_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, Np, Kp);
   SS_CHECK_LAUNCH("ss_split3_weights");
   return SS_OK;
 }

@@ -289,11 +289,12 @@ def wino43_conv(A, W, out, *, k, dilation, **kw):
 
 
 def split3_weights(Wp, Kp):
-    """packed F(4,3) weights [Np][6 * Kp] fp32 -> [Np][6][3][Kp] bf16: every element as its three bf16 terms."""
+    """packed F(4,3) weights [Np][6 * Kp] fp32 -> Np * 18 * Kp bf16: every element as its three bf16 terms, in the fetch order of
+    ss_wino43_gate16x ([n tile][wave][K chunk][component][plane][lane][8])."""
     Wp = Wp.contiguous().float()
-    rows = Wp.numel() // Kp
-    out = torch.empty(Wp.shape[0], 3 * Wp.shape[1], device=Wp.device, dtype=torch.bfloat16)
-    check(load().ss_split3_weights(ptr(Wp), ptr(out), rows, Kp, stream_ptr()), "ss_split3_weights")
+    Np = Wp.shape[0]
+    out = torch.empty(Np, 3 * Wp.shape[1], device=Wp.device, dtype=torch.bfloat16)
+    check(load().ss_split3_weights(ptr(Wp), ptr(out), Np, Kp, stream_ptr()), "ss_split3_weights")
     return out
 
 
