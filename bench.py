@@ -133,7 +133,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         kw = dict(B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=dstep[0, l], epi=L.EPI_GATE, E=E[:, :, l * 2 * C:],
                   lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
         if wino and wino_m == 4 and g16:   # what run_residual_stack launches (diffusion.hip): the library picks the tiling per launch
-            L.wino43_gate16(X, packs[f"w_dil_wino.{l}"], G, dilation=d, mt=0 if g16 == 1 else g16, **kw)
+            L.wino43_gate16(X, packs[f"w_dil_wino.{l}"], G, dilation=d, mt=0 if g16 == 1 else g16, W16=packs.get(f"w_dil_wino16.{l}"), **kw)
         elif wino:
             (L.wino43_gate if wino_m == 4 else L.wino_gate)(X, packs[f"w_dil_wino.{l}"], G, dilation=d, **kw)
         else:

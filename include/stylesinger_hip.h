@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 11 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3) */
+#define SS_ABI_VERSION 11 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -150,6 +150,11 @@ int ss_gemm16_pick(int B, int T, int N);
  * K = Cin = Kp multiple of 32, one tap; same 16*mt x 64 tiles as ss_gemm16_res. */
 int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream);
 
+/* ss_wino43_gate16 with the weights of the 16x16x4 tilings in their fetch order: W16 = ss_pack_gate16_weights(args->W) (same size;
+ * [n tile][wave][K chunk][component][half][lane][4 floats]: one fetch instruction of a wave = 1 KB contiguous). args->W (packed rows) is
+ * still what the 32x32x2 fallback reads when the pick returns 0; with grouped launches both use args->w_group_stride (floats). */
+int ss_wino43_gate16w(const ss_conv_gemm_args* args, const float* W16, int dilation, int mt, void* stream);
+int ss_pack_gate16_weights(const float* src, float* dst, int Np, int Kp, void* stream);
 /* "bf16x3" form of ss_wino43_gate16 (opt-in precision mode): the same F(4,3) gate with every fp32 product computed on the BF16 matrix cores
  * from operands split into three bf16 terms (a = hi + mid + lo, round-to-nearest each; six partial products hi.hi, hi.mid, mid.hi, hi.lo,
  * lo.hi, mid.mid accumulated in fp32, smallest first). Wx = ss_split3_weights of the packed F(4,3) weights (Np * 18 * Kp bf16; with
@@ -402,6 +407,8 @@ typedef struct ss_wavenet {
   /* optional split copies of the F(4,3) gate weights: ss_split3_weights of w_dil_wino (2C * 18 * Kp bf16, fetch order of the kernel); gs in bf16 elements */
   const uint16_t* w_dil_x3[SS_MAX_LAYERS];
   int64_t gs_w_dil_x3;
+  /* optional copies of w_dil_wino (F(4,3) only) in the fetch order of the 16x16x4 gate kernel (ss_pack_gate16_weights); same group stride */
+  const float* w_dil_wino16[SS_MAX_LAYERS];
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

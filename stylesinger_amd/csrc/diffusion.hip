@@ -270,7 +270,9 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
         SS_PROPAGATE(ss_wino43_gate16x(&a, net->w_dil_x3[l], d, 0, stream));
       } else if (net->wino_m == 4) {
         const int g16 = g_ss_tuning.gate16;  // 0: 32x32x2 tiles; 1: per-launch pick; 2 / 3: 16x16x4 tiles of 16*MT quads
-        SS_PROPAGATE(g16 == 0 ? ss_wino43_gate(&a, d, stream) : ss_wino43_gate16(&a, d, g16 == 1 ? 0 : g16, stream));
+        if (g16 == 0) SS_PROPAGATE(ss_wino43_gate(&a, d, stream));
+        else if (net->w_dil_wino16[l]) SS_PROPAGATE(ss_wino43_gate16w(&a, net->w_dil_wino16[l], d, g16 == 1 ? 0 : g16, stream));
+        else SS_PROPAGATE(ss_wino43_gate16(&a, d, g16 == 1 ? 0 : g16, stream));
       } else {
         SS_PROPAGATE(ss_wino_gate(&a, d, stream));
       }

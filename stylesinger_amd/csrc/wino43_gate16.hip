@@ -54,9 +54,12 @@ __device__ __forceinline__ float2 vadd(const float2& a, const float2& b) { retur
 __device__ __forceinline__ float4 vsub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-template <int MT, bool KS>
-__global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, int q_tiles_per_item, int q_tiles, int n_tiles,
-                                                               int log2d, unsigned long long* clock_probe) {
+// WL = weight layout: false = the packed rows of ss_pack_conv_weight ([Np][6][Kp], shared with the 32x32x2 kernel); true = the
+// lane-contiguous repack of ss_pack_gate16_weights ([n tile][wave][K chunk][component][half][lane][4 floats]): one fetch instruction of
+// a wave is 1 KB contiguous (8 cache lines) instead of 16 columns x 64 B (16 lines).
+template <int MT, bool KS, bool WL>
+__global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int q_tiles_per_item,
+                                                               int q_tiles, int n_tiles, int log2d, unsigned long long* clock_probe) {
   constexpr int BQ = 16 * MT;
   constexpr int NFULL = BQ / 32;             // staging passes of 32 rows x 8 sixteen-byte slots
   constexpr bool HALF = (BQ % 32) != 0;      // + one pass of 16 rows x 16 eight-byte half slots
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
 
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
-  const float* Wg = a.W + (int64_t)grp_w * a.w_group_stride;
+  const float* Wg = (WL ? W16 : a.W) + (int64_t)grp_w * a.w_group_stride;
   const float* abiasg = a.a_bias ? a.a_bias + (int64_t)grp_w * a.a_bias_group_stride : nullptr;
   const int kchunks = a.Kp / BK;
   const int ldw = NC * a.Kp;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   // ---- B operand: lane (lc, kg) of wave w owns packed column pc and K floats [8kg, 8kg+8) of every chunk
   const int c7 = lc & 7, chi = lc >> 3;
   const int pc = n0 + 8 * wave + c7 + 32 * chi;
-  const int w_voff = (pc * ldw + kg * 8) * 4;
+  const int w_voff = WL ? (nt * ldw * BN + wave * (ldw * BN / 4)) * 4 + lane * 16 : (pc * ldw + kg * 8) * 4;
 
   u32x4 rr4[NFULL > 0 ? NFULL : 1][6];
   u32x2 rr2[6];
@@ -159,11 +162,17 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
     }
   };
   float4 bst[3][2];
-  auto load_b = [&](auto stag, int cb) {  // cb = byte offset of the weight chunk inside a packed row (wave-uniform)
+  auto load_b = [&](auto stag, int comp, int k) {  // weights of component `comp`, K chunk k (wave-uniform offsets)
     constexpr int S = decltype(stag)::value;
-    cb = __builtin_amdgcn_readfirstlane(cb);
-    bst[S][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, cb, 0));
-    bst[S][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, cb, 0));
+    if constexpr (WL) {
+      const int cb = __builtin_amdgcn_readfirstlane(((k * NC + comp) * 2) * 1024);
+      bst[S][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, cb, 0));
+      bst[S][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, cb + 1024, 0));
+    } else {
+      const int cb = __builtin_amdgcn_readfirstlane((comp * a.Kp + k * BK) * 4);
+      bst[S][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, cb, 0));
+      bst[S][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, cb, 0));
+    }
   };
   int a_wr4[NFULL > 0 ? NFULL : 1];
 #pragma unroll
@@ -237,8 +246,8 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   const int cs = BK * 4;    // bytes of one K chunk
   // chunk (k, p): weights of component ORD[p] at byte ORD[p]*kb + k*cs of a packed row; register stage p % 3; LDS buffer p & 1
   load_rows(0);
-  load_b(P0{}, ORD[0] * kb);
-  load_b(P1{}, ORD[1] * kb);
+  load_b(P0{}, ORD[0], 0);
+  load_b(P1{}, ORD[1], 0);
   store_a(As, P0{});
   if constexpr (KS) {
     // K-staged form: the six components of chunk k+1 are built during chunk k (one per position, into the OTHER half of the LDS), so a
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
     }
     __builtin_amdgcn_sched_barrier(0);  // stores first, then the fetches into the SAME registers
     if constexpr (decltype(fetch_b_tag)::value && SS_G16_ABL != 1 && SS_G16_ABL != 7)
-      load_b(std::integral_constant<int, (P + 2) % 3>{}, ORD[P2N] * kb + (k + (P + 2) / 6) * cs);
+      load_b(std::integral_constant<int, (P + 2) % 3>{}, ORD[P2N], k + (P + 2) / 6);
     if constexpr (decltype(fetch_rows_tag)::value && SS_G16_ABL != 1 && SS_G16_ABL != 8) load_rows((k + (KS ? 2 : 1)) * cs);
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(std::integral_constant<int, ORD[P]>{}, af1, bst[S][1]);
@@ -473,8 +482,8 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   }
 }
 
-template <int MT, bool KS>
-int launch16(const ss_conv_gemm_args& a, int dilation, int log2d, hipStream_t stream) {
+template <int MT, bool KS, bool WL>
+int launch16(const ss_conv_gemm_args& a, const float* W16, int dilation, int log2d, hipStream_t stream) {
   constexpr int BQ = 16 * MT;
   const int quads_per_item = ss_cdiv(a.T, 4 * dilation) * dilation;
   const int q_tiles_per_item = ss_cdiv(quads_per_item, BQ);
@@ -483,11 +492,11 @@ int launch16(const ss_conv_gemm_args& a, int dilation, int log2d, hipStream_t st
   const int grid = ss_cdiv(q_tiles, 8) * 8 * n_tiles;
   const size_t lds = (size_t)(KS ? 12 : 2) * BQ * LD * sizeof(float);
   if constexpr (KS && MT == 3) {   // 72 KB of dynamic LDS: above the 64 KB a kernel gets without asking
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino43_gate16_kernel<MT, KS>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino43_gate16_kernel<MT, KS, WL>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
   }
-  hipLaunchKernelGGL((wino43_gate16_kernel<MT, KS>), dim3(grid), dim3(256), lds, stream, a, q_tiles_per_item, q_tiles, n_tiles, log2d,
+  hipLaunchKernelGGL((wino43_gate16_kernel<MT, KS, WL>), dim3(grid), dim3(256), lds, stream, a, W16, q_tiles_per_item, q_tiles, n_tiles, log2d,
                      g_ss_tuning.clock_probe);
   return 0;
 }
@@ -516,30 +525,75 @@ extern "C" int ss_wino43_gate16_pick(int B, int T, int Np, int dilation) {
   return best;
 }
 
-extern "C" int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int mt, void* stream) {
-  SS_CHECK_ARG(args != nullptr, "ss_wino43_gate16: null args");
+namespace {
+
+// [Np][6][Kp] fp32 -> [n tile (64 columns)][wave][K chunk][component][half][lane][4 floats]: lane = kg * 16 + chi * 8 + c7 holds column
+// 64 nt + 8 w + c7 + 32 chi, K elements 32 k + 8 kg + 4 half + (0..3)
+__global__ void pack_gate16_kernel(const float* __restrict__ src, float* __restrict__ dst, int Np, int Kp) {
+  const int64_t n = (int64_t)Np * NC * Kp;
+  const int kchunks = Kp / BK;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % Kp);
+    const int j = (int)((i / Kp) % NC);
+    const int col = (int)(i / ((int64_t)Kp * NC));
+    const int nt = col / BN, cl = col % BN;
+    const int chi = cl / 32, w = (cl % 32) / 8, c7 = cl % 8;
+    const int k = kk / BK, kg = (kk % BK) / 8, h = (kk % 8) / 4, e = kk % 4;
+    const int lane = kg * 16 + chi * 8 + c7;
+    dst[((((int64_t)(nt * 4 + w) * kchunks + k) * NC + j) * 2 + h) * 256 + lane * 4 + e] = src[i];
+  }
+}
+
+int gate16_impl(const ss_conv_gemm_args* args, const float* W16, int dilation, int mt, void* stream, const char* who) {
+  SS_CHECK_ARG(args != nullptr, "%s: null args", who);
   const ss_conv_gemm_args& a = *args;
-  SS_CHECK_ARG(a.A && a.W && a.C, "ss_wino43_gate16: null A/W/C");
-  SS_CHECK_ARG(dilation >= 1 && (dilation & (dilation - 1)) == 0 && dilation <= 64, "ss_wino43_gate16: dilation %d must be a power of two <= 64", dilation);
-  SS_CHECK_ARG((a.Cin % BK) == 0 && a.Kp == a.Cin && (a.lda & 3) == 0, "ss_wino43_gate16: Cin=%d must be a multiple of 32 and Kp == Cin", a.Cin);
-  SS_CHECK_ARG((a.Np % 64) == 0 && 2 * a.N <= a.Np, "ss_wino43_gate16: Np=%d must be a multiple of 64 and >= 2*N", a.Np);
+  SS_CHECK_ARG(a.A && a.W && a.C, "%s: null A/W/C", who);
+  SS_CHECK_ARG(dilation >= 1 && (dilation & (dilation - 1)) == 0 && dilation <= 64, "%s: dilation %d must be a power of two <= 64", who, dilation);
+  SS_CHECK_ARG((a.Cin % BK) == 0 && a.Kp == a.Cin && (a.lda & 3) == 0, "%s: Cin=%d must be a multiple of 32 and Kp == Cin", who, a.Cin);
+  SS_CHECK_ARG((a.Np % 64) == 0 && 2 * a.N <= a.Np, "%s: Np=%d must be a multiple of 64 and >= 2*N", who, a.Np);
   SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (!a.E || (int64_t)a.T * a.lde * 4 < (1ll << 31)) &&
                    (int64_t)a.Np * NC * a.Kp * 4 < (1ll << 31),
-               "ss_wino43_gate16: item too large for 32-bit offsets");
-  SS_CHECK_ARG((int64_t)a.T * a.ldc * 4 < (1ll << 31), "ss_wino43_gate16: output item too large for 32-bit offsets");
-  SS_CHECK_ARG(mt == 0 || mt == 2 || mt == 3, "ss_wino43_gate16: mt=%d must be 0 (auto), 2 or 3", mt);
+               "%s: item too large for 32-bit offsets", who);
+  SS_CHECK_ARG((int64_t)a.T * a.ldc * 4 < (1ll << 31), "%s: output item too large for 32-bit offsets", who);
+  SS_CHECK_ARG(mt == 0 || mt == 2 || mt == 3, "%s: mt=%d must be 0 (auto), 2 or 3", who, mt);
   int log2d = 0;
   while ((1 << log2d) < dilation) ++log2d;
   if (mt == 0) {
     mt = ss_wino43_gate16_pick(a.B, a.T, a.Np, dilation);
-    if (mt == 0) return ss_wino43_gate(args, dilation, stream);
+    if (mt == 0) return ss_wino43_gate(args, dilation, stream);   // the 32x32x2 kernel reads the packed rows in args->W
   }
   // K-staged form (one barrier per K chunk, six components staged at once): needs at least two K chunks
   const bool ks = g_ss_tuning.gate16_ks != 0 && a.Kp >= 2 * BK;
+  hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (mt == 2) rc = ks ? launch16<2, true>(a, dilation, log2d, (hipStream_t)stream) : launch16<2, false>(a, dilation, log2d, (hipStream_t)stream);
-  else rc = ks ? launch16<3, true>(a, dilation, log2d, (hipStream_t)stream) : launch16<3, false>(a, dilation, log2d, (hipStream_t)stream);
-  SS_CHECK_ARG(rc == 0, "ss_wino43_gate16: hipFuncSetAttribute failed (%d)", rc);
-  SS_CHECK_LAUNCH("ss_wino43_gate16");
+  if (W16) {
+    if (mt == 2) rc = ks ? launch16<2, true, true>(a, W16, dilation, log2d, st) : launch16<2, false, true>(a, W16, dilation, log2d, st);
+    else rc = ks ? launch16<3, true, true>(a, W16, dilation, log2d, st) : launch16<3, false, true>(a, W16, dilation, log2d, st);
+  } else {
+    if (mt == 2) rc = ks ? launch16<2, true, false>(a, nullptr, dilation, log2d, st) : launch16<2, false, false>(a, nullptr, dilation, log2d, st);
+    else rc = ks ? launch16<3, true, false>(a, nullptr, dilation, log2d, st) : launch16<3, false, false>(a, nullptr, dilation, log2d, st);
+  }
+  SS_CHECK_ARG(rc == 0, "%s: hipFuncSetAttribute failed (%d)", who, rc);
+  SS_CHECK_LAUNCH(who);
+  return SS_OK;
+}
+
+}  // namespace
+
+extern "C" int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int mt, void* stream) {
+  return gate16_impl(args, nullptr, dilation, mt, stream, "ss_wino43_gate16");
+}
+
+extern "C" int ss_wino43_gate16w(const ss_conv_gemm_args* args, const float* W16, int dilation, int mt, void* stream) {
+  SS_CHECK_ARG(W16 != nullptr, "ss_wino43_gate16w: null W16");
+  return gate16_impl(args, W16, dilation, mt, stream, "ss_wino43_gate16w");
+}
+
+extern "C" int ss_pack_gate16_weights(const float* src, float* dst, int Np, int Kp, void* stream) {
+  SS_CHECK_ARG(src && dst && src != dst && Np > 0 && (Np % BN) == 0 && Kp > 0 && (Kp % BK) == 0, "ss_pack_gate16_weights: Np %% 64, Kp %% 32, out of place");
+  const int64_t n = (int64_t)Np * NC * Kp;
+  const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_gate16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, Np, Kp);
+  SS_CHECK_LAUNCH("ss_pack_gate16_weights");
   return SS_OK;
 }

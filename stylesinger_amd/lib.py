@@ -66,7 +66,7 @@ class WaveNet(C.Structure):
            ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("mfma_x3", C.c_int32),
            ("w_dil_h", _vp * SS_MAX_LAYERS), ("w_out_h", _vp * SS_MAX_LAYERS), ("w_skipall_h", _vp), ("w_cond_h", _vp),
            ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64),
-           ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64)]
+           ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS)]
 
 
 class GemmBf16Args(C.Structure):
@@ -242,10 +242,22 @@ def wino43_gate(A, Wt, out, *, dilation, **kw):
     check(load().ss_wino43_gate(C.byref(a), int(dilation), stream_ptr()), "ss_wino43_gate")
 
 
-def wino43_gate16(A, Wt, out, *, dilation, mt=0, **kw):
-    """The F(4,3) gate on 16x16x4 MFMA tiles (ss_wino43_gate16); mt = 0 lets the library pick, 2 / 3 force the row-tile count."""
+def pack_gate16_weights(Wp, Kp):
+    """packed F(4,3) weights [Np][6 * Kp] -> the same floats in the fetch order of the 16x16x4 gate kernel (ss_pack_gate16_weights)."""
+    Wp = Wp.contiguous().float()
+    out = torch.empty_like(Wp)
+    check(load().ss_pack_gate16_weights(ptr(Wp), ptr(out), Wp.shape[0], Kp, stream_ptr()), "ss_pack_gate16_weights")
+    return out
+
+
+def wino43_gate16(A, Wt, out, *, dilation, mt=0, W16=None, **kw):
+    """The F(4,3) gate on 16x16x4 MFMA tiles (ss_wino43_gate16); mt = 0 lets the library pick, 2 / 3 force the row-tile count.
+    W16 = pack_gate16_weights(Wt): the weights in the kernel's fetch order (ss_wino43_gate16w)."""
     kw.setdefault("epi", EPI_GATE)
     a = _fill_args(A, Wt, out, **kw)
+    if W16 is not None:
+        check(load().ss_wino43_gate16w(C.byref(a), ptr(W16), int(dilation), int(mt), stream_ptr()), "ss_wino43_gate16w")
+        return
     check(load().ss_wino43_gate16(C.byref(a), int(dilation), int(mt), stream_ptr()), "ss_wino43_gate16")
 
 

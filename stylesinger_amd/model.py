@@ -289,6 +289,8 @@ class StyleSingerHIP(torch.nn.Module):
                 wsrc = self.p(p + ".dilated_conv.weight").contiguous()
                 wt = L.wino43_weight(wsrc) if self._wino_form(C, cycle) == 4 else L.wino_weight(wsrc)
                 t[f"w_dil_wino.{l}"] = L.pack_conv_weight(wt, interleave_half=C)
+                if self._wino_form(C, cycle) == 4 and t[f"w_dil_wino.{l}"].shape[0] % 64 == 0:   # the 16x16x4 kernel's fetch order
+                    t[f"w_dil_wino16.{l}"] = L.pack_gate16_weights(t[f"w_dil_wino.{l}"], dil.Kp)
                 if self.x3 and self._wino_form(C, cycle) == 4:
                     t[f"w_dil_x3.{l}"] = L.split3_weights(t[f"w_dil_wino.{l}"], dil.Kp)
             if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
@@ -354,6 +356,8 @@ class StyleSingerHIP(torch.nn.Module):
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
                 net.wino_m = self._wino_form(C, cycle)
+                if f"w_dil_wino16.{l}" in packs[0]:
+                    net.w_dil_wino16[l], _ = place(f"w_dil_wino16.{l}")
                 if self.x3 and f"w_dil_x3.{l}" in packs[0]:
                     ptr_, gs = place(f"w_dil_x3.{l}")
                     net.w_dil_x3[l] = ptr_

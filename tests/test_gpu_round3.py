@@ -151,12 +151,14 @@ def test_gate16_k_staged_form_is_bit_identical(mt):
                 if grouped:
                     kw.update(group_size=2, w_gs=Wt[0].numel(), bias_gs=Np, a_bias_gs=C)
                 outs = []
-                for ks in (0, 1):
+                W16 = torch.stack([L.pack_gate16_weights(Wt[i], C) for i in range(nw)]).contiguous()
+                for ks, w16 in ((0, None), (1, None), (1, W16), (0, W16)):   # K staging x weight layout: the same arithmetic, the same order
                     L.check(lib.ss_set_tuning(b"gate16_ks", ks), "ss_set_tuning")
                     o = torch.full((B, T, C), 9.0, device=dv)
-                    L.wino43_gate16(x, Wt if grouped else Wt[0], o, mt=mt, **kw)
+                    L.wino43_gate16(x, Wt if grouped else Wt[0], o, mt=mt, W16=None if w16 is None else (w16 if grouped else w16[0]), **kw)
                     outs.append(o)
-                assert torch.equal(outs[0], outs[1]), (B, T, C, d, (outs[0] - outs[1]).abs().max().item())
+                for o in outs[1:]:
+                    assert torch.equal(outs[0], o), (B, T, C, d, (outs[0] - o).abs().max().item())
     finally:
         L.check(lib.ss_set_tuning(b"gate16_ks", before), "ss_set_tuning")
 

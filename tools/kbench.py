@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--T", type=int, default=1500)
     ap.add_argument("--prio", type=int, default=-1, help="ss_set_tuning('wave_prio', N)")
     ap.add_argument("--mt", default="-1,3,2", help="wino43_16: comma list of tilings (-1 = the 32x32x2 kernel, 0 = library pick, 2, 3)")
+    ap.add_argument("--w16", type=int, default=1, help="wino43_16: 1 = weights in the kernel's fetch order (ss_wino43_gate16w), 0 = packed rows")
     ap.add_argument("--x3", action="store_true", help="wino43_16: the bf16x3 form (ss_wino43_gate16x: split operands on the bf16 matrix cores)")
     ap.add_argument("--pair", type=int, default=1, help="wino43_16: time the f0 launch with 2B items (both nets), as the loop launches it")
     ap.add_argument("--e-layout", default="row", help="conditioner addend: 'row' = [B][T][L*2C] (one row holds all layers), 'layer' = [L][B][T][2C]")
@@ -117,6 +118,7 @@ def main():
         if a.which in ("wino43_16", "all"):
             Wt4 = L.pack_conv_weight(L.wino43_weight(w), interleave_half=C)
             Wx4 = L.split3_weights(Wt4, C)
+            W16 = L.pack_gate16_weights(Wt4, C)
             Bn = B * (2 if name == "f0" and a.pair else 1)   # the f0 launch of the real loop carries both nets: 2B items
             Xn = torch.randn(Bn, T, C, device=d)
             Gn = torch.empty(Bn, T, C, device=d)
@@ -133,7 +135,7 @@ def main():
                     elif a.x3:
                         L.wino43_gate16x(Xn, Wx4, Gn, mt=mt, **kwx)
                     else:
-                        L.wino43_gate16(Xn, Wt4, Gn, mt=mt, **kw)
+                        L.wino43_gate16(Xn, Wt4, Gn, mt=mt, W16=W16 if a.w16 else None, **kw)
                 s = timeit(fw16, a.iters)
                 fl = 2.0 * Bn * T * 3 * C * 2 * C
                 res.append((f"{name} F(4,3) gate {'32x32x2 tiles' if mt < 0 else ('bf16x3 mt=%d' if a.x3 else '16x16x4 mt=%d') % mt} rows={Bn * T}", s, fl))
