@@ -150,6 +150,10 @@ int ss_gemm16_pick(int B, int T, int N);
  * K = Cin = Kp multiple of 32, one tap; same 16*mt x 64 tiles as ss_gemm16_res. */
 int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream);
 
+/* ss_gemm16_res with its weights in fetch order: W16 = ss_pack_gemm16_weights(first N rows of args->W) ([n tile][wave][K chunk][half]
+ * [lane][4 floats], N % 64 == 0); with grouped launches args->w_group_stride is the stride of W16 */
+int ss_gemm16_resw(const ss_conv_gemm_args* args, const float* W16, int mt, void* stream);
+int ss_pack_gemm16_weights(const float* src, float* dst, int Np, int Kp, void* stream);
 /* ss_wino43_gate16 with the weights of the 16x16x4 tilings in their fetch order: W16 = ss_pack_gate16_weights(args->W) (same size;
  * [n tile][wave][K chunk][component][half][lane][4 floats]: one fetch instruction of a wave = 1 KB contiguous). args->W (packed rows) is
  * still what the 32x32x2 fallback reads when the pick returns 0; with grouped launches both use args->w_group_stride (floats). */
@@ -409,6 +413,10 @@ typedef struct ss_wavenet {
   int64_t gs_w_dil_x3;
   /* optional copies of w_dil_wino (F(4,3) only) in the fetch order of the 16x16x4 gate kernel (ss_pack_gate16_weights); same group stride */
   const float* w_dil_wino16[SS_MAX_LAYERS];
+  /* optional copies of the RESIDUAL half of w_out ([C][Kp], C a multiple of 64) in the fetch order of ss_gemm16_res
+   * (ss_pack_gemm16_weights); gs_w_out16 = floats between the two nets of a pair */
+  const float* w_out16[SS_MAX_LAYERS];
+  int64_t gs_w_out16;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -311,7 +311,10 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       o.bias_group_stride = net->gs_b_out;
     }
     const int r16 = g_ss_tuning.res16;
-    if (defer && r16 != 0 && !net->mfma_bf16 && (C == 192 || C == 256)) {
+    if (defer && r16 != 0 && !net->mfma_bf16 && (C == 192 || C == 256) && net->w_out16[l]) {   // weights in the kernel's fetch order
+      o.w_group_stride = net->gs_w_out16;
+      SS_PROPAGATE(ss_gemm16_resw(&o, net->w_out16[l], r16 == 1 ? 0 : r16, stream));
+    } else if (defer && r16 != 0 && !net->mfma_bf16 && (C == 192 || C == 256)) {
       SS_PROPAGATE(ss_gemm16_res(&o, r16 == 1 ? 0 : r16, stream));   // 16x16x4 tiles, balanced single round (gemm16.hip)
     } else {
       SS_PROPAGATE(ss_conv_gemm(&o, stream));

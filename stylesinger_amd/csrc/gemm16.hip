@@ -52,8 +52,11 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, float* lds_d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
 
-template <int MT, int KCH>
-__global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
+// WL = weight layout: false = packed rows [Np][Kp]; true = the lane-contiguous repack of ss_pack_gemm16_weights
+// ([n tile][wave][K chunk][half][lane][4 floats]): one fetch instruction of a wave = 1 KB contiguous instead of 16 columns x 64 B
+template <int MT, int KCH, bool WL>
+__global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int m_tiles_per_item,
+                                                                           int m_tiles, int n_tiles) {
   constexpr int BM = 16 * MT;
   constexpr int GROUPS = BM / 8;                 // DMA instructions per chunk (8 rows x 128 B each)
   constexpr int DPW = (GROUPS + 3) / 4;          // ... per wave
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(a.W + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane(a.Np * a.Kp * 4), 0x00020000);
+      uniform_ptr((WL ? W16 : a.W) + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane(a.Np * a.Kp * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<float*>(a.R) + (int64_t)b * a.r_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldr * 4)),
       0x00020000);
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
 
   // ---- the wave's weight slice: column n0 + 16 w + lc, K floats [32 j + 8 kg, +8) of every chunk j -> registers, once
   const int col = n0 + 16 * wave + lc;
-  const int w_voff = (col * a.Kp + kg * 8) * 4;
+  const int w_voff = WL ? ((nt * 4 + wave) * KCH * 512) * 4 + lane * 16 : (col * a.Kp + kg * 8) * 4;
   // streamed two chunks ahead through a ring of 3 register stages, issued right after the A pieces of the same chunk: the VMEM
   // counter retires in order, so weights fetched up front would all have to land before the first MFMA (ablation: 3.3 of 22 us)
   float4 bw[3][2];
@@ -105,11 +108,16 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
       bw[j % 3][0] = make_float4(0.01f * lane, 0.02f, 0.03f * j, 0.04f);
       bw[j % 3][1] = make_float4(0.05f, 0.06f * lane, 0.07f, 0.08f * j);
     } else {
-      bw[j % 3][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, j * (BK * 4), 0));
-      bw[j % 3][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, j * (BK * 4), 0));
+      if constexpr (WL) {
+        bw[j % 3][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, j * 2048, 0));
+        bw[j % 3][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, j * 2048 + 1024, 0));
+      } else {
+        bw[j % 3][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, j * (BK * 4), 0));
+        bw[j % 3][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + 16, j * (BK * 4), 0));
+      }
     }
   };
-  constexpr int WL = SS_R16_ABL == 1 ? 0 : 2;   // VMEM instructions of one weight stage
+  constexpr int WLD = SS_R16_ABL == 1 ? 0 : 2;   // VMEM instructions of one weight stage
   // ---- epilogue operands: residual-stream tile (rows 16 m + 4 kg + r, column col) and the bias
   const bool col_ok = col < a.N;
   const int oob = col_ok ? 0 : (int)0x80000000;
@@ -164,8 +172,8 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
     // RC+1 - the 4 MT residual loads and the bias load
     constexpr int RC = KCH >= 3 ? KCH - 3 : 0;   // the chunk that issues the residual-stream loads (before its DMA)
     if constexpr (c + 1 >= KCH) wait_vmcnt<0>();
-    else if constexpr (c == RC + 1 && KCH >= 3) wait_vmcnt<DPW + WL + 1 + (SS_R16_ABL == 4 ? 0 : 4 * MT)>();
-    else wait_vmcnt<DPW + WL>();
+    else if constexpr (c == RC + 1 && KCH >= 3) wait_vmcnt<DPW + WLD + 1 + (SS_R16_ABL == 4 ? 0 : 4 * MT)>();
+    else wait_vmcnt<DPW + WLD>();
     if constexpr (SS_R16_ABL != 6) __builtin_amdgcn_s_barrier();
     const float* Ac = bufs[c % NBUF];
     float4 af[MT][2];
@@ -375,14 +383,28 @@ int launch_store(const ss_conv_gemm_args& a, hipStream_t stream) {
 }
 
 template <int MT, int KCH>
-int launch_res(const ss_conv_gemm_args& a, hipStream_t stream) {
+int launch_res(const ss_conv_gemm_args& a, const float* W16, hipStream_t stream) {
   constexpr int BM = 16 * MT;
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
   const int n_tiles = ss_cdiv(a.N, BN);
   const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
-  hipLaunchKernelGGL((gemm16_res_kernel<MT, KCH>), dim3(grid), dim3(256), 0, stream, a, m_tiles_per_item, m_tiles, n_tiles);
+  if (W16) hipLaunchKernelGGL((gemm16_res_kernel<MT, KCH, true>), dim3(grid), dim3(256), 0, stream, a, W16, m_tiles_per_item, m_tiles, n_tiles);
+  else hipLaunchKernelGGL((gemm16_res_kernel<MT, KCH, false>), dim3(grid), dim3(256), 0, stream, a, W16, m_tiles_per_item, m_tiles, n_tiles);
   return 0;
+}
+
+// [Np][Kp] fp32 -> [n tile (64 columns)][wave][K chunk][half][lane][4 floats]: lane = kg * 16 + lc holds column 64 nt + 16 w + lc,
+// K elements 32 j + 8 kg + 4 half + (0..3)
+__global__ void pack_gemm16_kernel(const float* __restrict__ src, float* __restrict__ dst, int Np, int Kp) {
+  const int64_t n = (int64_t)Np * Kp;
+  const int kch = Kp / BK;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % Kp), col = (int)(i / Kp);
+    const int nt = col / BN, w = (col % BN) / 16, lc = col % 16;
+    const int j = kk / BK, kg = (kk % BK) / 8, h = (kk % 8) / 4, e = kk % 4;
+    dst[((((int64_t)(nt * 4 + w) * kch + j) * 2 + h) * 64 + kg * 16 + lc) * 4 + e] = src[i];
+  }
 }
 
 }  // namespace
@@ -403,26 +425,43 @@ extern "C" int ss_gemm16_pick(int B, int T, int N) {
   return best;
 }
 
-extern "C" int ss_gemm16_res(const ss_conv_gemm_args* args, int mt, void* stream) {
-  SS_CHECK_ARG(args != nullptr, "ss_gemm16_res: null args");
+static int gemm16_res_impl(const ss_conv_gemm_args* args, const float* W16, int mt, void* stream, const char* who) {
+  SS_CHECK_ARG(args != nullptr, "%s: null args", who);
   const ss_conv_gemm_args& a = *args;
-  SS_CHECK_ARG(a.A && a.W && a.C && a.R, "ss_gemm16_res: null A/W/C/R");
-  SS_CHECK_ARG(a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm16_res: one tap at offset 0 only");
-  SS_CHECK_ARG(a.Kp == a.Cin && (a.Kp == 192 || a.Kp == 256) && (a.lda & 3) == 0, "ss_gemm16_res: K=%d must be 192 or 256 (= Kp), lda %% 4 == 0", a.Cin);
-  SS_CHECK_ARG(a.N > 0 && a.N <= a.Np && (a.Np & 15) == 0, "ss_gemm16_res: bad N=%d Np=%d", a.N, a.Np);
-  SS_CHECK_ARG(a.a_scale == 1.0f && a.a_lrelu == 1.0f && a.a_bias == nullptr && a.mfma_bf16 == 0, "ss_gemm16_res: no A prologue, fp32 only");
+  SS_CHECK_ARG(a.A && a.W && a.C && a.R, "%s: null A/W/C/R", who);
+  SS_CHECK_ARG(a.ntaps == 1 && a.tap_off[0] == 0, "%s: one tap at offset 0 only", who);
+  SS_CHECK_ARG(a.Kp == a.Cin && (a.Kp == 192 || a.Kp == 256) && (a.lda & 3) == 0, "%s: K=%d must be 192 or 256 (= Kp), lda %% 4 == 0", who, a.Cin);
+  SS_CHECK_ARG(a.N > 0 && a.N <= a.Np && (a.Np & 15) == 0, "%s: bad N=%d Np=%d", who, a.N, a.Np);
+  SS_CHECK_ARG(!W16 || (a.N % BN) == 0, "%s: the fetch-order weights need N %% 64 == 0 (N=%d)", who, a.N);
+  SS_CHECK_ARG(a.a_scale == 1.0f && a.a_lrelu == 1.0f && a.a_bias == nullptr && a.mfma_bf16 == 0, "%s: no A prologue, fp32 only", who);
   SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (int64_t)a.T * a.ldr * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 4 < (1ll << 31) &&
-                   (int64_t)a.Np * a.Kp * 4 < (1ll << 31), "ss_gemm16_res: item too large for 32-bit offsets");
-  SS_CHECK_ARG(mt == 0 || mt == 4 || mt == 6 || mt == 8, "ss_gemm16_res: mt=%d must be 0 (auto), 4, 6 or 8", mt);
+                   (int64_t)a.Np * a.Kp * 4 < (1ll << 31), "%s: item too large for 32-bit offsets", who);
+  SS_CHECK_ARG(mt == 0 || mt == 4 || mt == 6 || mt == 8, "%s: mt=%d must be 0 (auto), 4, 6 or 8", who, mt);
   if (mt == 0) mt = ss_gemm16_pick(a.B, a.T, a.N);
   hipStream_t s = (hipStream_t)stream;
   const bool k6 = a.Kp == 192;
   switch (mt) {
-    case 4: k6 ? launch_res<4, 6>(a, s) : launch_res<4, 8>(a, s); break;
-    case 6: k6 ? launch_res<6, 6>(a, s) : launch_res<6, 8>(a, s); break;
-    default: k6 ? launch_res<8, 6>(a, s) : launch_res<8, 8>(a, s); break;
+    case 4: k6 ? launch_res<4, 6>(a, W16, s) : launch_res<4, 8>(a, W16, s); break;
+    case 6: k6 ? launch_res<6, 6>(a, W16, s) : launch_res<6, 8>(a, W16, s); break;
+    default: k6 ? launch_res<8, 6>(a, W16, s) : launch_res<8, 8>(a, W16, s); break;
   }
-  SS_CHECK_LAUNCH("ss_gemm16_res");
+  SS_CHECK_LAUNCH(who);
+  return SS_OK;
+}
+
+extern "C" int ss_gemm16_res(const ss_conv_gemm_args* args, int mt, void* stream) { return gemm16_res_impl(args, nullptr, mt, stream, "ss_gemm16_res"); }
+
+extern "C" int ss_gemm16_resw(const ss_conv_gemm_args* args, const float* W16, int mt, void* stream) {
+  SS_CHECK_ARG(W16 != nullptr, "ss_gemm16_resw: null W16");
+  return gemm16_res_impl(args, W16, mt, stream, "ss_gemm16_resw");
+}
+
+extern "C" int ss_pack_gemm16_weights(const float* src, float* dst, int Np, int Kp, void* stream) {
+  SS_CHECK_ARG(src && dst && src != dst && Np > 0 && (Np % BN) == 0 && Kp > 0 && (Kp % BK) == 0, "ss_pack_gemm16_weights: Np %% 64, Kp %% 32, out of place");
+  const int64_t n = (int64_t)Np * Kp;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_gemm16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, Np, Kp);
+  SS_CHECK_LAUNCH("ss_pack_gemm16_weights");
   return SS_OK;
 }
 

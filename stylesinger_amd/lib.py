@@ -66,7 +66,8 @@ class WaveNet(C.Structure):
            ("gs_w_skipall", C.c_int64), ("gs_b_skipall", C.c_int64), ("skipall_folded", C.c_int32), ("mfma_x3", C.c_int32),
            ("w_dil_h", _vp * SS_MAX_LAYERS), ("w_out_h", _vp * SS_MAX_LAYERS), ("w_skipall_h", _vp), ("w_cond_h", _vp),
            ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64),
-           ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS)]
+           ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS),
+           ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64)]
 
 
 class GemmBf16Args(C.Structure):
@@ -242,6 +243,14 @@ def wino43_gate(A, Wt, out, *, dilation, **kw):
     check(load().ss_wino43_gate(C.byref(a), int(dilation), stream_ptr()), "ss_wino43_gate")
 
 
+def pack_gemm16_weights(Wp, Kp):
+    """packed weight rows [Np][Kp] (Np % 64 == 0) -> the same floats in the fetch order of ss_gemm16_res (ss_pack_gemm16_weights)."""
+    Wp = Wp.contiguous().float()
+    out = torch.empty_like(Wp)
+    check(load().ss_pack_gemm16_weights(ptr(Wp), ptr(out), Wp.shape[0], Kp, stream_ptr()), "ss_pack_gemm16_weights")
+    return out
+
+
 def pack_gate16_weights(Wp, Kp):
     """packed F(4,3) weights [Np][6 * Kp] -> the same floats in the fetch order of the 16x16x4 gate kernel (ss_pack_gate16_weights)."""
     Wp = Wp.contiguous().float()
@@ -261,9 +270,13 @@ def wino43_gate16(A, Wt, out, *, dilation, mt=0, W16=None, **kw):
     check(load().ss_wino43_gate16(C.byref(a), int(dilation), int(mt), stream_ptr()), "ss_wino43_gate16")
 
 
-def gemm16_res(A, W, out, *, mt=0, **kw):
-    """Residual projection C = (R + A.W^T + bias) * post_scale on 16x16x4 tiles (ss_gemm16_res); same keyword arguments as conv_gemm."""
+def gemm16_res(A, W, out, *, mt=0, W16=None, **kw):
+    """Residual projection C = (R + A.W^T + bias) * post_scale on 16x16x4 tiles (ss_gemm16_res); same keyword arguments as conv_gemm.
+    W16 = pack_gemm16_weights(first N rows of W): the weights in the kernel's fetch order (ss_gemm16_resw)."""
     a = _fill_args(A, W, out, **kw)
+    if W16 is not None:
+        check(load().ss_gemm16_resw(C.byref(a), ptr(W16), int(mt), stream_ptr()), "ss_gemm16_resw")
+        return
     check(load().ss_gemm16_res(C.byref(a), int(mt), stream_ptr()), "ss_gemm16_res")
 
 

@@ -285,6 +285,8 @@ class StyleSingerHIP(torch.nn.Module):
             cnd = self._pack_conv(p + ".conditioner_projection.weight", p + ".conditioner_projection.bias", half=C,
                                   bias2=self.p(p + ".dilated_conv.bias"))
             t[f"w_dil.{l}"], t[f"w_out.{l}"], t[f"b_out.{l}"] = dil.W, out.W, out.bias
+            if self.defer_skip and not self.bf16 and C % 64 == 0:   # residual half in the fetch order of ss_gemm16_res
+                t[f"w_out16.{l}"] = L.pack_gemm16_weights(out.W[:C].contiguous(), out.Kp)
             if self.use_wino:
                 wsrc = self.p(p + ".dilated_conv.weight").contiguous()
                 wt = L.wino43_weight(wsrc) if self._wino_form(C, cycle) == 4 else L.wino_weight(wsrc)
@@ -356,6 +358,9 @@ class StyleSingerHIP(torch.nn.Module):
                 net.w_dil_wino[l] = ptr_
                 net.gs_w_dil_wino = gs
                 net.wino_m = self._wino_form(C, cycle)
+            if f"w_out16.{l}" in packs[0]:
+                net.w_out16[l], net.gs_w_out16 = place(f"w_out16.{l}")
+            if self.use_wino:
                 if f"w_dil_wino16.{l}" in packs[0]:
                     net.w_dil_wino16[l], _ = place(f"w_dil_wino16.{l}")
                 if self.x3 and f"w_dil_x3.{l}" in packs[0]:

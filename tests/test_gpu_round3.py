@@ -276,6 +276,11 @@ def test_gemm16_res_matches_torch_and_the_generic_kernel(C, B, T, groups, mt):
     S = torch.zeros(B, T, C, device=dv)
     L.conv_gemm(A, Wp, x2, epi=L.EPI_RESSKIP, R=x2, Nh=C, C2=S, ldc2=C, c2_bs=T * C, tile=3, **kw)
     assert (x1 - x2).abs().max().item() <= 1e-5
+    # the same launch with the weights in the kernel's fetch order (ss_gemm16_resw): bit-identical
+    W16 = torch.stack([L.pack_gemm16_weights(Wp[i][:C].contiguous(), Wp.shape[2]) for i in range(groups)]).contiguous()
+    x3 = x.to(dv).clone()
+    L.gemm16_res(A, Wp, x3, mt=mt, R=x3, W16=W16, **dict(kw, w_gs=W16[0].numel()))
+    assert torch.equal(x1, x3), (x1 - x3).abs().max().item()
 
 
 @pytest.mark.parametrize("mt", [0, 4, 6, 8])

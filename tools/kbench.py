@@ -146,6 +146,7 @@ def main():
             Sn = torch.zeros(Bn, T, C, device=d)
             ln = torch.full((Bn,), T, device=d, dtype=torch.int32)
             kwr = dict(B=Bn, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lda=Lyr * C, a_bs=T * Lyr * C, lens=ln, bias=bop, ldr=C, ldc=C, post_scale=0.7071)
+            Wo16 = L.pack_gemm16_weights(Wo[:C].contiguous(), C)
             for mt in [int(v) for v in a.mt.split(",")]:
                 def fr():
                     layer[0] = (layer[0] + 1) % Lyr
@@ -153,7 +154,7 @@ def main():
                     if mt < 0:
                         L.conv_gemm(Al, Wo, Xn, epi=L.EPI_RESSKIP, R=Xn, Nh=C, C2=Sn, ldc2=C, c2_bs=T * C, tile=3, **kwr)
                     else:
-                        L.gemm16_res(Al, Wo, Xn, mt=mt, R=Xn, **kwr)
+                        L.gemm16_res(Al, Wo, Xn, mt=mt, R=Xn, W16=Wo16 if a.w16 else None, **kwr)
                 s = timeit(fr, a.iters)
                 fl = 2.0 * Bn * T * C * C
                 res.append((f"{name} residual projection {'conv_gemm 64x64' if mt < 0 else 'gemm16 mt=%d' % mt} rows={Bn * T} K=N={C}", s, fl))
