@@ -167,6 +167,12 @@ int ss_pack_gate16_weights(const float* src, float* dst, int Np, int Kp, void* s
  * [n tile][wave][K chunk][component][plane][lane][8] (Np % 64 == 0, Kp % 32 == 0). */
 int ss_wino43_gate16x(const ss_conv_gemm_args* args, const void* Wx, int dilation, int mt, void* stream);
 int ss_split3_weights(const float* src, void* dst, int Np, int Kp, void* stream);
+/* "bf16x3" form of ss_gemm16_store (same argument rules): Wx = ss_split3_gemm16_weights(args->W as [Np][Kp] fp32) - the three bf16 terms of
+ * every weight in fetch order [n tile (64 columns, zero padded)][wave][K chunk][plane][lane][8]; A stays fp32 in HBM and is split when it is
+ * staged. args->W is ignored; with grouped launches args->w_group_stride counts bf16 elements (ss_split3_gemm16_elems per weight set). */
+int ss_gemm16x_store(const ss_conv_gemm_args* args, const void* Wx, int mt, void* stream);
+int ss_split3_gemm16_weights(const float* src, void* dst, int Np, int Kp, void* stream);
+int64_t ss_split3_gemm16_elems(int Np, int Kp);
 /* Grouped Winograd F(4,3) form of a k-tap (3 | 7 | 11) dilated (1 | 3 | 5) C -> C conv with the SS_EPI_STORE epilogue (act none | leaky-relu,
  * bias, residual R, post_scale, accumulate, row mask) and the input leaky-relu of the HiFi-GAN ResBlocks (hifigan_nsf.py:54-61 /
  * hifigan.py ResBlock1): the taps are split into ceil(k/3) groups of three, each an F(4,3) product, six accumulators over all groups.
@@ -417,6 +423,9 @@ typedef struct ss_wavenet {
    * (ss_pack_gemm16_weights); gs_w_out16 = floats between the two nets of a pair */
   const float* w_out16[SS_MAX_LAYERS];
   int64_t gs_w_out16;
+  /* bf16x3 mode: ss_split3_gemm16_weights of w_skipall (used with skipall_folded); gs in bf16 elements */
+  const uint16_t* w_skipall_x3;
+  int64_t gs_w_skipall_x3;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

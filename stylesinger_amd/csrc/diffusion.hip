@@ -342,11 +342,17 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       k.w_group_stride = net->gs_w_skipall;
       k.bias_group_stride = net->gs_b_skipall;
     }
-    const int s16 = g_ss_tuning.skip16;
+    int s16 = g_ss_tuning.skip16;
     const bool use16 = s16 != 0 && !net->mfma_bf16 && k.Kp == k.Cin;   // 16x16x4 tiles, both operands by LDS-DMA (gemm16.hip)
+    // long-K launch: when 64-row tiles also fit one round at three workgroups per CU they beat the 96-row pick (mel at C2: 240.7 vs 250.7 us)
+    if (s16 == 1 && (long)((T + 63) / 64) * B * ((C + 63) / 64) <= 768 && !(net->mfma_x3 && net->w_skipall_x3)) s16 = 4;
     if (net->skipall_folded) {  // w_skipall already carries skip_projection / sqrt(L): this GEMM + ReLU is the stack's output
       k.act = SS_ACT_RELU;
       k.C = w.G;
+      if (use16 && net->mfma_x3 && net->w_skipall_x3) {   // opt-in bf16x3 mode: split operands on the bf16 matrix cores (gemm16x.hip)
+        k.w_group_stride = net->gs_w_skipall_x3;
+        return ss_gemm16x_store(&k, net->w_skipall_x3, s16 == 1 ? 0 : s16, stream);
+      }
       return use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream);
     }
     SS_PROPAGATE(use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream));

@@ -67,7 +67,7 @@ class WaveNet(C.Structure):
            ("w_dil_h", _vp * SS_MAX_LAYERS), ("w_out_h", _vp * SS_MAX_LAYERS), ("w_skipall_h", _vp), ("w_cond_h", _vp),
            ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64),
            ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS),
-           ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64)]
+           ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64), ("w_skipall_x3", _vp), ("gs_w_skipall_x3", C.c_int64)]
 
 
 class GemmBf16Args(C.Structure):
@@ -321,6 +321,21 @@ def split3_weights(Wp, Kp):
     out = torch.empty(Np, 3 * Wp.shape[1], device=Wp.device, dtype=torch.bfloat16)
     check(load().ss_split3_weights(ptr(Wp), ptr(out), Np, Kp, stream_ptr()), "ss_split3_weights")
     return out
+
+
+def split3_gemm16_weights(Wp, Kp):
+    """packed weight rows [Np][Kp] fp32 -> their three bf16 terms in the fetch order of ss_gemm16x_store."""
+    Wp = Wp.contiguous().float()
+    Np = Wp.shape[0]
+    out = torch.empty(int(load().ss_split3_gemm16_elems(Np, Kp)), device=Wp.device, dtype=torch.bfloat16)
+    check(load().ss_split3_gemm16_weights(ptr(Wp), ptr(out), Np, Kp, stream_ptr()), "ss_split3_gemm16_weights")
+    return out
+
+
+def gemm16x_store(A, W, Wx, out, *, mt=0, **kw):
+    """bf16x3 form of gemm16_store (ss_gemm16x_store); W only supplies Np / Kp for the argument struct."""
+    a = _fill_args(A, W, out, **kw)
+    check(load().ss_gemm16x_store(C.byref(a), ptr(Wx), int(mt), stream_ptr()), "ss_gemm16x_store")
 
 
 def wino43_gate16x(A, Wx, out, *, dilation, mt=0, **kw):

@@ -310,6 +310,8 @@ class StyleSingerHIP(torch.nn.Module):
                 bsk = (ws_ @ bsk.double() * r + bs_).float()
                 wsk = (ws_ @ wsk.double() * r).float()
             t["w_skipall"] = L.pack_conv_weight(wsk[:, :, None].contiguous())
+            if self.x3 and self.fold_skip:
+                t["w_skipall_x3"] = L.split3_gemm16_weights(t["w_skipall"], t["w_skipall"].shape[1])
             t["b_skipall"] = L.pack_bias(bsk.contiguous())
         t["dstep"] = dstep
         t["w_cond"] = torch.cat(wc_rows, 0).contiguous()
@@ -373,6 +375,8 @@ class StyleSingerHIP(torch.nn.Module):
                     ptr_, gs = place(f"{key}.{l}")
                     arr[l] = ptr_
                     setattr(net, "gs_" + key, gs)
+        if "w_skipall_x3" in packs[0]:
+            net.w_skipall_x3, net.gs_w_skipall_x3 = place("w_skipall_x3")
         if self.bf16_hbm:
             for key in ("w_cond_h", "w_skipall_h"):
                 ptr_, gs = place(key)

@@ -311,6 +311,16 @@ def test_gemm16_store_matches_torch(K, N, B, T, groups, relu, mt):
     assert err <= 3e-5, err
     for i in range(B):
         assert torch.all(out[i, int(lens[i]):] == 0)
+    # the bf16x3 form (ss_gemm16x_store: operands as three bf16 terms, six exact bf16 MFMA products, fp32 accumulate): the same bar
+    Wx = torch.stack([L.split3_gemm16_weights(Wp[i], Wp.shape[2]) for i in range(groups)]).contiguous()
+    outx = torch.full((B, T, N), 5.0, device=dv)
+    L.gemm16x_store(A.to(dv), Wp, Wx, outx, mt=mt, B=B, T=T, Cin=K, N=N, Np=Wp.shape[1], Kp=Wp.shape[2], lens=lens.to(dv), bias=bp,
+                    act=L.ACT_RELU if relu else L.ACT_NONE, mask_rows=True, group_size=(B // groups if groups > 1 else 0), w_gs=Wx[0].numel(),
+                    bias_gs=bp[0].numel())
+    errx = (outx.cpu() - ref).abs().max().item()
+    assert errx <= 3e-5, errx
+    for i in range(B):
+        assert torch.all(outx[i, int(lens[i]):] == 0)
 
 
 @pytest.mark.parametrize("C,d,T,B", [(256, 1, 300, 2), (256, 2, 777, 3), (256, 4, 256, 1), (256, 8, 1100, 2), (192, 8, 530, 2)])

@@ -39,3 +39,8 @@ for (name, B, T, C, Lyr) in (("mel", 8, 1500, 256, 20), ("f0", 16, 1500, 192, 10
         s = timeit(g16, 20)
         fl = 2.0 * B * T * Lyr * C * C
         print(f"{name} skip GEMM K={Lyr * C} N={C} gemm16_store mt={mt}: {s * 1e6:7.1f} us  {fl / s / 1e12:6.1f} TF/s ({fl / s / 157.3e12 * 100:.1f} % of peak)")
+    Wsx = L.split3_gemm16_weights(Ws, Ws.shape[1])
+    def g16x():
+        L.gemm16x_store(Gall, Ws, Wsx, S, mt=6, B=B, T=T, Cin=Lyr * C, N=C, Np=Ws.shape[0], Kp=Ws.shape[1], lens=lens, bias=bo, act=L.ACT_RELU)
+    s = timeit(g16x, 20)
+    print(f"{name} skip GEMM K={Lyr * C} N={C} gemm16x_store (bf16x3) mt=6: {s * 1e6:7.1f} us  {fl / s / 1e12:6.1f} TF/s algorithmic")
