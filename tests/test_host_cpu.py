@@ -300,3 +300,17 @@ def test_norm_interp_f0_matches_the_reference_function(golden_dir):
         assert torch.equal(f0, c["f0"]), (key, (f0 - c["f0"]).abs().max().item())
         f0t, uvt = pitch.norm_interp_f0(c["hz"], hp)   # torch input, as the reference also accepts
         assert torch.equal(f0t, c["f0"]) and torch.equal(uvt, c["uv"]), key
+
+
+def test_lds_swizzles_are_conflict_free_in_the_bank_model():
+    """tools/lds_sim.py (lane groups / bank functions of MI355X_MICROARCH.md): the fragment reads and staging writes of the 16x16 kernels
+    (128-byte fp32 rows with swz16, 64-byte bf16 rows with swz64) cost the conflict-free number of LDS cycles; the unswizzled reads do not
+    (the model is not vacuous). On the GPU the fp32 form reads SQ_LDS_BANK_CONFLICT = 0 (profiles/r03_pmc_gate.json)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_sim", os.path.join(root, "tools", "lds_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    assert sim.main() == 0
+    c, ideal = sim.cycles("ds_read_b128", lambda lane: (lane & 15) * 128 + ((2 * (lane >> 4)) << 4))
+    assert c > ideal
