@@ -242,9 +242,8 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(c
   using P5 = std::integral_constant<int, 5>;
   // ORD[p] = component consumed at position p
   constexpr int ORD[6] = {1, 0, 5, 2, 3, 4};
-  const int kb = a.Kp * 4;  // bytes of one component in a packed weight row
   const int cs = BK * 4;    // bytes of one K chunk
-  // chunk (k, p): weights of component ORD[p] at byte ORD[p]*kb + k*cs of a packed row; register stage p % 3; LDS buffer p & 1
+  // chunk (k, p): weights of component ORD[p], K chunk k (load_b); register stage p % 3; LDS buffer p & 1
   load_rows(0);
   load_b(P0{}, ORD[0], 0);
   load_b(P1{}, ORD[1], 0);
