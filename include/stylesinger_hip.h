@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 11 /* 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 12 /* 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -44,7 +44,9 @@ int ss_struct_sizes(int64_t* out, int n);
  * "skip_tile" = SS_TILE_* override for the residual-half projection / the K = L*C skip GEMM (0 = built-in choice); "gate256" = 0|1 bf16 GATE launches on the 256x256 LDS-DMA kernel when they
  * qualify (default 1); "res16" / "skip16" = 0|1|4|6|8
  * residual-half projection on ss_gemm16_res / skip GEMM on ss_gemm16_store (1 = on, row tile picked per launch, default; 0 =
- * ss_conv_gemm; 4|6|8 = force 16*mt rows) */
+ * ss_conv_gemm; 4|6|8 = force 16*mt rows); experiment switches "htile" = 0|64|128 (row tile of the generic bf16 kernel), "wino_tn" = 0|1|2 and
+ * "wino_v1" = 0|1 (F(2,3) gate: column tile, round-1 kernel); "voc_wino_max_mb" = 1..2048: vocoder items whose stage panel reaches this many MiB
+ * take the direct conv kernel instead of the grouped-Winograd one (32-bit offsets; default 2048 = the real limit, tests lower it) */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -251,6 +253,14 @@ typedef struct ss_gemm_bf16_args {
   int64_t c_batch_stride;
   int32_t mask_rows;
   int32_t group_size;
+  /* split-operand form ("bf16x2" precision, BASELINE config 4 at fp32-grade parity): split = 1 -> every bf16 operand is a PAIR of bf16 terms
+   * v = hi + mid (hi = RNE(v), mid = RNE(v - hi): 16 significand bits) and the matrix cores run the three products hi*hi + hi*mid + mid*hi
+   * (fp32 accumulate, the small terms first). The mid term of A[t][k] sits a_mid_off ELEMENTS after its hi term in the same row, that of
+   * W[n][j*K + k] w_mid_off elements after its hi term (rows of 2*ntaps*K: ss_split_bf16 of the packed weights). bf16 OUTPUTS are written as
+   * (hi, mid) pairs c_mid_off (GATE's C) / y_mid_off (RESX's Y) elements apart. split = 2: A has no mid term (products hi*hi + hi*mid). */
+  int32_t split;
+  int32_t a_mid_off, w_mid_off, c_mid_off, y_mid_off;
+  int32_t reserved_;
 } ss_gemm_bf16_args;
 int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
 /* The SS_HEPI_GATE form of ss_gemm_bf16 for many-round launches (BASELINE config 4): three taps (-d, 0, d) with d <= 8, K = 192 | 256,
@@ -263,6 +273,9 @@ int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* args);
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
                int group_size, int64_t bias_group_stride, void* stream);
+/* The split form of ss_to_bf16: v = x + bias -> y[.][c] = hi = RNE(v), y[.][mid_off + c] = RNE(v - hi) (same row, ldy >= mid_off + C). */
+int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, int mid_off, const int32_t* lens,
+                  int group_size, int64_t bias_group_stride, void* stream);
 
 /* Weight packing (device -> device).  src is the torch parameter layout [Cout][Cin][k] (conv1d,
  * k=1 for nn.Linear [out][in]).  dst is [Np][k*Kp] with zero fill.  If scale0 != NULL (from
@@ -426,6 +439,12 @@ typedef struct ss_wavenet {
   /* bf16x3 mode: ss_split3_gemm16_weights of w_skipall (used with skipall_folded); gs in bf16 elements */
   const uint16_t* w_skipall_x3;
   int64_t gs_w_skipall_x3;
+  /* 1 = "bf16x2" precision (BASELINE config 4 at fp32-grade parity; needs mfma_bf16 = 1 and the w_*_h packs): the w_*_h tensors are SPLIT packs
+   * (ss_split_bf16 of the packed fp32 weights: rows [ntaps*K hi | ntaps*K mid]) and the hidden activations travel as (hi, mid) bf16 pairs;
+   * every hidden GEMM runs hi*hi + hi*mid + mid*hi on the bf16 matrix cores (ss_gemm_bf16_args.split), the hoisted conditioner projection in
+   * exact fp32 (w_cond_h unused). With skipall_folded the K = L*C GEMM + ReLU is the stack output, as in fp32 mode. */
+  int32_t mfma_split;
+  int32_t reserved_;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */
@@ -442,12 +461,15 @@ int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int T);
 int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
                       const float* noise, uint64_t seed, const uint64_t* seed_dev, int step_lo, int step_hi,
                       int precompute_cond, void* ws, int64_t ws_bytes, void* stream);
-/* Strided deterministic (DDIM, eta=0) sampler over the same denoiser: network times ts[0] > ts[1] > ... (HOST array),
- * alphas_cumprod = HOST schedule table [steps]. BASELINE config 5; the reference has no such sampler (its strided
- * option is PLMS, shallow_diffusion_tts.py:165-197), so parity is against the oracle's restatement only. */
+/* Strided DDIM-family sampler over the same denoiser (Song et al. 2021, eq. 12/16): network times ts[0] > ts[1] > ... (HOST array),
+ * alphas_cumprod = HOST schedule table [steps] in DOUBLE precision (cumprod(1 - betas); 1 - ac loses its digits in float at small t).
+ *   eta = 0: deterministic sampler of BASELINE config 5 (the reference has no such sampler; its strided option is PLMS).
+ *   eta = 1 with ts = K-1 ... 0: the reference's ancestral p_sample (shallow_diffusion_tts.py:136-162) - c1/c2 become
+ *            posterior_mean_coef1/2, sigma^2 the posterior variance - which pins this entry point to golden acoustic_t64_s100.
+ *   noise [steps][B][T][80] tape (index = network time t) or NULL -> Philox(seed + *seed_dev); only read when eta > 0. */
 int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
-                           const int32_t* ts, int n_ts, const float* alphas_cumprod, int precompute_cond, void* ws,
-                           int64_t ws_bytes, void* stream);
+                           const int32_t* ts, int n_ts, const double* alphas_cumprod, float eta, const float* noise, uint64_t seed,
+                           const uint64_t* seed_dev, int precompute_cond, void* ws, int64_t ws_bytes, void* stream);
 
 /* PLMS ("pndm_speedup") sampler of the reference: modules/diff/shallow_diffusion_tts.py:165-197 (p_sample_plms) driven as
  * in :254-260 - network times reversed(range(0, step_hi, interval)) with step_hi = K_step (the shallow-diffusion depth x

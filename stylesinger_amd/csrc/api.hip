@@ -14,51 +14,49 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1};
+SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048};
+
+namespace {
+struct Knob { const char* key; int* slot; bool (*ok)(int); };
+bool ok_01(int v) { return v == 0 || v == 1; }
+bool ok_012(int v) { return v >= 0 && v <= 2; }
+bool ok_0123(int v) { return v >= 0 && v <= 3; }
+bool ok_mt(int v) { return v == 0 || v == 1 || v == 4 || v == 6 || v == 8; }
+bool ok_tile(int v) { return v >= SS_TILE_AUTO && v <= SS_TILE_128x32; }
+bool ok_htile(int v) { return v == 0 || v == 64 || v == 128; }
+bool ok_mb(int v) { return v >= 1 && v <= 2048; }
+const Knob* knobs(int* n) {
+  static const Knob k[] = {
+      {"wave_prio", &g_ss_tuning.wave_prio, ok_012},   {"gate16", &g_ss_tuning.gate16, ok_0123},     {"gate16_ks", &g_ss_tuning.gate16_ks, ok_01},
+      {"gate256", &g_ss_tuning.gate256, ok_01},        {"res16", &g_ss_tuning.res16, ok_mt},          {"skip16", &g_ss_tuning.skip16, ok_mt},
+      {"res_tile", &g_ss_tuning.res_tile, ok_tile},    {"skip_tile", &g_ss_tuning.skip_tile, ok_tile}, {"htile", &g_ss_tuning.htile, ok_htile},
+      {"wino_tn", &g_ss_tuning.wino_tn, ok_012},       {"wino_v1", &g_ss_tuning.wino_v1, ok_01},      {"voc_wino_max_mb", &g_ss_tuning.voc_wino_max_mb, ok_mb},
+  };
+  *n = (int)(sizeof(k) / sizeof(k[0]));
+  return k;
+}
+}  // namespace
 
 extern "C" int ss_set_tuning(const char* key, int value) {
   if (!key) {
     ss_set_error("ss_set_tuning: null key");
     return SS_ERR_ARG;
   }
-  if (strcmp(key, "wave_prio") == 0 && value >= 0 && value <= 2) {
-    g_ss_tuning.wave_prio = value;
-    return SS_OK;
-  }
-  if ((strcmp(key, "res16") == 0 || strcmp(key, "skip16") == 0) && (value == 0 || value == 1 || value == 4 || value == 6 || value == 8)) {
-    (key[0] == 'r' ? g_ss_tuning.res16 : g_ss_tuning.skip16) = value;
-    return SS_OK;
-  }
-  if (strcmp(key, "gate256") == 0 && (value == 0 || value == 1)) {
-    g_ss_tuning.gate256 = value;
-    return SS_OK;
-  }
-  if (strcmp(key, "gate16_ks") == 0 && (value == 0 || value == 1)) {
-    g_ss_tuning.gate16_ks = value;
-    return SS_OK;
-  }
-  if (strcmp(key, "gate16") == 0 && value >= 0 && value <= 3) {
-    g_ss_tuning.gate16 = value;
-    return SS_OK;
-  }
-  if ((strcmp(key, "res_tile") == 0 || strcmp(key, "skip_tile") == 0) && value >= SS_TILE_AUTO && value <= SS_TILE_128x32) {
-    (key[0] == 'r' ? g_ss_tuning.res_tile : g_ss_tuning.skip_tile) = value;
-    return SS_OK;
-  }
+  int n;
+  const Knob* k = knobs(&n);
+  for (int i = 0; i < n; ++i)
+    if (strcmp(key, k[i].key) == 0 && k[i].ok(value)) {
+      *k[i].slot = value;
+      return SS_OK;
+    }
   ss_set_error("ss_set_tuning: unknown key/value %s=%d", key, value);
   return SS_ERR_ARG;
 }
 extern "C" int ss_get_tuning(const char* key) {
-  if (key) {
-    if (strcmp(key, "wave_prio") == 0) return g_ss_tuning.wave_prio;
-    if (strcmp(key, "gate16") == 0) return g_ss_tuning.gate16;
-    if (strcmp(key, "gate256") == 0) return g_ss_tuning.gate256;
-    if (strcmp(key, "gate16_ks") == 0) return g_ss_tuning.gate16_ks;
-    if (strcmp(key, "res16") == 0) return g_ss_tuning.res16;
-    if (strcmp(key, "skip16") == 0) return g_ss_tuning.skip16;
-    if (strcmp(key, "res_tile") == 0) return g_ss_tuning.res_tile;
-    if (strcmp(key, "skip_tile") == 0) return g_ss_tuning.skip_tile;
-  }
+  int n;
+  const Knob* k = knobs(&n);
+  for (int i = 0; key && i < n; ++i)
+    if (strcmp(key, k[i].key) == 0) return *k[i].slot;
   ss_set_error("ss_get_tuning: unknown key %s", key ? key : "(null)");
   return SS_ERR_ARG;
 }

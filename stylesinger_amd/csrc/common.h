@@ -53,7 +53,12 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     of LDS); 0 = one component per barrier (8 / 12 KB).
 //   gate256: 1 (default) = bf16 GATE launches that qualify (ss_gemm_bf16_gate256_ok) run on the 256x256 LDS-DMA kernel; 0 = always the
 //     generic bf16 kernel.
-struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks; };
+//   htile: row tile of the generic bf16 kernel (0 = built-in choice, 64 | 128 = force); wino_tn: column tile of the F(2,3) gate (0 = pick,
+//     1 = 64, 2 = 128 columns); wino_v1: 1 = the round-1 F(2,3) kernel (A/B against v2).
+//   voc_wino_max_mb: the vocoder's grouped-Winograd convs address an item with 32-bit byte offsets; items whose stage panel (+ halo) reaches
+//     this many MiB take the direct kernel instead (default 2048 = the real limit; tests lower it to force that fallback).
+struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
+                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; };
 extern SsTuning g_ss_tuning;
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)

@@ -31,7 +31,11 @@ struct WsLayout {
   int64_t bytes;
 };
 
-inline bool hmode(const ss_wavenet* net) { return net->mfma_bf16 && net->w_dil_h[0] && net->w_skipall_h && net->w_cond_h; }
+// hmode: the hidden activations travel as bf16 in HBM. split (net->mfma_split, "bf16x2" precision): every bf16 operand is a (hi, mid) pair in
+// the same row - Yh rows [C hi | C mid], GAh rows [L*C hi | L*C mid], weight rows [ntaps*K hi | ntaps*K mid] - and the matrix cores run
+// hi*hi + hi*mid + mid*hi (ss_gemm_bf16_args.split); the hoisted conditioner projection then runs in exact fp32 (it is outside the step loop).
+inline bool smode(const ss_wavenet* net) { return net->mfma_split != 0; }
+inline bool hmode(const ss_wavenet* net) { return net->mfma_bf16 && net->w_dil_h[0] && net->w_skipall_h && (net->w_cond_h || smode(net)); }
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -52,9 +56,10 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.O = take(rows * 4);
   const bool h = hmode(net);
   w.GA = (net->w_skipall && !h) ? take(rows * net->L * net->C) : nullptr;
-  w.Yh = h ? (uint16_t*)take((rows * net->C + 1) / 2) : nullptr;
-  w.GAh = h ? (uint16_t*)take((rows * net->L * net->C + 1) / 2) : nullptr;
-  w.condh = h ? (uint16_t*)take((rows * net->cond_dim + 1) / 2) : nullptr;
+  const int planes = smode(net) ? 2 : 1;
+  w.Yh = h ? (uint16_t*)take((rows * net->C * planes + 1) / 2) : nullptr;
+  w.GAh = h ? (uint16_t*)take((rows * net->L * net->C * planes + 1) / 2) : nullptr;
+  w.condh = (h && !smode(net)) ? (uint16_t*)take((rows * net->cond_dim + 1) / 2) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -93,7 +98,7 @@ inline ss_gemm_bf16_args base_args_h(const ss_wavenet* net, int B, int T, const 
 int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* lens, int B, int T, const WsLayout& w,
                     hipStream_t stream) {
   const int NE = net->L * 2 * net->C;
-  if (hmode(net)) {  // cond rounded once to bf16, then E = cond . Wc^T + (bc + b_dil) on the bf16 kernel (fp32 out)
+  if (hmode(net) && !smode(net)) {  // cond rounded once to bf16, then E = cond . Wc^T + (bc + b_dil) on the bf16 kernel (fp32 out)
     SS_PROPAGATE(ss_to_bf16(cond, nullptr, w.condh, B, T, net->cond_dim, net->cond_dim, net->cond_dim, nullptr, 0, 0, stream));
     ss_gemm_bf16_args h = base_args_h(net, B, T, lens);
     h.A = w.condh;
@@ -128,7 +133,7 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
   a.ldc = NE;
   a.c_batch_stride = (int64_t)T * NE;
   a.mask_rows = 0;
-  a.mfma_bf16 = net->mfma_bf16;
+  a.mfma_bf16 = smode(net) ? 0 : net->mfma_bf16;   // split mode: exact fp32 (a fixed rounding error of E would enter every step)
   if (net->n_groups > 1) {
     a.group_size = B / net->n_groups;
     a.w_group_stride = net->gs_w_cond;
@@ -147,12 +152,17 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
 int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
   const int C = net->C, L = net->L;
   const int NE = L * 2 * C;
+  const int sp = smode(net) ? 1 : 0, pl = sp + 1;   // planes per bf16 row
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % net->dil_cycle);
     ss_gemm_bf16_args g = base_args_h(net, B, T, lens);
     g.A = w.Yh;
-    g.lda = C;
-    g.a_batch_stride = (int64_t)T * C;
+    g.lda = C * pl;
+    g.a_batch_stride = (int64_t)T * C * pl;
+    g.split = sp;
+    g.a_mid_off = C;
+    g.w_mid_off = 3 * C;
+    g.c_mid_off = L * C;
     g.K = C;
     g.ntaps = 3;
     g.tap_off[0] = -d;
@@ -168,13 +178,17 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     g.lde = NE;
     g.e_batch_stride = (int64_t)T * NE;
     g.C = w.GAh + (int64_t)l * C;
-    g.ldc = L * C;
-    g.c_batch_stride = (int64_t)T * L * C;
+    g.ldc = L * C * pl;
+    g.c_batch_stride = (int64_t)T * L * C * pl;
     SS_PROPAGATE(ss_gemm_bf16(&g, stream));
     ss_gemm_bf16_args o = base_args_h(net, B, T, lens);
     o.A = w.GAh + (int64_t)l * C;
-    o.lda = L * C;
-    o.a_batch_stride = (int64_t)T * L * C;
+    o.lda = L * C * pl;
+    o.a_batch_stride = (int64_t)T * L * C * pl;
+    o.split = sp;
+    o.a_mid_off = L * C;
+    o.w_mid_off = C;
+    o.y_mid_off = C;
     o.K = C;
     o.W = net->w_out_h[l];
     o.w_group_stride = net->gs_w_out_h;
@@ -191,15 +205,18 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
       o.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
       o.next_bias_group_stride = net->gs_dstep;
       o.Y = w.Yh;
-      o.ldy = C;
-      o.y_batch_stride = (int64_t)T * C;
+      o.ldy = C * pl;
+      o.y_batch_stride = (int64_t)T * C * pl;
     }
     SS_PROPAGATE(ss_gemm_bf16(&o, stream));
   }
   ss_gemm_bf16_args k = base_args_h(net, B, T, lens);
   k.A = w.GAh;
-  k.lda = L * C;
-  k.a_batch_stride = (int64_t)T * L * C;
+  k.lda = L * C * pl;
+  k.a_batch_stride = (int64_t)T * L * C * pl;
+  k.split = sp;
+  k.a_mid_off = L * C;
+  k.w_mid_off = L * C;
   k.K = L * C;
   k.W = net->w_skipall_h;
   k.w_group_stride = net->gs_w_skipall_h;
@@ -211,11 +228,18 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   k.C = w.S;
   k.ldc = C;
   k.c_batch_stride = (int64_t)T * C;
+  if (net->skipall_folded) {   // w_skipall_h already carries skip_projection / sqrt(L): this GEMM + ReLU is the stack's output
+    k.act = SS_ACT_RELU;
+    k.C = w.G;
+  }
   return ss_gemm_bf16(&k, stream);
 }
 
 // Yh = bf16(X + dstep[step][0]) : the first layer's conv operand (bf16-in-HBM mode)
 int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
+  if (smode(net))
+    return ss_split_bf16(w.X, net->dstep + (int64_t)step * net->L * net->C, w.Yh, B, T, net->C, net->C, 2 * net->C, net->C, lens,
+                         net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);
   return ss_to_bf16(w.X, net->dstep + (int64_t)step * net->L * net->C, w.Yh, B, T, net->C, net->C, net->C, lens,
                     net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);
 }
@@ -227,6 +251,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
   if (hmode(net)) {
     SS_PROPAGATE(stack_entry_h(net, step, lens, B, T, w, stream));
     SS_PROPAGATE(run_residual_stack_h(net, step, lens, B, T, w, stream));
+    if (net->skipall_folded) return SS_OK;
   } else
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % net->dil_cycle);
@@ -374,7 +399,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
   s.C = w.G;
   s.ldc = C;
   s.c_batch_stride = (int64_t)T * C;
-  s.mfma_bf16 = net->mfma_bf16;
+  s.mfma_bf16 = smode(net) ? 0 : net->mfma_bf16;
   if (net->n_groups > 1) {
     s.group_size = B / net->n_groups;
     s.w_group_stride = net->gs_w_skip;
@@ -690,30 +715,39 @@ extern "C" int ss_prodiff_sample(const ss_wavenet* net, float* x, const float* c
   return SS_OK;
 }
 
-// Strided deterministic sampler (DDIM, eta = 0) over the SAME denoiser: visits network times ts[0] > ts[1] > ... and jumps
-// x_{ts[i]} -> x_{ts[i+1]} (-> x_0 after the last).  With x0 = clamp(...), eps' = (x - sqrt(ac_t) x0)/sqrt(1-ac_t):
-//   x_prev = sqrt(ac_prev) x0 + sqrt(1-ac_prev) eps' = c1 x0 + c2 x,  c2 = sqrt((1-ac_prev)/(1-ac_t)), c1 = sqrt(ac_prev) - c2 sqrt(ac_t)
-// i.e. the DDPM epilogue with other coefficients and sigma = 0.  The reference has no such sampler (BASELINE config 5
-// "new; no reference sampler"): parity is against oracle/restatement.py::mel_ddim only.
+// Strided sampler (DDIM family, Song et al. 2021 eq. 12 / 16) over the SAME denoiser: visits network times ts[0] > ts[1] > ... and jumps
+// x_{ts[i]} -> x_{ts[i+1]} (-> x_0 after the last).  With x0 = clamp(...), eps' = (x - sqrt(ac_t) x0)/sqrt(1-ac_t) and
+//   sigma = eta * sqrt((1-ac_prev)/(1-ac_t)) * sqrt(1 - ac_t/ac_prev):
+//   x_prev = sqrt(ac_prev) x0 + sqrt(1-ac_prev-sigma^2) eps' + sigma z = c1 x0 + c2 x + sigma z,
+//   c2 = sqrt((1-ac_prev-sigma^2)/(1-ac_t)), c1 = sqrt(ac_prev) - c2 sqrt(ac_t)
+// i.e. the DDPM epilogue with other coefficients.  eta = 0 is the deterministic sampler of BASELINE config 5 (the reference has none);
+// eta = 1 with ts = K-1 ... 0 IS the reference's ancestral p_sample (shallow_diffusion_tts.py:136-162: c1, c2 become
+// posterior_mean_coef1/2 and sigma^2 the posterior variance), which is how this entry point is pinned to the reference
+// (golden acoustic_t64_s100).  The schedule comes in DOUBLE precision (1 - ac_prev loses its digits in a float table at small t).
 extern "C" int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const float* cond, const int32_t* lens, int B, int T,
-                                      const int32_t* ts, int n_ts, const float* alphas_cumprod, int do_precompute, void* ws,
-                                      int64_t ws_bytes, void* stream_) {
+                                      const int32_t* ts, int n_ts, const double* alphas_cumprod, float eta, const float* noise,
+                                      uint64_t seed, const uint64_t* seed_dev, int do_precompute, void* ws, int64_t ws_bytes,
+                                      void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SS_CHECK_ARG(net && x && cond && ws && ts && alphas_cumprod && n_ts > 0, "ss_meldiff_sample_ddim: null pointer");
   SS_CHECK_ARG(net->n_groups <= 1 && net->L > 0 && net->L <= SS_MAX_LAYERS, "ss_meldiff_sample_ddim: bad net");
+  SS_CHECK_ARG(eta >= 0.0f && eta <= 1.0f, "ss_meldiff_sample_ddim: eta=%g outside [0, 1]", (double)eta);
   const WsLayout w = ws_layout(net, B, T, ws);
   SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_meldiff_sample_ddim: workspace too small");
   for (int i = 0; i < n_ts; ++i)
     SS_CHECK_ARG(ts[i] >= 0 && ts[i] < net->steps && (i == 0 || ts[i] < ts[i - 1]), "ss_meldiff_sample_ddim: ts must be strictly decreasing in [0,steps)");
+  const int M = net->in_dim;
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
   for (int i = 0; i < n_ts; ++i) {
     const int t = ts[i];
-    const float ac_t = alphas_cumprod[t];
-    const float ac_p = (i + 1 < n_ts) ? alphas_cumprod[ts[i + 1]] : 1.0f;
-    const float c2 = sqrtf((1.0f - ac_p) / (1.0f - ac_t));
-    const float c1 = sqrtf(ac_p) - c2 * sqrtf(ac_t);
-    SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], c1, c2, 0.0f, nullptr, 0, nullptr,
-                          (uint32_t)t, stream));
+    const double ac_t = alphas_cumprod[t];
+    const double ac_p = (i + 1 < n_ts) ? alphas_cumprod[ts[i + 1]] : 1.0;
+    const double sig = (double)eta * sqrt((1.0 - ac_p) / (1.0 - ac_t)) * sqrt(fmax(0.0, 1.0 - ac_t / ac_p));
+    const double c2 = sqrt(fmax(0.0, 1.0 - ac_p - sig * sig) / (1.0 - ac_t));
+    const double c1 = sqrt(ac_p) - c2 * sqrt(ac_t);
+    const bool draw = eta > 0.0f;  // like p_sample, a stochastic run draws at every step (sigma = 0 on the last)
+    SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], (float)c1, (float)c2, (float)sig,
+                          (draw && noise) ? noise + (int64_t)t * B * T * M : nullptr, seed, draw ? seed_dev : nullptr, (uint32_t)t, stream));
   }
   return SS_OK;
 }

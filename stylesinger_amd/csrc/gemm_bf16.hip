@@ -38,6 +38,8 @@ __device__ __forceinline__ uint16_t f2bf(float x) {  // RNE, like torch's .bfloa
   return __builtin_bit_cast(uint16_t, (__bf16)x);
 }
 
+__device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
 // SS_HABL (debug builds only, tools/ablate_h.sh): timing ablations. 1 = no global fetches in the loop, 2 = no MFMAs,
 // 3 = no addend loads in the epilogue, 4 = no epilogue stores. Results are wrong by design.
 #ifndef SS_HABL
@@ -70,8 +72,13 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const int nchunks_tap = a.K / BKH;
-  const int nchunks = a.ntaps * nchunks_tap;
-  const int ldw = a.ntaps * a.K;  // bf16 per packed weight row
+  const int nchunks1 = a.ntaps * nchunks_tap;
+  // split-operand form (a.split): the chunk sequence runs 3 (2) times over K - pass q = 0: A mid x W hi, 1: A hi x W mid, 2: A hi x W hi
+  // (small terms first; split = 2 has no A mid term and starts at q = 1); only the SGPR offsets of the fetches change
+  const int npass = a.split == 1 ? 3 : a.split == 2 ? 2 : 1;
+  const int nchunks = nchunks1 * npass;
+  const int ldw = a.ntaps * a.K * (a.split ? 2 : 1);  // bf16 per packed weight row
+  const int a_mid2 = a.a_mid_off * 2, w_mid2 = a.w_mid_off * 2;
 
   auto uniform_ptr = [](const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -101,8 +108,13 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 
   // chunk c = (tap, k0): SGPR byte offsets of the A fetch (tap row shift + channel offset) and of the W fetch
   auto a_soff = [&](int c) {
-    const int tap = c / nchunks_tap, k0 = (c - tap * nchunks_tap) * BKH;
-    return a.tap_off[tap] * lda2 + k0 * 2;
+    const int p = c / nchunks1, cc = c - p * nchunks1;
+    const int tap = cc / nchunks_tap, k0 = (cc - tap * nchunks_tap) * BKH;
+    return a.tap_off[tap] * lda2 + k0 * 2 + ((p + 3 - npass) == 0 ? a_mid2 : 0);
+  };
+  auto w_soff = [&](int c) {
+    const int p = c / nchunks1, cc = c - p * nchunks1;
+    return cc * (BKH * 2) + ((p + 3 - npass) == 1 ? w_mid2 : 0);
   };
   u32x4 ra[2][AP], rb[2][BP];  // two register stages
   auto fetch = [&](auto st_tag, int c, int dead) {
@@ -114,8 +126,9 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #endif
 #pragma unroll
     for (int i = 0; i < AP; ++i) ra[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[i] + so) | dead, 0, 0);
+    const int wo = w_soff(c);
 #pragma unroll
-    for (int i = 0; i < BP; ++i) rb[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i] | dead, c * (BKH * 2), 0);
+    for (int i = 0; i < BP; ++i) rb[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i] | dead, wo, 0);
   };
   auto stage = [&](auto st_tag, auto buf_tag) {
     constexpr int ST = decltype(st_tag)::value;
@@ -282,7 +295,9 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #if SS_HABL == 4
           if (g == 12345.678f)
 #endif
-          __builtin_amdgcn_raw_buffer_store_b16(f2bf(g), rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
+          const uint16_t gh = f2bf(g);
+          __builtin_amdgcn_raw_buffer_store_b16(gh, rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
+          if (a.split) __builtin_amdgcn_raw_buffer_store_b16(f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, a.c_mid_off * 2, 0);
         }
       }
     }
@@ -317,7 +332,10 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
           const bool pad = row0 + rr >= row_lim;
           if (pad) xn = 0.f;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xn), rsrc_x, xoff + rr * ldx4, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b16(pad ? (uint16_t)0 : f2bf(xn + nb), rsrc_y, yoff + rr * ldy2, 0, 0);
+          const float yv = pad ? 0.f : xn + nb;
+          const uint16_t yh = f2bf(yv);
+          __builtin_amdgcn_raw_buffer_store_b16(yh, rsrc_y, yoff + rr * ldy2, 0, 0);
+          if (a.split == 1) __builtin_amdgcn_raw_buffer_store_b16(f2bf(yv - bf2f(yh)), rsrc_y, yoff + rr * ldy2, a.y_mid_off * 2, 0);
         }
       }
     }
@@ -346,7 +364,7 @@ template <int EPI>
 int launch_tiles(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const int n_cols = (EPI == SS_HEPI_GATE) ? a.Np : a.N;
   const long big = (long)ss_cdiv(a.T, 128) * a.B * ss_cdiv(n_cols, 128);
-  static const int env_tile = getenv("SS_HTILE") ? atoi(getenv("SS_HTILE")) : 0;  // experiments: 64 / 128 force the row tile
+  const int env_tile = g_ss_tuning.htile;  // experiments: 64 / 128 force the row tile
   if (env_tile == 64) return launch_h<64, 128, EPI>(a, stream);
   if (env_tile == 128) return launch_h<128, 128, EPI>(a, stream);
   if (big >= 512) return launch_h<128, 128, EPI>(a, stream);
@@ -373,6 +391,28 @@ __global__ void to_bf16_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+// the split form: hi = RNE(v), mid = RNE(v - hi) at mid_off elements further in the same row
+__global__ void split_bf16_kernel(const float* __restrict__ x, const float* __restrict__ bias, uint16_t* __restrict__ y, int B, int T, int C,
+                                  int ldx, int ldy, int mid_off, const int32_t* __restrict__ lens, int group_size, int64_t bias_gs) {
+  const int64_t n = (int64_t)B * T * (C / 4);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (C / 4)) * 4;
+    const int64_t r = i / (C / 4);
+    const int b = (int)(r / T), t = (int)(r % T);
+    float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4);
+    if (bias) {
+      const float* bp = bias + (group_size > 0 ? (int64_t)(b / group_size) * bias_gs : 0) + c4;
+      v.x += bp[0]; v.y += bp[1]; v.z += bp[2]; v.w += bp[3];
+    }
+    if (lens && t >= lens[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    ushort4 h, m;
+    h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
+    m.x = f2bf(v.x - bf2f(h.x)); m.y = f2bf(v.y - bf2f(h.y)); m.z = f2bf(v.z - bf2f(h.z)); m.w = f2bf(v.w - bf2f(h.w));
+    *reinterpret_cast<ushort4*>(y + r * ldy + c4) = h;
+    *reinterpret_cast<ushort4*>(y + r * ldy + mid_off + c4) = m;
+  }
+}
+
 }  // namespace
 
 extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
@@ -387,6 +427,13 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
   SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16: A/W must be 16-byte aligned");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldx * 4 < (1ll << 31) &&
                    (int64_t)a.T * a.ldc * 4 < (1ll << 31), "ss_gemm_bf16: item too large for 32-bit offsets");
+  SS_CHECK_ARG(a.split >= 0 && a.split <= 2, "ss_gemm_bf16: split=%d", a.split);
+  if (a.split) {
+    SS_CHECK_ARG(a.w_mid_off == a.ntaps * a.K && (a.split == 2 || (a.a_mid_off > 0 && (a.a_mid_off % 8) == 0 && a.a_mid_off + a.K <= a.lda)),
+                 "ss_gemm_bf16: split operands need w_mid_off = ntaps*K (%d) and an a_mid_off (%d) inside the row", a.w_mid_off, a.a_mid_off);
+    SS_CHECK_ARG(a.epi != SS_HEPI_GATE || (a.c_mid_off > 0 && a.c_mid_off + a.N <= a.ldc), "ss_gemm_bf16: split GATE needs c_mid_off inside ldc");
+    SS_CHECK_ARG(a.epi != SS_HEPI_RESX || a.split == 2 || !a.Y || (a.y_mid_off > 0 && a.y_mid_off + a.N <= a.ldy), "ss_gemm_bf16: split RESX needs y_mid_off inside ldy");
+  }
   switch (a.epi) {
     case SS_HEPI_STORE:
       SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: STORE needs C");
@@ -394,7 +441,7 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
     case SS_HEPI_GATE:
       SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: GATE needs C");
       // many-round launches of the 3-tap dilated conv (BASELINE config 4) go to the 256x256 / 8-wave / LDS-DMA kernel
-      if (g_ss_tuning.gate256 && ss_gemm_bf16_gate256_ok(&a)) return ss_gemm_bf16_gate256(&a, stream_);
+      if (g_ss_tuning.gate256 && ss_gemm_bf16_gate256_ok(&a)) return ss_gemm_bf16_gate256(&a, stream_);   // (returns 0 for split operands)
       return launch_tiles<SS_HEPI_GATE>(a, stream);
     case SS_HEPI_RESX:
       SS_CHECK_ARG(a.X != nullptr, "ss_gemm_bf16: RESX needs X");
@@ -413,5 +460,17 @@ extern "C" int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B,
   hipLaunchKernelGGL(to_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, lens, group_size,
                      bias_group_stride);
   SS_CHECK_LAUNCH("ss_to_bf16");
+  return SS_OK;
+}
+
+extern "C" int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, int mid_off, const int32_t* lens,
+                             int group_size, int64_t bias_group_stride, void* stream) {
+  SS_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (mid_off & 3) == 0 && mid_off >= C &&
+                   mid_off + C <= ldy, "ss_split_bf16: bad args");
+  const int64_t n = (int64_t)B * T * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, mid_off, lens, group_size,
+                     bias_group_stride);
+  SS_CHECK_LAUNCH("ss_split_bf16");
   return SS_OK;
 }

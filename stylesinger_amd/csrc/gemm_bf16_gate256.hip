@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
 // 1 if ss_gemm_bf16 should hand this GATE launch to the 256x256 kernel: three symmetric taps, dilation <= 8, K a multiple of 64,
 // Np a multiple of 256, and enough rows that 256-row tiles fill the chip several times over
 extern "C" int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* a) {
-  if (!a || a->epi != SS_HEPI_GATE || a->ntaps != 3) return 0;
+  if (!a || a->epi != SS_HEPI_GATE || a->ntaps != 3 || a->split) return 0;
   const int d = a->tap_off[2];
   if (d < 1 || d > HALO || a->tap_off[0] != -d || a->tap_off[1] != 0) return 0;
   if (a->K != 256 || (a->Np % BN) != 0 || (a->lda % 8) != 0 || (a->N % 8) != 0) return 0;

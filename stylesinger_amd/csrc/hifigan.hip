@@ -385,7 +385,8 @@ int conv_same(const float* A, int B, int Trows, int C, const int32_t* lens, cons
     a.act = SS_ACT_LRELU_;
     a.act_slope = 0.1f;
   }
-  if (W_wino && ((int64_t)Trows + 1024) * C * 4 < (1ll << 31)) {   // (32-bit row offsets inside an item; longer items take the direct kernel)
+  // 32-bit byte offsets inside an item: longer items take the direct kernel ("voc_wino_max_mb" knob, default 2048 MiB = the real limit)
+  if (W_wino && ((int64_t)Trows + 1024) * C * 4 < ((int64_t)g_ss_tuning.voc_wino_max_mb << 20)) {
     a.W = W_wino;
     return ss_wino43_conv(&a, k, d, stream);
   }

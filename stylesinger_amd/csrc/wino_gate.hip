@@ -808,15 +808,15 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
   // (752 / 376 blocks) TN=1 84.0 us; f0 pair (1152 / 576 blocks) TN=1 104.7 vs TN=2 112.0 us -> TN=1 while its grid is
   // at most two rounds; beyond that a makespan model picks (TN=2 wins once there are many rounds).
   int tn = a.tile == SS_TILE_64x128 ? 2 : a.tile == SS_TILE_64x64 ? 1 : 0;
-  static const int env_tn = getenv("SS_WINO_TN") ? atoi(getenv("SS_WINO_TN")) : 0;  // experiments: force the tile of every auto launch
+  const int env_tn = g_ss_tuning.wino_tn;  // experiments: force the tile of every auto launch
   if (tn == 0 && (env_tn == 1 || env_tn == 2)) tn = env_tn;
   if (tn == 0) {
     const long b2 = (long)p_tiles * ss_cdiv(a.Np, 128), b1 = (long)p_tiles * (a.Np / 64);
     const double t2 = (double)ss_cdiv(b2, 256) * 2.0 / 0.92, t1 = (double)ss_cdiv(b1, 256) * 1.0 / 0.75;
     tn = ((a.Np % 128) == 0 && b1 > 2 * 768 && t2 <= t1) ? 2 : 1;
   }
-  // version 2 (VALU diet) needs whole 32-channel K chunks and an even chunk count; SS_WINO_V1=1 forces the first version (A/B)
-  static const bool force_v1 = getenv("SS_WINO_V1") != nullptr;
+  // version 2 (VALU diet) needs whole 32-channel K chunks and an even chunk count; the "wino_v1" knob forces the first version (A/B)
+  const bool force_v1 = g_ss_tuning.wino_v1 != 0;
   const bool v2 = !force_v1 && (a.Cin % BK) == 0 && a.Kp == a.Cin && ((a.Kp / BK) % 2) == 0;
   if (tn == 2) {
     SS_CHECK_ARG((a.Np % 128) == 0, "ss_wino_gate: TN=2 needs Np multiple of 128");
@@ -828,7 +828,11 @@ extern "C" int ss_wino_gate(const ss_conv_gemm_args* args, int dilation, void* s
   } else {
     const int n_tiles = a.Np / 64;
     const int grid = ss_cdiv(p_tiles, 8) * 8 * n_tiles;
-    static const size_t lds_pad = getenv("SS_WINO_LDS_PAD") ? (size_t)atoi(getenv("SS_WINO_LDS_PAD")) : 0;  // occupancy experiments only
+#ifdef SS_EXPERIMENT_KNOBS   // occupancy experiments of the ablation builds only (tools/ablate.sh)
+    static const size_t lds_pad = getenv("SS_WINO_LDS_PAD") ? (size_t)atoi(getenv("SS_WINO_LDS_PAD")) : 0;
+#else
+    const size_t lds_pad = 0;
+#endif
     const size_t lds = (size_t)2 * (BP + 64) * LD * sizeof(float) + lds_pad;
     if (lds_pad) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gate_kernel_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -8,6 +8,8 @@ waveforms stay sharded).  Sharding rule = the reference's dataloader rule `x[ran
 (tasks/tts/tts_base.py:129-132).  When the item count is not a multiple of the world size the short
 shards are padded with empty slots (len 0) so that every rank contributes the same shape to the collective.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,8 +24,16 @@ def shard_slots(n_items, world):
     return (n_items + world - 1) // world
 
 
+# A world of one rank has nothing to exchange, so the collective is skipped there - unless this flag is set (env SS_FORCE_COLLECTIVE=1
+# or dist.FORCE_COLLECTIVE = True): then an initialised process group of ANY size, W = 1 included, takes the real
+# all_gather_into_tensor branch. That is how a 1-GPU box drives the RCCL code path (tests/test_gpu_round4.py).
+FORCE_COLLECTIVE = os.environ.get("SS_FORCE_COLLECTIVE", "0") == "1"
+
+
 def _is_dist(group=None):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVE
 
 
 _comm_streams = {}

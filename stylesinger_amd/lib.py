@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 11  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 12  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -67,7 +67,8 @@ class WaveNet(C.Structure):
            ("w_dil_h", _vp * SS_MAX_LAYERS), ("w_out_h", _vp * SS_MAX_LAYERS), ("w_skipall_h", _vp), ("w_cond_h", _vp),
            ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64),
            ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS),
-           ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64), ("w_skipall_x3", _vp), ("gs_w_skipall_x3", C.c_int64)]
+           ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64), ("w_skipall_x3", _vp), ("gs_w_skipall_x3", C.c_int64),
+           ("mfma_split", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class GemmBf16Args(C.Structure):
@@ -78,6 +79,8 @@ class GemmBf16Args(C.Structure):
         ("gate_mode", C.c_int32), ("e_batch_stride", C.c_int64), ("X", _vp), ("x_batch_stride", C.c_int64), ("ldx", C.c_int32),
         ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
         ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
+        ("split", C.c_int32), ("a_mid_off", C.c_int32), ("w_mid_off", C.c_int32), ("c_mid_off", C.c_int32), ("y_mid_off", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -411,8 +414,19 @@ def to_bf16(x, bias=None, lens=None):
     return y
 
 
+def split_bf16(x, bias=None, lens=None):
+    """fp32 device tensor [..., C] -> [..., 2C] bf16 bits: (hi | mid) per row, hi = RNE(v), mid = RNE(v - hi) (ss_split_bf16)."""
+    x = x.contiguous().float()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty(tuple(x.shape[:-1]) + (2 * Cc,), device=x.device, dtype=torch.bfloat16)
+    check(load().ss_split_bf16(ptr(x), ptr(bias), ptr(y), 1, rows, Cc, Cc, 2 * Cc, Cc, ptr(lens), 0, 0, stream_ptr()), "ss_split_bf16")
+    return y
+
+
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
-              next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False):
+              next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False,
+              split=0, a_mid_off=0, c_mid_off=0, y_mid_off=0):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -431,6 +445,7 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.C = ptr(out); a.ldc = ldc if ldc is not None else (out.shape[-1] if out is not None else 0)
     a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
     a.mask_rows = int(mask_rows)
+    a.split = split; a.a_mid_off = a_mid_off; a.w_mid_off = len(taps) * K if split else 0; a.c_mid_off = c_mid_off; a.y_mid_off = y_mid_off
     if gate256:   # the 256x256 LDS-DMA kernel directly (ss_gemm_bf16 picks it by itself for many-round launches)
         check(load().ss_gemm_bf16_gate256(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate256")
         return

@@ -175,16 +175,26 @@ class StyleSingerHIP(torch.nn.Module):
         assert self.wino_m in (2, 4), "SS_WINO_M must be 2 or 4"
         # per-layer output projection = residual half only; skip sum of all layers as one K = L*C GEMM per step
         self.defer_skip = os.environ.get("SS_DEFER_SKIP", "1") not in ("0", "off", "false")
-        self.bf16 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16"
+        prec = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32"))
+        if prec not in ("fp32", "bf16", "bf16x2", "bf16x3"):
+            raise ValueError(f"mfma_precision={prec!r}: expected fp32 | bf16 | bf16x2 | bf16x3")
+        # "bf16x2" (BASELINE config 4 at fp32-grade parity): the bf16 mode's data path (hidden GEMMs on the bf16 matrix cores, operands bf16
+        # in HBM) with every operand a (hi, mid) PAIR of bf16 terms and three products hi*hi + hi*mid + mid*hi per GEMM; the step-invariant
+        # conditioner projection in exact fp32, skip_projection folded into the K = L*C skip GEMM as in fp32 mode. Measured on the reference's
+        # 1000-step golden: plain bf16 operands 2.5e-3 mel L1 (bar 1e-4), this mode 4e-6 (oracle/bf16x3_numerics.py, tools/../study in DESIGN 3.1h).
+        self.split = prec == "bf16x2"
+        self.bf16 = prec in ("bf16", "bf16x2")
         # opt-in "bf16x3": fp32 products of the F(4,3) gate from operands split into three bf16 terms on the bf16 matrix cores
         # (ss_wino43_gate16x; fp32-grade results, oracle/bf16x3_numerics.py); everything else as the fp32 mode
-        self.x3 = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32")) == "bf16x3"
+        self.x3 = prec == "bf16x3"
         # fold skip_projection / sqrt(L) into the skip-all weights (fp32 mode only: in bf16 mode the operand rounding of the
         # two separate GEMMs is part of the stated arithmetic)
-        self.fold_skip = self.defer_skip and not self.bf16 and os.environ.get("SS_FOLD_SKIP", "1") not in ("0", "off", "false")
+        self.fold_skip = self.defer_skip and (not self.bf16 or self.split) and os.environ.get("SS_FOLD_SKIP", "1") not in ("0", "off", "false")
         # bf16 mode: hidden-layer weights AND activations as bf16 in HBM (ss_gemm_bf16; SS_BF16_HBM=0 keeps the round-1 form
         # that rounds fp32 operands inside the fp32 kernel's BF16 template mode); needs the deferred-skip layout
-        self.bf16_hbm = self.bf16 and self.defer_skip and os.environ.get("SS_BF16_HBM", "1") not in ("0", "off", "false")
+        self.bf16_hbm = self.bf16 and self.defer_skip and (self.split or os.environ.get("SS_BF16_HBM", "1") not in ("0", "off", "false"))
+        if self.split and not (self.defer_skip and self.fold_skip):
+            raise ValueError("mfma_precision=bf16x2 needs the deferred, folded skip form (SS_DEFER_SKIP / SS_FOLD_SKIP left on)")
         if self.bf16:
             self.use_wino = False  # the transform would amplify the operand rounding; the matrix pipe is not the limit in bf16
         # diffusion plans (workspaces + captured hipGraphs) are keyed by (B, T bucket): frames are padded up to a multiple of
@@ -296,8 +306,9 @@ class StyleSingerHIP(torch.nn.Module):
                 if self.x3 and self._wino_form(C, cycle) == 4:
                     t[f"w_dil_x3.{l}"] = L.split3_weights(t[f"w_dil_wino.{l}"], dil.Kp)
             if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
-                t[f"w_dil_h.{l}"] = L.to_bf16(dil.W)
-                t[f"w_out_h.{l}"] = L.to_bf16(out.W)
+                to_h = L.split_bf16 if self.split else L.to_bf16   # split: rows [ntaps*K hi | ntaps*K mid]
+                t[f"w_dil_h.{l}"] = to_h(dil.W)
+                t[f"w_out_h.{l}"] = to_h(out.W)
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
         if self.defer_skip:  # skip halves of all output projections side by side: [C][L*C], column l*C + ci
@@ -317,8 +328,8 @@ class StyleSingerHIP(torch.nn.Module):
         t["w_cond"] = torch.cat(wc_rows, 0).contiguous()
         t["b_cond"] = torch.cat(bc_rows, 0).contiguous()
         if self.bf16_hbm:
-            t["w_cond_h"] = L.to_bf16(t["w_cond"])
-            t["w_skipall_h"] = L.to_bf16(t["w_skipall"])
+            t["w_cond_h"] = L.to_bf16(t["w_cond"])     # (unused in split mode: the hoisted projection runs in fp32 there)
+            t["w_skipall_h"] = (L.split_bf16 if self.split else L.to_bf16)(t["w_skipall"])
         skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
         fin = self._pack_conv(prefix + ".output_projection.weight", prefix + ".output_projection.bias")
         t["w_skip"], t["b_skip"], t["w_final"], t["b_final"] = skip.W, skip.bias, fin.W, fin.bias
@@ -383,6 +394,7 @@ class StyleSingerHIP(torch.nn.Module):
                 setattr(net, key, ptr_)
                 setattr(net, "gs_" + key, gs)
         net.mfma_bf16 = 1 if self.bf16 else 0
+        net.mfma_split = 1 if self.split else 0
         net.skipall_folded = 1 if self.fold_skip else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):
@@ -398,6 +410,10 @@ class StyleSingerHIP(torch.nn.Module):
         sched = {k: self.p(f"{gen}.{k}").detach().cpu() for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod")}
         if not f0:
             sched["alphas_cumprod_np"] = np.ascontiguousarray(self.p(f"{gen}.alphas_cumprod").detach().cpu().numpy().astype(np.float32))
+            # DDIM coefficients need 1 - alphas_cumprod at small t: rebuilt in float64 from the betas buffer as the reference builds its
+            # own tables (shallow_diffusion_tts.py:77-80: np.cumprod(1 - betas)); the float32 buffer has only ~3 digits of 1 - ac_0
+            betas64 = self.p(f"{gen}.betas").detach().cpu().numpy().astype(np.float64)
+            sched["alphas_cumprod_f64"] = np.ascontiguousarray(np.cumprod(1.0 - betas64))
         return dict(net=net, keep=keep, sched=sched, packs=packs)
 
     def _pack_fft(self, prefix, n_layers):
@@ -613,9 +629,9 @@ class StyleSingerHIP(torch.nn.Module):
         K = self.hp["K_step"]
         return sorted({int(round(v)) for v in np.linspace(0, K - 1, max(1, min(n, K)))}, reverse=True)
 
-    def _run_mel(self, pl, tape=None, ddim_ts=None, plms_interval=None):
+    def _run_mel(self, pl, tape=None, ddim_ts=None, plms_interval=None, eta=0.0):
         """q_sample + the shallow reverse loop (batch halves on two streams); `ddim_ts` switches to the strided
-        deterministic sampler (BASELINE config 5), `plms_interval` to the reference's PLMS sampler (pndm_speedup)."""
+        DDIM sampler (BASELINE config 5; `eta` = 0 deterministic ... 1 ancestral), `plms_interval` to the reference's PLMS sampler (pndm_speedup)."""
         lib, pk, hp = _lib(), self._pk, self.hp
         B, T, M = pl.B, pl.T, hp["audio_num_mel_bins"]
         net = pk["mel"]["net"]
@@ -642,8 +658,9 @@ class StyleSingerHIP(torch.nn.Module):
             return
         if ddim_ts is not None:
             ts = np.ascontiguousarray(np.asarray(ddim_ts, dtype=np.int32))
+            ac64 = pk["mel"]["sched"]["alphas_cumprod_f64"]
             L.check(lib.ss_meldiff_sample_ddim(C_byref(net), L.ptr(pl.xm), L.ptr(pl.cond_mel), L.ptr(pl.lens), B, T, L.hptr(ts), len(ts),
-                                               L.hptr(ac), 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff ddim")
+                                               L.hptr(ac64), float(eta), L.ptr(zs_n), 31, sdp, 1, L.ptr(wsp), wsb, L.stream_ptr()), "meldiff ddim")
             return
         nsplit = len(pl.ws_mel)
         main = torch.cuda.current_stream()
@@ -661,7 +678,8 @@ class StyleSingerHIP(torch.nn.Module):
             main.wait_stream(sd_)
 
     @torch.no_grad()
-    def mel_stage(self, coarse_mel, cond, lens=None, z_q=None, z_steps=None, sampler="ddpm", ddim_steps=None, plms_interval=None, seed=1234):
+    def mel_stage(self, coarse_mel, cond, lens=None, z_q=None, z_steps=None, sampler="ddpm", ddim_steps=None, plms_interval=None, seed=1234,
+                  eta=0.0):
         """The shallow mel diffusion alone (a11 output -> a12): coarse mel [B,T,80] + condition [B,T,256] -> mel [B,T,80].
         z_q [B,1,80,T] / z_steps [K,B,1,80,T]: optional recorded noise (reference layout); default device Philox."""
         self._ensure_packed()
@@ -677,7 +695,7 @@ class StyleSingerHIP(torch.nn.Module):
         zq_n = None if z_q is None else z_q.to(dev).reshape(B, M, T).transpose(1, 2).contiguous().float()
         zs_n = None if z_steps is None else z_steps.to(dev).reshape(K, B, M, T).transpose(2, 3).contiguous().float()
         self._run_mel(pl, (zq_n, zs_n), ddim_ts=self.ddim_timesteps(ddim_steps) if sampler == "ddim" else None,
-                      plms_interval=plms_interval if sampler == "plms" else None)
+                      plms_interval=plms_interval if sampler == "plms" else None, eta=eta)
         mel_out = torch.empty(B, T, M, device=dev, dtype=torch.float32)
         L.check(lib.ss_mel_denorm(L.ptr(pl.xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(pl.lens),
                                   L.stream_ptr()), "denorm")
@@ -742,8 +760,9 @@ class StyleSingerHIP(torch.nn.Module):
         """Mirror of StyleSinger.forward (modules/StyleSinger/stylesinger.py:119-187), inference branch only.
 
         Extra keyword arguments: `noise` (dict from synth.draw_acoustic_noise: a recorded noise tape for
-        parity tests; default = on-device Philox), `seed` (Philox seed), `sampler="ddim", ddim_steps=n` (strided
-        deterministic mel sampler, BASELINE config 5; default = the reference's 100-step ancestral sampler),
+        parity tests; default = on-device Philox), `seed` (Philox seed), `sampler="ddim", ddim_steps=n, eta=0.0` (strided
+        DDIM mel sampler, BASELINE config 5; eta = 0 deterministic, eta = 1 with ddim_steps = K_step IS the reference's ancestral
+        sampler; default = the reference's 100-step ancestral sampler),
         `sampler="plms", plms_interval=n` (the reference's PLMS sampler, hparams['pndm_speedup'],
         shallow_diffusion_tts.py:165-197), `plan_slot` (workspace/graph set to use: give concurrent forwards on different streams
         different slots), `style_cache` (the dict encode_style() returned for these references: skips
@@ -976,15 +995,18 @@ class StyleSingerHIP(torch.nn.Module):
             zq_n = None if noise is None else mel_tape(noise["mel"]["z_q"], ())
             self._run_mel(pl, (zq_n, None), plms_interval=int(plms))
         elif ddim_ts is not None:
+            eta = float(kwargs.get("eta", 0.0))
             if noise is not None:
-                self._run_mel(pl, (mel_tape(noise["mel"]["z_q"], ()), None), ddim_ts=ddim_ts)
-            elif graphs:  # one captured graph per (B, T bucket, number of sampler steps)
-                key = len(ddim_ts)
+                nz = noise["mel"]
+                zs = mel_tape(nz["z_steps"], (K,)) if (eta > 0.0 and "z_steps" in nz) else None
+                self._run_mel(pl, (mel_tape(nz["z_q"], ()), zs), ddim_ts=ddim_ts, eta=eta)
+            elif graphs:  # one captured graph per (B, T bucket, number of sampler steps, eta)
+                key = (len(ddim_ts), eta)
                 if key not in pl.g_ddim:
-                    pl.g_ddim[key] = self._capture(lambda: self._run_mel(pl, ddim_ts=ddim_ts))
+                    pl.g_ddim[key] = self._capture(lambda: self._run_mel(pl, ddim_ts=ddim_ts, eta=eta))
                 pl.g_ddim[key].replay()
             else:
-                self._run_mel(pl, ddim_ts=ddim_ts)
+                self._run_mel(pl, ddim_ts=ddim_ts, eta=eta)
         elif noise is not None:
             nz = noise["mel"]
             self._run_mel(pl, (mel_tape(nz["z_q"], ()), mel_tape(nz["z_steps"], (K,))))
