@@ -255,12 +255,13 @@ typedef struct ss_gemm_bf16_args {
   int32_t group_size;
   /* split-operand form ("bf16x2" precision, BASELINE config 4 at fp32-grade parity): split = 1 -> every bf16 operand is a PAIR of bf16 terms
    * v = hi + mid (hi = RNE(v), mid = RNE(v - hi): 16 significand bits) and the matrix cores run the three products hi*hi + hi*mid + mid*hi
-   * (fp32 accumulate, the small terms first). The mid term of A[t][k] sits a_mid_off ELEMENTS after its hi term in the same row, that of
-   * W[n][j*K + k] w_mid_off elements after its hi term (rows of 2*ntaps*K: ss_split_bf16 of the packed weights). bf16 OUTPUTS are written as
-   * (hi, mid) pairs c_mid_off (GATE's C) / y_mid_off (RESX's Y) elements apart. split = 2: A has no mid term (products hi*hi + hi*mid). */
+   * (fp32 accumulate). Layout ("pairs interleaved by 32"): a logical row of n channels is 2n bf16 - for every 32-channel chunk j the 32 hi terms
+   * at [64j, 64j+32) followed by the 32 mid terms at [64j+32, 64j+64), i.e. one 128-byte line = one K chunk of both planes. That holds for A
+   * (lda = physical row stride; K = logical channels per tap, a multiple of 32), for W (rows of 2*ntaps*K, ss_split_bf16 of the packed fp32
+   * weights) and for the bf16 OUTPUTS (GATE's C, RESX's Y: logical channel c of the output lands at (c >> 5) * 64 + (c & 31), its mid term 32
+   * further; ldc / ldy are physical strides). */
   int32_t split;
-  int32_t a_mid_off, w_mid_off, c_mid_off, y_mid_off;
-  int32_t reserved_;
+  int32_t reserved_[5];
 } ss_gemm_bf16_args;
 int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
 /* The SS_HEPI_GATE form of ss_gemm_bf16 for many-round launches (BASELINE config 4): three taps (-d, 0, d) with d <= 8, K = 192 | 256,
@@ -273,8 +274,9 @@ int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* args);
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
                int group_size, int64_t bias_group_stride, void* stream);
-/* The split form of ss_to_bf16: v = x + bias -> y[.][c] = hi = RNE(v), y[.][mid_off + c] = RNE(v - hi) (same row, ldy >= mid_off + C). */
-int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, int mid_off, const int32_t* lens,
+/* The split form of ss_to_bf16 (C a multiple of 32, ldy >= 2C): v = x + bias -> hi = RNE(v) at y[.][(c >> 5) * 64 + (c & 31)], mid = RNE(v - hi)
+ * 32 elements further ("pairs interleaved by 32", see ss_gemm_bf16_args.split). */
+int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
                   int group_size, int64_t bias_group_stride, void* stream);
 
 /* Weight packing (device -> device).  src is the torch parameter layout [Cout][Cin][k] (conv1d,
@@ -440,7 +442,7 @@ typedef struct ss_wavenet {
   const uint16_t* w_skipall_x3;
   int64_t gs_w_skipall_x3;
   /* 1 = "bf16x2" precision (BASELINE config 4 at fp32-grade parity; needs mfma_bf16 = 1 and the w_*_h packs): the w_*_h tensors are SPLIT packs
-   * (ss_split_bf16 of the packed fp32 weights: rows [ntaps*K hi | ntaps*K mid]) and the hidden activations travel as (hi, mid) bf16 pairs;
+   * (ss_split_bf16 of the packed fp32 weights: rows of 2*ntaps*K, pairs interleaved by 32) and the hidden activations travel as (hi, mid) bf16 pairs;
    * every hidden GEMM runs hi*hi + hi*mid + mid*hi on the bf16 matrix cores (ss_gemm_bf16_args.split), the hoisted conditioner projection in
    * exact fp32 (w_cond_h unused). With skipall_folded the K = L*C GEMM + ReLU is the stack output, as in fp32 mode. */
   int32_t mfma_split;

@@ -31,9 +31,10 @@ struct WsLayout {
   int64_t bytes;
 };
 
-// hmode: the hidden activations travel as bf16 in HBM. split (net->mfma_split, "bf16x2" precision): every bf16 operand is a (hi, mid) pair in
-// the same row - Yh rows [C hi | C mid], GAh rows [L*C hi | L*C mid], weight rows [ntaps*K hi | ntaps*K mid] - and the matrix cores run
-// hi*hi + hi*mid + mid*hi (ss_gemm_bf16_args.split); the hoisted conditioner projection then runs in exact fp32 (it is outside the step loop).
+// hmode: the hidden activations travel as bf16 in HBM. split (net->mfma_split, "bf16x2" precision): every bf16 operand is a (hi, mid) pair,
+// pairs interleaved by 32 channels (one 128-byte line = 32 channels of both planes; rows of Yh / GAh / the weights are twice as long) - and
+// the matrix cores run hi*hi + hi*mid + mid*hi (ss_gemm_bf16_args.split); the hoisted conditioner projection then runs in exact fp32 (it is
+// outside the step loop).
 inline bool smode(const ss_wavenet* net) { return net->mfma_split != 0; }
 inline bool hmode(const ss_wavenet* net) { return net->mfma_bf16 && net->w_dil_h[0] && net->w_skipall_h && (net->w_cond_h || smode(net)); }
 
@@ -160,9 +161,6 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     g.lda = C * pl;
     g.a_batch_stride = (int64_t)T * C * pl;
     g.split = sp;
-    g.a_mid_off = C;
-    g.w_mid_off = 3 * C;
-    g.c_mid_off = L * C;
     g.K = C;
     g.ntaps = 3;
     g.tap_off[0] = -d;
@@ -177,18 +175,15 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     g.E = w.E + (int64_t)l * 2 * C;
     g.lde = NE;
     g.e_batch_stride = (int64_t)T * NE;
-    g.C = w.GAh + (int64_t)l * C;
+    g.C = w.GAh + (int64_t)l * C * pl;
     g.ldc = L * C * pl;
     g.c_batch_stride = (int64_t)T * L * C * pl;
     SS_PROPAGATE(ss_gemm_bf16(&g, stream));
     ss_gemm_bf16_args o = base_args_h(net, B, T, lens);
-    o.A = w.GAh + (int64_t)l * C;
+    o.A = w.GAh + (int64_t)l * C * pl;
     o.lda = L * C * pl;
     o.a_batch_stride = (int64_t)T * L * C * pl;
     o.split = sp;
-    o.a_mid_off = L * C;
-    o.w_mid_off = C;
-    o.y_mid_off = C;
     o.K = C;
     o.W = net->w_out_h[l];
     o.w_group_stride = net->gs_w_out_h;
@@ -215,8 +210,6 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   k.lda = L * C * pl;
   k.a_batch_stride = (int64_t)T * L * C * pl;
   k.split = sp;
-  k.a_mid_off = L * C;
-  k.w_mid_off = L * C;
   k.K = L * C;
   k.W = net->w_skipall_h;
   k.w_group_stride = net->gs_w_skipall_h;
@@ -238,7 +231,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
 // Yh = bf16(X + dstep[step][0]) : the first layer's conv operand (bf16-in-HBM mode)
 int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
   if (smode(net))
-    return ss_split_bf16(w.X, net->dstep + (int64_t)step * net->L * net->C, w.Yh, B, T, net->C, net->C, 2 * net->C, net->C, lens,
+    return ss_split_bf16(w.X, net->dstep + (int64_t)step * net->L * net->C, w.Yh, B, T, net->C, net->C, 2 * net->C, lens,
                          net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);
   return ss_to_bf16(w.X, net->dstep + (int64_t)step * net->L * net->C, w.Yh, B, T, net->C, net->C, net->C, lens,
                     net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);

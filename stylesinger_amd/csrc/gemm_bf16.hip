@@ -46,7 +46,9 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(fl
 #define SS_HABL 0
 #endif
 
-template <int BM, int BN, int EPI>
+// SPLIT ("bf16x2"): operands are (hi, mid) bf16 pairs interleaved by 32 channels - a 128-byte K chunk holds 32 channels of BOTH planes (slots
+// 0-3 hi, 4-7 mid), the fetch / staging code is the same, and a chunk feeds 2 k-steps x 3 products (mid*hi, hi*mid, hi*hi) instead of 4 x 1.
+template <int BM, int BN, int EPI, bool SPLIT>
 __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
   constexpr int WM = 2, WN = 2;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -71,14 +73,10 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
   const int l31 = lane & 31, lh = lane >> 5;
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
-  const int nchunks_tap = a.K / BKH;
-  const int nchunks1 = a.ntaps * nchunks_tap;
-  // split-operand form (a.split): the chunk sequence runs 3 (2) times over K - pass q = 0: A mid x W hi, 1: A hi x W mid, 2: A hi x W hi
-  // (small terms first; split = 2 has no A mid term and starts at q = 1); only the SGPR offsets of the fetches change
-  const int npass = a.split == 1 ? 3 : a.split == 2 ? 2 : 1;
-  const int nchunks = nchunks1 * npass;
-  const int ldw = a.ntaps * a.K * (a.split ? 2 : 1);  // bf16 per packed weight row
-  const int a_mid2 = a.a_mid_off * 2, w_mid2 = a.w_mid_off * 2;
+  constexpr int KCH = SPLIT ? 32 : 64;   // channels per 128-byte K chunk
+  const int nchunks_tap = a.K / KCH;
+  const int nchunks = a.ntaps * nchunks_tap;
+  const int ldw = a.ntaps * a.K * (SPLIT ? 2 : 1);  // bf16 per packed weight row
 
   auto uniform_ptr = [](const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -108,13 +106,8 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 
   // chunk c = (tap, k0): SGPR byte offsets of the A fetch (tap row shift + channel offset) and of the W fetch
   auto a_soff = [&](int c) {
-    const int p = c / nchunks1, cc = c - p * nchunks1;
-    const int tap = cc / nchunks_tap, k0 = (cc - tap * nchunks_tap) * BKH;
-    return a.tap_off[tap] * lda2 + k0 * 2 + ((p + 3 - npass) == 0 ? a_mid2 : 0);
-  };
-  auto w_soff = [&](int c) {
-    const int p = c / nchunks1, cc = c - p * nchunks1;
-    return cc * (BKH * 2) + ((p + 3 - npass) == 1 ? w_mid2 : 0);
+    const int tap = c / nchunks_tap, cc = c - tap * nchunks_tap;
+    return a.tap_off[tap] * lda2 + cc * (BKH * 2);
   };
   u32x4 ra[2][AP], rb[2][BP];  // two register stages
   auto fetch = [&](auto st_tag, int c, int dead) {
@@ -126,9 +119,8 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #endif
 #pragma unroll
     for (int i = 0; i < AP; ++i) ra[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[i] + so) | dead, 0, 0);
-    const int wo = w_soff(c);
 #pragma unroll
-    for (int i = 0; i < BP; ++i) rb[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i] | dead, wo, 0);
+    for (int i = 0; i < BP; ++i) rb[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i] | dead, c * (BKH * 2), 0);
   };
   auto stage = [&](auto st_tag, auto buf_tag) {
     constexpr int ST = decltype(st_tag)::value;
@@ -154,6 +146,36 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     constexpr int BUF = decltype(buf_tag)::value;
     const char* Ac = As + BUF * BM * (LDH * 2) + a_row;
     const char* Bc = Bs + BUF * BN * (LDH * 2) + b_row;
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // 2 k-steps of 16 channels: slots 2 ks + lh (hi) and 4 + 2 ks + lh (mid) of the row
+        const int sh = ((2 * ks + lh) ^ swz) << 4, sm = ((4 + 2 * ks + lh) ^ swz) << 4;
+        bf16x8 ah[TM], am[TM], bh[TN], bm[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+          ah[m] = *reinterpret_cast<const bf16x8*>(Ac + m * 32 * (LDH * 2) + sh);
+          am[m] = *reinterpret_cast<const bf16x8*>(Ac + m * 32 * (LDH * 2) + sm);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          bh[n] = *reinterpret_cast<const bf16x8*>(Bc + n * 32 * (LDH * 2) + sh);
+          bm[n] = *reinterpret_cast<const bf16x8*>(Bc + n * 32 * (LDH * 2) + sm);
+        }
+        // product outermost: consecutive MFMAs write different accumulators
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bm[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {  // 4 k-steps of 16: lane (l31, lh) feeds k = 16*ks + 8*lh .. +8 of its row (same for A and B)
       const int so = ((2 * ks + lh) ^ swz) << 4;
@@ -172,6 +194,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
 #endif
         }
+    }
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -286,7 +309,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
         const int row0 = row_base + m * 32;
-        const int coff = (row0 * a.ldc + oc) * 2 | dead;
+        const int coff = (row0 * a.ldc + (SPLIT ? (oc >> 5) * 64 + (oc & 31) : oc)) * 2 | dead;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #endif
           const uint16_t gh = f2bf(g);
           __builtin_amdgcn_raw_buffer_store_b16(gh, rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
-          if (a.split) __builtin_amdgcn_raw_buffer_store_b16(f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, a.c_mid_off * 2, 0);
+          if constexpr (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, 64, 0);   // mid: 32 elements further
         }
       }
     }
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
       for (int m = 0; m < TM; ++m) {
         const int row0 = row_base + m * 32;
         const int xoff = (row0 * a.ldx + col) * 4 | dead;
-        const int yoff = (row0 * a.ldy + col) * 2 | dead;
+        const int yoff = (row0 * a.ldy + (SPLIT ? (col >> 5) * 64 + (col & 31) : col)) * 2 | dead;
         float xv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -335,14 +358,14 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
           const float yv = pad ? 0.f : xn + nb;
           const uint16_t yh = f2bf(yv);
           __builtin_amdgcn_raw_buffer_store_b16(yh, rsrc_y, yoff + rr * ldy2, 0, 0);
-          if (a.split == 1) __builtin_amdgcn_raw_buffer_store_b16(f2bf(yv - bf2f(yh)), rsrc_y, yoff + rr * ldy2, a.y_mid_off * 2, 0);
+          if constexpr (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(f2bf(yv - bf2f(yh)), rsrc_y, yoff + rr * ldy2, 64, 0);
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int EPI, bool SPLIT>
 int launch_h(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
@@ -352,23 +375,27 @@ int launch_h(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * (BM + BN) * (LDH * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(grid), dim3(256), lds, stream, a, m_tiles_per_item, m_tiles, n_tiles);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, SPLIT>), dim3(grid), dim3(256), lds, stream, a, m_tiles_per_item, m_tiles, n_tiles);
   SS_CHECK_LAUNCH("ss_gemm_bf16");
   return SS_OK;
 }
 
-template <int EPI>
-int launch_tiles(const ss_gemm_bf16_args& a, hipStream_t stream) {
+template <int EPI, bool SPLIT>
+int launch_tiles_s(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const int n_cols = (EPI == SS_HEPI_GATE) ? a.Np : a.N;
   const long big = (long)ss_cdiv(a.T, 128) * a.B * ss_cdiv(n_cols, 128);
   const int env_tile = g_ss_tuning.htile;  // experiments: 64 / 128 force the row tile
-  if (env_tile == 64) return launch_h<64, 128, EPI>(a, stream);
-  if (env_tile == 128) return launch_h<128, 128, EPI>(a, stream);
-  if (big >= 512) return launch_h<128, 128, EPI>(a, stream);
-  return launch_h<64, 128, EPI>(a, stream);
+  if (env_tile == 64) return launch_h<64, 128, EPI, SPLIT>(a, stream);
+  if (env_tile == 128) return launch_h<128, 128, EPI, SPLIT>(a, stream);
+  if (big >= 512) return launch_h<128, 128, EPI, SPLIT>(a, stream);
+  return launch_h<64, 128, EPI, SPLIT>(a, stream);
+}
+template <int EPI>
+int launch_tiles(const ss_gemm_bf16_args& a, hipStream_t stream) {
+  return a.split ? launch_tiles_s<EPI, true>(a, stream) : launch_tiles_s<EPI, false>(a, stream);
 }
 
 // x[r][c] (+ bias[c]) -> bf16 ; rows >= lens[b] -> 0
@@ -391,9 +418,9 @@ __global__ void to_bf16_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
-// the split form: hi = RNE(v), mid = RNE(v - hi) at mid_off elements further in the same row
+// the split form, pairs interleaved by 32: hi = RNE(v) at (c >> 5) * 64 + (c & 31), mid = RNE(v - hi) 32 elements further
 __global__ void split_bf16_kernel(const float* __restrict__ x, const float* __restrict__ bias, uint16_t* __restrict__ y, int B, int T, int C,
-                                  int ldx, int ldy, int mid_off, const int32_t* __restrict__ lens, int group_size, int64_t bias_gs) {
+                                  int ldx, int ldy, const int32_t* __restrict__ lens, int group_size, int64_t bias_gs) {
   const int64_t n = (int64_t)B * T * (C / 4);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % (C / 4)) * 4;
@@ -408,8 +435,9 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, const float* __re
     ushort4 h, m;
     h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
     m.x = f2bf(v.x - bf2f(h.x)); m.y = f2bf(v.y - bf2f(h.y)); m.z = f2bf(v.z - bf2f(h.z)); m.w = f2bf(v.w - bf2f(h.w));
-    *reinterpret_cast<ushort4*>(y + r * ldy + c4) = h;
-    *reinterpret_cast<ushort4*>(y + r * ldy + mid_off + c4) = m;
+    uint16_t* yp = y + r * ldy + (c4 >> 5) * 64 + (c4 & 31);
+    *reinterpret_cast<ushort4*>(yp) = h;
+    *reinterpret_cast<ushort4*>(yp + 32) = m;
   }
 }
 
@@ -422,17 +450,16 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
   SS_CHECK_ARG(a.A && a.W, "ss_gemm_bf16: null A/W");
   SS_CHECK_ARG(a.B > 0 && a.T > 0 && a.N > 0, "ss_gemm_bf16: bad dims B=%d T=%d N=%d", a.B, a.T, a.N);
   SS_CHECK_ARG(a.ntaps >= 1 && a.ntaps <= 4, "ss_gemm_bf16: ntaps=%d out of range", a.ntaps);
-  SS_CHECK_ARG(a.K > 0 && (a.K % BKH) == 0 && (a.lda % 8) == 0, "ss_gemm_bf16: K=%d must be a multiple of 64, lda=%d of 8", a.K, a.lda);
+  SS_CHECK_ARG(a.K > 0 && (a.K % (a.split ? 32 : BKH)) == 0 && (a.lda % 8) == 0, "ss_gemm_bf16: K=%d must be a multiple of 64 (32 when split), lda=%d of 8", a.K, a.lda);
   SS_CHECK_ARG((a.Np & 31) == 0 && (a.epi == SS_HEPI_GATE ? (a.Np & 63) == 0 && 2 * a.N <= a.Np : a.Np >= a.N), "ss_gemm_bf16: bad Np=%d for N=%d", a.Np, a.N);
   SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16: A/W must be 16-byte aligned");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldx * 4 < (1ll << 31) &&
                    (int64_t)a.T * a.ldc * 4 < (1ll << 31), "ss_gemm_bf16: item too large for 32-bit offsets");
-  SS_CHECK_ARG(a.split >= 0 && a.split <= 2, "ss_gemm_bf16: split=%d", a.split);
-  if (a.split) {
-    SS_CHECK_ARG(a.w_mid_off == a.ntaps * a.K && (a.split == 2 || (a.a_mid_off > 0 && (a.a_mid_off % 8) == 0 && a.a_mid_off + a.K <= a.lda)),
-                 "ss_gemm_bf16: split operands need w_mid_off = ntaps*K (%d) and an a_mid_off (%d) inside the row", a.w_mid_off, a.a_mid_off);
-    SS_CHECK_ARG(a.epi != SS_HEPI_GATE || (a.c_mid_off > 0 && a.c_mid_off + a.N <= a.ldc), "ss_gemm_bf16: split GATE needs c_mid_off inside ldc");
-    SS_CHECK_ARG(a.epi != SS_HEPI_RESX || a.split == 2 || !a.Y || (a.y_mid_off > 0 && a.y_mid_off + a.N <= a.ldy), "ss_gemm_bf16: split RESX needs y_mid_off inside ldy");
+  SS_CHECK_ARG(a.split == 0 || a.split == 1, "ss_gemm_bf16: split=%d", a.split);
+  if (a.split) {   // pairs interleaved by 32: physical rows hold 2 x the logical channels
+    SS_CHECK_ARG((a.K % 32) == 0 && a.lda >= 2 * a.K, "ss_gemm_bf16: split operands need K %% 32 == 0 and lda >= 2 K (K=%d lda=%d)", a.K, a.lda);
+    SS_CHECK_ARG(a.epi != SS_HEPI_GATE || (a.ldc >= 2 * a.N && (a.N % 32) == 0), "ss_gemm_bf16: split GATE writes 2 N bf16 per row (ldc=%d N=%d)", a.ldc, a.N);
+    SS_CHECK_ARG(a.epi != SS_HEPI_RESX || !a.Y || (a.ldy >= 2 * a.N && (a.N % 32) == 0), "ss_gemm_bf16: split RESX writes 2 N bf16 per row of Y");
   }
   switch (a.epi) {
     case SS_HEPI_STORE:
@@ -463,13 +490,12 @@ extern "C" int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B,
   return SS_OK;
 }
 
-extern "C" int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, int mid_off, const int32_t* lens,
+extern "C" int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
                              int group_size, int64_t bias_group_stride, void* stream) {
-  SS_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (mid_off & 3) == 0 && mid_off >= C &&
-                   mid_off + C <= ldy, "ss_split_bf16: bad args");
+  SS_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && (C & 31) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldy >= 2 * C, "ss_split_bf16: bad args");
   const int64_t n = (int64_t)B * T * (C / 4);
   const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, mid_off, lens, group_size,
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, lens, group_size,
                      bias_group_stride);
   SS_CHECK_LAUNCH("ss_split_bf16");
   return SS_OK;

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
 #include <type_traits>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -43,9 +44,18 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ds
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
 
-template <int CCS>
+// SPLIT ("bf16x2" precision, ss_gemm_bf16_args.split): operands are (hi, mid) bf16 pairs interleaved by 32 channels, so a 128-byte LDS row is
+// 32 channels of BOTH planes (slots 0-3 hi, 4-7 mid) and every line of the DMA / LDS plan below is unchanged; a step then covers 32 channels
+// (CCS = K / 32 chunks per tap: 24 steps for K = 256) and runs 2 k-steps x 3 products (mid*hi, hi*mid, hi*hi) = 48 MFMAs per wave from 12
+// fragment reads per k-step - 1.5x the matrix work per byte staged. Outputs leave as (hi, mid) pairs in the same interleaved layout.
+template <class F, int... I>
+__device__ __forceinline__ void unrolled_steps(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+template <int CCS, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int d) {
-  extern __shared__ __attribute__((aligned(16))) char smem_g256[];   // 144 KB: one workgroup per CU
+  extern __shared__ __attribute__((aligned(16))) char smem_g256[];   // 144 KB (split: 160 KB, the epilogue's staging tile is twice as wide): one workgroup per CU
   // [A0 40 K][B0 32 K][A1 40 K][B1 32 K]: the operands of the LAST step live in A1 / B1, so the first 72 KB are free while it runs
   char* const A0 = smem_g256;
   char* const B0 = A0 + AROWS * ROWB;
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   const int l31 = lane & 31, lh = lane >> 5;
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
-  const int ldw = 3 * a.K;            // bf16 per packed weight row (3 taps)
+  const int ldw = 3 * a.K * (SPLIT ? 2 : 1);            // bf16 per packed weight row (3 taps; both planes when split)
 
   auto uniform_ptr = [](const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -103,9 +113,15 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
       // SGPR part would leave valid rows of later pieces out of range
       glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | dead | (j == 4 ? a_tail_dead : 0), cc * (BKH * 2));
   };
+  auto piece_a = [&](char* buf, int cc, int j) {
+    glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | (j == 4 ? a_tail_dead : 0), cc * (BKH * 2));
+  };
+  auto piece_b = [&](char* buf, int cc, int tap, int j) {
+    glds16(rsrc_w, buf + (wave + 8 * j) * 8 * ROWB, b_voff, (tap * CCS + cc) * (BKH * 2) + 64 * j * ldw * 2);
+  };
   auto dma_b = [&](char* buf, int cc, int tap, int dead) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(rsrc_w, buf + (wave + 8 * j) * 8 * ROWB, b_voff | dead, (tap * a.K + cc * BKH) * 2 + 64 * j * ldw * 2);
+    for (int j = 0; j < 4; ++j) glds16(rsrc_w, buf + (wave + 8 * j) * 8 * ROWB, b_voff | dead, (tap * CCS + cc) * (BKH * 2) + 64 * j * ldw * 2);
   };
 
   // ---- fragment addresses. A, tap j: row = HALO + (j - 1) d + 128 wm + 32 m + l31; k-step ks reads slot (2 ks + lh) ^ swz(row).
@@ -127,6 +143,9 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(Eb ? (const void*)Eb : (const void*)a.W), 0, __builtin_amdgcn_readfirstlane(Eb ? (int)((int64_t)a.T * a.lde * 4) : 0), 0x00020000);
   const int e_voff = ((t0 + wave) * a.lde + n0) * 4 + lane * 16;   // piece w + 8 j: 8 j rows further (j < 4), 128 + 8 (j - 4) for j >= 4
+  auto piece_e = [&](char* buf, int q, int j) {
+    glds16(rsrc_e, buf + (wave + 8 * j) * 1024, e_voff, (q * 32 + (j < 4 ? 8 * j : 128 + 8 * (j - 4))) * a.lde * 4);
+  };
   auto dma_e = [&](char* buf, int q) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -146,6 +165,93 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   // step AFTER that step's weight pieces, so at the top of the tap-2 step its 5 pieces may still fly; barrier (everyone's pieces landed,
   // everyone finished reading step S-1); then the weight pieces of step S+1 (and, at tap 1, the A chunk cc+1) are issued and fly under
   // this step's MFMAs. Weight tiles alternate B0 / B1 every step, A chunks A0 / A1 every channel chunk.
+  // ---- SPLIT: 2 k-steps x 3 product groups of 8 MFMAs per step: G0 = mid x hi, G1 = hi x mid, G2 = hi x hi (G2 reuses G1's A and G0's B
+  // fragments). Software pipeline ACROSS the step barrier: the last two groups of a step (G1, G2 of its second k-step: 16 MFMAs whose
+  // fragments already sit in registers) are issued AFTER the next step's barrier, with that step's DMA pieces placed between them and its
+  // first fragment reads in flight - so the matrix pipe has work while every wave of the workgroup is issuing DMA / waiting on LDS
+  // (before: ~2 k of a step's 5.2 k cycles with the pipe idle, 410 us per C4 launch).
+  [[maybe_unused]] bf16x8 p_ah[4], p_bh[2], p_bm[2];
+  auto mfma8 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+  };
+  auto step_split = [&](auto stag) {
+    constexpr int S = decltype(stag)::value;
+    constexpr int CC = S / 3, TAP = S % 3;
+    constexpr bool LAST = S + 1 >= 3 * CCS;
+    const char* Ac = (CC & 1) ? A1 : A0;
+    const char* Bc = (S & 1) ? B1 : B0;
+    char* Bn = (S & 1) ? B0 : B1;
+    char* An = (CC & 1) ? A0 : A1;
+    if constexpr (TAP == 2 && CC + 1 < CCS) wait_vmcnt<5>();   // the 5 pieces of A chunk cc+1, issued last step after its weight pieces
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    auto rd_a = [&](int slot, bf16x8 (&f)[4]) {   // a_swz / b_swz carry lh: slot (2 ks) ^ swz = hi, (4 + 2 ks) ^ swz = mid of k-step ks
+      const int ao = a_base[TAP] + ((slot ^ a_swz[TAP]) << 4);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) f[m] = *reinterpret_cast<const bf16x8*>(Ac + ao + m * 32 * ROWB);
+    };
+    auto rd_b = [&](int slot, bf16x8 (&f)[2]) {
+      const int bo = b_base + ((slot ^ b_swz) << 4);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) f[n] = *reinterpret_cast<const bf16x8*>(Bc + bo + n * 32 * ROWB);
+    };
+    bf16x8 am0[4], bh0[2];
+    rd_a(4, am0);
+    rd_b(0, bh0);
+    __builtin_amdgcn_sched_barrier(0);
+    // DMA pieces this step issues (same order as dma_b, dma_a, dma_e: the vmcnt counts above rely on it): the weight tile of step S+1, at tap
+    // 1 the A chunk cc+1, in the last step the first addend quarter (into A0 / B0, which that step does not read)
+    constexpr int NB = LAST ? 0 : 4, NA = (TAP == 1 && CC + 1 < CCS) ? 5 : 0, NE = LAST ? 8 : 0, NP = NB + NA + NE;
+    auto piece = [&](int i) {
+      if (i < NB) piece_b(Bn, (S + 1) / 3, (S + 1) % 3, i);
+      else if (i < NB + NA) piece_a(An, CC + 1, i - NB);
+      else piece_e(EQ0, 0, i - NB - NA);
+    };
+    if constexpr (S > 0) {   // the 16 MFMAs deferred by step S-1, one DMA piece after every MFMA until the pieces are out
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i >> 1) & 3, n = i & 1;
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p_ah[m], i < 8 ? p_bm[n] : p_bh[n], acc[m][n], 0, 0, 0);
+        if (i < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece(i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      static_assert(NP <= 16, "more DMA pieces than deferred MFMAs");
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) piece(i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 ah0[4], bm0[2], am1[4], bh1[2];
+    rd_a(0, ah0);
+    rd_b(4, bm0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(am0, bh0);          // G0(0)
+    __builtin_amdgcn_sched_barrier(0);
+    rd_a(6, am1);
+    rd_b(2, bh1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(ah0, bm0);          // G1(0)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(ah0, bh0);          // G2(0)
+    __builtin_amdgcn_sched_barrier(0);
+    rd_a(2, p_ah);
+    rd_b(6, p_bm);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(am1, bh1);          // G0(1); G1(1) = p_ah x p_bm and G2(1) = p_ah x p_bh run after the next barrier
+#pragma unroll
+    for (int n = 0; n < 2; ++n) p_bh[n] = bh1[n];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LAST) {
+      mfma8(p_ah, p_bm);
+      mfma8(p_ah, p_bh);
+    }
+  };
   auto step = [&](auto stag) {
     constexpr int S = decltype(stag)::value;
     constexpr int CC = S / 3, TAP = S % 3;
@@ -166,6 +272,9 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
       dma_e(EQ0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SPLIT) {
+      static_assert(!SPLIT, "the split form has its own step (step_split)");
+    } else {
     // fragments of k-step ks+1 are read before the MFMAs of k-step ks issue (two register sets of 6 x 16 B): the two waves of a SIMD
     // belong to the same workgroup and leave every barrier in lockstep, so a partner's MFMAs do NOT cover this wave's LDS latency
     bf16x8 af[2][4], bf[2][2];
@@ -191,18 +300,15 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
   };
   dma_a(A0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   dma_b(B0, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
-  auto run = [&](auto... ss) { (step(ss), ...); };
-  using std::integral_constant;
-  run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{},
-      integral_constant<int, 4>{}, integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{},
-      integral_constant<int, 8>{});
-  static_assert(CCS == 4, "the epilogue's LDS plan assumes the last step reads A1 / B1");
-  run(integral_constant<int, 9>{}, integral_constant<int, 10>{}, integral_constant<int, 11>{});
+  static_assert((CCS & 1) == 0, "the epilogue's LDS plan assumes the last step reads A1 / B1");
+  if constexpr (SPLIT) unrolled_steps(step_split, std::make_integer_sequence<int, 3 * CCS>{});
+  else unrolled_steps(step, std::make_integer_sequence<int, 3 * CCS>{});
 
   // ---- epilogue. A single workgroup per CU has nobody to overlap its epilogue with, so nothing here may wait on HBM or issue narrow
   // stores (ablation: with plain per-lane addend loads and 2-byte stores the epilogue took 2/3 of the launch):
@@ -226,16 +332,18 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   __builtin_amdgcn_s_barrier();   // everyone is done with A1 / B1: the second quarter and the staging tile may overwrite them
   dma_e(EQ1, 1);
   const int e_rd = (32 * wm + 4 * lh) * 1024 + pcl * 4;        // + rr * 1024 (+ 128 for the second operand)
-  const int o_wr = (32 * wm + 4 * lh) * 256 + ocl * 2;         // + rr * 256
+  constexpr int OROW = SPLIT ? 512 : 256;                       // bytes per staged output row: 128 channels (split: hi and mid, interleaved by 32)
+  const int o_wr = (32 * wm + 4 * lh) * OROW + (SPLIT ? wn * 128 + l31 * 2 : ocl * 2);   // + rr * OROW
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const char* Eq = (q & 1) ? EQ1 : EQ0;
     // my pieces of quarter q have landed; younger operations that may still fly, in issue order
-    //   E0 | E1 | pass 0: E2, 2 stores | pass 1: E3, 2 stores | pass 2: 2 stores | pass 3: 2 stores
+    //   E0 | E1 | pass 0: E2, NST stores | pass 1: E3, NST stores | pass 2: NST stores | pass 3: NST stores
+    constexpr int NST = SPLIT ? 4 : 2;   // stores per thread and pass
     if (q == 0) wait_vmcnt<8>();
-    else if (q == 1) wait_vmcnt<10>();
-    else if (q == 2) wait_vmcnt<12>();
-    else wait_vmcnt<4>();
+    else if (q == 1) wait_vmcnt<8 + NST>();
+    else if (q == 2) wait_vmcnt<8 + 2 * NST>();
+    else wait_vmcnt<2 * NST>();
     __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone finished reading the staging tile of quarter q-1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -244,11 +352,25 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
       const float e1 = *reinterpret_cast<const float*>(Eq + e_rd + rr * 1024 + 128);
       float g = act(acc[q][0][r] + b0 + e0, m0, s0, h0) * act(acc[q][1][r] + b1 + e1, m1, s1, h1);
       if (t0 + 128 * wm + 32 * q + 4 * lh + rr >= row_lim) g = 0.f;
-      *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * 256) = f2bf(g);
+      const uint16_t gh = f2bf(g);
+      *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW) = gh;
+      if constexpr (SPLIT) *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW + 64) = f2bf(g - __builtin_bit_cast(float, (uint32_t)gh << 16));
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my staging writes are done
     __builtin_amdgcn_s_barrier();         // the staging tile is complete; everyone finished reading addend quarter q
     if (q + 2 < 4) dma_e((q & 1) ? EQ1 : EQ0, q + 2);
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // 64 rows x 512 B = 2048 pieces of 16 B, four per thread: piece p = (row p >> 5, 16 bytes p & 31 of the row's 512)
+        const int p = tid + 512 * j;
+        const int k = p >> 5, c16 = p & 31;
+        const int grow = t0 + 128 * (k >> 5) + 32 * q + (k & 31);
+        const uint4 v = *reinterpret_cast<const uint4*>(OUT + p * 16);
+        const bool ok = (n0 >> 1) + 32 * (c16 >> 3) < a.N;   // N is a multiple of 32 (checked by the launcher)
+        const int off = ok ? grow * a.ldc * 2 + n0 * 2 + c16 * 16 : (int)0x80000000;   // logical channel n0/2 sits at physical element n0
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_c, off, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {   // 64 rows x 256 B = 1024 pieces of 16 B, two per thread: piece p = (row p >> 4, 8 channels p & 15)
       const int p = tid + 512 * j;
@@ -259,6 +381,7 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
       const int off = ok ? (grow * a.ldc + (n0 >> 1) + 8 * c8) * 2 : (int)0x80000000;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_c, off, 0, 0);   // rows >= T dropped
     }
+    }
   }
 }
 
@@ -267,10 +390,13 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
 // 1 if ss_gemm_bf16 should hand this GATE launch to the 256x256 kernel: three symmetric taps, dilation <= 8, K a multiple of 64,
 // Np a multiple of 256, and enough rows that 256-row tiles fill the chip several times over
 extern "C" int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* a) {
-  if (!a || a->epi != SS_HEPI_GATE || a->ntaps != 3 || a->split) return 0;
+  if (!a || a->epi != SS_HEPI_GATE || a->ntaps != 3) return 0;
   const int d = a->tap_off[2];
   if (d < 1 || d > HALO || a->tap_off[0] != -d || a->tap_off[1] != 0) return 0;
-  if (a->K != 256 || (a->Np % BN) != 0 || (a->lda % 8) != 0 || (a->N % 8) != 0) return 0;
+  if (a->K != 256 || (a->Np % BN) != 0 || (a->lda % 8) != 0 || (a->N % 8) != 0 || (a->ldc % 8) != 0) return 0;
+  if (a->split && ((a->N % 32) != 0 || a->lda < 2 * a->K || a->ldc < 2 * a->N)) return 0;
+  // 32-bit offsets inside an item (the launcher asserts the same): longer items take the generic kernel
+  if ((int64_t)a->T * a->lda * 2 >= (1ll << 31) || (int64_t)a->T * a->lde * 4 >= (1ll << 31) || (int64_t)a->T * a->ldc * 2 >= (1ll << 31)) return 0;
   const long tiles = (long)ss_cdiv(a->T, BM) * a->B * (a->Np / BN);
   return tiles >= 1024 ? 1 : 0;
 }
@@ -284,21 +410,26 @@ extern "C" int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream)
   SS_CHECK_ARG(a.K == 256 && (a.Np % BN) == 0 && 2 * a.N <= a.Np && (a.lda % 8) == 0 && (a.N % 8) == 0 && (a.ldc % 8) == 0,
                "ss_gemm_bf16_gate256: K = 256, Np %% 256, lda %% 8, N %% 8, ldc %% 8");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 2 < (1ll << 31) &&
-                   (int64_t)a.Np * 3 * a.K * 2 < (1ll << 31), "ss_gemm_bf16_gate256: item too large for 32-bit offsets");
+                   (int64_t)a.Np * 3 * a.K * 4 < (1ll << 31), "ss_gemm_bf16_gate256: item too large for 32-bit offsets");
+  SS_CHECK_ARG(a.split == 0 || (a.split == 1 && (a.N % 32) == 0 && a.lda >= 2 * a.K && a.ldc >= 2 * a.N), "ss_gemm_bf16_gate256: split operands need N %% 32 == 0, lda >= 2 K, ldc >= 2 N");
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
   const int n_tiles = a.Np / BN;
   const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
-  const size_t lds = (size_t)2 * AROWS * ROWB + (size_t)2 * BN * ROWB;
+  // operands 144 KB; the split epilogue's view is 2 x 64 KB addend quarters + a 32 KB staging tile = all 160 KB of the CU
+  const size_t lds = a.split ? (size_t)160 * 1024 : (size_t)2 * AROWS * ROWB + (size_t)2 * BN * ROWB;
   auto go = [&](auto kern) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
+    // the attribute is per device and cheap: set on every launch (a process may drive several GPUs), failures are reported, not cached
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      ss_set_error("ss_gemm_bf16_gate256: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
+      return SS_ERR_HIP;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, n_tiles, a.tap_off[2]);
+    return SS_OK;
   };
-  go(&gate256_kernel<4>);   // 12 steps: the last one reads A1 / B1, which is what the epilogue's LDS plan relies on
+  // plain: 4 channel chunks of 64 x 3 taps = 12 steps; split: 8 chunks of 32 (both planes) x 3 taps = 24 steps
+  SS_PROPAGATE(a.split ? go(&gate256_kernel<8, true>) : go(&gate256_kernel<4, false>));
   SS_CHECK_LAUNCH("ss_gemm_bf16_gate256");
   return SS_OK;
 }

@@ -79,8 +79,7 @@ class GemmBf16Args(C.Structure):
         ("gate_mode", C.c_int32), ("e_batch_stride", C.c_int64), ("X", _vp), ("x_batch_stride", C.c_int64), ("ldx", C.c_int32),
         ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
         ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
-        ("split", C.c_int32), ("a_mid_off", C.c_int32), ("w_mid_off", C.c_int32), ("c_mid_off", C.c_int32), ("y_mid_off", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("split", C.c_int32), ("reserved_", C.c_int32 * 5),
     ]
 
 
@@ -415,18 +414,25 @@ def to_bf16(x, bias=None, lens=None):
 
 
 def split_bf16(x, bias=None, lens=None):
-    """fp32 device tensor [..., C] -> [..., 2C] bf16 bits: (hi | mid) per row, hi = RNE(v), mid = RNE(v - hi) (ss_split_bf16)."""
+    """fp32 device tensor [..., C] -> [..., 2C] bf16 bits, pairs interleaved by 32: per 32-channel chunk the 32 hi = RNE(v) terms, then the 32
+    mid = RNE(v - hi) terms (ss_split_bf16; the operand layout of ss_gemm_bf16_args.split)."""
     x = x.contiguous().float()
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y = torch.empty(tuple(x.shape[:-1]) + (2 * Cc,), device=x.device, dtype=torch.bfloat16)
-    check(load().ss_split_bf16(ptr(x), ptr(bias), ptr(y), 1, rows, Cc, Cc, 2 * Cc, Cc, ptr(lens), 0, 0, stream_ptr()), "ss_split_bf16")
+    check(load().ss_split_bf16(ptr(x), ptr(bias), ptr(y), 1, rows, Cc, Cc, 2 * Cc, ptr(lens), 0, 0, stream_ptr()), "ss_split_bf16")
     return y
+
+
+def split_planes(y):
+    """[..., 2C] pairs-interleaved-by-32 bf16 -> (hi [..., C], mid [..., C]) as float (host-side view for tests / debugging)."""
+    v = y.float().reshape(*y.shape[:-1], y.shape[-1] // 64, 2, 32)
+    return v[..., 0, :].reshape(*y.shape[:-1], -1), v[..., 1, :].reshape(*y.shape[:-1], -1)
 
 
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
               next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False,
-              split=0, a_mid_off=0, c_mid_off=0, y_mid_off=0):
+              split=0):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -445,7 +451,7 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.C = ptr(out); a.ldc = ldc if ldc is not None else (out.shape[-1] if out is not None else 0)
     a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
     a.mask_rows = int(mask_rows)
-    a.split = split; a.a_mid_off = a_mid_off; a.w_mid_off = len(taps) * K if split else 0; a.c_mid_off = c_mid_off; a.y_mid_off = y_mid_off
+    a.split = split
     if gate256:   # the 256x256 LDS-DMA kernel directly (ss_gemm_bf16 picks it by itself for many-round launches)
         check(load().ss_gemm_bf16_gate256(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate256")
         return

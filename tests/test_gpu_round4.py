@@ -199,9 +199,11 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
     x = torch.randn(B, T, C, generator=g).to(dev) * 3.0
     for b in range(B):
         x[b, lens[b]:] = 0
-    xs = L.split_bf16(x)                                   # [B,T,2C]: hi | mid
+    xs = L.split_bf16(x)                                   # [B,T,2C]: (hi, mid) pairs interleaved by 32 channels
     xh, xm = _split_ref(x)
-    assert torch.equal(xs[..., :C].float(), xh) and torch.equal(xs[..., C:].float(), xm)
+    ph, pm = L.split_planes(xs)
+    assert torch.equal(ph, xh) and torch.equal(pm, xm)
+    assert torch.equal(xs[..., 64:96].float(), xh[..., 32:64]) and torch.equal(xs[..., 32:64].float(), xm[..., :32])   # the layout itself
     assert (xh + xm - x).abs().max().item() <= 3.0 * 6 * 2.0 ** -17
     d = 4
     w = (torch.randn(2 * C, C, 3, generator=g) / (3 * C) ** 0.5).to(dev)
@@ -216,10 +218,10 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
     for p in range(C // 32):
         Ep[..., 64 * p:64 * p + 32] = E[..., 32 * p:32 * p + 32]
         Ep[..., 64 * p + 32:64 * p + 64] = E[..., C + 32 * p:C + 32 * p + 32]
-    Lyr = 2                                                # the output lands in layer slot 1 of a [rows][2 * Lyr * C] (hi | mid) buffer
+    Lyr = 2                                                # the output lands in layer slot 1 (physical columns [2C, 4C)) of a [rows][2 * Lyr * C] buffer
     GA = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.bfloat16)
-    L.gemm_bf16(xs, Ws, B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, E=Ep, lde=2 * C, out=GA[..., C:],
-                ldc=2 * Lyr * C, c_bs=T * 2 * Lyr * C, lda=2 * C, split=1, a_mid_off=C, c_mid_off=Lyr * C, gate256=force256)
+    L.gemm_bf16(xs, Ws, B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, E=Ep, lde=2 * C, out=GA[..., 2 * C:],
+                ldc=2 * Lyr * C, c_bs=T * 2 * Lyr * C, lda=2 * C, split=1, gate256=force256)
     z = y3 + E.double()
     g_ref = (torch.sigmoid(z[..., :C]) * torch.tanh(z[..., C:])).float()
     z2 = y_exact + E.double()
@@ -227,11 +229,12 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
     for b in range(B):
         g_ref[b, lens[b]:] = 0
         g_exact[b, lens[b]:] = 0
-    got = GA[..., C:2 * C].float() + GA[..., Lyr * C + C:Lyr * C + 2 * C].float()
+    gah, gam = L.split_planes(GA)                          # logical [B,T,Lyr*C] planes
+    got = gah[..., C:] + gam[..., C:]
     e3, ex = (got - g_ref).abs().max().item(), (got - g_exact).abs().max().item()
     print(f"split GATE T={T} K={K} gate256={force256}: vs float64 of the 3 products {e3:.2e}, vs exact operands {ex:.2e}")
-    assert e3 <= 2e-5 and ex <= 6e-5, (e3, ex)             # (hi, mid) output pair: 2^-17 of values in (-1, 1) + hardware exp/rcp
-    assert torch.all(GA[..., :C].float() == 7.0) and torch.all(GA[..., 2 * C:Lyr * C + C].float() == 7.0), "neighbouring layer slots untouched"
+    assert e3 <= 2e-5 and ex <= 2e-4, (e3, ex)             # e3: (hi, mid) output pair = 2^-17 of values in (-1, 1) + hardware exp/rcp; ex: + the dropped mid*mid terms of |x| <= 12 sums over K = 768 (plain bf16 operands: ~1e-2)
+    assert torch.all(GA[..., :2 * C].float() == 7.0), "the neighbouring layer slot is untouched"
     # RESX on the layer-slot operand: x <- (x + G . Wo^T + b) / sqrt(2); Y = split(x + next_bias)
     wo = (torch.randn(C, C, 1, generator=g) / C ** 0.5).to(dev)
     Wos = L.split_bf16(L.pack_conv_weight(wo))
@@ -240,9 +243,9 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
     X = torch.randn(B, T, C, generator=g).to(dev)
     X0 = X.clone()
     Y = torch.empty(B, T, 2 * C, device=dev, dtype=torch.bfloat16)
-    L.gemm_bf16(GA[..., C:], Wos, B=B, T=T, K=C, taps=(0,), N=C, Np=Wos.shape[0], epi=L.HEPI_RESX, lens=lens, bias=L.pack_bias(bo), X=X,
-                post_scale=0.5 ** 0.5, next_bias=nb, Y=Y, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=1, a_mid_off=Lyr * C, y_mid_off=C)
-    gh, gm = GA[..., C:2 * C].double(), GA[..., Lyr * C + C:Lyr * C + 2 * C].double()
+    L.gemm_bf16(GA[..., 2 * C:], Wos, B=B, T=T, K=C, taps=(0,), N=C, Np=Wos.shape[0], epi=L.HEPI_RESX, lens=lens, bias=L.pack_bias(bo), X=X,
+                post_scale=0.5 ** 0.5, next_bias=nb, Y=Y, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=1)
+    gh, gm = gah[..., C:].double(), gam[..., C:].double()
     woh, wom = (t.double() for t in _split_ref(wo[:, :, 0]))
     x_ref = ((X0.double() + (gm @ woh.t() + gh @ wom.t() + gh @ woh.t() + bo.double())) * (0.5 ** 0.5)).float()
     for b in range(B):
@@ -251,13 +254,15 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
     y_ref = x_ref + nb
     for b in range(B):
         y_ref[b, lens[b]:] = 0
-    assert ((Y[..., :C].float() + Y[..., C:].float()) - y_ref).abs().max().item() <= 1e-4
+    yh, ym = L.split_planes(Y)
+    assert ((yh + ym) - y_ref).abs().max().item() <= 1e-4
     # STORE with ReLU on the K = Lyr * C (skip-GEMM form) operand
     w2 = (torch.randn(C, Lyr * C, 1, generator=g) / (Lyr * C) ** 0.5).to(dev)
     S = torch.empty(B, T, C, device=dev)
+    GA[..., :2 * C] = L.split_bf16(torch.randn(B, T, C, generator=g).to(dev))   # fill layer slot 0 with real operands
     L.gemm_bf16(GA, L.split_bf16(L.pack_conv_weight(w2)), B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=L.round_up(C, 32), epi=L.HEPI_STORE,
-                lens=lens, act=L.ACT_RELU, out=S, lda=2 * Lyr * C, split=1, a_mid_off=Lyr * C)
-    ah, am = GA[..., :Lyr * C].double(), GA[..., Lyr * C:].double()
+                lens=lens, act=L.ACT_RELU, out=S, lda=2 * Lyr * C, split=1)
+    ah, am = (t.double() for t in L.split_planes(GA))
     w2h, w2m = (t.double() for t in _split_ref(w2[:, :, 0]))
     s_ref = torch.relu(am @ w2h.t() + ah @ w2m.t() + ah @ w2h.t()).float()
     for b in range(B):
