@@ -46,7 +46,12 @@ CONFIGS = {
     "c4": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="bf16x2", sampler="ddpm"),
     # the same workload with plain bf16 operands (one product; 2.5e-3 from the fp32 reference after 1000 steps: does NOT meet north_star)
     "c4bf16": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="bf16", sampler="ddpm"),
-    "c5": dict(batch=32, frames=1500, mel_steps=100, f0_steps=50, precision="fp32", sampler="ddim", ddim_steps=50, targets=8),
+    # one GPU's share of configs[4] (256 refs x 256 targets over 8 GPUs = 32 refs x 256 targets per GPU), at a representative size: 64 references x
+    # 32 targets = 2048 pairs per step, batches of 32 references per target (the per-GPU reference count of the full sweep)
+    "c5": dict(batch=32, refs=64, frames=1500, mel_steps=100, f0_steps=50, precision="fp32", sampler="ddim", ddim_steps=50, targets=32),
+    # configs[0]'s shape on the GPU: ONE 4 s utterance (T = 750), the shape inference/StyleSinger.py:175-186 actually calls - a latency figure
+    # (one utterance at a time, one stream), reported under `secondary.c1_gpu`
+    "c1": dict(batch=1, frames=750, mel_steps=100, f0_steps=100, precision="fp32", sampler="ddpm"),
     # c2 in the opt-in "bf16x3" precision mode (F(4,3) gates on the bf16 matrix cores from operands split into three bf16 terms; fp32-grade
     # parity): reported under `secondary`, never as the headline value
     "c2x3": dict(batch=8, frames=1500, mel_steps=100, f0_steps=100, precision="bf16x3", sampler="ddpm"),
@@ -265,6 +270,15 @@ def mel_loop_in_run(infer, B, T, S_mel, executed_flop_per_frame_step, peak):
             "executed_mfma_frac": executed_flop_per_frame_step * S_mel * B * T / (ms * 1e-3) / peak, "frames": B * T}
 
 
+def _parity_record(name):
+    pj = os.path.join(ROOT, "profiles", "r04_parity.json")
+    try:
+        rec = json.load(open(pj))
+        return rec.get("measurements", rec).get(name)
+    except (OSError, ValueError):
+        return None
+
+
 def _parity_from_profile(mode):
     """Parity block of a precision mode, read from the round's committed measurement record (profiles/r04_parity.json, written by the GPU tests
     through tests/conftest.py::record_measurement) - never a constant in this file."""
@@ -292,7 +306,7 @@ def secondary_configs():
     Each runs in its own process AFTER the c2 line's timed region (own plans / graphs / precision mode, memory returned on exit) and
     reports value, ms_per_step, dtype and its own live roofline block; c4 also carries its parity status (bf16 operands: unpinned)."""
     out = {}
-    for name, steps, streams in (("c5", 2, 1), ("c4", 1, 1), ("c4bf16", 1, 1), ("c2x3", 6, 3)):
+    for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4bf16", 1, 1), ("c2x3", 6, 3)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "1" if streams == 1 else "3",
                "--streams", str(streams), "--no-cpu-baseline", "--no-secondary"]
         t0 = time.perf_counter()
@@ -307,14 +321,17 @@ def secondary_configs():
             out[name] = {"error": repr(e)[:400]}
             continue
         rl = d.get("roofline") or {}
-        out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
+        out["c1_gpu" if name == "c1" else name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
                      "workload": d["config"]["workload"], "hipgraph_captures": d["config"].get("hipgraph_captures"),
                      "e2e_fraction_of_mfma_peak": d["config"].get("e2e_fraction_of_mfma_peak"),
                      "roofline": {k: rl.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_frac", "executed_mfma_frac", "traffic",
                                                          "traffic_source", "us_per_launch", "hbm_frac", "algorithmic_bytes_per_launch")},
                      "wall_s_incl_setup": round(time.perf_counter() - t0, 1)}
+        name = "c1_gpu" if name == "c1" else name
         if "parity" in d:
             out[name]["parity"] = d["parity"]
+        if "style_cache" in d:
+            out[name]["style_cache"] = d["style_cache"]
         if "one_batch_at_a_time" in d:
             out[name]["one_batch_at_a_time"] = d["one_batch_at_a_time"]
     return out
@@ -440,7 +457,7 @@ def main():
     if sweep_mode:
         from stylesinger_amd.sweep import style_transfer_sweep
         refs, targets = [], []
-        for i in range(B):   # B references per GPU ...
+        for i in range(cfg.get("refs", B)):   # references on this GPU, batched B per target ...
             it = synth.synth_utterance(1000 * rank + i, 16, 4, Tr, hp, 1234)
             refs.append({k: it[k].to(dev) for k in ("ref_mels", "ref_f0", "spk_embed", "emo_embed")})
         for j in range(cfg["targets"]):   # ... x `targets` target scores
@@ -460,8 +477,10 @@ def main():
     def step(i, r=None):
         r = rank if r is None else r
         if sweep_mode:
-            n_pairs, n_frames = style_transfer_sweep(infer, refs, targets, rank=0, world=1, batch=B, ddim_steps=cfg["ddim_steps"], seed=1234 + i)
+            st = {}
+            n_pairs, n_frames = style_transfer_sweep(infer, refs, targets, rank=0, world=1, batch=B, ddim_steps=cfg["ddim_steps"], seed=1234 + i, stats=st)
             last["frames"] = n_frames
+            last["sweep_stats"] = st
             return None
         res = infer.infer_batch(batches[r], seed=1234 + 7919 * i + r, vocode=False, plan_slot=(i % args.streams) if step_streams else 0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -563,9 +582,10 @@ def main():
                       f"2x{cfg['f0_steps']} f0 diffusion steps + HiFi-GAN-NSF",
                 "c4": f"batch={B} long-form {T / 187.5:.0f}s utterances (T={T} frames, Tp={Tp}, Tr={Tr}), {cfg['mel_steps']}-step mel + "
                       f"2x{cfg['f0_steps']}-step f0 diffusion + HiFi-GAN-NSF",
-                "c5": f"style-transfer sweep share of one GPU: {B} refs x {cfg.get('targets', 0)} targets (T={T}), {cfg.get('ddim_steps', 0)}-step DDIM mel "
+                "c5": f"style-transfer sweep share of one GPU: {cfg.get('refs', B)} refs x {cfg.get('targets', 0)} targets per step in batches of {B} refs (T={T}), {cfg.get('ddim_steps', 0)}-step DDIM mel "
                       f"sampler + 2x{cfg['f0_steps']}-step f0 loops + HiFi-GAN-NSF, per-reference style cache"}
         desc["c2x3"] = desc["c2"]
+        desc["c1"] = desc["c2"].replace("utterances per GPU", "utterance (latency shape of inference/StyleSinger.py:175-186), one at a time")
         desc["c4bf16"] = desc["c4"]
         desc = desc[args.config]
         x3 = getattr(infer.model, "x3", False)
@@ -601,6 +621,15 @@ def main():
         }
         if single is not None:
             out["one_batch_at_a_time"] = single
+        if sweep_mode and last.get("sweep_stats"):
+            out["style_cache"] = dict(last["sweep_stats"], note="per step: every reference is encoded once (style_encodes) and served from the "
+                                                                "cache for each further target (style_cache_hits)")
+            # the sampler of this config is pinned to the reference through eta = 1 / stride 1 == p_sample (tests/test_gpu_round4.py,
+            # tests/test_oracle_golden.py); the deterministic eta = 0 form used here shares every line of it but sigma
+            out["parity"] = {"pinned": True, "sampler": "ss_meldiff_sample_ddim eta=0, 50 of 100 network times",
+                             "pin": "eta=1, stride 1 reproduces the reference's ancestral chain (golden acoustic_t64_s100)",
+                             "measured_on": "profiles/r04_parity.json: ddim_eta1_vs_reference_golden_t64_s100",
+                             "mel_l1_eta1_vs_reference_golden": (_parity_record("ddim_eta1_vs_reference_golden_t64_s100") or {}).get("mel_l1")}
         if world > 1:
             out["dist"] = {"ranks": dist.get_world_size(), "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
                            "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "collective": "all_gather_into_tensor, once per step",

@@ -151,6 +151,12 @@ int ss_gemm16_pick(int B, int T, int N);
  * lens[b] written as 0 when mask_rows. Both operands arrive by LDS-DMA (shared A ring, per-wave B ring), no VALU work in the loop.
  * K = Cin = Kp multiple of 32, one tap; same 16*mt x 64 tiles as ss_gemm16_res. */
 int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream);
+/* Split-K form of ss_gemm16_store for launches that leave most CUs idle (one short utterance - the B = 1 latency shape of
+ * inference/StyleSinger.py:175-186: the K = L*C skip GEMM is 48 workgroups x 160 K chunks): `ksplit` slices of K run as separate workgroups
+ * into `partials` (ksplit * B * T * N floats) and a second launch adds them in slice order (deterministic) + bias / activation / row mask.
+ * ksplit = 1 is ss_gemm16_store. ss_gemm16_ksplit_pick: the slice count the denoiser loops use for a launch (1 = do not split). */
+int ss_gemm16_store_splitk(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream);
+int ss_gemm16_ksplit_pick(int B, int T, int N, int K);
 
 /* ss_gemm16_res with its weights in fetch order: W16 = ss_pack_gemm16_weights(first N rows of args->W) ([n tile][wave][K chunk][half]
  * [lane][4 floats], N % 64 == 0); with grouped launches args->w_group_stride is the stride of W16 */
@@ -264,7 +270,7 @@ typedef struct ss_gemm_bf16_args {
   int32_t reserved_[5];
 } ss_gemm_bf16_args;
 int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
-/* The SS_HEPI_GATE form of ss_gemm_bf16 for many-round launches (BASELINE config 4): three taps (-d, 0, d) with d <= 8, K = 192 | 256,
+/* The SS_HEPI_GATE form of ss_gemm_bf16 for many-round launches (BASELINE config 4): three taps (-d, 0, d) with d <= 8, K = 256,
  * Np a multiple of 256. 256 rows x 256 packed columns per workgroup, 8 waves, both operands by LDS-DMA, the A tile staged once per
  * channel chunk with its dilation halo. ss_gemm_bf16 dispatches here when ss_gemm_bf16_gate256_ok(args) (and the "gate256" tuning knob)
  * say so; same arithmetic contract, results equal up to the K summation order. */

@@ -66,6 +66,17 @@ extern "C" int ss_set_clock_probe(void* dev_u64x2) {
 }
 extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
 
+int ss_n_cu() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    hipDeviceProp_t prop;
+    cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cached[dev];
+}
+
 extern "C" int ss_device_info(int dev, int* n_cu, char* arch, int arch_len) {
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, dev);

@@ -60,6 +60,9 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
                   int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; };
 extern SsTuning g_ss_tuning;
+// compute units of the current device (cached per device; 256 when no device can be queried): the tiling picks model a launch as
+// workgroup layers per CU, so the count must be the device's, not MI355X's
+int ss_n_cu();
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)
 __device__ __forceinline__ void ss_apply_wave_prio(int mode) {
@@ -77,7 +80,8 @@ __device__ __forceinline__ void ss_apply_wave_prio(int mode) {
 __device__ __forceinline__ int ss_uniform_len(const int* lens, int b, int T) {
   if (!lens) return T;
   const auto* p = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(lens));
-  return p[__builtin_amdgcn_readfirstlane(b)];
+  const int n = p[__builtin_amdgcn_readfirstlane(b)];
+  return n < T ? (n < 0 ? 0 : n) : T;   // a length beyond the buffer is clamped: the A-operand buffer range of the kernels is len * lda bytes
 }
 __device__ __forceinline__ float ss_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Gate nonlinearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error

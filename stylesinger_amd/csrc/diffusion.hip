@@ -24,6 +24,8 @@ struct WsLayout {
   float* S;   // [B*T][C]
   float* O;   // [B*T][4]   (f0 net output)
   float* GA;  // [B*T][L*C] gate outputs of ALL layers (deferred-skip mode only, else null)
+  float* KP;  // [ksplit][B*T][C] partial sums of the split-K skip GEMM (small launches only, else null)
+  int ksplit; // K slices of the skip GEMM for this (B, T): ss_gemm16_ksplit_pick
   // bf16-in-HBM mode (net->w_dil_h set): the hidden activations travel as bf16
   uint16_t* Yh;     // [B*T][C]        x + dstep of the next layer (the dilated conv's operand)
   uint16_t* GAh;    // [B*T][L*C]      gate outputs of all layers
@@ -57,6 +59,8 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.O = take(rows * 4);
   const bool h = hmode(net);
   w.GA = (net->w_skipall && !h) ? take(rows * net->L * net->C) : nullptr;
+  w.ksplit = (net->w_skipall && !h && !net->mfma_bf16 && g_ss_tuning.skip16 != 0 && (net->C & 3) == 0) ? ss_gemm16_ksplit_pick(B, T, net->C, net->L * net->C) : 1;
+  w.KP = w.ksplit > 1 ? take((int64_t)w.ksplit * rows * net->C) : nullptr;
   const int planes = smode(net) ? 2 : 1;
   w.Yh = h ? (uint16_t*)take((rows * net->C * planes + 1) / 2) : nullptr;
   w.GAh = h ? (uint16_t*)take((rows * net->L * net->C * planes + 1) / 2) : nullptr;
@@ -363,7 +367,7 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
     int s16 = g_ss_tuning.skip16;
     const bool use16 = s16 != 0 && !net->mfma_bf16 && k.Kp == k.Cin;   // 16x16x4 tiles, both operands by LDS-DMA (gemm16.hip)
     // long-K launch: when 64-row tiles also fit one round at three workgroups per CU they beat the 96-row pick (mel at C2: 240.7 vs 250.7 us)
-    if (s16 == 1 && (long)((T + 63) / 64) * B * ((C + 63) / 64) <= 768 && !(net->mfma_x3 && net->w_skipall_x3)) s16 = 4;
+    if (s16 == 1 && (long)((T + 63) / 64) * B * ((C + 63) / 64) <= 3L * ss_n_cu() && !(net->mfma_x3 && net->w_skipall_x3)) s16 = 4;
     if (net->skipall_folded) {  // w_skipall already carries skip_projection / sqrt(L): this GEMM + ReLU is the stack's output
       k.act = SS_ACT_RELU;
       k.C = w.G;
@@ -371,9 +375,11 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
         k.w_group_stride = net->gs_w_skipall_x3;
         return ss_gemm16x_store(&k, net->w_skipall_x3, s16 == 1 ? 0 : s16, stream);
       }
+      if (use16 && w.ksplit > 1) return ss_gemm16_store_splitk(&k, 4, w.ksplit, w.KP, stream);   // one short utterance: split K over the idle CUs
       return use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream);
     }
-    SS_PROPAGATE(use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream));
+    if (use16 && w.ksplit > 1) SS_PROPAGATE(ss_gemm16_store_splitk(&k, 4, w.ksplit, w.KP, stream));
+    else SS_PROPAGATE(use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream));
   }
   // x = relu(skip_projection(sum(skip) / sqrt(L)))   (net.py:124-127)
   ss_conv_gemm_args s = base_args(B, T, lens);

@@ -250,8 +250,13 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
 //   B ring: 2 buffers of [16 columns][32 floats] PER WAVE (a wave only ever reads its own 16 columns, so its pieces need no barrier).
 // Chunk c: wait for my pieces of chunk c (vmcnt 0: nothing younger is in flight), barrier, issue the DMA of chunk c+1 into the buffers
 // chunk c-1 used, read the fragments of chunk c, 8 MT MFMAs. One chunk of MFMA time (x the waves sharing the SIMD) covers the DMA latency.
+// Split-K form (ksplit > 1; launches that leave most CUs without a workgroup - one short utterance, the K = L*C skip GEMM is then 48
+// workgroups x 160 K chunks): workgroup (tile, s) runs K chunks [s * kchunks / ksplit, (s + 1) * kchunks / ksplit) and stores its raw partial
+// sums to P[s][b][t][n] (no bias, no activation); splitk_reduce_kernel adds the ksplit partials in a FIXED order (deterministic: graph replay
+// and eager runs stay bit-identical) and applies bias / activation / row mask.
 template <int MT>
-__global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
+__global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int ksplit,
+                                                              float* __restrict__ P) {
   constexpr int BM = 16 * MT;
   constexpr int GROUPS = BM / 8;
   constexpr int DPW = GROUPS / 4;
@@ -261,7 +266,9 @@ __global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm
   __shared__ __attribute__((aligned(16))) float B0[4 * 16 * LD];
   __shared__ __attribute__((aligned(16))) float B1[4 * 16 * LD];
 
-  const int id = blockIdx.x;
+  const int tiles_grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  const int id = blockIdx.x % tiles_grid;
+  const int ksi = blockIdx.x / tiles_grid;   // split-K slice (0 when ksplit == 1)
   const int grp = id / (8 * n_tiles);
   const int rem = id % (8 * n_tiles);
   const int mt = grp * 8 + (rem & 7);
@@ -274,7 +281,8 @@ __global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm
   const int lc = lane & 15, kg = lane >> 4;
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
-  const int kchunks = a.Kp / BK;
+  const int kch_all = a.Kp / BK;
+  const int kbeg = (int)((long)ksi * kch_all / ksplit), kchunks = (int)((long)(ksi + 1) * kch_all / ksplit);   // this slice: chunks [kbeg, kchunks)
 
   auto uniform_ptr = [](const float* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -345,8 +353,8 @@ __global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  dma(A0, B0, 0);
-  int c = 0;
+  dma(A0, B0, kbeg);
+  int c = kbeg;
   for (; c + 2 <= kchunks; c += 2) {
     chunk(A0, B0, A1, B1, c, true);
     chunk(A1, B1, A0, B0, c + 1, c + 2 < kchunks);
@@ -356,6 +364,19 @@ __global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm
   const int col = n0 + 16 * wave + lc;
   const bool col_ok = col < a.N;
   const int oob = col_ok ? 0 : (int)0x80000000;
+  if (ksplit > 1) {   // raw partial sums -> P[ksi][b][t][col] (rows >= T dropped by the range check)
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(P + ((int64_t)ksi * a.B + b) * a.T * a.N), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.N * 4)), 0x00020000);
+    const int p_base = ((t0 + 4 * kg) * a.N + col) * 4 + oob;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[m][r];   // (bit_cast straight from the vector element stored element 0 four times: hipcc 7.2)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_p, p_base, (16 * m + r) * a.N * 4, 0);
+      }
+    return;
+  }
   const float bs = (a.bias && col_ok) ? a.bias[(int64_t)grp_w * a.bias_group_stride + col] : 0.f;
   const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
   const int c_base = ((t0 + 4 * kg) * a.ldc + col) * 4 + oob;
@@ -371,14 +392,41 @@ __global__ __launch_bounds__(256, 3) void gemm16_store_kernel(const ss_conv_gemm
     }
 }
 
+// C[b][t][n] = act(bias[n] + sum_s P[s][b][t][n]) in slice order s = 0, 1, ...; rows >= lens[b] -> 0 when mask_rows
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, const ss_conv_gemm_args a, int ksplit) {
+  const int64_t per = (int64_t)a.B * a.T * a.N;
+  const int n4 = a.N / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per / 4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % n4) * 4;
+    const int64_t r = i / n4;
+    const int b = (int)(r / a.T), t = (int)(r % a.T);
+    float4 v = *reinterpret_cast<const float4*>(P + i * 4);
+    for (int s = 1; s < ksplit; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(P + s * per + i * 4);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (a.bias) {
+      const float* bp = a.bias + (a.group_size > 0 ? (int64_t)(b / a.group_size) * a.bias_group_stride : 0) + c4;
+      v.x += bp[0]; v.y += bp[1]; v.z += bp[2]; v.w += bp[3];
+    }
+    if (a.act == SS_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    if (a.mask_rows && a.lens && t >= a.lens[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(a.C + (int64_t)b * a.c_batch_stride + (int64_t)t * a.ldc + c4) = v;
+  }
+}
+
 template <int MT>
-int launch_store(const ss_conv_gemm_args& a, hipStream_t stream) {
+int launch_store(const ss_conv_gemm_args& a, int ksplit, float* P, hipStream_t stream) {
   constexpr int BM = 16 * MT;
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
   const int n_tiles = ss_cdiv(a.N, BN);
   const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
-  hipLaunchKernelGGL(gemm16_store_kernel<MT>, dim3(grid), dim3(256), 0, stream, a, m_tiles_per_item, m_tiles, n_tiles);
+  hipLaunchKernelGGL(gemm16_store_kernel<MT>, dim3(grid * ksplit), dim3(256), 0, stream, a, m_tiles_per_item, m_tiles, n_tiles, ksplit, P);
+  if (ksplit > 1) {
+    const int64_t n = (int64_t)a.B * a.T * a.N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, stream, P, a, ksplit);
+  }
   return 0;
 }
 
@@ -416,7 +464,7 @@ extern "C" int ss_gemm16_pick(int B, int T, int N) {
   long best_cost = -1;
   for (int mt = 8; mt >= 4; mt -= 2) {   // 128, 96, 64 rows
     const long wgs = (long)ss_cdiv(T, 16 * mt) * B * n_tiles;
-    const long cost = (long)mt * ss_cdiv(wgs, 256);
+    const long cost = (long)mt * ss_cdiv(wgs, ss_n_cu());
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       best = mt;
@@ -465,26 +513,49 @@ extern "C" int ss_pack_gemm16_weights(const float* src, float* dst, int Np, int 
   return SS_OK;
 }
 
-extern "C" int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream) {
-  SS_CHECK_ARG(args != nullptr, "ss_gemm16_store: null args");
+static int gemm16_store_impl(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream, const char* who) {
+  SS_CHECK_ARG(args != nullptr, "%s: null args", who);
   const ss_conv_gemm_args& a = *args;
-  SS_CHECK_ARG(a.A && a.W && a.C, "ss_gemm16_store: null A/W/C");
-  SS_CHECK_ARG(a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm16_store: one tap at offset 0 only");
-  SS_CHECK_ARG(a.Kp == a.Cin && (a.Kp % BK) == 0 && (a.lda & 3) == 0, "ss_gemm16_store: K=%d must equal Kp and be a multiple of 32, lda %% 4 == 0", a.Cin);
-  SS_CHECK_ARG(a.N > 0 && a.N <= a.Np, "ss_gemm16_store: bad N=%d Np=%d", a.N, a.Np);
+  SS_CHECK_ARG(a.A && a.W && a.C, "%s: null A/W/C", who);
+  SS_CHECK_ARG(a.ntaps == 1 && a.tap_off[0] == 0, "%s: one tap at offset 0 only", who);
+  SS_CHECK_ARG(a.Kp == a.Cin && (a.Kp % BK) == 0 && (a.lda & 3) == 0, "%s: K=%d must equal Kp and be a multiple of 32, lda %% 4 == 0", who, a.Cin);
+  SS_CHECK_ARG(a.N > 0 && a.N <= a.Np, "%s: bad N=%d Np=%d", who, a.N, a.Np);
   SS_CHECK_ARG(a.a_scale == 1.0f && a.a_lrelu == 1.0f && a.a_bias == nullptr && a.mfma_bf16 == 0 && a.pre_scale == 1.0f && a.post_scale == 1.0f &&
                    a.R == nullptr && !a.accumulate && (a.act == SS_ACT_NONE || a.act == SS_ACT_RELU),
-               "ss_gemm16_store: plain C = act(A.W^T + bias) only (act none | relu), fp32");
+               "%s: plain C = act(A.W^T + bias) only (act none | relu), fp32", who);
   SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 4 < (1ll << 31) && (int64_t)a.Np * a.Kp * 4 < (1ll << 31),
-               "ss_gemm16_store: item too large for 32-bit offsets");
-  SS_CHECK_ARG(mt == 0 || mt == 4 || mt == 6 || mt == 8, "ss_gemm16_store: mt=%d must be 0 (auto), 4, 6 or 8", mt);
-  if (mt == 0) mt = ss_gemm16_pick(a.B, a.T, a.N);
+               "%s: item too large for 32-bit offsets", who);
+  SS_CHECK_ARG(mt == 0 || mt == 4 || mt == 6 || mt == 8, "%s: mt=%d must be 0 (auto), 4, 6 or 8", who, mt);
+  SS_CHECK_ARG(ksplit >= 1 && ksplit <= 16 && ksplit <= a.Kp / BK && (ksplit == 1 || (partials && (a.N & 3) == 0 && (a.ldc & 3) == 0)),
+               "%s: ksplit=%d needs a partials buffer of ksplit*B*T*N floats, N %% 4 == 0 and at most Kp/32 slices", who, ksplit);
+  if (mt == 0) mt = ksplit > 1 ? 4 : ss_gemm16_pick(a.B, a.T, a.N);
   hipStream_t s = (hipStream_t)stream;
   switch (mt) {
-    case 4: launch_store<4>(a, s); break;
-    case 6: launch_store<6>(a, s); break;
-    default: launch_store<8>(a, s); break;
+    case 4: launch_store<4>(a, ksplit, partials, s); break;
+    case 6: launch_store<6>(a, ksplit, partials, s); break;
+    default: launch_store<8>(a, ksplit, partials, s); break;
   }
-  SS_CHECK_LAUNCH("ss_gemm16_store");
+  SS_CHECK_LAUNCH(who);
   return SS_OK;
+}
+
+extern "C" int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stream) {
+  return gemm16_store_impl(args, mt, 1, nullptr, stream, "ss_gemm16_store");
+}
+
+extern "C" int ss_gemm16_store_splitk(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream) {
+  return gemm16_store_impl(args, mt, ksplit, partials, stream, "ss_gemm16_store_splitk");
+}
+
+// K slices for a long-K launch of B items x T rows x N columns x K: 1 unless 64-row tiles leave most CUs without a workgroup; then as many
+// slices as keep >= 8 K chunks per slice and at most ~one workgroup per CU
+extern "C" int ss_gemm16_ksplit_pick(int B, int T, int N, int K) {
+  const long wgs = (long)ss_cdiv(T, 64) * B * ss_cdiv(N, BN);
+  const int n_cu = ss_n_cu();
+  if (wgs * 2 > n_cu || K < 512) return 1;
+  int s = (int)(n_cu / wgs);
+  const int smax = K / BK / 8;
+  if (s > smax) s = smax;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
 }

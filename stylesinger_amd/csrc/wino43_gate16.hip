@@ -58,7 +58,7 @@ __device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { retur
 // lane-contiguous repack of ss_pack_gate16_weights ([n tile][wave][K chunk][component][half][lane][4 floats]): one fetch instruction of
 // a wave is 1 KB contiguous (8 cache lines) instead of 16 columns x 64 B (16 lines).
 template <int MT, bool KS, bool WL>
-__global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int q_tiles_per_item,
+__global__ __launch_bounds__(256, (MT <= 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int q_tiles_per_item,
                                                                int q_tiles, int n_tiles, int log2d, unsigned long long* clock_probe) {
   constexpr int BQ = 16 * MT;
   constexpr int NFULL = BQ / 32;             // staging passes of 32 rows x 8 sixteen-byte slots
@@ -490,9 +490,10 @@ int launch16(const ss_conv_gemm_args& a, const float* W16, int dilation, int log
   const int n_tiles = a.Np / BN;
   const int grid = ss_cdiv(q_tiles, 8) * 8 * n_tiles;
   const size_t lds = (size_t)(KS ? 12 : 2) * BQ * LD * sizeof(float);
-  if constexpr (KS && MT == 3) {   // 72 KB of dynamic LDS: above the 64 KB a kernel gets without asking
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino43_gate16_kernel<MT, KS, WL>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if constexpr (KS && MT == 3) {   // 72 KB of dynamic LDS: above the 64 KB a kernel gets without asking. The attribute is per device and
+    // cheap, so it is set on every launch (a process may drive several GPUs) and a failure is reported, never cached
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino43_gate16_kernel<MT, KS, WL>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
   }
   hipLaunchKernelGGL((wino43_gate16_kernel<MT, KS, WL>), dim3(grid), dim3(256), lds, stream, a, W16, q_tiles_per_item, q_tiles, n_tiles, log2d,
@@ -507,12 +508,16 @@ int launch16(const ss_conv_gemm_args& a, const float* W16, int dilation, int log
 extern "C" int ss_wino43_gate16_pick(int B, int T, int Np, int dilation) {
   const int quads_per_item = ss_cdiv(T, 4 * dilation) * dilation;
   const int n_tiles = Np / BN;
-  auto layers = [&](int bq) { return ss_cdiv((long)ss_cdiv(quads_per_item, bq) * B * n_tiles, 256); };
+  const int n_cu = ss_n_cu();
+  auto layers = [&](int bq) { return ss_cdiv((long)ss_cdiv(quads_per_item, bq) * B * n_tiles, n_cu); };
   // many rounds per launch: tile granularity no longer matters and the 32x32 tile moves half the LDS bytes per flop
   if (layers(64) >= 6) return 0;
   int best = 0;  // the 64-quad tile of the 32x32x2 kernel
   long best_cost = 4L * layers(64);
-  for (int mt = 3; mt >= 2; --mt) {
+  // MT = 1 (16 quads = 64 frames per workgroup) only for launches whose MT = 2 grid leaves CUs without a workgroup (one short utterance:
+  // the B = 1 latency shape of inference/StyleSinger.py:175-186): half the work per workgroup, twice the workgroups
+  const bool tiny = (long)ss_cdiv(quads_per_item, 32) * B * n_tiles <= n_cu;
+  for (int mt = 3; mt >= (tiny ? 1 : 2); --mt) {
     const long cost = (long)mt * layers(16 * mt);
     // ties go to the smaller tile: MT = 2 fits three workgroups per CU (168 registers; MT = 3: 252 -> two) and measured 1 % faster where
     // both fill the chip evenly (BASELINE config 2: mel 768 workgroups of MT = 2 vs 512 of MT = 3)
@@ -554,7 +559,7 @@ int gate16_impl(const ss_conv_gemm_args* args, const float* W16, int dilation, i
                    (int64_t)a.Np * NC * a.Kp * 4 < (1ll << 31),
                "%s: item too large for 32-bit offsets", who);
   SS_CHECK_ARG((int64_t)a.T * a.ldc * 4 < (1ll << 31), "%s: output item too large for 32-bit offsets", who);
-  SS_CHECK_ARG(mt == 0 || mt == 2 || mt == 3, "%s: mt=%d must be 0 (auto), 2 or 3", who, mt);
+  SS_CHECK_ARG(mt >= 0 && mt <= 3, "%s: mt=%d must be 0 (auto), 1, 2 or 3", who, mt);
   int log2d = 0;
   while ((1 << log2d) < dilation) ++log2d;
   if (mt == 0) {
@@ -565,7 +570,10 @@ int gate16_impl(const ss_conv_gemm_args* args, const float* W16, int dilation, i
   const bool ks = g_ss_tuning.gate16_ks != 0 && a.Kp >= 2 * BK;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (W16) {
+  if (mt == 1) {   // small launches only: the K-staged form with the weights in whichever layout the caller has
+    SS_CHECK_ARG(ks, "%s: mt = 1 needs the K-staged form (Kp >= 64, gate16_ks on)", who);
+    rc = W16 ? launch16<1, true, true>(a, W16, dilation, log2d, st) : launch16<1, true, false>(a, nullptr, dilation, log2d, st);
+  } else if (W16) {
     if (mt == 2) rc = ks ? launch16<2, true, true>(a, W16, dilation, log2d, st) : launch16<2, false, true>(a, W16, dilation, log2d, st);
     else rc = ks ? launch16<3, true, true>(a, W16, dilation, log2d, st) : launch16<3, false, true>(a, W16, dilation, log2d, st);
   } else {

@@ -98,11 +98,16 @@ class StyleSingerInfer:
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(main)
             return res
-        batches = list(batches)
-        if batches:   # lazily built shared state is created here, on the caller's stream, not inside a forward on a side stream
-            longest = max(int(b["mel2ph"].shape[1]) if b.get("mel2ph") is not None else 0 for b in batches)
-            self.model.warm_caches(max(longest, max(int(b["ref_mels"].shape[1]) for b in batches), 2048), self.device)
+        # `batches` may be a lazy producer (a dataset loop placing batches on the GPU): it is consumed one batch at a time, so at most
+        # `in_flight` batches are resident. Lazily built shared state is created here, on the caller's stream, not inside a forward on a
+        # side stream: a default size up front, and a batch longer than that grows it when the batch is pulled (the tables only grow).
+        warm = 2048
+        self.model.warm_caches(warm, self.device)
         for i, batch in enumerate(batches):
+            need = max(int(batch["mel2ph"].shape[1]) if batch.get("mel2ph") is not None else 0, int(batch["ref_mels"].shape[1]))
+            if need > warm:
+                warm = need
+                self.model.warm_caches(warm, self.device)
             strm = self._flight_streams[i % in_flight]
             strm.wait_stream(main)   # the batch's inputs were produced on the caller's stream
             with torch.cuda.stream(strm):

@@ -288,6 +288,13 @@ def gemm16_store(A, W, out, *, mt=0, **kw):
     check(load().ss_gemm16_store(C.byref(a), int(mt), stream_ptr()), "ss_gemm16_store")
 
 
+def gemm16_store_splitk(A, W, out, *, ksplit, mt=0, **kw):
+    """ss_gemm16_store_splitk: the long-K GEMM with K split over `ksplit` workgroup slices + a fixed-order reduction (small launches)."""
+    a = _fill_args(A, W, out, **kw)
+    part = torch.empty(max(1, ksplit) * a.B * a.T * a.N, device=out.device, dtype=torch.float32)
+    check(load().ss_gemm16_store_splitk(C.byref(a), int(mt), int(ksplit), ptr(part), stream_ptr()), "ss_gemm16_store_splitk")
+
+
 def wino43_weight(w):
     """conv weight [Cout][Cin][3] (device) -> F(4,3)-transformed [Cout][Cin][6]."""
     w = w.contiguous().float()

@@ -50,8 +50,10 @@ def norm_interp_f0(f0, hparams):
 @torch.no_grad()
 def norm_interp_f0_device(f0_hz, lens=None, hparams=None):
     """f0_hz fp32 [B, T] on the device (0 = unvoiced), lens int32 [B] valid frames per item (default T) ->
-    (f0 [B, T], uv [B, T]) fp32: per item exactly `norm_interp_f0` of its first lens[b] frames (log2 and the interpolation run
-    in double on the device and round once to fp32, like numpy on the tracker's float64 output); frames >= lens[b] are 0."""
+    (f0 [B, T], uv [B, T]) fp32: per item `norm_interp_f0` of its first lens[b] frames; frames >= lens[b] are 0. Contract: the entry takes
+    FP32 Hz, i.e. what numpy computes on a float32 contour (log2 and the interpolation weights in double, the interpolation endpoints rounded to
+    fp32 first); against the reference's float64 tracker output that is within 1 fp32 ulp of values in [6, 10] (tests allow 2e-6), not
+    bit-identical to the host path `norm_interp_f0` of this module, which `input_to_batch` uses on the float64 contour."""
     hp = hparams or {}
     if hp.get("pitch_norm", "log") != "log" or not hp.get("use_uv", True):
         raise NotImplementedError("norm_interp_f0_device: only pitch_norm='log' with use_uv (the reference's setting)")

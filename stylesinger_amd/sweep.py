@@ -39,9 +39,14 @@ class StyleCache:
     def __init__(self, model):
         self.model = model
         self.items = {}
+        self.hits = 0      # lookups served from the cache (a reference seen before: every target after its first)
+        self.encodes = 0   # style-encoder runs (one per reference)
 
     def get(self, idx, ref):
-        if idx not in self.items:
+        if idx in self.items:
+            self.hits += 1
+        else:
+            self.encodes += 1
             dev = next(iter(self.model.buffers())).device
             sc = self.model.encode_style(ref["ref_mels"][None].to(dev), ref["ref_f0"][None].to(dev))
             self.items[idx] = {k: v[0] for k, v in sc.items()}
@@ -60,11 +65,13 @@ class StyleCache:
 
 
 @torch.no_grad()
-def style_transfer_sweep(infer, refs, targets, rank=0, world=1, batch=32, ddim_steps=50, t_bucket=1, vocode=True, emit=None, seed=None):
+def style_transfer_sweep(infer, refs, targets, rank=0, world=1, batch=32, ddim_steps=50, t_bucket=1, vocode=True, emit=None, seed=None,
+                         stats=None):
     """refs[i] = dict(ref_mels [Tr,80], ref_f0 [Tr], spk_embed [256], emo_embed [256]);
     targets[j] = dict(txt_tokens [Tp], note [Tp], note_dur [Tp], note_type [Tp], mel2ph [T]).
     Calls emit(ref_idx, target_idx, mel [T,80], f0 [T], wav [T*hop] or None) per pair; returns the number of pairs done and
-    the number of mel frames produced by this rank."""
+    the number of mel frames produced by this rank. `stats` (a dict, optional) receives the per-reference style-cache accounting of this
+    call: references on this rank, style-encoder runs, cache hits, hit rate."""
     model, dev = infer.model, infer.device
     cache = StyleCache(model)
     n_pairs = n_frames = 0
@@ -91,4 +98,8 @@ def style_transfer_sweep(infer, refs, targets, rank=0, world=1, batch=32, ddim_s
         if emit is not None:
             for k, r_idx in enumerate(ref_idxs):
                 emit(r_idx, t_idx, mel[k, :T], f0[k, :T], None if wav is None else wav[k, :T * infer.vocoder.model.hop])
+    if stats is not None:
+        look = cache.hits + cache.encodes
+        stats.update(refs_on_rank=len(shard_indices(len(refs), rank, world)), style_encodes=cache.encodes, style_cache_hits=cache.hits,
+                     style_cache_hit_rate=(cache.hits / look) if look else 0.0, pairs=n_pairs)
     return n_pairs, n_frames

@@ -88,7 +88,7 @@ def test_c4_shape_item_matches_oracle_with_100_step_chains():
     assert l1k <= 1e-5 and mxk <= 1e-3, (l1k, mxk)
 
 
-@pytest.mark.parametrize("mt", [2, 3])
+@pytest.mark.parametrize("mt", [1, 2, 3])   # 1 = the small-launch tiling (round 4: one short utterance leaves most CUs idle at MT = 2)
 def test_gate16_grouped_pair_launch_matches_the_32x32_kernel(mt):
     """The f0-pair form of the launch (C = 192, two weight sets selected by b // group_size, conditioner slab with a layer stride,
     ragged lens, a gate_mode-1 pass as the RSA uses it) on 16x16x4 tiles vs the round-2 32x32x2 kernel: same arithmetic up to the
@@ -120,6 +120,7 @@ def test_gate16_grouped_pair_launch_matches_the_32x32_kernel(mt):
     lib = L.load()
     assert lib.ss_wino43_gate16_pick(8, 1500, 512, 2) == 2 and lib.ss_wino43_gate16_pick(16, 1500, 384, 1) == 3   # mel: 768 x MT=2, f0 pair: 768 x MT=3
     assert lib.ss_wino43_gate16_pick(32, 5625, 512, 4) == 0      # many rounds per launch: the 32x32x2 tiles
+    assert lib.ss_wino43_gate16_pick(1, 750, 512, 2) == 1 and lib.ss_wino43_gate16_pick(2, 750, 384, 8) == 1   # one 4 s utterance: 16-quad tiles
 
 
 @pytest.mark.parametrize("mt", [2, 3])

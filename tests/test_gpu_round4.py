@@ -331,3 +331,69 @@ def test_bf16x2_mode_at_the_c4_shape_matches_the_fp32_oracle():
                        coarse_flips=int(cf.sum()))
     assert flips == 0 and cf.float().mean().item() <= 1e-3
     assert dm.mean().item() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the B = 1 latency shape (inference/StyleSinger.py:175-186 runs ONE utterance): small-launch tilings
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N,B,T,groups,ksplit", [(5120, 256, 1, 750, 1, 5), (1920, 192, 2, 333, 2, 3), (5120, 256, 1, 64, 1, 16), (96, 80, 1, 70, 1, 3)])
+def test_gemm16_store_splitk_matches_torch_and_is_deterministic(K, N, B, T, groups, ksplit):
+    """ss_gemm16_store_splitk: K split over workgroup slices + fixed-order reduction (bias, ReLU, row mask in the reduction) vs torch float64
+    and vs the unsplit kernel; two runs give identical bits (hipGraph replay == eager depends on it)."""
+    import math
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(K + N + ksplit)
+    A = torch.randn(B, T, K, generator=g)
+    ws = [torch.randn(N, K, 1, generator=g) / math.sqrt(K) for _ in range(groups)]
+    bs = [torch.randn(N, generator=g) * 0.1 for _ in range(groups)]
+    lens = torch.tensor([max(1, T - 9 * i) for i in range(B)], dtype=torch.int32)
+    ref = torch.zeros(B, T, N)
+    for i in range(B):
+        n, gi = int(lens[i]), i * groups // B
+        ref[i, :n] = (A[i, :n].double() @ ws[gi][:, :, 0].double().t() + bs[gi].double()).clamp_min(0).float()
+    Wp = torch.stack([L.pack_conv_weight(w.to(dv)) for w in ws]).contiguous()
+    bp = torch.stack([L.pack_bias(b_.to(dv)) for b_ in bs]).contiguous()
+    kw = dict(B=B, T=T, Cin=K, N=N, Np=Wp.shape[1], Kp=Wp.shape[2], lens=lens.to(dv), bias=bp, act=L.ACT_RELU, mask_rows=True,
+              group_size=(B // groups if groups > 1 else 0), w_gs=Wp[0].numel(), bias_gs=bp[0].numel())
+    outs = []
+    for _ in range(2):
+        out = torch.full((B, T, N), 3.0, device=dv)
+        L.gemm16_store_splitk(A.to(dv), Wp, out, ksplit=ksplit, **kw)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    one = torch.full((B, T, N), 4.0, device=dv)
+    L.gemm16_store(A.to(dv), Wp, one, **kw)
+    err, err1 = (outs[0].cpu() - ref).abs().max().item(), (outs[0] - one).abs().max().item()
+    assert err <= 3e-5 and err1 <= 3e-5, (err, err1)
+    for i in range(B):
+        assert torch.all(outs[0][i, int(lens[i]):] == 0)
+    lib = L.load()
+    assert lib.ss_gemm16_ksplit_pick(1, 750, 256, 5120) == 5 and lib.ss_gemm16_ksplit_pick(8, 1500, 256, 5120) == 1
+    assert lib.ss_gemm16_ksplit_pick(2, 750, 192, 1920) >= 2
+
+
+def test_one_utterance_latency_shape_matches_the_oracle():
+    """B = 1, T = 750 (BASELINE configs[0]'s shape: one 4 s utterance - what inference/StyleSinger.py:175-186 runs) through the small-launch
+    tilings (16-quad gate tiles, split-K skip GEMM), 20 + 2 x 20 steps, against the oracle on this box; graph replay == eager bit for bit."""
+    S = 20
+    hp = config.make_hparams(dict(timesteps=S, K_step=S, f0_timesteps=S))
+    B, T, Tp, Tr = 1, 750, 14, 750
+    batch = synth.synth_batch(B, T, Tp, Tr, hp, 31)
+    sd = synth.synth_acoustic_state_dict(hp, 31)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(32), B, T, S, S)
+    m = _model(hp, sd)
+    b = {k: v.cuda() for k, v in batch.items()}
+    got = _fwd(m, b, noise=noise)
+    with torch.no_grad():
+        ref = R.acoustic_forward(sd, hp, batch, synth.NoiseTape(32), mel2ph=batch["mel2ph"])
+    dm = (got["mel_out"].cpu() - ref["mel_out"]).abs()
+    flips = (got["uv_a"].cpu().long() != ref["uv_a"]).sum().item() + (got["uv_b"].cpu().long() != ref["uv_b"]).sum().item()
+    print(f"B=1 T=750, {S} steps vs oracle: mel L1 {dm.mean().item():.3e} max {dm.max().item():.3e}; voicing flips {flips}")
+    record_measurement("c1_shape_b1_t750_vs_oracle", mel_l1=dm.mean().item(), mel_max=dm.max().item(), voicing_flips=flips)
+    assert flips == 0 and dm.mean().item() <= 1e-5
+    m.use_graphs = "on"
+    g1 = _fwd(m, b, seed=5)["mel_out"]
+    g2 = _fwd(m, b, seed=5)["mel_out"]
+    m.use_graphs = "off"
+    e1 = _fwd(m, b, seed=5)["mel_out"]
+    assert torch.equal(g1, g2) and torch.equal(g1, e1)
