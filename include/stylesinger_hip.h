@@ -46,7 +46,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * residual-half projection on ss_gemm16_res / skip GEMM on ss_gemm16_store (1 = on, row tile picked per launch, default; 0 =
  * ss_conv_gemm; 4|6|8 = force 16*mt rows); experiment switches "htile" = 0|64|128 (row tile of the generic bf16 kernel), "wino_tn" = 0|1|2 and
  * "wino_v1" = 0|1 (F(2,3) gate: column tile, round-1 kernel); "voc_wino_max_mb" = 1..2048: vocoder items whose stage panel reaches this many MiB
- * take the direct conv kernel instead of the grouped-Winograd one (32-bit offsets; default 2048 = the real limit, tests lower it) */
+ * take the direct conv kernel instead of the grouped-Winograd one (32-bit offsets; default 2048 = the real limit, tests lower it); "e16" = 0|1
+ * the fp32 denoiser loops hand the 16x16x4 gate its conditioner addend in fetch order (ss_gate16_tile_addend once per forward; default 1) */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -136,6 +137,11 @@ typedef struct ss_conv_gemm_args {
   /* DDPM epilogue variant: 0 = v is the predicted NOISE (x0 = clamp(recip*x - recipm1*v, -1, 1), shallow_diffusion_tts.py:130-153);
    * 1 = v is the predicted x0 itself, no clamp (ProDiffusion.p_sample, modules/diff/prodiff.py:150-153) */
   int32_t ddpm_x0_pred;
+  /* ss_wino43_gate16 / 16w only: 1 = E is this launch's conditioner addend in the kernel's FETCH ORDER (ss_gate16_tile_addend with the same
+   * dilation and mt; mt must then be given explicitly): per workgroup tile [wave][row tile m][quad r][lane][frame o] floats, so a wave reads
+   * 1 KB contiguous per instruction (16 bytes per lane) instead of 8 cache lines x 32 B. lde / e_batch_stride are ignored. */
+  int32_t e_tiled;
+  int32_t reserved2_;
 } ss_conv_gemm_args;
 
 int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream);
@@ -208,6 +214,11 @@ int ss_wino43_gate(const ss_conv_gemm_args* args, int dilation, void* stream);
  * Same arguments, same weights (ss_wino43_weight_transform + ss_pack_conv_weight(k=6, interleave_half=C)), same arithmetic up to
  * the summation order over K (tests/test_gpu_round3.py). */
 int ss_wino43_gate16(const ss_conv_gemm_args* args, int dilation, int mt, void* stream);
+/* The conditioner addend of one layer in the fetch order of the 16x16x4 gate kernel (ss_conv_gemm_args.e_tiled): E [B][T][lde] (this layer's
+ * Np packed columns at E, row stride lde, batch stride e_batch_stride floats) -> E16, ss_gate16_tiled_floats(B, T, Np, dilation, mt) floats.
+ * Frames >= T of the last tile of an item are written as 0. */
+int ss_gate16_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* E16, int B, int T, int Np, int dilation, int mt, void* stream);
+int64_t ss_gate16_tiled_floats(int B, int T, int Np, int dilation, int mt);
 /* the tiling ss_wino43_gate16(mt = 0) uses for a launch of B items x T frames x Np packed columns: 2 | 3, or 0 = the 32x32x2 kernel */
 int ss_wino43_gate16_pick(int B, int T, int Np, int dilation);
 /* src [Cout][Cin][3] -> dst [Cout][Cin][6]: g0=w0/4, g1=-(w0+w1+w2)/6, g2=-(w0-w1+w2)/6, g3=w0/24+w1/12+w2/6,

@@ -55,10 +55,12 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     generic bf16 kernel.
 //   htile: row tile of the generic bf16 kernel (0 = built-in choice, 64 | 128 = force); wino_tn: column tile of the F(2,3) gate (0 = pick,
 //     1 = 64, 2 = 128 columns); wino_v1: 1 = the round-1 F(2,3) kernel (A/B against v2).
+//   e16: 1 (default) = the fp32 denoiser loops re-lay the conditioner addend of every 16x16x4 gate launch in that kernel's fetch order once per
+//     forward (ss_gate16_tile_addend); 0 = the gate reads the row-major slab (A/B; results are bit-identical).
 //   voc_wino_max_mb: the vocoder's grouped-Winograd convs address an item with 32-bit byte offsets; items whose stage panel (+ halo) reaches
 //     this many MiB take the direct kernel instead (default 2048 = the real limit; tests lower it to force that fallback).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
-                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; };
+                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; };
 extern SsTuning g_ss_tuning;
 // compute units of the current device (cached per device; 256 when no device can be queried): the tiling picks model a launch as
 // workgroup layers per CU, so the count must be the device's, not MI355X's

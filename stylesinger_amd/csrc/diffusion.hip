@@ -24,6 +24,8 @@ struct WsLayout {
   float* S;   // [B*T][C]
   float* O;   // [B*T][4]   (f0 net output)
   float* GA;  // [B*T][L*C] gate outputs of ALL layers (deferred-skip mode only, else null)
+  float* E16[SS_MAX_LAYERS];  // per layer: the conditioner addend in the 16x16x4 gate kernel's fetch order (null: the layer reads E)
+  int mt16[SS_MAX_LAYERS];    // ... and the tiling it was laid out for (0 = none)
   float* KP;  // [ksplit][B*T][C] partial sums of the split-K skip GEMM (small launches only, else null)
   int ksplit; // K slices of the skip GEMM for this (B, T): ss_gemm16_ksplit_pick
   // bf16-in-HBM mode (net->w_dil_h set): the hidden activations travel as bf16
@@ -59,6 +61,22 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.O = take(rows * 4);
   const bool h = hmode(net);
   w.GA = (net->w_skipall && !h) ? take(rows * net->L * net->C) : nullptr;
+  // fp32 F(4,3) loops on the 16x16x4 gate kernel: every layer's slab of E is re-laid once per forward in that kernel's fetch order
+  // (ss_gate16_tile_addend), so that a wave's addend fetch is 1 KB contiguous per instruction instead of 8 lines x 32 B ("e16" knob)
+  for (int l = 0; l < SS_MAX_LAYERS; ++l) {
+    w.E16[l] = nullptr;
+    w.mt16[l] = 0;
+  }
+  if (!h && !net->mfma_bf16 && !net->mfma_x3 && net->wino_m == 4 && g_ss_tuning.gate16 != 0 && g_ss_tuning.e16 != 0)
+    for (int l = 0; l < net->L && l < SS_MAX_LAYERS; ++l) {
+      if (!net->w_dil_wino[l] || !net->w_dil_wino16[l]) continue;
+      const int d = 1 << (l % net->dil_cycle);
+      const int mt = g_ss_tuning.gate16 == 1 ? ss_wino43_gate16_pick(B, T, 2 * net->C, d) : g_ss_tuning.gate16;
+      const int64_t fl = mt > 0 ? ss_gate16_tiled_floats(B, T, 2 * net->C, d, mt) : -1;
+      if (fl <= 0 || fl * 4 >= (1ll << 31)) continue;
+      w.E16[l] = take(fl);
+      w.mt16[l] = mt;
+    }
   w.ksplit = (net->w_skipall && !h && !net->mfma_bf16 && g_ss_tuning.skip16 != 0 && (net->C & 3) == 0) ? ss_gemm16_ksplit_pick(B, T, net->C, net->L * net->C) : 1;
   w.KP = w.ksplit > 1 ? take((int64_t)w.ksplit * rows * net->C) : nullptr;
   const int planes = smode(net) ? 2 : 1;
@@ -144,7 +162,12 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
     a.w_group_stride = net->gs_w_cond;
     a.bias_group_stride = net->gs_b_cond;
   }
-  return ss_conv_gemm(&a, stream);
+  SS_PROPAGATE(ss_conv_gemm(&a, stream));
+  for (int l = 0; l < net->L; ++l)
+    if (w.E16[l])
+      SS_PROPAGATE(ss_gate16_tile_addend(w.E + (int64_t)l * 2 * net->C, NE, (int64_t)T * NE, w.E16[l], B, T, 2 * net->C, 1 << (l % net->dil_cycle),
+                                         w.mt16[l], stream));
+  return SS_OK;
 }
 
 // the L residual layers + skip projection; X in/out, leaves relu(skip_projection) in G.
@@ -293,7 +316,11 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       } else if (net->wino_m == 4) {
         const int g16 = g_ss_tuning.gate16;  // 0: 32x32x2 tiles; 1: per-launch pick; 2 / 3: 16x16x4 tiles of 16*MT quads
         if (g16 == 0) SS_PROPAGATE(ss_wino43_gate(&a, d, stream));
-        else if (net->w_dil_wino16[l]) SS_PROPAGATE(ss_wino43_gate16w(&a, net->w_dil_wino16[l], d, g16 == 1 ? 0 : g16, stream));
+        else if (net->w_dil_wino16[l] && w.E16[l]) {   // addend in fetch order, laid out for exactly this tiling
+          a.E = w.E16[l];
+          a.e_tiled = 1;
+          SS_PROPAGATE(ss_wino43_gate16w(&a, net->w_dil_wino16[l], d, w.mt16[l], stream));
+        } else if (net->w_dil_wino16[l]) SS_PROPAGATE(ss_wino43_gate16w(&a, net->w_dil_wino16[l], d, g16 == 1 ? 0 : g16, stream));
         else SS_PROPAGATE(ss_wino43_gate16(&a, d, g16 == 1 ? 0 : g16, stream));
       } else {
         SS_PROPAGATE(ss_wino_gate(&a, d, stream));

@@ -379,6 +379,23 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : 2)) void wino43_gate16_kernel(c
   const int lde4 = a.lde * 4, ldc4 = a.ldc * 4;
   float pe[MT][4][4];
   auto fetch_addend = [&]() {
+    if (a.e_tiled) {   // the addend in this kernel's fetch order (ss_gate16_tile_addend): [tile][wave][m][r][lane][o], 16 bytes per lane
+      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.E), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)q_tiles * n_tiles * (MT * 4096) * 4)), 0x00020000);
+      const int tile_b = __builtin_amdgcn_readfirstlane(((qt * n_tiles + nt) * (MT * 4096) + wave * (MT * 1024)) * 4);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4 v = SS_G16_ABL == 5 ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                           : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, lane_e * 16, tile_b + (m * 4 + r) * 1024, 0));
+          pe[m][r][0] = v.x;
+          pe[m][r][1] = v.y;
+          pe[m][r][2] = v.z;
+          pe[m][r][3] = v.w;
+        }
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int qm = q0 + 16 * m + 4 * kg;          // multiple of 4
@@ -548,6 +565,37 @@ __global__ void pack_gate16_kernel(const float* __restrict__ src, float* __restr
   }
 }
 
+// E [B][T][lde] (Np packed columns of one layer) -> the fetch order of wino43_gate16_kernel<MT>: one float4 (frames o = 0..3 of a quad) per
+// (tile, wave, row tile m, quad r, lane); the index math is the kernel's own (fetch_addend / epilogue)
+__global__ void gate16_tile_addend_kernel(const float* __restrict__ E, int lde, int64_t e_bs, float4* __restrict__ out, int B, int T, int Np,
+                                          int d, int MT, int q_tiles_per_item) {
+  const int n_tiles = Np / BN;
+  const int64_t n = (int64_t)B * q_tiles_per_item * n_tiles * MT * 1024;   // float4 count
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const int mr = (int)((i >> 6) % (MT * 4));
+    const int wave = (int)((i / (64 * MT * 4)) & 3);
+    const int64_t tile = i / (MT * 1024);
+    const int nt = (int)(tile % n_tiles);
+    const int qt = (int)(tile / n_tiles);
+    const int b = qt / q_tiles_per_item, q0 = (qt % q_tiles_per_item) * 16 * MT;
+    const int m = mr >> 2, r = mr & 3;
+    const int lc = lane & 15, kg = lane >> 4, c7 = lc & 7, chi = lc >> 3;
+    const int pc = nt * BN + 8 * wave + c7 + 32 * chi;
+    const int qm = q0 + 16 * m + 4 * kg;
+    const int tm = qm + 3 * (qm & ~(d - 1));
+    const int dr = r + 3 * (r & ~(d - 1));
+    const float* Eb = E + (int64_t)b * e_bs + pc;
+    float v[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int t = tm + dr + o * d;
+      v[o] = t < T ? Eb[(int64_t)t * lde] : 0.f;
+    }
+    out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 int gate16_impl(const ss_conv_gemm_args* args, const float* W16, int dilation, int mt, void* stream, const char* who) {
   SS_CHECK_ARG(args != nullptr, "%s: null args", who);
   const ss_conv_gemm_args& a = *args;
@@ -560,6 +608,7 @@ int gate16_impl(const ss_conv_gemm_args* args, const float* W16, int dilation, i
                "%s: item too large for 32-bit offsets", who);
   SS_CHECK_ARG((int64_t)a.T * a.ldc * 4 < (1ll << 31), "%s: output item too large for 32-bit offsets", who);
   SS_CHECK_ARG(mt >= 0 && mt <= 3, "%s: mt=%d must be 0 (auto), 1, 2 or 3", who, mt);
+  SS_CHECK_ARG(!a.e_tiled || (mt != 0 && a.E), "%s: a tiled addend (e_tiled) is laid out for ONE tiling: give mt explicitly", who);
   int log2d = 0;
   while ((1 << log2d) < dilation) ++log2d;
   if (mt == 0) {
@@ -602,5 +651,27 @@ extern "C" int ss_pack_gate16_weights(const float* src, float* dst, int Np, int 
   const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   hipLaunchKernelGGL(pack_gate16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, Np, Kp);
   SS_CHECK_LAUNCH("ss_pack_gate16_weights");
+  return SS_OK;
+}
+
+extern "C" int64_t ss_gate16_tiled_floats(int B, int T, int Np, int dilation, int mt) {
+  if (B <= 0 || T <= 0 || Np <= 0 || (Np % BN) != 0 || dilation < 1 || mt < 1 || mt > 3) return -1;
+  const int quads_per_item = ss_cdiv(T, 4 * dilation) * dilation;
+  return (int64_t)ss_cdiv(quads_per_item, 16 * mt) * B * (Np / BN) * mt * 4096;
+}
+
+extern "C" int ss_gate16_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* E16, int B, int T, int Np, int dilation, int mt,
+                                     void* stream) {
+  SS_CHECK_ARG(E && E16 && B > 0 && T > 0 && Np > 0 && (Np % BN) == 0 && lde >= Np && mt >= 1 && mt <= 3, "ss_gate16_tile_addend: bad args");
+  SS_CHECK_ARG(dilation >= 1 && (dilation & (dilation - 1)) == 0 && dilation <= 64, "ss_gate16_tile_addend: dilation %d must be a power of two <= 64", dilation);
+  SS_CHECK_ARG((((uintptr_t)E16) & 15) == 0, "ss_gate16_tile_addend: E16 must be 16-byte aligned");
+  const int quads_per_item = ss_cdiv(T, 4 * dilation) * dilation;
+  const int q_tiles_per_item = ss_cdiv(quads_per_item, 16 * mt);
+  const int64_t n = (int64_t)B * q_tiles_per_item * (Np / BN) * mt * 1024;
+  SS_CHECK_ARG(n * 16 < (1ll << 31), "ss_gate16_tile_addend: launch too large for the kernel's 32-bit offsets");
+  const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipLaunchKernelGGL(gate16_tile_addend_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, E, lde, e_batch_stride, reinterpret_cast<float4*>(E16), B, T, Np,
+                     dilation, mt, q_tiles_per_item);
+  SS_CHECK_LAUNCH("ss_gate16_tile_addend");
   return SS_OK;
 }

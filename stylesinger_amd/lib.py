@@ -46,7 +46,7 @@ class ConvGemmArgs(C.Structure):
         ("ddpm_recip", C.c_float), ("ddpm_recipm1", C.c_float), ("ddpm_c1", C.c_float), ("ddpm_c2", C.c_float),
         ("ddpm_sigma", C.c_float), ("noise", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("step", C.c_uint32), ("tile", C.c_int32),
         ("group_size", C.c_int32), ("w_group_stride", C.c_int64), ("bias_group_stride", C.c_int64), ("a_bias_group_stride", C.c_int64),
-        ("mfma_bf16", C.c_int32), ("ddpm_x0_pred", C.c_int32),
+        ("mfma_bf16", C.c_int32), ("ddpm_x0_pred", C.c_int32), ("e_tiled", C.c_int32), ("reserved2_", C.c_int32),
     ]
 
 
@@ -161,7 +161,8 @@ def load():
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
-    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE16_KS", b"gate16_ks"), ("SS_GATE256", b"gate256"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile")):
+    for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE16_KS", b"gate16_ks"), ("SS_GATE256", b"gate256"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile"), ("SS_E16", b"e16"), ("SS_HTILE", b"htile"),
+                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")
@@ -210,7 +211,7 @@ def conv_gemm(A, W, out, **kw):
 def _fill_args(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,), lens=None, a_bias=None, a_scale=1.0,
                a_lrelu=1.0, epi=EPI_STORE, bias=None, pre_scale=1.0, act=ACT_NONE, act_slope=0.0, E=None, lde=0, e_bs=0,
                gate_mode=0, R=None, ldr=0, r_bs=None, post_scale=1.0, accumulate=False, mask_rows=True, ldc=None, c_bs=None,
-               C2=None, ldc2=0, c2_bs=0, Nh=0, tile=0, group_size=0, w_gs=0, bias_gs=0, a_bias_gs=0, bf16=False):
+               C2=None, ldc2=0, c2_bs=0, Nh=0, tile=0, group_size=0, w_gs=0, bias_gs=0, a_bias_gs=0, bf16=False, e_tiled=False):
     a = ConvGemmArgs()
     a.A = ptr(A); a.lda = lda if lda is not None else Cin
     a.a_batch_stride = a_bs if a_bs is not None else T * a.lda
@@ -228,7 +229,16 @@ def _fill_args(A, W, out, *, B, T, Cin, N, Np, Kp, lda=None, a_bs=None, taps=(0,
     a.C2 = ptr(C2); a.ldc2 = ldc2; a.c2_batch_stride = c2_bs; a.Nh = Nh; a.tile = tile
     a.group_size = group_size; a.w_group_stride = w_gs; a.bias_group_stride = bias_gs; a.a_bias_group_stride = a_bias_gs
     a.mfma_bf16 = 1 if bf16 else 0
+    a.e_tiled = 1 if e_tiled else 0
     return a
+
+
+def gate16_tile_addend(E, *, B, T, Np, lde, e_bs, dilation, mt):
+    """E (this layer's Np packed columns, row stride lde) -> the addend in the 16x16x4 gate kernel's fetch order (ss_gate16_tile_addend)."""
+    n = load().ss_gate16_tiled_floats(B, T, Np, int(dilation), int(mt))
+    out = torch.empty(n, device=E.device, dtype=torch.float32)
+    check(load().ss_gate16_tile_addend(ptr(E), lde, e_bs, ptr(out), B, T, Np, int(dilation), int(mt), stream_ptr()), "ss_gate16_tile_addend")
+    return out
 
 
 def wino_gate(A, Wt, out, *, dilation, **kw):

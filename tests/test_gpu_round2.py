@@ -98,6 +98,19 @@ def test_c2_batch_item_matches_oracle_at_full_size_and_100_steps():
     record_measurement("c2_item3_t1500_100steps_vs_oracle", mel_l1=l1, mel_max=mx, mel_l1_away_from_flips=l1k, voicing_flips=flips,
                        coarse_flips=cflips, f0_max_err_hz=f0e)
     assert l1k <= 1e-5 and mxk <= 1e-3, (l1k, mxk, cflips)
+    # the same item in the split-operand precision modes against the same oracle run (round-4 hardening: these modes were only checked on the
+    # two small goldens): "bf16x3" = F(4,3) gates from 3 bf16 terms per operand, 6 products; "bf16x2" = all hidden GEMMs from (hi, mid) pairs
+    for mode in ("bf16x3", "bf16x2"):
+        m2 = StyleSingerHIP(None, hparams=dict(hp, mfma_precision=mode))
+        m2.load_state_dict(sd)
+        m2.eval().to("cuda:0")
+        got = _fwd(m2, {k: v[i:i + 1].cuda() for k, v in batch.items()}, noise={k: ({kk: vv[:, i:i + 1] if kk in ("z_steps", "u_steps") else vv[i:i + 1] for kk, vv in v.items()}) for k, v in noise.items()})
+        fl = (got["uv_a"][0].cpu().long() != ref["uv_a"][0]).sum().item() + (got["uv_b"][0].cpu().long() != ref["uv_b"][0]).sum().item()
+        d2 = (got["mel_out"][0].cpu() - ref["mel_out"][0]).abs()
+        print(f"C2 item {i} in {mode} mode: mel L1 {d2.mean().item():.3e} max {d2.max().item():.3e}; voicing flips {fl}")
+        record_measurement(f"c2_item3_t1500_100steps_{mode}_vs_oracle", mel_l1=d2.mean().item(), mel_max=d2.max().item(), voicing_flips=fl)
+        assert fl == 0 and d2.mean().item() <= 2e-5, (mode, d2.mean().item())
+        del m2
 
 
 def test_winograd_f43_f23_and_direct_forms_agree_through_the_whole_path(monkeypatch):

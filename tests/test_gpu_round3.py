@@ -86,6 +86,14 @@ def test_c4_shape_item_matches_oracle_with_100_step_chains():
     assert flips == 0
     assert cf.float().mean().item() <= 1e-3
     assert l1k <= 1e-5 and mxk <= 1e-3, (l1k, mxk)
+    # the opt-in bf16x3 mode at this shape against the same oracle run (round-4 hardening; bf16x2 has its own test in test_gpu_round4.py)
+    m3 = _model(dict(hp, mfma_precision="bf16x3"), 2025)
+    got3 = _fwd(m3, {k: v.cuda() for k, v in batch.items()}, noise=noise)
+    d3 = (got3["mel_out"].cpu() - ref["mel_out"]).abs()
+    fl3 = (got3["uv_a"].cpu().long() != ref["uv_a"]).sum().item() + (got3["uv_b"].cpu().long() != ref["uv_b"]).sum().item()
+    print(f"C4 shape in bf16x3 mode: mel L1 {d3.mean().item():.3e} max {d3.max().item():.3e}; voicing flips {fl3}")
+    record_measurement("c4_shape_t5625_100steps_bf16x3_vs_oracle", mel_l1=d3.mean().item(), mel_max=d3.max().item(), voicing_flips=fl3)
+    assert fl3 == 0 and d3.mean().item() <= 2e-5
 
 
 @pytest.mark.parametrize("mt", [1, 2, 3])   # 1 = the small-launch tiling (round 4: one short utterance leaves most CUs idle at MT = 2)

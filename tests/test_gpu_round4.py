@@ -397,3 +397,31 @@ def test_one_utterance_latency_shape_matches_the_oracle():
     m.use_graphs = "off"
     e1 = _fwd(m, b, seed=5)["mel_out"]
     assert torch.equal(g1, g2) and torch.equal(g1, e1)
+
+
+@pytest.mark.parametrize("mt", [1, 2, 3])
+def test_gate16_with_the_addend_in_fetch_order_is_bit_identical(mt):
+    """ss_gate16_tile_addend + ss_conv_gemm_args.e_tiled: the conditioner addend re-laid in the 16x16x4 gate kernel's fetch order (1 KB
+    contiguous per wave instruction instead of 8 lines x 32 B) feeds the SAME values into the same arithmetic - outputs equal the row-major
+    form bit for bit, for the mel shape and the grouped f0-pair shape, every dilation of the cycle, ragged lens (zero-filled tile tails)."""
+    import math
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 + mt)
+    for (B, T, C, Lyr, groups) in ((3, 333, 256, 3, 1), (4, 150, 192, 2, 2)):
+        x = torch.randn(B, T, C, generator=g).to(dv)
+        ws = [torch.randn(2 * C, C, 3, generator=g) / math.sqrt(3 * C) for _ in range(groups)]
+        Wt = torch.stack([L.pack_conv_weight(L.wino43_weight(w.to(dv)), interleave_half=C) for w in ws]).contiguous()
+        Np = Wt.shape[1]
+        W16 = torch.stack([L.pack_gate16_weights(Wt[i], C) for i in range(groups)]).contiguous()
+        ab = torch.randn(groups, C, generator=g).to(dv)
+        E = torch.randn(B, T, Lyr * Np, generator=g).to(dv)
+        lens = torch.tensor([T, T - 5, 1, T - 40][:B], dtype=torch.int32).to(dv)
+        for d in (1, 2, 4, 8):
+            kw = dict(dilation=d, B=B, T=T, Cin=C, N=C, Np=Np, Kp=C, lens=lens, a_bias=ab, ldc=C, mask_rows=True, W16=W16,
+                      group_size=(B // groups if groups > 1 else 0), w_gs=W16[0].numel(), a_bias_gs=C)
+            want = torch.full((B, T, C), 7.0, device=dv)
+            got = torch.full((B, T, C), 9.0, device=dv)
+            L.wino43_gate16(x, Wt, want, mt=mt, E=E[:, :, Np:], lde=Lyr * Np, e_bs=T * Lyr * Np, **kw)
+            E16 = L.gate16_tile_addend(E[:, :, Np:], B=B, T=T, Np=Np, lde=Lyr * Np, e_bs=T * Lyr * Np, dilation=d, mt=mt)
+            L.wino43_gate16(x, Wt, got, mt=mt, E=E16, e_tiled=True, **kw)
+            assert torch.equal(got, want), (mt, C, d, (got - want).abs().max().item())
