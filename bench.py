@@ -221,7 +221,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # above runs the kernel back to back, where the chip clocks down; in the loop it alternates with the projections): average duration of
     # the C2 launches and the executed-MFMA fraction that follows from it. null when no such profile exists for this kernel / shape.
     in_loop = None
-    csv_path = os.path.join(ROOT, "profiles", "r03_bench_c2_1stream_kernel_stats.csv")
+    csv_path = os.path.join(ROOT, "profiles", "r04_bench_c2_1stream_kernel_stats.csv")
     if wino_m == 4 and mt and not x3 and B * T == 12000 and os.path.exists(csv_path):
         try:
             import csv
@@ -229,7 +229,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                 if f"wino43_gate16_kernel<{mt}" in row["Name"]:
                     us = float(row["AverageNs"]) * 1e-3
                     in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak,
-                               "source": "profiles/r03_bench_c2_1stream_kernel_stats.csv"}
+                               "source": "profiles/r04_bench_c2_1stream_kernel_stats.csv"}
                     break
         except (KeyError, ValueError, OSError):
             in_loop = None

@@ -71,7 +71,8 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
     for (int l = 0; l < net->L && l < SS_MAX_LAYERS; ++l) {
       if (!net->w_dil_wino[l] || !net->w_dil_wino16[l]) continue;
       const int d = 1 << (l % net->dil_cycle);
-      const int mt = g_ss_tuning.gate16 == 1 ? ss_wino43_gate16_pick(B, T, 2 * net->C, d) : g_ss_tuning.gate16;
+      int mt = g_ss_tuning.gate16 == 1 ? ss_wino43_gate16_pick(B, T, 2 * net->C, d) : g_ss_tuning.gate16;
+      if (mt == 1 && !(g_ss_tuning.gate16_ks != 0 && net->C >= 64)) mt = 2;   // as ss_wino43_gate16 resolves it (MT = 1 is K-staged only)
       const int64_t fl = mt > 0 ? ss_gate16_tiled_floats(B, T, 2 * net->C, d, mt) : -1;
       if (fl <= 0 || fl * 4 >= (1ll << 31)) continue;
       w.E16[l] = take(fl);

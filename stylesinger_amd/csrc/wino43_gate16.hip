@@ -611,12 +611,13 @@ int gate16_impl(const ss_conv_gemm_args* args, const float* W16, int dilation, i
   SS_CHECK_ARG(!a.e_tiled || (mt != 0 && a.E), "%s: a tiled addend (e_tiled) is laid out for ONE tiling: give mt explicitly", who);
   int log2d = 0;
   while ((1 << log2d) < dilation) ++log2d;
+  // K-staged form (one barrier per K chunk, six components staged at once): needs at least two K chunks
+  const bool ks = g_ss_tuning.gate16_ks != 0 && a.Kp >= 2 * BK;
   if (mt == 0) {
     mt = ss_wino43_gate16_pick(a.B, a.T, a.Np, dilation);
     if (mt == 0) return ss_wino43_gate(args, dilation, stream);   // the 32x32x2 kernel reads the packed rows in args->W
+    if (mt == 1 && !ks) mt = 2;   // the 16-quad tiling only exists in the K-staged form
   }
-  // K-staged form (one barrier per K chunk, six components staged at once): needs at least two K chunks
-  const bool ks = g_ss_tuning.gate16_ks != 0 && a.Kp >= 2 * BK;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
   if (mt == 1) {   // small launches only: the K-staged form with the weights in whichever layout the caller has

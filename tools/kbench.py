@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--net", default="both", help="mel|f0|both")
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--T", type=int, default=1500)
+    ap.add_argument("--e16", action="store_true", help="wino43_16: conditioner addend in the kernel's fetch order (ss_gate16_tile_addend)")
     ap.add_argument("--prio", type=int, default=-1, help="ss_set_tuning('wave_prio', N)")
     ap.add_argument("--mt", default="-1,3,2", help="wino43_16: comma list of tilings (-1 = the 32x32x2 kernel, 0 = library pick, 2, 3)")
     ap.add_argument("--w16", type=int, default=1, help="wino43_16: 1 = weights in the kernel's fetch order (ss_wino43_gate16w), 0 = packed rows")
@@ -125,11 +126,16 @@ def main():
             En = torch.randn(Bn, T, Lyr * 2 * C, device=d)
             ln = torch.full((Bn,), T, device=d, dtype=torch.int32)
             for mt in [int(v) for v in a.mt.split(",")]:
+                # --e16: the addend of every layer slab in the kernel's fetch order (what the loops launch since round 4)
+                E16s = [L.gate16_tile_addend(En[:, :, l * 2 * C:], B=Bn, T=T, Np=2 * C, lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, dilation=2, mt=mt)
+                        for l in range(Lyr)] if (a.e16 and mt > 0 and not a.x3) else None
                 def fw16():
                     layer[0] = (layer[0] + 1) % Lyr
                     kw = dict(dilation=2, B=Bn, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=ln, a_bias=ab,
                               E=En[:, :, layer[0] * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C)
                     kwx = kw
+                    if E16s is not None:
+                        kw = dict(kw, E=E16s[layer[0]], e_tiled=True)
                     if mt < 0:
                         L.wino43_gate(Xn, Wt4, Gn, **kw)
                     elif a.x3:

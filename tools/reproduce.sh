@@ -7,6 +7,7 @@
 #   bench [args]     python bench.py [args]                   (the driver's line; default = c2 + cpu_baseline + secondary c5 / c4)
 #   profile [args]   rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary [args]`
 #   pmc-gate         PMC passes on the dominant kernel launch (one counter block per pass, --kernel-trace --pmc only)
+#   pmc-gate-c4x2    the same for the split-operand (bf16x2) 256x256 gate kernel at the C4 shape (tools/pmc_split.sh)
 #   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs direct vs grouped F(4,3))
 #   ablate-gate16    timing ablations of the 16x16-tile gate kernel (debug builds: tools/ablate_g16.sh build, in the container)
 #   ablate-res16     the same for the residual-projection kernel (tools/ablate_r16.sh build, in the container)
@@ -26,13 +27,15 @@ case "$sec" in
     grep -E "^\{" gpurun_out/prof_bench.log | cut -c1-600
     head -30 "$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)" | cut -c1-220 ;;
   pmc-gate)
-    K="python $R/tools/kbench.py --which wino43_16 --net mel --iters 20 --mt ${1:-3}"
+    K="python $R/tools/kbench.py --which wino43_16 --net mel --iters 20 --e16 --mt ${1:-2}"
     bash tools/pmc.sh g16_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -- $K
     bash tools/pmc.sh g16_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS -- $K
     bash tools/pmc.sh g16_grbm GRBM_GUI_ACTIVE -- $K
     bash tools/pmc.sh g16_fetch FETCH_SIZE -- $K
     bash tools/pmc.sh g16_write WRITE_SIZE -- $K
     bash tools/pmc.sh g16_tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -- $K ;;
+  pmc-gate-c4x2)
+    bash tools/pmc_split.sh ;;
   kbench)
     python tools/kbench.py --which wino43_16 --iters 60 --mt=-1,3,2
     python tools/kbench.py --which res16 --iters 60 --mt 6
