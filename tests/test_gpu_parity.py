@@ -312,9 +312,12 @@ def test_style_transfer_sweep_equals_uncached_batches():
         it = synth.synth_utterance(200 + j, T, Tp, 8, hp, 5)
         targets.append({k: it[k] for k in ("txt_tokens", "note", "note_dur", "note_type", "mel2ph")})
     got = {}
-    n_pairs, n_frames = style_transfer_sweep(inf, refs, targets, batch=2, ddim_steps=4, seed=77,
+    stats = {}
+    n_pairs, n_frames = style_transfer_sweep(inf, refs, targets, batch=2, ddim_steps=4, seed=77, stats=stats,
                                              emit=lambda r, t, mel, f0, wav: got.__setitem__((r, t), (mel.clone(), f0.clone(), wav.clone())))
     assert n_pairs == 6 and n_frames == 3 * (48 + 64) and len(got) == 6
+    # per-reference style cache: 3 references encoded once each, served from the cache for the second target
+    assert stats["style_encodes"] == 3 and stats["style_cache_hits"] == 3 and stats["pairs"] == 6 and stats["refs_on_rank"] == 3
     dev = inf.device
     for t, tgt in enumerate(targets):
         for ridx in ([0, 1], [2]):

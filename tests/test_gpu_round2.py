@@ -332,6 +332,20 @@ def test_batches_in_flight_equal_sequential_runs():
     for i, b in enumerate(batches):
         want = inf.infer_batch(b, seed=40 + i)
         assert torch.equal(got[i]["mel"], want["mel"]) and torch.equal(got[i]["wav"], want["wav"]), i
+    # a LAZY producer (round 4): the generator is consumed one batch at a time - at most in_flight batches have been pulled
+    # when the first result comes back - and the results are the same bits
+    pulled = []
+
+    def producer():
+        for i, b in enumerate(batches):
+            pulled.append(i)
+            yield b
+    it = inf.infer_batches(producer(), in_flight=2, seed=40)
+    first = next(it)
+    assert len(pulled) <= 3, pulled          # two in flight + the one whose arrival released the first result
+    rest = [first] + list(it)
+    torch.cuda.synchronize()
+    assert len(rest) == 5 and all(torch.equal(rest[i]["mel"], got[i]["mel"]) for i in range(5))
 
 
 def test_bf16_mode_on_the_1000_step_golden_reports_its_distance_to_the_fp32_reference():
