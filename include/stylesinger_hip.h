@@ -278,7 +278,12 @@ typedef struct ss_gemm_bf16_args {
    * weights) and for the bf16 OUTPUTS (GATE's C, RESX's Y: logical channel c of the output lands at (c >> 5) * 64 + (c & 31), its mid term 32
    * further; ldc / ldy are physical strides). */
   int32_t split;
-  int32_t reserved_[5];
+  int32_t reserved_[3];
+  /* RESX with split operands and X == NULL ("pair-only residual stream"): the stream lives ONLY as the (hi, mid) pair Y = x + cur_bias (16
+   * significand bits - measured harmless on the reference's 1000-step golden: 2.4e-6 either way, oracle/bf16x2_numerics.py). The epilogue reads
+   * its element of Y, recovers x = hi + mid - cur_bias, and writes Y = pair(x_new + next_bias) in place: 3 instead of 4 KB per row of traffic. */
+  const float* cur_bias;
+  int64_t cur_bias_group_stride;
 } ss_gemm_bf16_args;
 int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
 /* The SS_HEPI_GATE form of ss_gemm_bf16 for many-round launches (BASELINE config 4): three taps (-d, 0, d) with d <= 8, K = 256,

@@ -319,7 +319,12 @@ def residual_stack(sd, prefix, x, cond, demb, L, cycle):
         d = 2 ** (l % cycle)
         ds = F.linear(demb, sd[p + ".diffusion_projection.weight"], sd[p + ".diffusion_projection.bias"])[:, None, :]
         c = conv1d_cl(cond, sd[p + ".conditioner_projection.weight"], sd[p + ".conditioner_projection.bias"], rounded="hoisted")
-        y = conv1d_cl(x + ds, sd[p + ".dilated_conv.weight"], sd[p + ".dilated_conv.bias"], dilation=d, rounded=True) + c
+        xin = x + ds
+        if _ROUND == "bf16x2":   # the HIP path keeps the residual stream ONLY as the (hi, mid) pair of x + dstep_l (16 significant bits)
+            hi, mid = _split2(xin)
+            xin = hi + mid
+            x = xin - ds
+        y = conv1d_cl(xin, sd[p + ".dilated_conv.weight"], sd[p + ".dilated_conv.bias"], dilation=d, rounded=True) + c
         y = torch.sigmoid(y[..., :C]) * torch.tanh(y[..., C:])
         y = conv1d_cl(y, sd[p + ".output_projection.weight"], sd[p + ".output_projection.bias"], rounded=True)
         x = (x + y[..., :C]) / math.sqrt(2.0)

@@ -207,6 +207,8 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     g.ldc = L * C * pl;
     g.c_batch_stride = (int64_t)T * L * C * pl;
     SS_PROPAGATE(ss_gemm_bf16(&g, stream));
+    // the residual stream of the LAST layer is never read (only the skip sum leaves the stack, net.py:120-127): no projection for it
+    if (l + 1 == L) break;
     ss_gemm_bf16_args o = base_args_h(net, B, T, lens);
     o.A = w.GAh + (int64_t)l * C * pl;
     o.lda = L * C * pl;
@@ -220,16 +222,19 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     o.epi = SS_HEPI_RESX;
     o.bias = net->b_out[l];
     o.bias_group_stride = net->gs_b_out;
-    o.X = w.X;
-    o.ldx = C;
-    o.x_batch_stride = (int64_t)T * C;
     o.post_scale = 0.70710678118654752440f;
-    if (l + 1 < L) {
-      o.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
-      o.next_bias_group_stride = net->gs_dstep;
-      o.Y = w.Yh;
-      o.ldy = C * pl;
-      o.y_batch_stride = (int64_t)T * C * pl;
+    o.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
+    o.next_bias_group_stride = net->gs_dstep;
+    o.Y = w.Yh;
+    o.ldy = C * pl;
+    o.y_batch_stride = (int64_t)T * C * pl;
+    if (sp) {   // split mode: the stream lives only as the pair Yh = x + dstep_l (16 significant bits; measured harmless, oracle/bf16x2_numerics.py)
+      o.cur_bias = net->dstep + ((int64_t)step * L + l) * C;
+      o.cur_bias_group_stride = net->gs_dstep;
+    } else {
+      o.X = w.X;
+      o.ldx = C;
+      o.x_batch_stride = (int64_t)T * C;
     }
     SS_PROPAGATE(ss_gemm_bf16(&o, stream));
   }
@@ -330,6 +335,8 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
       SS_PROPAGATE(ss_conv_gemm(&a, stream));
     }
     // y = output_projection(g) ; x = (x + y[:C]) / sqrt(2) ; skip += y[C:]   (net.py:75-77)
+    // deferred-skip form: this launch only produces the residual stream, and the LAST layer's stream is never read (net.py:120-127)
+    if (defer && l + 1 == L) break;
     ss_conv_gemm_args o = base_args(B, T, lens);
     o.A = Gl;
     o.lda = ldg;

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     }
   } else {  // SS_HEPI_RESX: x <- (x + acc + bias) * post_scale (fp32, in place); y = bf16(x_new + next_bias) for the next layer's conv
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(a.X + (int64_t)b * a.x_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldx * 4)), 0x00020000);
+        uniform_ptr(a.X ? (void*)(a.X + (int64_t)b * a.x_batch_stride) : (void*)a.W), 0, __builtin_amdgcn_readfirstlane(a.X ? (int)((int64_t)a.T * a.ldx * 4) : 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(a.Y ? (void*)(a.Y + (int64_t)b * a.y_batch_stride) : (void*)a.X), 0,
         __builtin_amdgcn_readfirstlane(a.Y ? (int)((int64_t)a.T * a.ldy * 2) : 0), 0x00020000);
@@ -345,16 +345,30 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
         const int xoff = (row0 * a.ldx + col) * 4 | dead;
         const int yoff = (row0 * a.ldy + (SPLIT ? (col >> 5) * 64 + (col & 31) : col)) * 2 | dead;
         float xv[16];
+        const bool pair_only = SPLIT && a.X == nullptr;   // the residual stream lives only as the (hi, mid) pair Y = x + cur_bias
+        if (pair_only) {
+          if constexpr (SPLIT) {
+            const float* cbg = a.cur_bias + (int64_t)grp_w * a.cur_bias_group_stride;
+            const float cb = dead ? 0.f : cbg[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = ((r & 3) + 8 * (r >> 2)) * ldy2;
+              const uint16_t h = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc_y, yoff + ro, 0, 0), mdl = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc_y, yoff + ro, 64, 0);
+              xv[r] = (bf2f(h) + bf2f(mdl)) - cb;
+            }
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           xv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, xoff + ((r & 3) + 8 * (r >> 2)) * ldx4, 0, 0));
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
           float xn = (xv[r] + (acc[m][n][r] + bs)) * a.post_scale;
           const bool pad = row0 + rr >= row_lim;
           if (pad) xn = 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xn), rsrc_x, xoff + rr * ldx4, 0, 0);
+          if (!pair_only) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xn), rsrc_x, xoff + rr * ldx4, 0, 0);
           const float yv = pad ? 0.f : xn + nb;
           const uint16_t yh = f2bf(yv);
           __builtin_amdgcn_raw_buffer_store_b16(yh, rsrc_y, yoff + rr * ldy2, 0, 0);
@@ -471,7 +485,7 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
       if (g_ss_tuning.gate256 && ss_gemm_bf16_gate256_ok(&a)) return ss_gemm_bf16_gate256(&a, stream_);   // (returns 0 for split operands)
       return launch_tiles<SS_HEPI_GATE>(a, stream);
     case SS_HEPI_RESX:
-      SS_CHECK_ARG(a.X != nullptr, "ss_gemm_bf16: RESX needs X");
+      SS_CHECK_ARG(a.X != nullptr || (a.split && a.Y && a.cur_bias), "ss_gemm_bf16: RESX needs X (or, with split operands, Y + cur_bias: the pair-only stream)");
       return launch_tiles<SS_HEPI_RESX>(a, stream);
     default: break;
   }

@@ -79,7 +79,7 @@ class GemmBf16Args(C.Structure):
         ("gate_mode", C.c_int32), ("e_batch_stride", C.c_int64), ("X", _vp), ("x_batch_stride", C.c_int64), ("ldx", C.c_int32),
         ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
         ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
-        ("split", C.c_int32), ("reserved_", C.c_int32 * 5),
+        ("split", C.c_int32), ("reserved_", C.c_int32 * 3), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
     ]
 
 
@@ -449,7 +449,7 @@ def split_planes(y):
 
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
               next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False,
-              split=0):
+              split=0, cur_bias=None):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -469,6 +469,7 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
     a.mask_rows = int(mask_rows)
     a.split = split
+    a.cur_bias = ptr(cur_bias)
     if gate256:   # the 256x256 LDS-DMA kernel directly (ss_gemm_bf16 picks it by itself for many-round launches)
         check(load().ss_gemm_bf16_gate256(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate256")
         return

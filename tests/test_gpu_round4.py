@@ -256,6 +256,20 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
         y_ref[b, lens[b]:] = 0
     yh, ym = L.split_planes(Y)
     assert ((yh + ym) - y_ref).abs().max().item() <= 1e-4
+    # the pair-only residual stream (X = NULL): Y holds x + cur_bias as a pair, is read, updated and rewritten in place
+    cb = torch.randn(C, generator=g).to(dev)
+    Yp = L.split_bf16(X0 + cb)
+    for b in range(B):
+        Yp[b, lens[b]:] = 0
+    y0h, y0m = L.split_planes(Yp)
+    L.gemm_bf16(GA[..., 2 * C:], Wos, B=B, T=T, K=C, taps=(0,), N=C, Np=Wos.shape[0], epi=L.HEPI_RESX, lens=lens, bias=L.pack_bias(bo), X=None,
+                post_scale=0.5 ** 0.5, next_bias=nb, Y=Yp, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=1, cur_bias=cb)
+    x_in = (y0h + y0m) - cb
+    xp_ref = ((x_in.double() + (gm @ woh.t() + gh @ wom.t() + gh @ woh.t() + bo.double())) * (0.5 ** 0.5)).float() + nb
+    for b in range(B):
+        xp_ref[b, lens[b]:] = 0
+    y1h, y1m = L.split_planes(Yp)
+    assert ((y1h + y1m) - xp_ref).abs().max().item() <= 1e-4
     # STORE with ReLU on the K = Lyr * C (skip-GEMM form) operand
     w2 = (torch.randn(C, Lyr * C, 1, generator=g) / (Lyr * C) ** 0.5).to(dev)
     S = torch.empty(B, T, C, device=dev)
