@@ -292,6 +292,12 @@ int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
  * say so; same arithmetic contract, results equal up to the K summation order. */
 int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* args);
+/* The split-operand 1-tap forms of ss_gemm_bf16 for many-round launches (BASELINE config 4 in bf16x2 precision): SS_HEPI_RESX on the pair-only
+ * stream (X = NULL) and SS_HEPI_STORE (the K = L*C skip GEMM), N <= 256, K a multiple of 64. 256 rows x all columns per workgroup, 8 waves, both
+ * operands by LDS-DMA, epilogues through LDS as 16-byte vectors. ss_gemm_bf16 dispatches here when ss_gemm_bf16_tile256_ok(args) (and the
+ * "gate256" knob) say so; same arithmetic contract, results equal up to the K summation order. */
+int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream);
+int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
 /* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,

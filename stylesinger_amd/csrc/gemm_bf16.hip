@@ -333,6 +333,65 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
     const float* nbg = a.next_bias ? a.next_bias + (int64_t)grp_w * a.next_bias_group_stride : nullptr;
     const int ldx4 = a.ldx * 4, ldy2 = a.ldy * 2;
+    if constexpr (SPLIT) {
+      if (a.X == nullptr) {
+        // Pair-only residual stream (the form the bf16x2 loops launch): the accumulator tile goes through LDS so that every thread owns 8
+        // CONSECUTIVE channels of a row - the (hi, mid) pairs of the stream are then read and written as 16-byte vectors (full lines per wave
+        // instruction) instead of 2-byte accesses per lane (the per-lane form was VMEM-instruction bound: 64 narrow accesses per thread).
+        static_assert(BM * BN * 4 <= 2 * (BM + BN) * (LDH * 2), "the staged accumulator tile must fit the operand buffers");
+        __syncthreads();   // every wave is done reading the last chunk's fragments
+        float* St = reinterpret_cast<float*>(smem_h);   // [BM][BN] fp32
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              St[(wm * 32 * TM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * 32 * TN + n * 32 + l31] = acc[m][n][r];
+        __syncthreads();
+        const int g8 = tid & 15, col0 = n0 + g8 * 8;    // this thread's 8 channels (N is a multiple of 32: the group is valid or not as a whole)
+        const int dead = col0 < a.N ? 0 : (int)0x80000000;
+        const float* cbg = a.cur_bias + (int64_t)grp_w * a.cur_bias_group_stride;
+        float bs[8], nb[8], cb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bs[e] = (biasg && !dead) ? biasg[col0 + e] : 0.f;
+          nb[e] = (nbg && !dead) ? nbg[col0 + e] : 0.f;
+          cb[e] = !dead ? cbg[col0 + e] : 0.f;
+        }
+        const int phys = (col0 >> 5) * 64 + (col0 & 31);   // element of the hi terms inside the row; the mid terms sit 32 elements (64 B) further
+#pragma unroll
+        for (int i = 0; i < BM / 16; ++i) {
+          const int row_l = (tid >> 4) + 16 * i, row = t0 + row_l;
+          const float4 a0 = *reinterpret_cast<const float4*>(St + row_l * BN + g8 * 8), a1 = *reinterpret_cast<const float4*>(St + row_l * BN + g8 * 8 + 4);
+          const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const int yo = (row * a.ldy + phys) * 2 | dead;
+          const u32x4 hv = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, yo, 0, 0), mv = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, yo, 64, 0);
+          const bool pad = row >= row_lim;
+          u32x4 ho, mo;
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            uint32_t hp = 0, mp = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int e = 2 * e2 + k;
+              const float hf = __builtin_bit_cast(float, k ? (hv[e2] & 0xffff0000u) : (hv[e2] << 16));
+              const float mf = __builtin_bit_cast(float, k ? (mv[e2] & 0xffff0000u) : (mv[e2] << 16));
+              const float xn = (((hf + mf) - cb[e]) + (av[e] + bs[e])) * a.post_scale;
+              const float yv = pad ? 0.f : xn + nb[e];
+              const uint16_t yh = f2bf(yv), ym = f2bf(yv - bf2f(yh));
+              hp |= (uint32_t)yh << (16 * k);
+              mp |= (uint32_t)ym << (16 * k);
+            }
+            ho[e2] = hp;
+            mo[e2] = mp;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(ho, rsrc_y, yo, 0, 0);    // rows >= T are out of range: dropped
+          __builtin_amdgcn_raw_buffer_store_b128(mo, rsrc_y, yo, 64, 0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = col_base + n * 32 + l31;
@@ -345,30 +404,16 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
         const int xoff = (row0 * a.ldx + col) * 4 | dead;
         const int yoff = (row0 * a.ldy + (SPLIT ? (col >> 5) * 64 + (col & 31) : col)) * 2 | dead;
         float xv[16];
-        const bool pair_only = SPLIT && a.X == nullptr;   // the residual stream lives only as the (hi, mid) pair Y = x + cur_bias
-        if (pair_only) {
-          if constexpr (SPLIT) {
-            const float* cbg = a.cur_bias + (int64_t)grp_w * a.cur_bias_group_stride;
-            const float cb = dead ? 0.f : cbg[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int ro = ((r & 3) + 8 * (r >> 2)) * ldy2;
-              const uint16_t h = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc_y, yoff + ro, 0, 0), mdl = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc_y, yoff + ro, 64, 0);
-              xv[r] = (bf2f(h) + bf2f(mdl)) - cb;
-            }
-          }
-        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           xv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, xoff + ((r & 3) + 8 * (r >> 2)) * ldx4, 0, 0));
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
           float xn = (xv[r] + (acc[m][n][r] + bs)) * a.post_scale;
           const bool pad = row0 + rr >= row_lim;
           if (pad) xn = 0.f;
-          if (!pair_only) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xn), rsrc_x, xoff + rr * ldx4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xn), rsrc_x, xoff + rr * ldx4, 0, 0);
           const float yv = pad ? 0.f : xn + nb;
           const uint16_t yh = f2bf(yv);
           __builtin_amdgcn_raw_buffer_store_b16(yh, rsrc_y, yoff + rr * ldy2, 0, 0);
@@ -387,10 +432,11 @@ int launch_h(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const int n_tiles = ss_cdiv(n_cols, BN);
   const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
   const size_t lds = (size_t)2 * (BM + BN) * (LDH * 2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // per device and cheap: set on every launch (a process may drive several GPUs), a failure is reported, never cached
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) {
+    ss_set_error("ss_gemm_bf16: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(attr));
+    return SS_ERR_HIP;
   }
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, SPLIT>), dim3(grid), dim3(256), lds, stream, a, m_tiles_per_item, m_tiles, n_tiles);
   SS_CHECK_LAUNCH("ss_gemm_bf16");
@@ -478,6 +524,7 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
   switch (a.epi) {
     case SS_HEPI_STORE:
       SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: STORE needs C");
+      if (g_ss_tuning.gate256 && ss_gemm_bf16_tile256_ok(&a)) return ss_gemm_bf16_tile256(&a, stream_);   // many-round split launches
       return launch_tiles<SS_HEPI_STORE>(a, stream);
     case SS_HEPI_GATE:
       SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: GATE needs C");
@@ -486,6 +533,7 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
       return launch_tiles<SS_HEPI_GATE>(a, stream);
     case SS_HEPI_RESX:
       SS_CHECK_ARG(a.X != nullptr || (a.split && a.Y && a.cur_bias), "ss_gemm_bf16: RESX needs X (or, with split operands, Y + cur_bias: the pair-only stream)");
+      if (g_ss_tuning.gate256 && ss_gemm_bf16_tile256_ok(&a)) return ss_gemm_bf16_tile256(&a, stream_);
       return launch_tiles<SS_HEPI_RESX>(a, stream);
     default: break;
   }

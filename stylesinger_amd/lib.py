@@ -470,8 +470,11 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.mask_rows = int(mask_rows)
     a.split = split
     a.cur_bias = ptr(cur_bias)
-    if gate256:   # the 256x256 LDS-DMA kernel directly (ss_gemm_bf16 picks it by itself for many-round launches)
-        check(load().ss_gemm_bf16_gate256(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate256")
+    if gate256:   # the 256-row LDS-DMA kernels directly (ss_gemm_bf16 picks them by itself for many-round launches)
+        if epi == HEPI_GATE:
+            check(load().ss_gemm_bf16_gate256(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate256")
+        else:
+            check(load().ss_gemm_bf16_tile256(C.byref(a), stream_ptr()), "ss_gemm_bf16_tile256")
         return
     check(load().ss_gemm_bf16(C.byref(a), stream_ptr()), "ss_gemm_bf16")
 

@@ -184,7 +184,7 @@ def _split_ref(x):
     return hi, (x - hi).to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("T,K,force256", [(200, 256, False), (333, 192, False), (5600, 256, False), (5600, 256, True)])
+@pytest.mark.parametrize("T,K,force256", [(200, 256, False), (333, 192, False), (5600, 256, False), (5600, 256, True), (777, 256, True)])
 def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K, force256):
     """ss_gemm_bf16 with split = 1 (A and W as (hi, mid) bf16 pairs in one row; hi*hi + hi*mid + mid*hi, fp32 accumulate) against float64
     math on the SAME split terms: GATE (3-tap dilated conv + addend, outputs written as (hi, mid) pairs), RESX (fp32 residual stream + the next
@@ -263,7 +263,8 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
         Yp[b, lens[b]:] = 0
     y0h, y0m = L.split_planes(Yp)
     L.gemm_bf16(GA[..., 2 * C:], Wos, B=B, T=T, K=C, taps=(0,), N=C, Np=Wos.shape[0], epi=L.HEPI_RESX, lens=lens, bias=L.pack_bias(bo), X=None,
-                post_scale=0.5 ** 0.5, next_bias=nb, Y=Yp, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=1, cur_bias=cb)
+                post_scale=0.5 ** 0.5, next_bias=nb, Y=Yp, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=1, cur_bias=cb,
+                gate256=force256)   # force256: the 256-row LDS-DMA kernel (ss_gemm_bf16_tile256) instead of the generic one
     x_in = (y0h + y0m) - cb
     xp_ref = ((x_in.double() + (gm @ woh.t() + gh @ wom.t() + gh @ woh.t() + bo.double())) * (0.5 ** 0.5)).float() + nb
     for b in range(B):
@@ -275,10 +276,10 @@ def test_gemm_bf16_split_operands_match_float64_of_the_same_three_products(T, K,
     S = torch.empty(B, T, C, device=dev)
     GA[..., :2 * C] = L.split_bf16(torch.randn(B, T, C, generator=g).to(dev))   # fill layer slot 0 with real operands
     L.gemm_bf16(GA, L.split_bf16(L.pack_conv_weight(w2)), B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=L.round_up(C, 32), epi=L.HEPI_STORE,
-                lens=lens, act=L.ACT_RELU, out=S, lda=2 * Lyr * C, split=1)
+                lens=lens, act=L.ACT_RELU, out=S, lda=2 * Lyr * C, split=1, bias=L.pack_bias(bo), gate256=force256)
     ah, am = (t.double() for t in L.split_planes(GA))
     w2h, w2m = (t.double() for t in _split_ref(w2[:, :, 0]))
-    s_ref = torch.relu(am @ w2h.t() + ah @ w2m.t() + ah @ w2h.t()).float()
+    s_ref = torch.relu(am @ w2h.t() + ah @ w2m.t() + ah @ w2h.t() + bo.double()).float()
     for b in range(B):
         s_ref[b, lens[b]:] = 0
     assert (S - s_ref).abs().max().item() <= 2e-5 * (Lyr * C) ** 0.5

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--which", default="all")
     ap.add_argument("--split", action="store_true", help="bf16x2: (hi, mid) operand pairs, three products (ss_gemm_bf16_args.split)")
+    ap.add_argument("--pair-only", action="store_true", help="res with --split: the pair-only residual stream (X = NULL, Y read + rewritten in place)")
     ap.add_argument("--no-e", action="store_true", help="gate without the conditioner addend (what-if: how much of the launch is the addend?)")
     ap.add_argument("--e-layout", default="row", help="'row' = [B][T][L*2C], 'layer' = [L][B][T][2C]")
     a = ap.parse_args()
@@ -57,12 +58,13 @@ def main():
         res.append(("bf16 gate K=768 N=512" + (" split x3" if a.split else ""), s, (3.0 if a.split else 1.0) * 2.0 * B * T * 3 * C * 2 * C,
                     B * T * (sp * 2.0 * C + 4.0 * 2 * C + sp * 2.0 * C)))
     if a.which in ("res", "all"):
+        po = a.split and a.pair_only
         def fr():
-            L.gemm_bf16(Gh, Woh, B=B, T=T, K=C, taps=(0,), N=C, Np=Woh.shape[0], epi=L.HEPI_RESX, lens=lens, X=X, post_scale=0.7071,
-                        next_bias=nb, Y=Yh, split=int(a.split))
+            L.gemm_bf16(Gh, Woh, B=B, T=T, K=C, taps=(0,), N=C, Np=Woh.shape[0], epi=L.HEPI_RESX, lens=lens, X=None if po else X, post_scale=0.7071,
+                        next_bias=nb, Y=Yh, split=int(a.split), cur_bias=nb if po else None)
         s = timeit(fr, a.iters)
-        res.append(("bf16 residual projection K=256 N=256" + (" split x3" if a.split else ""), s, (3.0 if a.split else 1.0) * 2.0 * B * T * C * C,
-                    B * T * (sp * 2.0 * C + 4.0 * C + 4.0 * C + sp * 2.0 * C)))
+        res.append(("bf16 residual projection K=256 N=256" + (" split x3" if a.split else "") + (" pair-only stream" if po else ""), s,
+                    (3.0 if a.split else 1.0) * 2.0 * B * T * C * C, B * T * (sp * 2.0 * C + (sp * 2.0 * C if po else 4.0 * C + 4.0 * C) + sp * 2.0 * C)))
     for name, s, fl, by in res:
         print(f"{name:40s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.1f} TF/s ({fl / s / 2.5e15 * 100:4.1f}% of bf16 peak)  {by / s / 1e12:5.2f} TB/s algorithmic HBM")
 
