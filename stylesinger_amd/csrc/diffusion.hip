@@ -469,69 +469,120 @@ __device__ __forceinline__ float log_add_exp(float a, float b) {
   return m + logf(expf(a - m) + expf(b - m));
 }
 
-// One reverse step of the joint sampler for every frame (gaussian_p_sample :326-333, p_sample :410-413,
-// q_posterior :374-397, log_sample_categorical :447-452).
-__global__ void f0_update_kernel(const float* __restrict__ O, float* __restrict__ f0, int32_t* __restrict__ uv,
-                                 const float* __restrict__ lo, const float* __restrict__ hi,
-                                 const float* __restrict__ noise, const float* __restrict__ gumbel_u, uint64_t seed,
-                                 const uint64_t* __restrict__ seed_dev, int step, int B, int T, float recip, float recipm1, float c1, float c2, float sigma,
-                                 float log_alpha_t, float log_1m_alpha_t, float log_cp_tm1, float log_1m_cp_tm1) {
-  const int64_t n = (int64_t)B * T;
-  const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
+// One reverse step of the joint sampler for one frame (gaussian_p_sample :326-333, p_sample :410-413,
+// q_posterior :374-397, log_sample_categorical :447-452): (eps, l0, l1) = the network's three outputs for frame i = (b, t).
+struct F0StepCoef {
+  float recip, recipm1, c1, c2, sigma, log_alpha_t, log_1m_alpha_t, log_cp_tm1, log_1m_cp_tm1;
+};
+__device__ __forceinline__ void f0_update_row(float eps, float l0, float l1, int64_t i, int b, int t, int T, float& f0v, int32_t& uvv, float lo, float hi,
+                                              const float* __restrict__ noise, const float* __restrict__ gumbel_u, const SsPhilox& rng, int step,
+                                              const F0StepCoef& k) {
   const float LOG2 = 0.69314718055994530942f;
   const float LOG_TINY = -69.07755278982137f;  // log(1e-30) as torch computes log(clamp(onehot, 1e-30))
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / T), t = (int)(i % T);
-    const float eps = O[i * 4 + 0];
-    const float l0 = O[i * 4 + 1], l1 = O[i * 4 + 2];
-    float z = 0.f, u0, u1;
-    if (noise) {
-      z = noise[i];
+  float z = 0.f, u0, u1;
+  if (noise) z = noise[i];
+  if (gumbel_u) {
+    u0 = gumbel_u[((int64_t)b * 2 + 0) * T + t];
+    u1 = gumbel_u[((int64_t)b * 2 + 1) * T + t];
+  }
+  if (!noise || !gumbel_u) {
+    uint32_t o[4];
+    rng.gen((uint32_t)t, (uint32_t)b, (uint32_t)step, 0x46305556u, o);  // counter = (frame, item): invariant to T padding
+    float z0, z1;
+    ss_boxmuller(o[0], o[1], z0, z1);
+    if (!noise) z = z0;
+    if (!gumbel_u) {
+      u0 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
+      u1 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
     }
-    if (gumbel_u) {
-      u0 = gumbel_u[((int64_t)b * 2 + 0) * T + t];
-      u1 = gumbel_u[((int64_t)b * 2 + 1) * T + t];
-    }
-    if (!noise || !gumbel_u) {
-      uint32_t o[4];
-      rng.gen((uint32_t)t, (uint32_t)b, (uint32_t)step, 0x46305556u, o);  // counter = (frame, item): invariant to T padding
-      float z0, z1;
-      ss_boxmuller(o[0], o[1], z0, z1);
-      if (!noise) z = z0;
-      if (!gumbel_u) {
-        u0 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
-        u1 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
+  }
+  // ---- Gaussian f0 ----
+  const float x = f0v;
+  float x0 = k.recip * x - k.recipm1 * eps;
+  x0 = fminf(fmaxf(x0, lo), hi);
+  const float mean = k.c1 * x0 + k.c2 * x;
+  f0v = mean + k.sigma * z;
+  // ---- multinomial uv ----
+  const int cls = uvv != 0 ? 1 : 0;
+  const float lx0 = cls == 0 ? 0.f : LOG_TINY, lx1 = cls == 1 ? 0.f : LOG_TINY;
+  // log_softmax
+  const float m = fmaxf(l0, l1);
+  const float lse = logf(expf(l0 - m) + expf(l1 - m));
+  const float p0 = (l0 - m) - lse, p1 = (l1 - m) - lse;
+  float ev0, ev1;
+  if (step == 0) {
+    ev0 = p0;
+    ev1 = p1;
+  } else {
+    ev0 = log_add_exp(p0 + k.log_cp_tm1, k.log_1m_cp_tm1 - LOG2);
+    ev1 = log_add_exp(p1 + k.log_cp_tm1, k.log_1m_cp_tm1 - LOG2);
+  }
+  const float un0 = ev0 + log_add_exp(lx0 + k.log_alpha_t, k.log_1m_alpha_t - LOG2);
+  const float un1 = ev1 + log_add_exp(lx1 + k.log_alpha_t, k.log_1m_alpha_t - LOG2);
+  const float mm = fmaxf(un0, un1);
+  const float nlse = mm + logf(expf(un0 - mm) + expf(un1 - mm));
+  const float q0 = un0 - nlse, q1 = un1 - nlse;
+  const float g0 = -logf(-logf(u0 + 1e-30f) + 1e-30f);
+  const float g1 = -logf(-logf(u1 + 1e-30f) + 1e-30f);
+  uvv = (g1 + q1) > (g0 + q0) ? 1 : 0;  // argmax, first max wins ties
+}
+
+// The tail of an f0 network evaluation in ONE launch (round 4): output projection (C -> 3: a GEMV per frame, not matrix-core work - it ran on a
+// 128x32 MFMA tile with 29 dead columns), the joint sampler update, and the NEXT evaluation's input row x[:, :C/2] = w*f0 + b ;
+// x[:, C/2:] = uv_embed[uv] (net.py:249-252): 3 launches per step -> 1. 16 lanes per frame: lane j owns the float4s j, j + 16, ... of the row.
+__global__ __launch_bounds__(256) void f0_tail_kernel(const float* __restrict__ G, const float* __restrict__ w_final, const float* __restrict__ b_final,
+                                                      float* __restrict__ f0, int32_t* __restrict__ uv, const float* __restrict__ lo,
+                                                      const float* __restrict__ hi, const float* __restrict__ noise,
+                                                      const float* __restrict__ gumbel_u, uint64_t seed, const uint64_t* __restrict__ seed_dev, int step,
+                                                      int B, int T, int C, F0StepCoef k, const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                      const float* __restrict__ uv_embed, float* __restrict__ X, const int32_t* __restrict__ lens,
+                                                      int group_size, int64_t gs_wf, int64_t gs_bf, int64_t gs_w, int64_t gs_b, int64_t gs_e) {
+  const int64_t n = (int64_t)B * T;
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (i >= n) return;   // whole 16-lane groups leave together
+  const int j = threadIdx.x & 15;
+  const int b = (int)(i / T), t = (int)(i % T);
+  const int g = group_size > 0 ? b / group_size : 0;
+  const float* Gr = G + i * C;
+  const float* W = w_final + g * gs_wf;   // packed rows [n][Kp = C]
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int q = j; q < C / 4; q += 16) {
+    const float4 gv = *reinterpret_cast<const float4*>(Gr + 4 * q);
+    const float4 w0 = *reinterpret_cast<const float4*>(W + 4 * q), w1 = *reinterpret_cast<const float4*>(W + C + 4 * q),
+                 w2 = *reinterpret_cast<const float4*>(W + 2 * C + 4 * q);
+    a0 = fmaf(gv.w, w0.w, fmaf(gv.z, w0.z, fmaf(gv.y, w0.y, fmaf(gv.x, w0.x, a0))));
+    a1 = fmaf(gv.w, w1.w, fmaf(gv.z, w1.z, fmaf(gv.y, w1.y, fmaf(gv.x, w1.x, a1))));
+    a2 = fmaf(gv.w, w2.w, fmaf(gv.z, w2.z, fmaf(gv.y, w2.y, fmaf(gv.x, w2.x, a2))));
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) {   // butterfly over the 16 lanes of the frame: every lane ends with the same three sums
+    a0 += __shfl_xor(a0, o, 16);
+    a1 += __shfl_xor(a1, o, 16);
+    a2 += __shfl_xor(a2, o, 16);
+  }
+  const float* bf = b_final + g * gs_bf;
+  const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
+  float f0v = f0[i];
+  int32_t uvv = uv[i];
+  f0_update_row(a0 + bf[0], a1 + bf[1], a2 + bf[2], i, b, t, T, f0v, uvv, lo[i], hi[i], noise, gumbel_u, rng, step, k);
+  if (j == 0) {
+    f0[i] = f0v;
+    uv[i] = uvv;
+  }
+  if (X) {   // the next evaluation's input row (exactly f0_input_kernel's values)
+    const int half = C / 2;
+    const bool pad = lens && t >= lens[b];
+    float* Xr = X + i * C;
+    for (int q = j; q < C / 4; q += 16) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        v[e] = c < half ? w_in[g * gs_w + c] * f0v + b_in[g * gs_b + c] : uv_embed[g * gs_e + (uvv != 0 ? 1 : 0) * half + (c - half)];
+        if (pad) v[e] = 0.f;
       }
+      *reinterpret_cast<float4*>(Xr + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    // ---- Gaussian f0 ----
-    const float x = f0[i];
-    float x0 = recip * x - recipm1 * eps;
-    x0 = fminf(fmaxf(x0, lo[i]), hi[i]);
-    const float mean = c1 * x0 + c2 * x;
-    f0[i] = mean + sigma * z;
-    // ---- multinomial uv ----
-    const int cls = uv[i] != 0 ? 1 : 0;
-    const float lx0 = cls == 0 ? 0.f : LOG_TINY, lx1 = cls == 1 ? 0.f : LOG_TINY;
-    // log_softmax
-    const float m = fmaxf(l0, l1);
-    const float lse = logf(expf(l0 - m) + expf(l1 - m));
-    const float p0 = (l0 - m) - lse, p1 = (l1 - m) - lse;
-    float ev0, ev1;
-    if (step == 0) {
-      ev0 = p0;
-      ev1 = p1;
-    } else {
-      ev0 = log_add_exp(p0 + log_cp_tm1, log_1m_cp_tm1 - LOG2);
-      ev1 = log_add_exp(p1 + log_cp_tm1, log_1m_cp_tm1 - LOG2);
-    }
-    const float un0 = ev0 + log_add_exp(lx0 + log_alpha_t, log_1m_alpha_t - LOG2);
-    const float un1 = ev1 + log_add_exp(lx1 + log_alpha_t, log_1m_alpha_t - LOG2);
-    const float mm = fmaxf(un0, un1);
-    const float nlse = mm + logf(expf(un0 - mm) + expf(un1 - mm));
-    const float q0 = un0 - nlse, q1 = un1 - nlse;
-    const float g0 = -logf(-logf(u0 + 1e-30f) + 1e-30f);
-    const float g1 = -logf(-logf(u1 + 1e-30f) + 1e-30f);
-    uv[i] = (g1 + q1) > (g0 + q0) ? 1 : 0;  // argmax, first max wins ties
   }
 }
 
@@ -870,39 +921,24 @@ extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, c
   const int C = net->C;
   const int64_t n = (int64_t)B * T;
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
+  const int gsz = net->n_groups > 1 ? B / net->n_groups : 0;
   for (int t = step_hi - 1; t >= step_lo; --t) {
-    hipLaunchKernelGGL(f0_input_kernel, dim3(grid_for(n * C)), dim3(256), 0, stream, f0, uv, net->w_in, net->b_in,
-                       net->uv_embed, w.X, B, T, C, lens, net->n_groups > 1 ? B / net->n_groups : 0, net->gs_w_in, net->gs_b_in,
-                       net->gs_uv_embed);
-    SS_CHECK_LAUNCH("f0_input_kernel");
-    SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream));
-    ss_conv_gemm_args f = base_args(B, T, lens);
-    f.A = w.G;
-    f.lda = C;
-    f.a_batch_stride = (int64_t)T * C;
-    f.Cin = C;
-    f.W = net->w_final;
-    f.N = 3;
-    f.Np = 32;
-    f.Kp = round_up32(C);
-    f.epi = SS_EPI_STORE;
-    f.bias = net->b_final;
-    f.C = w.O;
-    f.ldc = 4;
-    f.c_batch_stride = (int64_t)T * 4;
-    if (net->n_groups > 1) {
-      f.group_size = B / net->n_groups;
-      f.w_group_stride = net->gs_w_final;
-      f.bias_group_stride = net->gs_b_final;
+    if (t == step_hi - 1) {   // the first evaluation's input; every later one is written by the previous step's tail kernel
+      hipLaunchKernelGGL(f0_input_kernel, dim3(grid_for(n * C)), dim3(256), 0, stream, f0, uv, net->w_in, net->b_in, net->uv_embed, w.X, B, T, C,
+                         lens, gsz, net->gs_w_in, net->gs_b_in, net->gs_uv_embed);
+      SS_CHECK_LAUNCH("f0_input_kernel");
     }
-    SS_PROPAGATE(ss_conv_gemm(&f, stream));
+    SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream));
     const int tm1 = t > 0 ? t - 1 : 0;
-    hipLaunchKernelGGL(f0_update_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w.O, f0, uv, lo, hi,
-                       noise ? noise + (int64_t)t * n : nullptr, gumbel_u ? gumbel_u + (int64_t)t * n * 2 : nullptr, seed,
-                       seed_dev, t, B, T, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
-                       t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f, net->log_alpha[t], net->log_1m_alpha[t],
-                       net->log_cumprod_alpha[tm1], net->log_1m_cumprod_alpha[tm1]);
-    SS_CHECK_LAUNCH("f0_update_kernel");
+    const F0StepCoef k = {net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
+                          t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f, net->log_alpha[t], net->log_1m_alpha[t],
+                          net->log_cumprod_alpha[tm1], net->log_1m_cumprod_alpha[tm1]};
+    // output projection (C -> 3) + joint sampler update + the next evaluation's input row, one launch (f0_tail_kernel)
+    hipLaunchKernelGGL(f0_tail_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, w.G, net->w_final, net->b_final, f0, uv, lo, hi,
+                       noise ? noise + (int64_t)t * n : nullptr, gumbel_u ? gumbel_u + (int64_t)t * n * 2 : nullptr, seed, seed_dev, t, B, T, C, k,
+                       net->w_in, net->b_in, net->uv_embed, t > step_lo ? w.X : nullptr, lens, gsz, net->gs_w_final, net->gs_b_final, net->gs_w_in,
+                       net->gs_b_in, net->gs_uv_embed);
+    SS_CHECK_LAUNCH("f0_tail_kernel");
   }
   return SS_OK;
 }

@@ -462,7 +462,9 @@ extern "C" int ss_gemm16_pick(int B, int T, int N) {
   const int n_tiles = ss_cdiv(N, BN);
   int best = 4;
   long best_cost = -1;
-  for (int mt = 8; mt >= 4; mt -= 2) {   // 128, 96, 64 rows
+  // 32-row tiles only for launches whose 64-row grid leaves at least half the CUs without a workgroup (one short utterance)
+  const bool tiny = (long)ss_cdiv(T, 64) * B * n_tiles * 2 <= ss_n_cu();
+  for (int mt = 8; mt >= (tiny ? 2 : 4); mt -= 2) {   // 128, 96, 64 (, 32) rows
     const long wgs = (long)ss_cdiv(T, 16 * mt) * B * n_tiles;
     const long cost = (long)mt * ss_cdiv(wgs, ss_n_cu());
     if (best_cost < 0 || cost < best_cost) {
@@ -484,11 +486,12 @@ static int gemm16_res_impl(const ss_conv_gemm_args* args, const float* W16, int 
   SS_CHECK_ARG(a.a_scale == 1.0f && a.a_lrelu == 1.0f && a.a_bias == nullptr && a.mfma_bf16 == 0, "%s: no A prologue, fp32 only", who);
   SS_CHECK_ARG((int64_t)a.T * a.lda * 4 < (1ll << 31) && (int64_t)a.T * a.ldr * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 4 < (1ll << 31) &&
                    (int64_t)a.Np * a.Kp * 4 < (1ll << 31), "%s: item too large for 32-bit offsets", who);
-  SS_CHECK_ARG(mt == 0 || mt == 4 || mt == 6 || mt == 8, "%s: mt=%d must be 0 (auto), 4, 6 or 8", who, mt);
+  SS_CHECK_ARG(mt == 0 || mt == 2 || mt == 4 || mt == 6 || mt == 8, "%s: mt=%d must be 0 (auto), 2, 4, 6 or 8", who, mt);
   if (mt == 0) mt = ss_gemm16_pick(a.B, a.T, a.N);
   hipStream_t s = (hipStream_t)stream;
   const bool k6 = a.Kp == 192;
   switch (mt) {
+    case 2: k6 ? launch_res<2, 6>(a, W16, s) : launch_res<2, 8>(a, W16, s); break;
     case 4: k6 ? launch_res<4, 6>(a, W16, s) : launch_res<4, 8>(a, W16, s); break;
     case 6: k6 ? launch_res<6, 6>(a, W16, s) : launch_res<6, 8>(a, W16, s); break;
     default: k6 ? launch_res<8, 6>(a, W16, s) : launch_res<8, 8>(a, W16, s); break;
@@ -529,6 +532,7 @@ static int gemm16_store_impl(const ss_conv_gemm_args* args, int mt, int ksplit, 
   SS_CHECK_ARG(ksplit >= 1 && ksplit <= 16 && ksplit <= a.Kp / BK && (ksplit == 1 || (partials && (a.N & 3) == 0 && (a.ldc & 3) == 0)),
                "%s: ksplit=%d needs a partials buffer of ksplit*B*T*N floats, N %% 4 == 0 and at most Kp/32 slices", who, ksplit);
   if (mt == 0) mt = ksplit > 1 ? 4 : ss_gemm16_pick(a.B, a.T, a.N);
+  if (mt == 2) mt = 4;   // (the 32-row tile exists for the residual projection only)
   hipStream_t s = (hipStream_t)stream;
   switch (mt) {
     case 4: launch_store<4>(a, ksplit, partials, s); break;
