@@ -265,7 +265,8 @@ def mel_loop_in_run(infer, B, T, S_mel, executed_flop_per_frame_step, peak):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    launches = S_mel * 43 + 2      # per evaluation: input projection, 20 x (gate, residual projection), skip GEMM, output projection + sampler update
+    launches = S_mel * 42 + 22     # per evaluation: input projection, 20 gates, 19 residual projections (the last layer's stream is never read), skip GEMM,
+                                   # output projection + sampler update; once per loop: q-sample, conditioner projection, 20 addend re-layouts
     return {"ms_per_loop": ms, "launches": launches, "avg_us_per_launch": ms * 1e3 / launches,
             "executed_mfma_frac": executed_flop_per_frame_step * S_mel * B * T / (ms * 1e-3) / peak, "frames": B * T}
 
