@@ -305,7 +305,8 @@ def secondary_configs():
     """The other single-GPU BASELINE configs, one step each, so that the driver's default run observes them too (round-2 verdict):
     c5 = one GPU's share of the style-transfer sweep (50-step DDIM), c4 = 32 x 30 s, 1000-step mel diffusion, bf16-operand MFMA.
     Each runs in its own process AFTER the c2 line's timed region (own plans / graphs / precision mode, memory returned on exit) and
-    reports value, ms_per_step, dtype and its own live roofline block; c4 also carries its parity status (bf16 operands: unpinned)."""
+    reports value, ms_per_step, dtype and its own live roofline block; c4 (bf16x2: meets north_star) and c4bf16 (plain bf16 operands: does not) carry
+    their parity status, c5 its style-cache accounting, c1 is the B = 1 latency shape (`c1_gpu`)."""
     out = {}
     for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4bf16", 1, 1), ("c2x3", 6, 3)):
         # (c5: a step is a whole 2048-pair sweep, ~45 s: no untimed warm-up sweep - the first timed step carries the one-off graph captures, ~2 s)
