@@ -47,7 +47,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * ss_conv_gemm; 4|6|8 = force 16*mt rows); experiment switches "htile" = 0|64|128 (row tile of the generic bf16 kernel), "wino_tn" = 0|1|2 and
  * "wino_v1" = 0|1 (F(2,3) gate: column tile, round-1 kernel); "voc_wino_max_mb" = 1..2048: vocoder items whose stage panel reaches this many MiB
  * take the direct conv kernel instead of the grouped-Winograd one (32-bit offsets; default 2048 = the real limit, tests lower it); "e16" = 0|1
- * the fp32 denoiser loops hand the 16x16x4 gate its conditioner addend in fetch order (ss_gate16_tile_addend once per forward; default 1) */
+ * the fp32 denoiser loops hand the 16x16x4 gate its conditioner addend in fetch order (ss_gate16_tile_addend once per forward; default 1);
+ * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);

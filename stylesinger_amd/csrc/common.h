@@ -57,14 +57,19 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     1 = 64, 2 = 128 columns); wino_v1: 1 = the round-1 F(2,3) kernel (A/B against v2).
 //   e16: 1 (default) = the fp32 denoiser loops re-lay the conditioner addend of every 16x16x4 gate launch in that kernel's fetch order once per
 //     forward (ss_gate16_tile_addend); 0 = the gate reads the row-major slab (A/B; results are bit-identical).
+//   mel_tail: 1 (default) = for launches of at most 8 frames per CU (one short utterance) the mel sampler runs output projection + DDPM update +
+//     the next input projection as one VALU launch (mel_tail_kernel); 0 = always the two matrix-core launches.
 //   voc_wino_max_mb: the vocoder's grouped-Winograd convs address an item with 32-bit byte offsets; items whose stage panel (+ halo) reaches
 //     this many MiB take the direct kernel instead (default 2048 = the real limit; tests lower it to force that fallback).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
-                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; };
+                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; };
 extern SsTuning g_ss_tuning;
 // compute units of the current device (cached per device; 256 when no device can be queried): the tiling picks model a launch as
 // workgroup layers per CU, so the count must be the device's, not MI355X's
 int ss_n_cu();
+struct ss_conv_gemm_args;
+// gemm16.hip, library-internal: split-K skip GEMM without its reduction launch (the tail kernels of diffusion.hip add the slices)
+int ss_gemm16_store_partials(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream);
 
 // static per-block wave priority (wave-uniform; s_setprio takes an immediate)
 __device__ __forceinline__ void ss_apply_wave_prio(int mode) {

@@ -270,8 +270,13 @@ int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, i
                     net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);
 }
 
+// partials_ok: the caller's next kernel (f0_tail_kernel / mel_tail_kernel) can add the split-K slices of the skip GEMM itself (skip_partials()
+// tells it whether it has to): the reduction launch is then left out
+inline bool skip_partials(const ss_wavenet* net, const WsLayout& w) {
+  return w.ksplit > 1 && net->skipall_folded && !hmode(net) && !net->mfma_bf16 && g_ss_tuning.skip16 != 0 && !(net->mfma_x3 && net->w_skipall_x3);
+}
 int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool partials_ok = false) {
   const int C = net->C, L = net->L;
   const int NE = L * 2 * C;
   if (hmode(net)) {
@@ -410,7 +415,8 @@ int run_residual_stack(const ss_wavenet* net, int step, const int32_t* lens, int
         k.w_group_stride = net->gs_w_skipall_x3;
         return ss_gemm16x_store(&k, net->w_skipall_x3, s16 == 1 ? 0 : s16, stream);
       }
-      if (use16 && w.ksplit > 1) return ss_gemm16_store_splitk(&k, 4, w.ksplit, w.KP, stream);   // one short utterance: split K over the idle CUs
+      if (use16 && w.ksplit > 1)   // one short utterance: split K over the idle CUs
+        return partials_ok && skip_partials(net, w) ? ss_gemm16_store_partials(&k, 4, w.ksplit, w.KP, stream) : ss_gemm16_store_splitk(&k, 4, w.ksplit, w.KP, stream);
       return use16 ? ss_gemm16_store(&k, s16 == 1 ? 0 : s16, stream) : ss_conv_gemm(&k, stream);
     }
     if (use16 && w.ksplit > 1) SS_PROPAGATE(ss_gemm16_store_splitk(&k, 4, w.ksplit, w.KP, stream));
@@ -527,10 +533,34 @@ __device__ __forceinline__ void f0_update_row(float eps, float l0, float l1, int
   uvv = (g1 + q1) > (g0 + q0) ? 1 : 0;  // argmax, first max wins ties
 }
 
+// where a tail kernel reads the stack output g = relu(skip GEMM) from: the reduced tensor G, or the split-K slices P[s][row][C] (+ bias, ReLU,
+// row mask - the arithmetic and order of splitk_reduce_kernel)
+struct SkipSrc {
+  const float* G;
+  const float* P;
+  const float* bias;
+  int ksplit;
+  int64_t per;   // floats per slice = B*T*C
+};
+__device__ __forceinline__ float4 skip_load4(const SkipSrc& s, const float* bias, int64_t row, int C, int k, bool masked) {
+  if (s.ksplit <= 1) return *reinterpret_cast<const float4*>(s.G + row * C + k);
+  float4 v = *reinterpret_cast<const float4*>(s.P + row * C + k);
+  for (int q = 1; q < s.ksplit; ++q) {
+    const float4 u = *reinterpret_cast<const float4*>(s.P + q * s.per + row * C + k);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  if (bias) {
+    v.x += bias[k]; v.y += bias[k + 1]; v.z += bias[k + 2]; v.w += bias[k + 3];
+  }
+  v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  if (masked) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  return v;
+}
+
 // The tail of an f0 network evaluation in ONE launch (round 4): output projection (C -> 3: a GEMV per frame, not matrix-core work - it ran on a
 // 128x32 MFMA tile with 29 dead columns), the joint sampler update, and the NEXT evaluation's input row x[:, :C/2] = w*f0 + b ;
 // x[:, C/2:] = uv_embed[uv] (net.py:249-252): 3 launches per step -> 1. 16 lanes per frame: lane j owns the float4s j, j + 16, ... of the row.
-__global__ __launch_bounds__(256) void f0_tail_kernel(const float* __restrict__ G, const float* __restrict__ w_final, const float* __restrict__ b_final,
+__global__ __launch_bounds__(256) void f0_tail_kernel(const SkipSrc src, int64_t gs_bskip, const float* __restrict__ w_final, const float* __restrict__ b_final,
                                                       float* __restrict__ f0, int32_t* __restrict__ uv, const float* __restrict__ lo,
                                                       const float* __restrict__ hi, const float* __restrict__ noise,
                                                       const float* __restrict__ gumbel_u, uint64_t seed, const uint64_t* __restrict__ seed_dev, int step,
@@ -543,11 +573,12 @@ __global__ __launch_bounds__(256) void f0_tail_kernel(const float* __restrict__ 
   const int j = threadIdx.x & 15;
   const int b = (int)(i / T), t = (int)(i % T);
   const int g = group_size > 0 ? b / group_size : 0;
-  const float* Gr = G + i * C;
   const float* W = w_final + g * gs_wf;   // packed rows [n][Kp = C]
+  const float* bsk = src.bias ? src.bias + g * gs_bskip : nullptr;
+  const bool masked = lens && t >= lens[b];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   for (int q = j; q < C / 4; q += 16) {
-    const float4 gv = *reinterpret_cast<const float4*>(Gr + 4 * q);
+    const float4 gv = skip_load4(src, bsk, i, C, 4 * q, masked);
     const float4 w0 = *reinterpret_cast<const float4*>(W + 4 * q), w1 = *reinterpret_cast<const float4*>(W + C + 4 * q),
                  w2 = *reinterpret_cast<const float4*>(W + 2 * C + 4 * q);
     a0 = fmaf(gv.w, w0.w, fmaf(gv.z, w0.z, fmaf(gv.y, w0.y, fmaf(gv.x, w0.x, a0))));
@@ -683,8 +714,15 @@ extern "C" int64_t ss_wavenet_workspace_bytes(const ss_wavenet* net, int B, int 
 }
 
 // x_in -> relu(input_projection) -> residual stack; leaves relu(skip_projection(.)) in w.G  (net.py:114-127)
+static int mel_input_proj(const ss_wavenet* net, const float* x_in, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream);
 static int mel_net_body(const ss_wavenet* net, const float* x_in, const int32_t* lens, int B, int T, const WsLayout& w, int t,
                         hipStream_t stream) {
+  SS_PROPAGATE(mel_input_proj(net, x_in, lens, B, T, w, stream));
+  return run_residual_stack(net, t, lens, B, T, w, stream);
+}
+
+// x_in -> w.X = relu(input_projection(x_in))  (net.py:114-116)
+static int mel_input_proj(const ss_wavenet* net, const float* x_in, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
   const int C = net->C, M = net->in_dim;
   ss_conv_gemm_args a = base_args(B, T, lens);
   a.A = x_in;
@@ -701,8 +739,97 @@ static int mel_net_body(const ss_wavenet* net, const float* x_in, const int32_t*
   a.C = w.X;
   a.ldc = C;
   a.c_batch_stride = (int64_t)T * C;
-  SS_PROPAGATE(ss_conv_gemm(&a, stream));
-  return run_residual_stack(net, t, lens, B, T, w, stream);
+  return ss_conv_gemm(&a, stream);
+}
+
+// The tail of a mel network evaluation for SMALL launches (one short utterance: the B = 1 latency shape) in ONE launch: output projection
+// (C -> M), the DDPM posterior step on x (shallow_diffusion_tts.py:130-162; same tape / Philox counters as the SS_EPI_DDPM epilogue) and the
+// NEXT evaluation's input projection relu(W_in x + b) - two 16-20 us MFMA launches of 24-48 workgroups become one ~8 us VALU launch. Exact
+// fp32 FMAs; only the summation order over K differs from the matrix-core form. 8 frames per workgroup.
+constexpr int MTR = 2;
+__global__ __launch_bounds__(256) void mel_tail_kernel(const SkipSrc src, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                       float* __restrict__ x, const float* __restrict__ noise, uint64_t seed,
+                                                       const uint64_t* __restrict__ seed_dev, uint32_t step, float recip, float recipm1, float c1,
+                                                       float c2, float sigma, const float* __restrict__ Win, const float* __restrict__ bin,
+                                                       float* __restrict__ X, const int32_t* __restrict__ lens, int B, int T, int C, int M, int Kp_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem_mt[];
+  float* gs = smem_mt;            // [MTR][C]
+  float* xs = smem_mt + MTR * C;    // [MTR][Kp_in] (zero padded beyond M)
+  const int64_t n_rows = (int64_t)B * T, r0 = (int64_t)blockIdx.x * MTR;
+  const int tid = threadIdx.x, C4 = C / 4;
+  for (int idx = tid; idx < MTR * C4; idx += 256) {
+    const int row = idx / C4, q = idx - row * C4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < n_rows) {
+      const int64_t i = r0 + row;
+      v = skip_load4(src, src.bias, i, C, 4 * q, lens && (int)(i % T) >= lens[i / T]);
+    }
+    *reinterpret_cast<float4*>(gs + row * C + 4 * q) = v;
+  }
+  for (int idx = tid; idx < MTR * Kp_in; idx += 256) xs[idx] = 0.f;
+  __syncthreads();
+  const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
+  for (int idx = tid; idx < MTR * M; idx += 256) {
+    const int row = idx / M, n = idx - row * M;
+    const int64_t i = r0 + row;
+    if (i >= n_rows) continue;
+    const float* wr = Wf + (int64_t)n * C;
+    const float* gr = gs + row * C;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < C4; ++q) {
+      const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * q), gv = *reinterpret_cast<const float4*>(gr + 4 * q);
+      acc = fmaf(gv.w, wv.w, fmaf(gv.z, wv.z, fmaf(gv.y, wv.y, fmaf(gv.x, wv.x, acc))));
+    }
+    const float eps = acc + bf[n];
+    const int b = (int)(i / T), t = (int)(i % T);
+    const float xv = x[i * M + n];
+    float x0 = recip * xv - recipm1 * eps;
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    const float mean = c1 * x0 + c2 * xv;
+    float z = 0.f;
+    if (sigma != 0.f) {
+      if (noise) z = noise[i * M + n];
+      else {
+        uint32_t o[4];  // counter = (element of the item, item): exactly the SS_EPI_DDPM epilogue's draw
+        rng.gen((uint32_t)(t * M + n), (uint32_t)b, step, 0x4d454c44u, o);
+        float z1;
+        ss_boxmuller(o[0], o[1], z, z1);
+      }
+    }
+    float xn = mean + sigma * z;
+    if (lens && t >= lens[b]) xn = 0.f;
+    x[i * M + n] = xn;
+    xs[row * Kp_in + n] = xn;
+  }
+  if (!X) return;   // block-uniform
+  __syncthreads();
+  const int K4 = Kp_in / 4;   // W_in is packed [C][Kp_in], zero filled beyond M
+  for (int c = tid; c < C; c += 256) {
+    float acc[MTR];
+#pragma unroll
+    for (int r = 0; r < MTR; ++r) acc[r] = 0.f;
+    const float* wr = Win + (int64_t)c * Kp_in;
+#pragma unroll 8
+    for (int q = 0; q < K4; ++q) {
+      const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * q);
+#pragma unroll
+      for (int r = 0; r < MTR; ++r) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + r * Kp_in + 4 * q);
+        acc[r] = fmaf(xv.w, wv.w, fmaf(xv.z, wv.z, fmaf(xv.y, wv.y, fmaf(xv.x, wv.x, acc[r]))));
+      }
+    }
+    const float bc = bin[c];
+#pragma unroll
+    for (int r = 0; r < MTR; ++r) {
+      const int64_t i = r0 + r;
+      if (i >= n_rows) continue;
+      const int b = (int)(i / T), t = (int)(i % T);
+      float v = fmaxf(acc[r] + bc, 0.f);
+      if (lens && t >= lens[b]) v = 0.f;
+      X[i * C + c] = v;
+    }
+  }
 }
 
 // eps_out [B][T][M] = DiffNet(x_in, t, cond)  (plain output projection, for samplers that keep a history of eps)
@@ -773,12 +900,29 @@ extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* c
   SS_CHECK_ARG(net->n_groups <= 1, "ss_meldiff_sample: grouped nets are only supported by the f0 sampler");
   const WsLayout w = ws_layout(net, B, T, ws);
   SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_meldiff_sample: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
-  const int M = net->in_dim;
+  const int M = net->in_dim, C = net->C;
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
-  for (int t = step_hi - 1; t >= step_lo; --t)
-    SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
-                          t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f, noise ? noise + (int64_t)t * B * T * M : nullptr, seed,
-                          seed_dev, (uint32_t)t, stream));
+  // launches that leave most CUs idle (one short utterance): the two small projections around the sampler update run as ONE VALU launch
+  const int Kp_in = round_up32(M);
+  const bool tail = g_ss_tuning.mel_tail != 0 && !net->mfma_bf16 && (int64_t)B * T <= 8L * ss_n_cu() && (C % 4) == 0 && (M % 4) == 0 &&
+                    (size_t)(MTR * C + MTR * Kp_in) * 4 <= 48 * 1024;
+  for (int t = step_hi - 1; t >= step_lo; --t) {
+    const float sigma = t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f;
+    const float* noise_t = noise ? noise + (int64_t)t * B * T * M : nullptr;
+    if (!tail) {
+      SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t], sigma, noise_t,
+                            seed, seed_dev, (uint32_t)t, stream));
+      continue;
+    }
+    if (t == step_hi - 1) SS_PROPAGATE(mel_input_proj(net, x, lens, B, T, w, stream));   // later evaluations get their input from the tail kernel
+    SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream, true));
+    const bool parts = skip_partials(net, w);
+    const SkipSrc src = {w.G, w.KP, parts ? net->b_skipall : nullptr, parts ? w.ksplit : 1, (int64_t)B * T * C};
+    hipLaunchKernelGGL(mel_tail_kernel, dim3((unsigned)(((int64_t)B * T + MTR - 1) / MTR)), dim3(256), (size_t)(MTR * C + MTR * Kp_in) * 4, stream, src, net->w_final,
+                       net->b_final, x, noise_t, seed, seed_dev, (uint32_t)t, net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t],
+                       net->post_c2[t], sigma, net->w_in, net->b_in, t > step_lo ? w.X : nullptr, lens, B, T, C, M, Kp_in);
+    SS_CHECK_LAUNCH("mel_tail_kernel");
+  }
   return SS_OK;
 }
 
@@ -928,13 +1072,15 @@ extern "C" int ss_f0diff_sample(const ss_wavenet* net, float* f0, int32_t* uv, c
                          lens, gsz, net->gs_w_in, net->gs_b_in, net->gs_uv_embed);
       SS_CHECK_LAUNCH("f0_input_kernel");
     }
-    SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream));
+    SS_PROPAGATE(run_residual_stack(net, t, lens, B, T, w, stream, true));
+    const bool parts = skip_partials(net, w);   // the skip GEMM left its split-K slices in w.KP: the tail kernel adds them
+    const SkipSrc src = {w.G, w.KP, parts ? net->b_skipall : nullptr, parts ? w.ksplit : 1, n * C};
     const int tm1 = t > 0 ? t - 1 : 0;
     const F0StepCoef k = {net->sqrt_recip_ac[t], net->sqrt_recipm1_ac[t], net->post_c1[t], net->post_c2[t],
                           t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f, net->log_alpha[t], net->log_1m_alpha[t],
                           net->log_cumprod_alpha[tm1], net->log_1m_cumprod_alpha[tm1]};
     // output projection (C -> 3) + joint sampler update + the next evaluation's input row, one launch (f0_tail_kernel)
-    hipLaunchKernelGGL(f0_tail_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, w.G, net->w_final, net->b_final, f0, uv, lo, hi,
+    hipLaunchKernelGGL(f0_tail_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, src, net->gs_b_skipall, net->w_final, net->b_final, f0, uv, lo, hi,
                        noise ? noise + (int64_t)t * n : nullptr, gumbel_u ? gumbel_u + (int64_t)t * n * 2 : nullptr, seed, seed_dev, t, B, T, C, k,
                        net->w_in, net->b_in, net->uv_embed, t > step_lo ? w.X : nullptr, lens, gsz, net->gs_w_final, net->gs_b_final, net->gs_w_in,
                        net->gs_b_in, net->gs_uv_embed);

@@ -416,14 +416,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, const ss_conv_
 }
 
 template <int MT>
-int launch_store(const ss_conv_gemm_args& a, int ksplit, float* P, hipStream_t stream) {
+int launch_store(const ss_conv_gemm_args& a, int ksplit, float* P, hipStream_t stream, bool reduce = true) {
   constexpr int BM = 16 * MT;
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
   const int n_tiles = ss_cdiv(a.N, BN);
   const int grid = ss_cdiv(m_tiles, 8) * 8 * n_tiles;
   hipLaunchKernelGGL(gemm16_store_kernel<MT>, dim3(grid * ksplit), dim3(256), 0, stream, a, m_tiles_per_item, m_tiles, n_tiles, ksplit, P);
-  if (ksplit > 1) {
+  if (ksplit > 1 && reduce) {
     const int64_t n = (int64_t)a.B * a.T * a.N / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, stream, P, a, ksplit);
   }
@@ -516,7 +516,7 @@ extern "C" int ss_pack_gemm16_weights(const float* src, float* dst, int Np, int 
   return SS_OK;
 }
 
-static int gemm16_store_impl(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream, const char* who) {
+static int gemm16_store_impl(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream, const char* who, bool reduce = true) {
   SS_CHECK_ARG(args != nullptr, "%s: null args", who);
   const ss_conv_gemm_args& a = *args;
   SS_CHECK_ARG(a.A && a.W && a.C, "%s: null A/W/C", who);
@@ -535,9 +535,9 @@ static int gemm16_store_impl(const ss_conv_gemm_args* args, int mt, int ksplit, 
   if (mt == 2) mt = 4;   // (the 32-row tile exists for the residual projection only)
   hipStream_t s = (hipStream_t)stream;
   switch (mt) {
-    case 4: launch_store<4>(a, ksplit, partials, s); break;
-    case 6: launch_store<6>(a, ksplit, partials, s); break;
-    default: launch_store<8>(a, ksplit, partials, s); break;
+    case 4: launch_store<4>(a, ksplit, partials, s, reduce); break;
+    case 6: launch_store<6>(a, ksplit, partials, s, reduce); break;
+    default: launch_store<8>(a, ksplit, partials, s, reduce); break;
   }
   SS_CHECK_LAUNCH(who);
   return SS_OK;
@@ -549,6 +549,12 @@ extern "C" int ss_gemm16_store(const ss_conv_gemm_args* args, int mt, void* stre
 
 extern "C" int ss_gemm16_store_splitk(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream) {
   return gemm16_store_impl(args, mt, ksplit, partials, stream, "ss_gemm16_store_splitk");
+}
+
+// library-internal (diffusion.hip): the split-K launch WITHOUT the reduction - the consumer (f0_tail_kernel / mel_tail_kernel) adds the slices itself,
+// in the same order and with the same bias / ReLU / row mask as splitk_reduce_kernel
+int ss_gemm16_store_partials(const ss_conv_gemm_args* args, int mt, int ksplit, float* partials, void* stream) {
+  return gemm16_store_impl(args, mt, ksplit, partials, stream, "ss_gemm16_store_partials", false);
 }
 
 // K slices for a long-K launch of B items x T rows x N columns x K: 1 unless 64-row tiles leave most CUs without a workgroup; then as many
