@@ -89,3 +89,35 @@ def test_single_process_is_identity():
     mel, f0, lens = torch.randn(2, 5, 80), torch.randn(2, 5), torch.tensor([5, 3], dtype=torch.int32)
     a, b, c = ssd.gather_mels(mel, f0, lens)
     assert a is mel and b is f0 and c is lens
+
+
+def _worker_forced(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    mel, f0 = torch.randn(3, 16, 80, generator=g), torch.rand(3, 16, generator=g) * 300
+    lens = torch.tensor([16, 0, 9], dtype=torch.int32)
+    plain = ssd.gather_mels(mel, f0, lens)                 # world of one: the short cut returns the inputs themselves
+    short_cut = plain[0] is mel
+    ssd.FORCE_COLLECTIVE = True                            # ... unless forced: the real all_gather_into_tensor branch (CPU form of it)
+    try:
+        m, f, l = ssd.gather_mels(mel, f0, lens)
+        res = ssd.run_sharded(lambda items: (mel[:len(items)], f0[:len(items)], lens[:len(items)]), lambda a, b, c: a.sum(-1), [0, 1, 2], 0, 1, 16)
+    finally:
+        ssd.FORCE_COLLECTIVE = False
+    q.put(dict(short_cut=short_cut, forced_is_copy=m is not mel, equal=bool(torch.equal(m, mel) and torch.equal(f, f0) and torch.equal(l, lens)),
+               dtype=str(l.dtype), sharded=bool(torch.equal(res["mel_all"], mel) and torch.equal(res["lens_all"], lens))))
+    dist.destroy_process_group()
+
+
+def test_forced_collective_runs_the_all_gather_branch_in_a_world_of_one():
+    """dist.FORCE_COLLECTIVE (env SS_FORCE_COLLECTIVE=1) lifts the world-size-1 short cut of gather_mels: how the 1-GPU box drives the RCCL
+    branch (tests/test_gpu_round4.py). Here on CPU with gloo: payload packing, bit-cast lengths and gathered order come back exact."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_forced, args=(0, 1, _free_port(), q))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(timeout=60)
+    assert out == dict(short_cut=True, forced_is_copy=True, equal=True, dtype="torch.int32", sharded=True), out
