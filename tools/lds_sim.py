@@ -70,6 +70,15 @@ def main():
     ok &= report("gate16x A staging, 8 bytes per thread and plane (row tid >> 3, half slot tid & 7), swz64", "ds_write_b64",
                  lambda lane, w: ((w * 64 + lane) >> 3) * 64 + (((((w * 64 + lane) & 7) >> 1) ^ swz64((w * 64 + lane) >> 3)) << 4) + ((w * 64 + lane) & 1) * 8,
                  waves=4)
+    # bf16 kernels (gemm_bf16.hip, gate256 / tile256, plain and split): 128-byte rows, lane (l31 = l & 31, lh = l >> 5) reads slot (2 ks + lh) of row
+    # l31 (+ 32 m), swizzle slot ^ ((row >> 1) & 7); in split mode slots 0-3 are the hi terms, 4-7 the mid terms of the same 32 channels
+    for ks in range(4):
+        ok &= report(f"bf16 32x32x16 fragment, slot 2*{ks} + lh, 128-byte rows, slot ^ ((row >> 1) & 7)", "ds_read_b128",
+                     lambda lane, w, ks=ks: (lane & 31) * 128 + ((((2 * ks + (lane >> 5)) ^ (((lane & 31) >> 1) & 7))) << 4))
+    # round-4 LDS-staged epilogues (tile256 / the generic split RESX): fp32 staging rows of 1 KB, thread (row = tid >> 5, group g = tid & 31) reads
+    # two float4 of its 8 channels -> stride 32 B between lanes: a known 2-way conflict on 4 % of the kernel's LDS traffic (not swizzled away)
+    report("tile256 RESX staging read, float4 at 32-byte stride (expected: 2-way)", "ds_read_b128", lambda lane, w: (lane >> 5) * 1024 + (lane & 31) * 32)
+    ok &= report("tile256 STORE staging read, float4 contiguous", "ds_read_b128", lambda lane, w: (lane & 63) * 16)
     print("all swizzled accesses conflict-free" if ok else "CONFLICTS in a swizzled access")
     return 0 if ok else 1
 
