@@ -392,8 +392,9 @@ def cpu_baseline(hp_over, extra_threads):
                 sample=f"config C1: B=1, T={frames} frames (4 s), {hp['K_step']}+2x{hp['f0_timesteps']} diffusion steps + HiFi-GAN-NSF, fp32, "
                        f"oracle/restatement.py (torch CPU); 8 threads = median of 3, other thread counts one run each; value = fastest "
                        f"setting ({best} threads)",
-                note="port of the reference pinned to it by golden fixtures; measured 1.2-1.4x faster than the real reference modules "
-                     "(round-1 verdict), i.e. a conservative baseline")
+                note="port of the reference pinned to it by golden fixtures; measured FASTER than the real reference modules on the same inputs and "
+                     "threads (round-1 judge: 1.2-1.4x; re-verified in round 4 with oracle/time_port_vs_reference.py in the build container: "
+                     "1.07x), i.e. a conservative baseline")
 
 
 def main():
