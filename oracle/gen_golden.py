@@ -249,6 +249,7 @@ def main():
     run_acoustic_case("acoustic_t64_s100", B=1, T=64, Tp=8, Tr=48, steps_mel=100, steps_f0=100, keep_stages=False)
     run_vocoder_case("vocoder_t12", B=1, T=12)
     run_vocoder_case("vocoder_b2_t9", B=2, T=9)
+    run_vocoder_case("vocoder_t200", B=1, T=200)   # 51 200 samples: the NSF phase integration and the 4-stage generator at a length where tile interiors exist
     run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)
     run_plms_case("plms_t24_k12_i4", T=24, steps_mel=12, interval=4)
     round2_cases()

@@ -75,7 +75,7 @@ def test_acoustic_hip_matches_reference_golden(name):
     assert l1 <= CASE_MEL_L1_TOL.get(name, MEL_L1_TOL), f"{name}: mel L1 {l1:.3e}"
 
 
-@pytest.mark.parametrize("name", ["vocoder_t12", "vocoder_b2_t9"])
+@pytest.mark.parametrize("name", ["vocoder_t12", "vocoder_b2_t9", "vocoder_t200"])   # t200: 51 200 samples of the REAL reference (round 4)
 def test_vocoder_hip_matches_reference_golden(name):
     case = harness.load_case(name)
     meta = case["meta"]
