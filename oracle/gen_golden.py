@@ -247,6 +247,8 @@ def main():
     run_acoustic_case("acoustic_b2_s3", B=2, T=40, Tp=5, Tr=36, steps_mel=3, steps_f0=3)
     run_acoustic_case("acoustic_dur_s2", B=1, T=0, Tp=7, Tr=32, steps_mel=2, steps_f0=2, give_mel2ph=False)
     run_acoustic_case("acoustic_t64_s100", B=1, T=64, Tp=8, Tr=48, steps_mel=100, steps_f0=100, keep_stages=False)
+    # round 4: 300 frames (1.6 s), full 100 + 2 x 100 step chains - several frame tiles of every kernel, directly against the real reference
+    run_acoustic_case("acoustic_t300_s100", B=1, T=300, Tp=12, Tr=200, steps_mel=100, steps_f0=100, keep_stages=False)
     run_vocoder_case("vocoder_t12", B=1, T=12)
     run_vocoder_case("vocoder_b2_t9", B=2, T=9)
     run_vocoder_case("vocoder_t200", B=1, T=200)   # 51 200 samples: the NSF phase integration and the 4-stage generator at a length where tile interiors exist

@@ -48,6 +48,7 @@ def _run_hip(meta):
 
 
 @pytest.mark.parametrize("name", ["acoustic_tiny_s4", "acoustic_b2_s3", "acoustic_dur_s2", "acoustic_t64_s100",
+                                  "acoustic_t300_s100",        # round 4: 300 frames x (100 + 2 x 100) steps of the REAL reference
                                   "acoustic_t32_mel1000",      # BASELINE config 4's schedule: 1000 mel steps, coefficients up to ~3e6
                                   "prodiff_t40_vpsde", "prodiff_b2_t32_linear"])   # hparams['decoder'] = 'prodiff' (8 teacher steps)
 def test_acoustic_hip_matches_reference_golden(name):
