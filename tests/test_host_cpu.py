@@ -339,3 +339,27 @@ def test_forward_signature_equals_the_reference_operator_surface():
     ALIAS = {"encoder_out": "encoder_out_text"}   # the reference overwrites ret['encoder_out'] later in forward; the stage value is kept under this name
     for k in gold:
         assert f'ret["{ALIAS.get(k, k)}"]' in src or f"'{ALIAS.get(k, k)}'" in src, k
+
+
+def test_launch_planning_functions_of_the_library_run_without_a_gpu():
+    """The host-side launch planners of the C-ABI (no kernel launch): tiling picks, split-K slice count, size of the addend re-layout, the tuning
+    knob table. Without a device the CU count falls back to MI355X's 256, so the BASELINE shapes give their documented answers."""
+    l = lib.load()
+    # fp32 F(4,3) gate tiling (DESIGN 3.1e): C2 mel / f0 pair, one 4 s utterance (16-quad tiles), the C4 shape (32x32x2 kernel)
+    assert l.ss_wino43_gate16_pick(8, 1500, 512, 2) == 2 and l.ss_wino43_gate16_pick(16, 1500, 384, 1) == 3
+    assert l.ss_wino43_gate16_pick(1, 750, 512, 4) == 1 and l.ss_wino43_gate16_pick(32, 5625, 512, 4) == 0
+    # addend in fetch order: [q tiles][n tiles][MT * 4096 floats]; C2 mel at d = 2: 375 quads -> 376 (groups of d) -> 12 tiles of 32 quads per item
+    assert l.ss_gate16_tiled_floats(8, 1500, 512, 2, 2) == 8 * 12 * 8 * 2 * 4096
+    assert l.ss_gate16_tiled_floats(8, 1500, 512, 2, 0) == -1 and l.ss_gate16_tiled_floats(8, 1500, 500, 2, 2) == -1
+    # split-K of the skip GEMM: only for launches that leave CUs idle
+    assert l.ss_gemm16_ksplit_pick(1, 750, 256, 5120) == 5 and l.ss_gemm16_ksplit_pick(8, 1500, 256, 5120) == 1 and l.ss_gemm16_ksplit_pick(1, 750, 256, 256) == 1
+    # residual-projection row tile: 96 rows at C2 (16 row tiles per 8 s item), 32 rows for one short utterance
+    assert l.ss_gemm16_pick(8, 1500, 256) == 6 and l.ss_gemm16_pick(1, 750, 256) == 2
+    # knob table: every documented key round-trips, bad values are refused with a message
+    for key, val in ((b"e16", 0), (b"mel_tail", 0), (b"gate16", 3), (b"htile", 128), (b"voc_wino_max_mb", 7), (b"wino_tn", 2)):
+        before = l.ss_get_tuning(key)
+        assert before >= 0
+        assert l.ss_set_tuning(key, val) == 0 and l.ss_get_tuning(key) == val
+        assert l.ss_set_tuning(key, before) == 0
+    assert l.ss_set_tuning(b"htile", 96) != 0 and b"htile" in l.ss_last_error()
+    assert l.ss_get_tuning(b"nope") < 0
