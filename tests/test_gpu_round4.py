@@ -442,3 +442,29 @@ def test_gate16_with_the_addend_in_fetch_order_is_bit_identical(mt):
             E16 = L.gate16_tile_addend(E[:, :, Np:], B=B, T=T, Np=Np, lde=Lyr * Np, e_bs=T * Lyr * Np, dilation=d, mt=mt)
             L.wino43_gate16(x, Wt, got, mt=mt, E=E16, e_tiled=True, **kw)
             assert torch.equal(got, want), (mt, C, d, (got - want).abs().max().item())
+
+
+def test_small_launch_tail_kernels_agree_with_the_matrix_core_launches():
+    """`mel_tail` knob A/B at the B = 1 shape: output projection + DDPM update + next input projection as ONE VALU launch (mel_tail_kernel, with the
+    split-K slices of the skip GEMM added inside) vs the two matrix-core launches + reduction launch. Same exact-fp32 products, another summation
+    order: mel within 1e-6, integer outputs identical; the knob really switches paths (the two results differ in the last bits)."""
+    S = 12
+    hp = config.make_hparams(dict(timesteps=S, K_step=S, f0_timesteps=3))
+    B, T = 1, 333
+    batch = synth.synth_batch(B, T, 8, 200, hp, 71)
+    sd = synth.synth_acoustic_state_dict(hp, 71)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(72), B, T, 3, S)
+    m = _model(hp, sd)
+    b = {k: v.cuda() for k, v in batch.items()}
+    lib = L.load()
+    assert lib.ss_get_tuning(b"mel_tail") == 1
+    fused = _fwd(m, b, noise=noise)
+    try:
+        L.check(lib.ss_set_tuning(b"mel_tail", 0), "knob")
+        split = _fwd(m, b, noise=noise)
+    finally:
+        L.check(lib.ss_set_tuning(b"mel_tail", 1), "knob")
+    d = (fused["mel_out"] - split["mel_out"]).abs()
+    print(f"mel tail kernel vs matrix-core launches: mel max diff {d.max().item():.3e}, mean {d.mean().item():.3e}")
+    assert torch.equal(fused["pitch_coarse"], split["pitch_coarse"]) and torch.equal(fused["uv_a"], split["uv_a"])
+    assert 0.0 < d.max().item() <= 1e-5 and d.mean().item() <= 1e-6
