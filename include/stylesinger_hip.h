@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 12 /* 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 13 /* 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -279,7 +279,14 @@ typedef struct ss_gemm_bf16_args {
    * weights) and for the bf16 OUTPUTS (GATE's C, RESX's Y: logical channel c of the output lands at (c >> 5) * 64 + (c & 31), its mid term 32
    * further; ldc / ldy are physical strides). */
   int32_t split;
-  int32_t reserved_[3];
+  /* split = 2 ("fp16x2" precision: BASELINE config 4 at parity with TWO products instead of three): the same pair layouts with FP16 terms, and
+   * only the WEIGHTS are read as pairs - W holds (hi, lo) = ss_split_f16 of w * 2^s, the A operand's hi term alone feeds the matrix cores
+   * (v_mfma_f32_32x32x16_f16: a*hi + a*lo), and the fp32 accumulator is multiplied by out_scale = 2^-s before bias / addend / residual are added.
+   * Outputs: GATE writes (fp16(g), 0); RESX reads and writes the stream as a true fp16 pair (22 significant bits). Why two products suffice:
+   * over 1000 reverse steps the weight rounding is the coherent error, the activation rounding averages out, and fp16's is 8x smaller than
+   * bf16's (oracle/bf16x2_numerics.py: 1.9e-5 vs the reference's 1000-step golden, bar 1e-4). */
+  float out_scale;
+  int32_t reserved_[2];
   /* RESX with split operands and X == NULL ("pair-only residual stream"): the stream lives ONLY as the (hi, mid) pair Y = x + cur_bias (16
    * significand bits - measured harmless on the reference's 1000-step golden: 2.4e-6 either way, oracle/bf16x2_numerics.py). The epilogue reads
    * its element of Y, recovers x = hi + mid - cur_bias, and writes Y = pair(x_new + next_bias) in place: 3 instead of 4 KB per row of traffic. */
@@ -307,6 +314,10 @@ int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int
  * 32 elements further ("pairs interleaved by 32", see ss_gemm_bf16_args.split). */
 int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
                   int group_size, int64_t bias_group_stride, void* stream);
+/* The same with FP16 terms of v = (x + bias) * scale (scale: a power of two - the weight shift 2^s of ss_gemm_bf16_args.split = 2, which keeps
+ * the lo terms of ordinary weights out of the fp16 subnormals; 1 for activations): hi = RNE16(v), lo = RNE16(v - hi), same interleaved layout. */
+int ss_split_f16(const float* x, const float* bias, float scale, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
+                 int group_size, int64_t bias_group_stride, void* stream);
 
 /* Weight packing (device -> device).  src is the torch parameter layout [Cout][Cin][k] (conv1d,
  * k=1 for nn.Linear [out][in]).  dst is [Np][k*Kp] with zero fill.  If scale0 != NULL (from
@@ -475,7 +486,10 @@ typedef struct ss_wavenet {
    * every hidden GEMM runs hi*hi + hi*mid + mid*hi on the bf16 matrix cores (ss_gemm_bf16_args.split), the hoisted conditioner projection in
    * exact fp32 (w_cond_h unused). With skipall_folded the K = L*C GEMM + ReLU is the stack output, as in fp32 mode. */
   int32_t mfma_split;
-  int32_t reserved_;
+  /* mfma_split = 2 = "fp16x2" precision: the w_*_h tensors are ss_split_f16 packs of the weights times 2^s, activations fp16 (pair layout, hi
+   * term read by the matrix cores, the stream a true fp16 pair), two products per GEMM (ss_gemm_bf16_args.split = 2);
+   * mfma_out_scale = 2^-s (every ss_gemm_bf16 launch of the stack passes it as out_scale) */
+  float mfma_out_scale;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -60,9 +60,18 @@ _ROUND = None
 # pinned: against the reference's fp32 goldens it stays at fp32-grade distance (tests/test_oracle_golden.py, 4e-6 on the 1000-step chain).
 
 
+# "fp16x2" (the HIP path's mfma_precision of the same name): the same GEMMs on the FP16 matrix cores with only the WEIGHTS split - the
+# activation is one fp16 term a = RNE16(v), a weight the pair (hi, lo) of fp16 terms of w * 2^FP16_WSHIFT (the shift keeps lo out of the fp16
+# subnormals; it is undone in fp32 after the accumulation), the product a*hi + a*lo: 2 matrix products instead of 3. Why that is enough
+# (oracle/bf16x2_numerics.py): the WEIGHT rounding is the coherent error that adds up over 1000 steps, the activation rounding averages out,
+# and fp16's 11 significand bits make the latter 8x smaller than bf16's. The residual stream lives as the fp16 pair of x + dstep_l (22 bits);
+# the conditioner projection stays exact fp32. Pinned like bf16x2: 1.9e-5 vs the reference's 1000-step golden (bar 1e-4).
+FP16_WSHIFT = 8
+
+
 def set_matmul_rounding(mode):
     global _ROUND
-    assert mode in (None, "fp32", "bf16", "bf16x2")
+    assert mode in (None, "fp32", "bf16", "bf16x2", "fp16x2")
     _ROUND = None if mode in (None, "fp32") else mode
 
 
@@ -73,6 +82,11 @@ def _r(x):
 def _split2(x):
     hi = x.bfloat16().float()
     return hi, (x - hi).bfloat16().float()
+
+
+def _split2h(x):
+    hi = x.half().float()
+    return hi, (x - hi).half().float()
 
 
 def conv1d_cl(x, w, b, dilation=1, rounded=False):
@@ -88,7 +102,15 @@ def conv1d_cl(x, w, b, dilation=1, rounded=False):
         if b is not None:
             y = y + b.view(1, -1, 1)
         return y.transpose(1, 2)
-    if rounded:
+    if rounded is True and _ROUND == "fp16x2":
+        xh = xt.half().float()
+        wh, wl = _split2h(w * float(2 ** FP16_WSHIFT))
+        y = F.conv1d(xh, wl, None, padding=pad, dilation=dilation) + F.conv1d(xh, wh, None, padding=pad, dilation=dilation)
+        y = y * float(2.0 ** -FP16_WSHIFT)
+        if b is not None:
+            y = y + b.view(1, -1, 1)
+        return y.transpose(1, 2)
+    if rounded and _ROUND == "bf16":
         xt, w = _r(xt), _r(w)
     return F.conv1d(xt, w, b, padding=pad, dilation=dilation).transpose(1, 2)
 
@@ -323,6 +345,10 @@ def residual_stack(sd, prefix, x, cond, demb, L, cycle):
         if _ROUND == "bf16x2":   # the HIP path keeps the residual stream ONLY as the (hi, mid) pair of x + dstep_l (16 significant bits)
             hi, mid = _split2(xin)
             xin = hi + mid
+            x = xin - ds
+        if _ROUND == "fp16x2":   # ... as the fp16 pair (22 significant bits); the matrix cores read its hi term only
+            hi, lo = _split2h(xin)
+            xin = hi + lo
             x = xin - ds
         y = conv1d_cl(xin, sd[p + ".dilated_conv.weight"], sd[p + ".dilated_conv.bias"], dilation=d, rounded=True) + c
         y = torch.sigmoid(y[..., :C]) * torch.tanh(y[..., C:])

@@ -38,7 +38,8 @@ struct WsLayout {
 // hmode: the hidden activations travel as bf16 in HBM. split (net->mfma_split, "bf16x2" precision): every bf16 operand is a (hi, mid) pair,
 // pairs interleaved by 32 channels (one 128-byte line = 32 channels of both planes; rows of Yh / GAh / the weights are twice as long) - and
 // the matrix cores run hi*hi + hi*mid + mid*hi (ss_gemm_bf16_args.split); the hoisted conditioner projection then runs in exact fp32 (it is
-// outside the step loop).
+// outside the step loop). mfma_split = 2 ("fp16x2"): the same layouts with fp16 terms, weights-only split (two products), accumulators scaled
+// by net->mfma_out_scale (ss_gemm_bf16_args.split = 2).
 inline bool smode(const ss_wavenet* net) { return net->mfma_split != 0; }
 inline bool hmode(const ss_wavenet* net) { return net->mfma_bf16 && net->w_dil_h[0] && net->w_skipall_h && (net->w_cond_h || smode(net)); }
 
@@ -181,7 +182,7 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
 int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
   const int C = net->C, L = net->L;
   const int NE = L * 2 * C;
-  const int sp = smode(net) ? 1 : 0, pl = sp + 1;   // planes per bf16 row
+  const int sp = smode(net) ? (net->mfma_split == 2 ? 2 : 1) : 0, pl = sp ? 2 : 1;   // split form; planes per 16-bit row
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % net->dil_cycle);
     ss_gemm_bf16_args g = base_args_h(net, B, T, lens);
@@ -189,6 +190,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     g.lda = C * pl;
     g.a_batch_stride = (int64_t)T * C * pl;
     g.split = sp;
+    g.out_scale = net->mfma_out_scale;
     g.K = C;
     g.ntaps = 3;
     g.tap_off[0] = -d;
@@ -214,6 +216,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     o.lda = L * C * pl;
     o.a_batch_stride = (int64_t)T * L * C * pl;
     o.split = sp;
+    o.out_scale = net->mfma_out_scale;
     o.K = C;
     o.W = net->w_out_h[l];
     o.w_group_stride = net->gs_w_out_h;
@@ -243,6 +246,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   k.lda = L * C * pl;
   k.a_batch_stride = (int64_t)T * L * C * pl;
   k.split = sp;
+  k.out_scale = net->mfma_out_scale;
   k.K = L * C;
   k.W = net->w_skipall_h;
   k.w_group_stride = net->gs_w_skipall_h;
@@ -263,6 +267,9 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
 
 // Yh = bf16(X + dstep[step][0]) : the first layer's conv operand (bf16-in-HBM mode)
 int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
+  if (net->mfma_split == 2)
+    return ss_split_f16(w.X, net->dstep + (int64_t)step * net->L * net->C, 1.0f, w.Yh, B, T, net->C, net->C, 2 * net->C, lens,
+                        net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);
   if (smode(net))
     return ss_split_bf16(w.X, net->dstep + (int64_t)step * net->L * net->C, w.Yh, B, T, net->C, net->C, 2 * net->C, lens,
                          net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);

@@ -19,10 +19,11 @@
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/stylesinger_hip.h"
+#include "pair16.h"
 #include <type_traits>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef ss_f32x16 f32x16;
+typedef ss_bf16x8 bf16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -46,9 +47,11 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(fl
 #define SS_HABL 0
 #endif
 
-// SPLIT ("bf16x2"): operands are (hi, mid) bf16 pairs interleaved by 32 channels - a 128-byte K chunk holds 32 channels of BOTH planes (slots
-// 0-3 hi, 4-7 mid), the fetch / staging code is the same, and a chunk feeds 2 k-steps x 3 products (mid*hi, hi*mid, hi*hi) instead of 4 x 1.
-template <int BM, int BN, int EPI, bool SPLIT>
+// SPLIT = 1 ("bf16x2"): operands are (hi, mid) bf16 pairs interleaved by 32 channels - a 128-byte K chunk holds 32 channels of BOTH planes
+// (slots 0-3 hi, 4-7 mid), the fetch / staging code is the same, and a chunk feeds 2 k-steps x 3 products (mid*hi, hi*mid, hi*hi) instead of 4 x 1.
+// SPLIT = 2 ("fp16x2"): the same layouts with fp16 terms; the A operand's second plane is not read (2 products: hi*lo, hi*hi) and the
+// accumulator is scaled by args.out_scale (the weights carry a power-of-two shift, pair16.h) before anything is added to it.
+template <int BM, int BN, int EPI, int SPLIT>
 __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
   constexpr int WM = 2, WN = 2;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -73,6 +76,8 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
   const int l31 = lane & 31, lh = lane >> 5;
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+  constexpr bool W2 = SPLIT == 2;        // fp16 terms, weights-only split
+  [[maybe_unused]] const float osc = a.out_scale;
   constexpr int KCH = SPLIT ? 32 : 64;   // channels per 128-byte K chunk
   const int nchunks_tap = a.K / KCH;
   const int nchunks = a.ntaps * nchunks_tap;
@@ -150,11 +155,12 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {  // 2 k-steps of 16 channels: slots 2 ks + lh (hi) and 4 + 2 ks + lh (mid) of the row
         const int sh = ((2 * ks + lh) ^ swz) << 4, sm = ((4 + 2 * ks + lh) ^ swz) << 4;
-        bf16x8 ah[TM], am[TM], bh[TN], bm[TN];
+        [[maybe_unused]] bf16x8 am[TM];
+        bf16x8 ah[TM], bh[TN], bm[TN];
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
           ah[m] = *reinterpret_cast<const bf16x8*>(Ac + m * 32 * (LDH * 2) + sh);
-          am[m] = *reinterpret_cast<const bf16x8*>(Ac + m * 32 * (LDH * 2) + sm);
+          if constexpr (!W2) am[m] = *reinterpret_cast<const bf16x8*>(Ac + m * 32 * (LDH * 2) + sm);
         }
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
@@ -162,18 +168,20 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
           bm[n] = *reinterpret_cast<const bf16x8*>(Bc + n * 32 * (LDH * 2) + sm);
         }
         // product outermost: consecutive MFMAs write different accumulators
+        if constexpr (!W2) {
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
+        }
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
-          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < TN; ++n) acc[m][n] = ss_mfma_32x32x16<W2>(ah[m], bm[n], acc[m][n]);
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
-          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bm[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < TN; ++n) acc[m][n] = ss_mfma_32x32x16<W2>(ah[m], bh[n], acc[m][n]);
       }
     } else {
 #pragma unroll
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
         for (int r = 0; r < 16; ++r) {
           const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
           if (row >= a.T) continue;
-          float v = ss_apply_act(acc[m][n][r] + bs, a.act, 0.f);
+          float v = ss_apply_act(W2 ? fmaf(acc[m][n][r], osc, bs) : acc[m][n][r] + bs, a.act, 0.f);
           if (row >= row_lim) v = 0.f;
           Cb[(int64_t)row * a.ldc + col] = v;
         }
@@ -313,14 +321,17 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
-          float g = act(acc[m][n][r] + b0 + pe0[m][n / 2][r], m0, s0, h0) * act(acc[m][n + 1][r] + b1 + pe1[m][n / 2][r], m1, s1, h1);
+          float g;
+          if constexpr (W2) g = act(fmaf(acc[m][n][r], osc, b0 + pe0[m][n / 2][r]), m0, s0, h0) * act(fmaf(acc[m][n + 1][r], osc, b1 + pe1[m][n / 2][r]), m1, s1, h1);
+          else g = act(acc[m][n][r] + b0 + pe0[m][n / 2][r], m0, s0, h0) * act(acc[m][n + 1][r] + b1 + pe1[m][n / 2][r], m1, s1, h1);
           if (row0 + rr >= row_lim) g = 0.f;
 #if SS_HABL == 4
           if (g == 12345.678f)
 #endif
-          const uint16_t gh = f2bf(g);
+          const uint16_t gh = ss_f2t<W2>(g);
           __builtin_amdgcn_raw_buffer_store_b16(gh, rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
-          if constexpr (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, 64, 0);   // mid: 32 elements further
+          // second term 32 elements further; fp16x2: the gate output is only ever a matrix-core A operand (hi term), its second term is 0
+          if constexpr (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(W2 ? (uint16_t)0 : f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, 64, 0);
         }
       }
     }
@@ -375,11 +386,25 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const int e = 2 * e2 + k;
-              const float hf = __builtin_bit_cast(float, k ? (hv[e2] & 0xffff0000u) : (hv[e2] << 16));
-              const float mf = __builtin_bit_cast(float, k ? (mv[e2] & 0xffff0000u) : (mv[e2] << 16));
-              const float xn = (((hf + mf) - cb[e]) + (av[e] + bs[e])) * a.post_scale;
+              float hf, mf, xn;
+              if constexpr (W2) {
+                hf = ss_t2f_packed<true>(hv[e2], k);
+                mf = ss_t2f_packed<true>(mv[e2], k);
+                xn = (((hf + mf) - cb[e]) + fmaf(av[e], osc, bs[e])) * a.post_scale;
+              } else {
+                hf = __builtin_bit_cast(float, k ? (hv[e2] & 0xffff0000u) : (hv[e2] << 16));
+                mf = __builtin_bit_cast(float, k ? (mv[e2] & 0xffff0000u) : (mv[e2] << 16));
+                xn = (((hf + mf) - cb[e]) + (av[e] + bs[e])) * a.post_scale;
+              }
               const float yv = pad ? 0.f : xn + nb[e];
-              const uint16_t yh = f2bf(yv), ym = f2bf(yv - bf2f(yh));
+              uint16_t yh, ym;
+              if constexpr (W2) {
+                yh = ss_f2t<true>(yv);
+                ym = ss_f2t<true>(yv - ss_t2f<true>(yh));
+              } else {
+                yh = f2bf(yv);
+                ym = f2bf(yv - bf2f(yh));
+              }
               hp |= (uint32_t)yh << (16 * k);
               mp |= (uint32_t)ym << (16 * k);
             }
@@ -410,21 +435,21 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
-          float xn = (xv[r] + (acc[m][n][r] + bs)) * a.post_scale;
+          float xn = (xv[r] + (W2 ? fmaf(acc[m][n][r], osc, bs) : acc[m][n][r] + bs)) * a.post_scale;
           const bool pad = row0 + rr >= row_lim;
           if (pad) xn = 0.f;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xn), rsrc_x, xoff + rr * ldx4, 0, 0);
           const float yv = pad ? 0.f : xn + nb;
-          const uint16_t yh = f2bf(yv);
+          const uint16_t yh = ss_f2t<W2>(yv);
           __builtin_amdgcn_raw_buffer_store_b16(yh, rsrc_y, yoff + rr * ldy2, 0, 0);
-          if constexpr (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(f2bf(yv - bf2f(yh)), rsrc_y, yoff + rr * ldy2, 64, 0);
+          if constexpr (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(ss_f2t<W2>(yv - ss_t2f<W2>(yh)), rsrc_y, yoff + rr * ldy2, 64, 0);
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int EPI, bool SPLIT>
+template <int BM, int BN, int EPI, int SPLIT>
 int launch_h(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
@@ -443,7 +468,7 @@ int launch_h(const ss_gemm_bf16_args& a, hipStream_t stream) {
   return SS_OK;
 }
 
-template <int EPI, bool SPLIT>
+template <int EPI, int SPLIT>
 int launch_tiles_s(const ss_gemm_bf16_args& a, hipStream_t stream) {
   const int n_cols = (EPI == SS_HEPI_GATE) ? a.Np : a.N;
   const long big = (long)ss_cdiv(a.T, 128) * a.B * ss_cdiv(n_cols, 128);
@@ -455,7 +480,7 @@ int launch_tiles_s(const ss_gemm_bf16_args& a, hipStream_t stream) {
 }
 template <int EPI>
 int launch_tiles(const ss_gemm_bf16_args& a, hipStream_t stream) {
-  return a.split ? launch_tiles_s<EPI, true>(a, stream) : launch_tiles_s<EPI, false>(a, stream);
+  return a.split == 2 ? launch_tiles_s<EPI, 2>(a, stream) : a.split ? launch_tiles_s<EPI, 1>(a, stream) : launch_tiles_s<EPI, 0>(a, stream);
 }
 
 // x[r][c] (+ bias[c]) -> bf16 ; rows >= lens[b] -> 0
@@ -478,9 +503,11 @@ __global__ void to_bf16_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
-// the split form, pairs interleaved by 32: hi = RNE(v) at (c >> 5) * 64 + (c & 31), mid = RNE(v - hi) 32 elements further
+// the split form, pairs interleaved by 32: hi = RNE(v) at (c >> 5) * 64 + (c & 31), mid = RNE(v - hi) 32 elements further; F16: fp16 terms of
+// v * scale (a power of two: the weights' shift of the "fp16x2" mode, 1 for activations)
+template <bool F16>
 __global__ void split_bf16_kernel(const float* __restrict__ x, const float* __restrict__ bias, uint16_t* __restrict__ y, int B, int T, int C,
-                                  int ldx, int ldy, const int32_t* __restrict__ lens, int group_size, int64_t bias_gs) {
+                                  int ldx, int ldy, const int32_t* __restrict__ lens, int group_size, int64_t bias_gs, float scale) {
   const int64_t n = (int64_t)B * T * (C / 4);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % (C / 4)) * 4;
@@ -492,9 +519,11 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, const float* __re
       v.x += bp[0]; v.y += bp[1]; v.z += bp[2]; v.w += bp[3];
     }
     if (lens && t >= lens[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (F16) v = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
     ushort4 h, m;
-    h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
-    m.x = f2bf(v.x - bf2f(h.x)); m.y = f2bf(v.y - bf2f(h.y)); m.z = f2bf(v.z - bf2f(h.z)); m.w = f2bf(v.w - bf2f(h.w));
+    h.x = ss_f2t<F16>(v.x); h.y = ss_f2t<F16>(v.y); h.z = ss_f2t<F16>(v.z); h.w = ss_f2t<F16>(v.w);
+    m.x = ss_f2t<F16>(v.x - ss_t2f<F16>(h.x)); m.y = ss_f2t<F16>(v.y - ss_t2f<F16>(h.y)); m.z = ss_f2t<F16>(v.z - ss_t2f<F16>(h.z));
+    m.w = ss_f2t<F16>(v.w - ss_t2f<F16>(h.w));
     uint16_t* yp = y + r * ldy + (c4 >> 5) * 64 + (c4 & 31);
     *reinterpret_cast<ushort4*>(yp) = h;
     *reinterpret_cast<ushort4*>(yp + 32) = m;
@@ -515,7 +544,8 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
   SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16: A/W must be 16-byte aligned");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldx * 4 < (1ll << 31) &&
                    (int64_t)a.T * a.ldc * 4 < (1ll << 31), "ss_gemm_bf16: item too large for 32-bit offsets");
-  SS_CHECK_ARG(a.split == 0 || a.split == 1, "ss_gemm_bf16: split=%d", a.split);
+  SS_CHECK_ARG(a.split >= 0 && a.split <= 2, "ss_gemm_bf16: split=%d", a.split);
+  SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16: split = 2 needs 0 < out_scale <= 1 (got %g)", (double)a.out_scale);
   if (a.split) {   // pairs interleaved by 32: physical rows hold 2 x the logical channels
     SS_CHECK_ARG((a.K % 32) == 0 && a.lda >= 2 * a.K, "ss_gemm_bf16: split operands need K %% 32 == 0 and lda >= 2 K (K=%d lda=%d)", a.K, a.lda);
     SS_CHECK_ARG(a.epi != SS_HEPI_GATE || (a.ldc >= 2 * a.N && (a.N % 32) == 0), "ss_gemm_bf16: split GATE writes 2 N bf16 per row (ldc=%d N=%d)", a.ldc, a.N);
@@ -557,8 +587,20 @@ extern "C" int ss_split_bf16(const float* x, const float* bias, uint16_t* y, int
   SS_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && (C & 31) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldy >= 2 * C, "ss_split_bf16: bad args");
   const int64_t n = (int64_t)B * T * (C / 4);
   const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, lens, group_size,
-                     bias_group_stride);
+  hipLaunchKernelGGL(split_bf16_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, lens, group_size,
+                     bias_group_stride, 1.0f);
   SS_CHECK_LAUNCH("ss_split_bf16");
+  return SS_OK;
+}
+
+extern "C" int ss_split_f16(const float* x, const float* bias, float scale, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
+                            int group_size, int64_t bias_group_stride, void* stream) {
+  SS_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && (C & 31) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldy >= 2 * C, "ss_split_f16: bad args");
+  SS_CHECK_ARG(scale > 0.f && scale < 65536.f, "ss_split_f16: scale=%g", (double)scale);
+  const int64_t n = (int64_t)B * T * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipLaunchKernelGGL(split_bf16_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, y, B, T, C, ldx, ldy, lens, group_size,
+                     bias_group_stride, scale);
+  SS_CHECK_LAUNCH("ss_split_f16");
   return SS_OK;
 }

@@ -14,11 +14,12 @@
 // hardware exp/rcp activations, bf16 gate output - the same values as gemm_bf16_kernel<GATE> up to the K summation order.
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
+#include "pair16.h"
 #include <type_traits>
 #include <utility>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef ss_f32x16 f32x16;
+typedef ss_bf16x8 bf16x8;
 
 // SS_G256_ABL (debug builds only; results wrong by design): 1 = no DMA inside the loop, 2 = no MFMAs, 3 = no barriers, 4 = no epilogue
 // loads/stores except one store per lane
@@ -48,12 +49,15 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ds
 // 32 channels of BOTH planes (slots 0-3 hi, 4-7 mid) and every line of the DMA / LDS plan below is unchanged; a step then covers 32 channels
 // (CCS = K / 32 chunks per tap: 24 steps for K = 256) and runs 2 k-steps x 3 products (mid*hi, hi*mid, hi*hi) = 48 MFMAs per wave from 12
 // fragment reads per k-step - 1.5x the matrix work per byte staged. Outputs leave as (hi, mid) pairs in the same interleaved layout.
+// SPLIT = 2 ("fp16x2"): the same image with fp16 terms; the A operand's second plane is staged but never read, a step runs 2 k-steps x 2
+// products (hi*hi, hi*lo) = 32 MFMAs from 8 + 8 fragment reads (step_w2), the accumulators are scaled by args.out_scale in the epilogue and the
+// output pair is (fp16(g), 0).
 template <class F, int... I>
 __device__ __forceinline__ void unrolled_steps(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
 }
 
-template <int CCS, bool SPLIT>
+template <int CCS, int SPLIT>
 __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem_g256[];   // 144 KB (split: 160 KB, the epilogue's staging tile is twice as wide): one workgroup per CU
   // [A0 40 K][B0 32 K][A1 40 K][B1 32 K]: the operands of the LAST step live in A1 / B1, so the first 72 KB are free while it runs
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   const int l31 = lane & 31, lh = lane >> 5;
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
+  constexpr bool W2 = SPLIT == 2;
   const int ldw = 3 * a.K * (SPLIT ? 2 : 1);            // bf16 per packed weight row (3 taps; both planes when split)
 
   auto uniform_ptr = [](const void* p) {
@@ -252,6 +257,79 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
       mfma8(p_ah, p_bh);
     }
   };
+  // ---- SPLIT = 2: products H0 = hi x hi, L0 = hi x lo of k-step 0 run inside the step, H1 / L1 of k-step 1 (fragments p_ah, p_bh, p_bm) are
+  // deferred past the next barrier exactly like G1(1) / G2(1) above: the same pipeline with one product group less per k-step.
+  auto step_w2 = [&](auto stag) {
+    constexpr int S = decltype(stag)::value;
+    constexpr int CC = S / 3, TAP = S % 3;
+    constexpr bool LAST = S + 1 >= 3 * CCS;
+    const char* Ac = (CC & 1) ? A1 : A0;
+    const char* Bc = (S & 1) ? B1 : B0;
+    char* Bn = (S & 1) ? B0 : B1;
+    char* An = (CC & 1) ? A0 : A1;
+    if constexpr (TAP == 2 && CC + 1 < CCS) wait_vmcnt<5>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    auto rd_a = [&](int slot, bf16x8 (&f)[4]) {
+      const int ao = a_base[TAP] + ((slot ^ a_swz[TAP]) << 4);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) f[m] = *reinterpret_cast<const bf16x8*>(Ac + ao + m * 32 * ROWB);
+    };
+    auto rd_b = [&](int slot, bf16x8 (&f)[2]) {
+      const int bo = b_base + ((slot ^ b_swz) << 4);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) f[n] = *reinterpret_cast<const bf16x8*>(Bc + bo + n * 32 * ROWB);
+    };
+    auto mm8 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2]) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = ss_mfma_32x32x16<true>(fa[m], fb[n], acc[m][n]);
+    };
+    bf16x8 ah0[4], bh0[2];
+    rd_a(0, ah0);
+    rd_b(0, bh0);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NB = LAST ? 0 : 4, NA = (TAP == 1 && CC + 1 < CCS) ? 5 : 0, NE = LAST ? 8 : 0, NP = NB + NA + NE;
+    auto piece = [&](int i) {
+      if (i < NB) piece_b(Bn, (S + 1) / 3, (S + 1) % 3, i);
+      else if (i < NB + NA) piece_a(An, CC + 1, i - NB);
+      else piece_e(EQ0, 0, i - NB - NA);
+    };
+    if constexpr (S > 0) {   // the 16 MFMAs deferred by step S-1 (L1 then H1), one DMA piece after every MFMA until the pieces are out
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i >> 1) & 3, n = i & 1;
+        acc[m][n] = ss_mfma_32x32x16<true>(p_ah[m], i < 8 ? p_bm[n] : p_bh[n], acc[m][n]);
+        if (i < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece(i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      static_assert(NP <= 16, "more DMA pieces than deferred MFMAs");
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) piece(i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 bm0[2];
+    rd_b(4, bm0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm8(ah0, bh0);            // H0
+    __builtin_amdgcn_sched_barrier(0);
+    rd_a(2, p_ah);
+    rd_b(2, p_bh);
+    __builtin_amdgcn_sched_barrier(0);
+    mm8(ah0, bm0);            // L0
+    __builtin_amdgcn_sched_barrier(0);
+    rd_b(6, p_bm);            // H1 = p_ah x p_bh and L1 = p_ah x p_bm run after the next barrier
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LAST) {
+      mm8(p_ah, p_bm);
+      mm8(p_ah, p_bh);
+    }
+  };
   auto step = [&](auto stag) {
     constexpr int S = decltype(stag)::value;
     constexpr int CC = S / 3, TAP = S % 3;
@@ -307,7 +385,8 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   dma_b(B0, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   static_assert((CCS & 1) == 0, "the epilogue's LDS plan assumes the last step reads A1 / B1");
-  if constexpr (SPLIT) unrolled_steps(step_split, std::make_integer_sequence<int, 3 * CCS>{});
+  if constexpr (W2) unrolled_steps(step_w2, std::make_integer_sequence<int, 3 * CCS>{});
+  else if constexpr (SPLIT) unrolled_steps(step_split, std::make_integer_sequence<int, 3 * CCS>{});
   else unrolled_steps(step, std::make_integer_sequence<int, 3 * CCS>{});
 
   // ---- epilogue. A single workgroup per CU has nobody to overlap its epilogue with, so nothing here may wait on HBM or issue narrow
@@ -350,11 +429,14 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
       const int rr = (r & 3) + 8 * (r >> 2);
       const float e0 = *reinterpret_cast<const float*>(Eq + e_rd + rr * 1024);
       const float e1 = *reinterpret_cast<const float*>(Eq + e_rd + rr * 1024 + 128);
-      float g = act(acc[q][0][r] + b0 + e0, m0, s0, h0) * act(acc[q][1][r] + b1 + e1, m1, s1, h1);
+      float g;
+      if constexpr (W2) g = act(fmaf(acc[q][0][r], a.out_scale, b0 + e0), m0, s0, h0) * act(fmaf(acc[q][1][r], a.out_scale, b1 + e1), m1, s1, h1);
+      else g = act(acc[q][0][r] + b0 + e0, m0, s0, h0) * act(acc[q][1][r] + b1 + e1, m1, s1, h1);
       if (t0 + 128 * wm + 32 * q + 4 * lh + rr >= row_lim) g = 0.f;
-      const uint16_t gh = f2bf(g);
+      const uint16_t gh = ss_f2t<W2>(g);
       *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW) = gh;
-      if constexpr (SPLIT) *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW + 64) = f2bf(g - __builtin_bit_cast(float, (uint32_t)gh << 16));
+      // second term; fp16x2: the gate output only ever feeds the matrix cores' A operand (hi term) - its second term is written as 0
+      if constexpr (SPLIT) *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW + 64) = W2 ? (uint16_t)0 : f2bf(g - __builtin_bit_cast(float, (uint32_t)gh << 16));
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my staging writes are done
     __builtin_amdgcn_s_barrier();         // the staging tile is complete; everyone finished reading addend quarter q
@@ -411,7 +493,8 @@ extern "C" int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream)
                "ss_gemm_bf16_gate256: K = 256, Np %% 256, lda %% 8, N %% 8, ldc %% 8");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldc * 2 < (1ll << 31) &&
                    (int64_t)a.Np * 3 * a.K * 4 < (1ll << 31), "ss_gemm_bf16_gate256: item too large for 32-bit offsets");
-  SS_CHECK_ARG(a.split == 0 || (a.split == 1 && (a.N % 32) == 0 && a.lda >= 2 * a.K && a.ldc >= 2 * a.N), "ss_gemm_bf16_gate256: split operands need N %% 32 == 0, lda >= 2 K, ldc >= 2 N");
+  SS_CHECK_ARG(a.split == 0 || ((a.split == 1 || a.split == 2) && (a.N % 32) == 0 && a.lda >= 2 * a.K && a.ldc >= 2 * a.N), "ss_gemm_bf16_gate256: split operands need N %% 32 == 0, lda >= 2 K, ldc >= 2 N");
+  SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16_gate256: split = 2 needs 0 < out_scale <= 1");
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
   const int n_tiles = a.Np / BN;
@@ -429,7 +512,7 @@ extern "C" int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream)
     return SS_OK;
   };
   // plain: 4 channel chunks of 64 x 3 taps = 12 steps; split: 8 chunks of 32 (both planes) x 3 taps = 24 steps
-  SS_PROPAGATE(a.split ? go(&gate256_kernel<8, true>) : go(&gate256_kernel<4, false>));
+  SS_PROPAGATE(a.split == 2 ? go(&gate256_kernel<8, 2>) : a.split ? go(&gate256_kernel<8, 1>) : go(&gate256_kernel<4, 0>));
   SS_CHECK_LAUNCH("ss_gemm_bf16_gate256");
   return SS_OK;
 }

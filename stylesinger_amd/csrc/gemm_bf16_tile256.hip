@@ -12,12 +12,15 @@
 //     stream / the fp32 outputs move as 16-byte vectors, full lines per wave instruction.
 // Arithmetic contract = gemm_bf16_kernel<..., SPLIT>: hi*hi + hi*mid + mid*hi of (hi, mid) bf16 pairs interleaved by 32 channels, fp32
 // accumulation (the order of the K products inside an accumulator differs: results agree to fp32 rounding).
+// W2 (ss_gemm_bf16_args.split = 2, "fp16x2"): fp16 terms, the A operand's second plane is staged but not read, two products hi*hi + hi*lo per
+// k-step (32 MFMAs per step, the 16 of the second k-step deferred), accumulators scaled by args.out_scale where the epilogue first touches them.
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
+#include "pair16.h"
 #include <type_traits>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef ss_f32x16 f32x16;
+typedef ss_bf16x8 bf16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -36,7 +39,7 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ds
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, bool W2>
 __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int kchunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_t256[];   // 128 KB: [A0 32 K][B0 32 K][A1 32 K][B1 32 K]; epilogue: 2 x 64 KB staging
   char* const A0 = smem_t256;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+      for (int n = 0; n < 2; ++n) acc[m][n] = ss_mfma_32x32x16<W2>(fa[m], fb[n], acc[m][n]);
   };
   auto step = [&](const char* Ac, const char* Bc, char* An, char* Bn, int c, bool more) {
     wait_vmcnt<0>();                  // my pieces of chunk c have landed (nothing younger is in flight)
@@ -122,14 +125,16 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
 #pragma unroll
       for (int n = 0; n < 2; ++n) f[n] = *reinterpret_cast<const bf16x8*>(Bc + bo + n * 32 * ROWB);
     };
-    bf16x8 am0[4], bh0[2];
-    rd_a(4, am0);
+    [[maybe_unused]] bf16x8 am0[4], ah0[4];
+    bf16x8 bh0[2];
+    if constexpr (W2) rd_a(0, ah0);
+    else rd_a(4, am0);
     rd_b(0, bh0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {    // the 16 MFMAs deferred by the previous step, one DMA piece of the next chunk after each of the first 8
       const int m = (i >> 1) & 3, n = i & 1;
-      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p_ah[m], i < 8 ? p_bm[n] : p_bh[n], acc[m][n], 0, 0, 0);
+      acc[m][n] = ss_mfma_32x32x16<W2>(p_ah[m], i < 8 ? p_bm[n] : p_bh[n], acc[m][n]);
       if (i < 8) {
         __builtin_amdgcn_sched_barrier(0);
         if (more) piece(An, Bn, c + 1, i);   // wave-uniform branch
@@ -137,7 +142,22 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 ah0[4], bm0[2], am1[4], bh1[2];
+    if constexpr (W2) {   // hi x hi, hi x lo of k-step 0 now; the second k-step's two groups (p_ah x p_bm, p_ah x p_bh) after the next barrier
+      bf16x8 bm0[2];
+      rd_b(4, bm0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(ah0, bh0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd_a(2, p_ah);
+      rd_b(2, p_bh);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(ah0, bm0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd_b(6, p_bm);
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
+    bf16x8 bm0[2], am1[4], bh1[2];
     rd_a(0, ah0);
     rd_b(4, bm0);
     __builtin_amdgcn_sched_barrier(0);
@@ -197,7 +217,8 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
         const int k = (tid >> 6) + 8 * j;   // staging row of piece tid + 512 j
         const int grow = t0 + 128 * (k >> 5) + 32 * q + (k & 31);
         float4 v = *reinterpret_cast<const float4*>(St + k * (BN * 4) + c4 * 4);
-        v.x += bs[0]; v.y += bs[1]; v.z += bs[2]; v.w += bs[3];
+        if constexpr (W2) v = make_float4(fmaf(v.x, a.out_scale, bs[0]), fmaf(v.y, a.out_scale, bs[1]), fmaf(v.z, a.out_scale, bs[2]), fmaf(v.w, a.out_scale, bs[3]));
+        else { v.x += bs[0]; v.y += bs[1]; v.z += bs[2]; v.w += bs[3]; }
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         if (grow >= row_lim) v = make_float4(0.f, 0.f, 0.f, 0.f);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_c, (grow * a.ldc + c4) * 4 | dead, 0, 0);   // rows >= T dropped
@@ -254,11 +275,25 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const int e = 2 * e2 + kk;
-            const float hf = __builtin_bit_cast(float, kk ? (hv[j][e2] & 0xffff0000u) : (hv[j][e2] << 16));
-            const float mf = __builtin_bit_cast(float, kk ? (mv[j][e2] & 0xffff0000u) : (mv[j][e2] << 16));
-            const float xn = (((hf + mf) - cb[e]) + (av[e] + bs[e])) * a.post_scale;
+            float hf, mf, xn;
+            if constexpr (W2) {
+              hf = ss_t2f_packed<true>(hv[j][e2], kk);
+              mf = ss_t2f_packed<true>(mv[j][e2], kk);
+              xn = (((hf + mf) - cb[e]) + fmaf(av[e], a.out_scale, bs[e])) * a.post_scale;
+            } else {
+              hf = __builtin_bit_cast(float, kk ? (hv[j][e2] & 0xffff0000u) : (hv[j][e2] << 16));
+              mf = __builtin_bit_cast(float, kk ? (mv[j][e2] & 0xffff0000u) : (mv[j][e2] << 16));
+              xn = (((hf + mf) - cb[e]) + (av[e] + bs[e])) * a.post_scale;
+            }
             const float yv = pad ? 0.f : xn + nb[e];
-            const uint16_t yh = f2bf(yv), ym = f2bf(yv - bf2f(yh));
+            uint16_t yh, ym;
+            if constexpr (W2) {
+              yh = ss_f2t<true>(yv);
+              ym = ss_f2t<true>(yv - ss_t2f<true>(yh));
+            } else {
+              yh = f2bf(yv);
+              ym = f2bf(yv - bf2f(yh));
+            }
             hp |= (uint32_t)yh << (16 * kk);
             mp |= (uint32_t)ym << (16 * kk);
           }
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
 // 1 if ss_gemm_bf16 should hand this launch to the 256-row kernel: split operands, one tap, STORE or RESX on the pair-only stream, N <= 256,
 // an even number of 32-channel chunks, and at least two rounds of 256-row tiles
 extern "C" int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* a) {
-  if (!a || a->split != 1 || a->ntaps != 1 || a->tap_off[0] != 0) return 0;
+  if (!a || (a->split != 1 && a->split != 2) || a->ntaps != 1 || a->tap_off[0] != 0) return 0;
   if (a->epi == SS_HEPI_RESX ? !(a->X == nullptr && a->Y && a->cur_bias && (a->N % 32) == 0 && a->ldy >= 2 * a->N) : a->epi != SS_HEPI_STORE) return 0;
   if (a->epi == SS_HEPI_STORE && ((a->N % 4) != 0 || (a->ldc % 4) != 0 || (a->act != SS_ACT_NONE_ && a->act != SS_ACT_RELU_))) return 0;
   if (a->N > BN || (a->K % 64) != 0 || a->lda < 2 * a->K || (a->lda % 8) != 0) return 0;
@@ -289,7 +324,8 @@ extern "C" int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* a) {
 extern "C" int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream) {
   SS_CHECK_ARG(args != nullptr, "ss_gemm_bf16_tile256: null args");
   const ss_gemm_bf16_args& a = *args;
-  SS_CHECK_ARG(a.A && a.W && a.split == 1 && a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm_bf16_tile256: split operands, one tap at offset 0");
+  SS_CHECK_ARG(a.A && a.W && (a.split == 1 || a.split == 2) && a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm_bf16_tile256: split operands, one tap at offset 0");
+  SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16_tile256: split = 2 needs 0 < out_scale <= 1");
   SS_CHECK_ARG(a.N > 0 && a.N <= BN && a.Np >= a.N && (a.K % 64) == 0 && a.lda >= 2 * a.K && (a.lda % 8) == 0, "ss_gemm_bf16_tile256: N <= 256, K %% 64 == 0, lda >= 2 K");
   SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16_tile256: A/W must be 16-byte aligned");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.Np * a.K * 4 < (1ll << 31), "ss_gemm_bf16_tile256: item too large for 32-bit offsets");
@@ -308,11 +344,11 @@ extern "C" int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream)
   if (a.epi == SS_HEPI_STORE) {
     SS_CHECK_ARG(a.C && (a.N % 4) == 0 && (a.ldc % 4) == 0 && (int64_t)a.T * a.ldc * 4 < (1ll << 31) && (a.act == SS_ACT_NONE_ || a.act == SS_ACT_RELU_),
                  "ss_gemm_bf16_tile256: STORE needs C, N %% 4 == 0, ldc %% 4 == 0, act none | relu");
-    SS_PROPAGATE(go(&tile256s_kernel<SS_HEPI_STORE>));
+    SS_PROPAGATE(a.split == 2 ? go(&tile256s_kernel<SS_HEPI_STORE, true>) : go(&tile256s_kernel<SS_HEPI_STORE, false>));
   } else {
     SS_CHECK_ARG(a.epi == SS_HEPI_RESX && a.X == nullptr && a.Y && a.cur_bias && (a.N % 32) == 0 && a.ldy >= 2 * a.N && (a.ldy % 8) == 0 &&
                      (int64_t)a.T * a.ldy * 2 < (1ll << 31), "ss_gemm_bf16_tile256: RESX on the pair-only stream (X = NULL, Y, cur_bias), N %% 32 == 0");
-    SS_PROPAGATE(go(&tile256s_kernel<SS_HEPI_RESX>));
+    SS_PROPAGATE(a.split == 2 ? go(&tile256s_kernel<SS_HEPI_RESX, true>) : go(&tile256s_kernel<SS_HEPI_RESX, false>));
   }
   SS_CHECK_LAUNCH("ss_gemm_bf16_tile256");
   return SS_OK;

@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 12  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 13  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -68,7 +68,7 @@ class WaveNet(C.Structure):
            ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64),
            ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS),
            ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64), ("w_skipall_x3", _vp), ("gs_w_skipall_x3", C.c_int64),
-           ("mfma_split", C.c_int32), ("reserved_", C.c_int32)]
+           ("mfma_split", C.c_int32), ("mfma_out_scale", C.c_float)]
 
 
 class GemmBf16Args(C.Structure):
@@ -79,7 +79,7 @@ class GemmBf16Args(C.Structure):
         ("gate_mode", C.c_int32), ("e_batch_stride", C.c_int64), ("X", _vp), ("x_batch_stride", C.c_int64), ("ldx", C.c_int32),
         ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
         ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
-        ("split", C.c_int32), ("reserved_", C.c_int32 * 3), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
+        ("split", C.c_int32), ("out_scale", C.c_float), ("reserved_", C.c_int32 * 2), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
     ]
 
 
@@ -441,15 +441,26 @@ def split_bf16(x, bias=None, lens=None):
     return y
 
 
+def split_f16(x, bias=None, lens=None, scale=1.0):
+    """fp32 device tensor [..., C] -> [..., 2C] fp16 bits in the same pairs-interleaved-by-32 layout: hi = RNE16(v), lo = RNE16(v - hi) of
+    v = (x + bias) * scale (ss_split_f16; the operand layout of ss_gemm_bf16_args.split = 2, scale = the weights' power-of-two shift)."""
+    x = x.contiguous().float()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty(tuple(x.shape[:-1]) + (2 * Cc,), device=x.device, dtype=torch.float16)
+    check(load().ss_split_f16(ptr(x), ptr(bias), _f(scale), ptr(y), 1, rows, Cc, Cc, 2 * Cc, ptr(lens), 0, 0, stream_ptr()), "ss_split_f16")
+    return y
+
+
 def split_planes(y):
-    """[..., 2C] pairs-interleaved-by-32 bf16 -> (hi [..., C], mid [..., C]) as float (host-side view for tests / debugging)."""
+    """[..., 2C] pairs-interleaved-by-32 bf16 / fp16 -> (hi [..., C], mid [..., C]) as float (host-side view for tests / debugging)."""
     v = y.float().reshape(*y.shape[:-1], y.shape[-1] // 64, 2, 32)
     return v[..., 0, :].reshape(*y.shape[:-1], -1), v[..., 1, :].reshape(*y.shape[:-1], -1)
 
 
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
               next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False,
-              split=0, cur_bias=None):
+              split=0, cur_bias=None, out_scale=1.0):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -469,6 +480,7 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.c_batch_stride = c_bs if c_bs is not None else T * a.ldc
     a.mask_rows = int(mask_rows)
     a.split = split
+    a.out_scale = out_scale
     a.cur_bias = ptr(cur_bias)
     if gate256:   # the 256-row LDS-DMA kernels directly (ss_gemm_bf16 picks them by itself for many-round launches)
         if epi == HEPI_GATE:

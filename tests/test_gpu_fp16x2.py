@@ -1,0 +1,203 @@
+""""fp16x2" precision (ss_gemm_bf16_args.split = 2): BASELINE configs[3] at north_star parity with TWO matrix products per GEMM - fp16 operands,
+only the weights split into (hi, lo) pairs. Unit tests of the three kernels that carry the mode (generic 128-row tiles, the 256x256 LDS-DMA gate
+kernel, the 256-row 1-tap kernel) against float64 math on the same terms, then the model against the REAL reference's goldens.
+
+Numerics first (CPU, tests/test_oracle_golden.py::test_fp16x2_restatement_meets_the_bar_on_the_1000_step_golden, oracle/bf16x2_numerics.py):
+1.9e-5 vs the reference's 1000-step golden where plain fp16 operands end at 1.9e-4 and bf16 with the same two products at 1.6e-4."""
+import os
+
+import pytest
+import torch
+
+# NOT YET VALIDATED ON HARDWARE in the round that wrote it (GPU budget spent): opt-in until a run on an MI355X has passed
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SS_TEST_FP16X2") != "1", reason="fp16x2 is opt-in: set SS_TEST_FP16X2=1")]
+
+from conftest import record_measurement  # noqa: E402
+from oracle import harness  # noqa: E402
+from oracle import restatement as R  # noqa: E402
+from stylesinger_amd import config, synth  # noqa: E402
+from stylesinger_amd import lib as L  # noqa: E402
+from stylesinger_amd.model import StyleSingerHIP  # noqa: E402
+
+WS = 8   # the weights' shift (StyleSingerHIP.FP16_WSHIFT, oracle.restatement.FP16_WSHIFT)
+
+
+def _fwd(model, b, **kw):
+    return model(b["txt_tokens"], mel2ph=b.get("mel2ph"), spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
+                 ref_f0=b["ref_f0"], global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"], **kw)
+
+
+def _split_ref(x, scale=1.0):
+    v = x * scale
+    hi = v.to(torch.float16).float()
+    return hi, (v - hi).to(torch.float16).float()
+
+
+@pytest.mark.parametrize("T,K,force256", [(200, 256, False), (333, 192, False), (5600, 256, False), (5600, 256, True), (777, 256, True)])
+def test_gemm_split2_matches_float64_of_the_same_two_products(T, K, force256):
+    """ss_gemm_bf16 with split = 2: A in the pair layout (only its hi fp16 term feeds the matrix cores), W = (hi, lo) fp16 pairs of w * 2^8,
+    a*hi + a*lo accumulated in fp32 and scaled by out_scale = 2^-8 - against float64 math on the SAME terms. GATE (3-tap dilated conv + addend,
+    output (fp16(g), 0)), RESX with the fp32 stream, RESX on the pair-only stream (a true fp16 pair: 22 bits) and STORE.
+    force256: ss_gemm_bf16_gate256 / ss_gemm_bf16_tile256 (the many-round kernels of the C4 shape) instead of the generic tiles."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(T + K + 2)
+    B, C = 3, K
+    sc, osc = float(2 ** WS), float(2.0 ** -WS)
+    lens = torch.tensor([T, T - 37, 5], dtype=torch.int32, device=dev)
+    x = torch.randn(B, T, C, generator=g).to(dev) * 3.0
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    xs = L.split_f16(x)                                    # [B,T,2C] fp16: (hi, lo) pairs interleaved by 32 channels
+    assert xs.dtype == torch.float16
+    xh, xl = _split_ref(x)
+    ph, pl = L.split_planes(xs)
+    assert torch.equal(ph, xh) and torch.equal(pl, xl)
+    assert torch.equal(xs[..., 64:96].float(), xh[..., 32:64]) and torch.equal(xs[..., 32:64].float(), xl[..., :32])   # the layout itself
+    assert (xh + xl - x).abs().max().item() <= 16.0 * 2.0 ** -22
+    d = 4
+    w = (torch.randn(2 * C, C, 3, generator=g) / (3 * C) ** 0.5).to(dev)
+    Wp = L.pack_conv_weight(w, interleave_half=C)          # [2C][3*Kp] gate-interleaved, fp32
+    Ws = L.split_f16(Wp, scale=sc)                         # [2C][2*3*Kp]
+    wh, wl = _split_ref(w, sc)
+    assert (wl.abs() > 0).float().mean().item() > 0.99 and wl[wl != 0].abs().min().item() >= 2.0 ** -24
+    conv = lambda a, ww: torch.nn.functional.conv1d(a.double().transpose(1, 2), ww.double(), padding=d, dilation=d).transpose(1, 2)
+    y2 = (conv(xh, wl) + conv(xh, wh)) * osc               # the two products, float64
+    y_exact = conv(x, w)
+    E = torch.randn(B, T, 2 * C, generator=g).to(dev) * 0.5
+    Ep = torch.empty_like(E)
+    for p in range(C // 32):
+        Ep[..., 64 * p:64 * p + 32] = E[..., 32 * p:32 * p + 32]
+        Ep[..., 64 * p + 32:64 * p + 64] = E[..., C + 32 * p:C + 32 * p + 32]
+    Lyr = 2
+    GA = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.float16)
+    L.gemm_bf16(xs, Ws, B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, E=Ep, lde=2 * C, out=GA[..., 2 * C:],
+                ldc=2 * Lyr * C, c_bs=T * 2 * Lyr * C, lda=2 * C, split=2, out_scale=osc, gate256=force256)
+    z = y2 + E.double()
+    g_ref = (torch.sigmoid(z[..., :C]) * torch.tanh(z[..., C:])).float()
+    z2 = y_exact + E.double()
+    g_exact = (torch.sigmoid(z2[..., :C]) * torch.tanh(z2[..., C:])).float()
+    for b in range(B):
+        g_ref[b, lens[b]:] = 0
+        g_exact[b, lens[b]:] = 0
+    gah, gal = L.split_planes(GA)                          # logical [B,T,Lyr*C] planes
+    got = gah[..., C:]
+    assert torch.all(gal[..., C:] == 0), "the gate output's second term is written as 0"
+    e2, ex = (got - g_ref).abs().max().item(), (got - g_exact).abs().max().item()
+    print(f"split=2 GATE T={T} K={K} gate256={force256}: vs float64 of the 2 products {e2:.2e}, vs exact operands {ex:.2e}")
+    assert e2 <= 3e-4 and ex <= 4e-3, (e2, ex)             # e2: one fp16 rounding of values in (-1, 1) = 2^-12 + hardware exp/rcp; ex: + the activations' fp16 rounding over K = 768
+    assert torch.all(GA[..., :2 * C].float() == 7.0), "the neighbouring layer slot is untouched"
+    # RESX on the layer-slot operand, fp32 stream: x <- (x + G . Wo^T + b) / sqrt(2); Y = pair(x + next_bias)
+    wo = (torch.randn(C, C, 1, generator=g) / C ** 0.5).to(dev)
+    Wos = L.split_f16(L.pack_conv_weight(wo), scale=sc)
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    nb = torch.randn(C, generator=g).to(dev)
+    X = torch.randn(B, T, C, generator=g).to(dev)
+    X0 = X.clone()
+    Y = torch.empty(B, T, 2 * C, device=dev, dtype=torch.float16)
+    L.gemm_bf16(GA[..., 2 * C:], Wos, B=B, T=T, K=C, taps=(0,), N=C, Np=Wos.shape[0], epi=L.HEPI_RESX, lens=lens, bias=L.pack_bias(bo), X=X,
+                post_scale=0.5 ** 0.5, next_bias=nb, Y=Y, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=2, out_scale=osc)
+    gh = gah[..., C:].double()
+    woh, wol = (t.double() for t in _split_ref(wo[:, :, 0], sc))
+    proj = (gh @ wol.t() + gh @ woh.t()) * osc
+    x_ref = ((X0.double() + (proj + bo.double())) * (0.5 ** 0.5)).float()
+    for b in range(B):
+        x_ref[b, lens[b]:] = 0
+    assert (X - x_ref).abs().max().item() <= 4e-6 * (C ** 0.5)
+    y_ref = x_ref + nb
+    for b in range(B):
+        y_ref[b, lens[b]:] = 0
+    yh, yl = L.split_planes(Y)
+    assert ((yh + yl) - y_ref).abs().max().item() <= 1e-5
+    assert torch.equal(yh, y_ref.to(torch.float16).float()) or (yh - y_ref).abs().max().item() <= 8 * 2.0 ** -11
+    # the pair-only residual stream (X = NULL): Y holds x + cur_bias as an fp16 pair, is read, updated and rewritten in place
+    cb = torch.randn(C, generator=g).to(dev)
+    Yp = L.split_f16(X0 + cb)
+    for b in range(B):
+        Yp[b, lens[b]:] = 0
+    y0h, y0l = L.split_planes(Yp)
+    L.gemm_bf16(GA[..., 2 * C:], Wos, B=B, T=T, K=C, taps=(0,), N=C, Np=Wos.shape[0], epi=L.HEPI_RESX, lens=lens, bias=L.pack_bias(bo), X=None,
+                post_scale=0.5 ** 0.5, next_bias=nb, Y=Yp, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=2, out_scale=osc, cur_bias=cb,
+                gate256=force256)
+    x_in = (y0h + y0l) - cb
+    xp_ref = ((x_in.double() + (proj + bo.double())) * (0.5 ** 0.5)).float() + nb
+    for b in range(B):
+        xp_ref[b, lens[b]:] = 0
+    y1h, y1l = L.split_planes(Yp)
+    assert ((y1h + y1l) - xp_ref).abs().max().item() <= 1e-5
+    # STORE with ReLU on the K = Lyr * C (skip-GEMM form) operand
+    w2 = (torch.randn(C, Lyr * C, 1, generator=g) / (Lyr * C) ** 0.5).to(dev)
+    S = torch.empty(B, T, C, device=dev)
+    GA[..., :2 * C] = L.split_f16(torch.randn(B, T, C, generator=g).to(dev))   # fill layer slot 0 with real operands
+    L.gemm_bf16(GA, L.split_f16(L.pack_conv_weight(w2), scale=sc), B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=L.round_up(C, 32), epi=L.HEPI_STORE,
+                lens=lens, act=L.ACT_RELU, out=S, lda=2 * Lyr * C, split=2, out_scale=osc, bias=L.pack_bias(bo), gate256=force256)
+    ah = L.split_planes(GA)[0].double()
+    w2h, w2l = (t.double() for t in _split_ref(w2[:, :, 0], sc))
+    s_ref = torch.relu((ah @ w2l.t() + ah @ w2h.t()) * osc + bo.double()).float()
+    for b in range(B):
+        s_ref[b, lens[b]:] = 0
+    assert (S - s_ref).abs().max().item() <= 2e-5 * (Lyr * C) ** 0.5
+
+
+def _model(hp, sd):
+    m = StyleSingerHIP(None, hparams=hp)
+    m.load_state_dict(sd)
+    m.eval().to("cuda:0")
+    return m
+
+
+def test_fp16x2_mode_meets_north_star_on_the_1000_step_golden():
+    """BASELINE configs[3] AS SPECIFIED - 1000 mel diffusion steps on the 16-bit matrix cores - against the REAL reference's fp32 golden
+    `acoustic_t32_mel1000` (/root/reference/modules/diff/shallow_diffusion_tts.py:99-162): north_star's mel L1 <= 1e-4, asserted at 6e-5 (the
+    CPU restatement of this arithmetic measures 1.9e-5)."""
+    case = harness.load_case("acoustic_t32_mel1000")
+    meta, gold = case["meta"], case["out"]
+    hp, sd, batch = harness.case_setup(meta)
+    b = {k: v.cuda() for k, v in batch.items()}
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(meta["tape_seed"]), meta["B"], meta["T"], meta["steps_f0"], meta["steps_mel"])
+    m = _model(dict(hp, mfma_precision="fp16x2"), sd)
+    assert m.bf16 and m.split and m.f16 and m.bf16_hbm and m.fold_skip and not m.use_wino
+    got = _fwd(m, b, noise=noise)
+    d = (got["mel_out"].cpu() - gold["mel_out"]).abs()
+    uv = ((got["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).sum().item()
+    f0e = (got["f0_denorm"].cpu() - gold["f0_denorm"]).abs().max().item()
+    print(f"fp16x2 mode, 1000-step golden of the real reference: mel L1 {d.mean().item():.3e} max {d.max().item():.3e}; voicing flips {uv}; f0 max err {f0e:.3e} Hz")
+    record_measurement("c4_fp16x2_t32_1000steps_vs_fp32_reference", mel_l1=d.mean().item(), mel_max=d.max().item(), voicing_flips=uv,
+                       f0_max_err_hz=f0e, pinned=True, north_star=1e-4)
+    assert uv == 0
+    assert d.mean().item() <= 6e-5, d.mean().item()
+    for name in ("acoustic_t64_s100", "acoustic_t300_s100"):
+        case = harness.load_case(name)
+        meta, gold = case["meta"], case["out"]
+        hp, sd, batch = harness.case_setup(meta)
+        noise = synth.draw_acoustic_noise(synth.NoiseTape(meta["tape_seed"]), meta["B"], meta["T"], meta["steps_f0"], meta["steps_mel"])
+        got = _fwd(_model(dict(hp, mfma_precision="fp16x2"), sd), {k: v.cuda() for k, v in batch.items()}, noise=noise)
+        d = (got["mel_out"].cpu() - gold["mel_out"]).abs()
+        uv = ((got["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).sum().item()
+        print(f"fp16x2 mode, {name}: mel L1 {d.mean().item():.3e} max {d.max().item():.3e}; voicing flips {uv}")
+        record_measurement(f"fp16x2_{name.split('_', 1)[1]}_vs_fp32_reference", mel_l1=d.mean().item(), mel_max=d.max().item(), voicing_flips=uv)
+        assert uv == 0 and d.mean().item() <= 6e-5
+
+
+@pytest.mark.skipif(os.environ.get("SS_TEST_FP16X2_LONG") != "1", reason="a minute of CPU oracle at T = 5625: set SS_TEST_FP16X2_LONG=1")
+def test_fp16x2_mode_at_the_c4_shape_matches_the_fp32_oracle():
+    """The C4 SHAPE (one 30 s item, T = 5625: gate256_kernel<8, 2> and tile256s_kernel<., true> run here) with 100 + 2 x 100 step chains in
+    fp16x2 mode against the fp32 oracle on this box."""
+    S = 100
+    hp = config.make_hparams(dict(timesteps=S, K_step=S, f0_timesteps=S))
+    B, T, Tp, Tr = 1, 5625, 105, 1500
+    batch = synth.synth_batch(B, T, Tp, Tr, hp, 2025)
+    sd = synth.synth_acoustic_state_dict(hp, 2025)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(78), B, T, S, S)
+    got = _fwd(_model(dict(hp, mfma_precision="fp16x2"), sd), {k: v.cuda() for k, v in batch.items()}, noise=noise)
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = R.acoustic_forward(sd, hp, batch, synth.NoiseTape(78), mel2ph=batch["mel2ph"])
+    flips = (got["uv_a"].cpu().long() != ref["uv_a"]).sum().item() + (got["uv_b"].cpu().long() != ref["uv_b"]).sum().item()
+    cf = (got["pitch_coarse"].cpu() != ref["pitch_coarse"])
+    dm = (got["mel_out"].cpu() - ref["mel_out"]).abs()
+    print(f"fp16x2 at T=5625, 100+100+100 steps vs the fp32 oracle: mel L1 {dm.mean().item():.3e} max {dm.max().item():.3e}; voicing flips {flips}; coarse flips {int(cf.sum())}")
+    record_measurement("c4_shape_t5625_100steps_fp16x2_vs_fp32_oracle", mel_l1=dm.mean().item(), mel_max=dm.max().item(), voicing_flips=flips,
+                       coarse_flips=int(cf.sum()))
+    assert flips == 0 and cf.float().mean().item() <= 1e-3
+    assert dm.mean().item() <= 6e-5
