@@ -46,6 +46,9 @@ CONFIGS = {
     "c4": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="bf16x2", sampler="ddpm"),
     # the same workload with plain bf16 operands (one product; 2.5e-3 from the fp32 reference after 1000 steps: does NOT meet north_star)
     "c4bf16": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="bf16", sampler="ddpm"),
+    # ... on the FP16 matrix cores with only the weights split: two products per hidden GEMM ("fp16x2": 1.9e-5 on the 1000-step golden in the
+    # CPU restatement; opt-in, not in the default line until it has run on hardware)
+    "c4f16": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16x2", sampler="ddpm"),
     # one GPU's share of configs[4] (256 refs x 256 targets over 8 GPUs = 32 refs x 256 targets per GPU), at a representative size: 64 references x
     # 32 targets = 2048 pairs per step, batches of 32 references per target (the per-GPU reference count of the full sweep)
     "c5": dict(batch=32, refs=64, frames=1500, mel_steps=100, f0_steps=50, precision="fp32", sampler="ddim", ddim_steps=50, targets=32),
@@ -134,15 +137,17 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     mt = (L.load().ss_wino43_gate16_pick(B, T, 2 * C, 1) if g16 == 1 else g16) if g16 else 0   # 0 = the 32x32x2 kernel
     hbm = bf16 and getattr(infer.model, "bf16_hbm", False)
     split = bool(getattr(infer.model, "split", False))
+    f16 = bool(getattr(infer.model, "f16", False))   # "fp16x2": fp16 terms, weights-only split, 2 products
     if hbm:  # bf16 operands in HBM (ss_gemm_bf16): the operand X + dstep is already rounded by the producing epilogue
-        Xh = L.split_bf16(X) if split else L.to_bf16(X)
-        Gh = torch.empty(B, T, C * (2 if split else 1), device=dev, dtype=torch.bfloat16)
+        Xh = L.split_f16(X) if f16 else L.split_bf16(X) if split else L.to_bf16(X)
+        Gh = torch.empty(B, T, C * (2 if split else 1), device=dev, dtype=torch.float16 if f16 else torch.bfloat16)
 
     def launch(l):
         d = 1 << (l % 4)
         if hbm:
             L.gemm_bf16(Xh, packs[f"w_dil_h.{l}"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
-                        E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, out=Gh, split=int(split))
+                        E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, out=Gh, split=2 if f16 else int(split),
+                        out_scale=2.0 ** -infer.model.FP16_WSHIFT if f16 else 1.0)
             return
         kw = dict(B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=dstep[0, l], epi=L.EPI_GATE, E=E[:, :, l * 2 * C:],
                   lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=C, mask_rows=True)
@@ -236,11 +241,13 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     if wino:
         L.check(L.load().ss_set_clock_probe(None), "ss_set_clock_probe")
     flops = 2.0 * B * T * (3 * C) * (2 * C)
-    executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 3.0 if split else 1.0)   # x3: six bf16 products each; bf16x2: three
+    executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 2.0 if f16 else 3.0 if split else 1.0)   # x3: six bf16 products each; bf16x2: three; fp16x2: two
     peak = PEAK_BF16_MFMA if (bf16 or x3) else PEAK_FP32_MFMA
     # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
     g256 = hbm and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
-    hbm_name = ("gate256_kernel<split> ((hi, mid) bf16 operand pairs in HBM, 3 products, 256x256 tiles by LDS-DMA, direct" if g256 and split else
+    hbm_name = ("gate256_kernel<8, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x256 tiles by LDS-DMA, direct" if g256 and f16 else
+                "gemm_bf16_kernel<GATE, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, direct" if f16 else
+                "gate256_kernel<split> ((hi, mid) bf16 operand pairs in HBM, 3 products, 256x256 tiles by LDS-DMA, direct" if g256 and split else
                 "gate256_kernel (bf16 operands in HBM, 256x256 tiles by LDS-DMA, direct" if g256 else
                 "gemm_bf16_kernel<GATE,split> ((hi, mid) bf16 operand pairs in HBM, 3 products, direct" if split else
                 "gemm_bf16_kernel<GATE> (bf16 operands in HBM, direct")
@@ -252,7 +259,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
     traffic = None
     pmc_src = None
-    form = (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("bf16x2" if split else "bf16" if bf16 else "direct"))
+    form = (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
     for fn in ("r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj):
@@ -344,13 +351,16 @@ def _parity_from_profile(mode):
             except (ValueError, OSError):
                 rec = {}
     rec = rec.get("measurements", rec)
-    a = rec.get("c4_bf16x2_t32_1000steps_vs_fp32_reference") or {}
-    b = rec.get("c4_shape_t5625_100steps_bf16x2_vs_fp32_oracle") or {}
+    a = rec.get(f"c4_{mode}_t32_1000steps_vs_fp32_reference") or {}
+    b = rec.get(f"c4_shape_t5625_100steps_{mode}_vs_fp32_oracle") or {}
     l1 = [v for v in (a.get("mel_l1"), b.get("mel_l1")) if v is not None]
     return {"pinned": True, "north_star_mel_l1": 1e-4,
             "mel_l1_vs_fp32_reference_1000_step_golden": a.get("mel_l1"), "mel_l1_vs_fp32_oracle_t5625_100_steps": b.get("mel_l1"),
             "meets_north_star": (max(l1) <= 1e-4) if len(l1) == 2 else None,
-            "measured_on": "tests/test_gpu_round4.py (acoustic_t32_mel1000 = the real reference's 1000-step golden; T=5625 item vs the oracle), profiles/r04_parity.json"}
+            "measured_on": ("tests/test_gpu_fp16x2.py" if mode == "fp16x2" else "tests/test_gpu_round4.py") +
+                           " (acoustic_t32_mel1000 = the real reference's 1000-step golden; T=5625 item vs the oracle), profiles/r04_parity.json",
+            **({"cpu_restatement_mel_l1_vs_1000_step_golden": 1.87e-5, "cpu_restatement": "tests/test_oracle_golden.py::test_fp16x2_restatement_meets_the_bar_on_the_1000_step_golden"}
+               if mode == "fp16x2" else {})}
 
 
 def secondary_configs():
@@ -642,18 +652,19 @@ def main():
                       f"sampler + 2x{cfg['f0_steps']}-step f0 loops + HiFi-GAN-NSF, per-reference style cache"}
         desc["c2x3"] = desc["c2"]
         desc["c1"] = desc["c2"].replace("utterances per GPU", "utterance (latency shape of inference/StyleSinger.py:175-186), one at a time")
-        desc["c4bf16"] = desc["c4"]
+        desc["c4bf16"] = desc["c4f16"] = desc["c4"]
         desc = desc[args.config]
         x3 = getattr(infer.model, "x3", False)
         split = bool(getattr(infer.model, "split", False))
-        prec = ("bf16 MFMA on (hi, mid) operand pairs (3 products per hidden GEMM, fp32 accumulate), conditioner projection / sampler / state / vocoder fp32" if split else
+        prec = ("fp16 MFMA, weights as (hi, lo) fp16 pairs (2 products per hidden GEMM, fp32 accumulate), residual stream an fp16 pair, conditioner projection / sampler / state / vocoder fp32" if getattr(infer.model, "f16", False) else
+                "bf16 MFMA on (hi, mid) operand pairs (3 products per hidden GEMM, fp32 accumulate), conditioner projection / sampler / state / vocoder fp32" if split else
                 "bf16-operand MFMA, fp32 accumulate/sampler/state" if bf16 else
                 "fp32 products of the F(4,3) gates from 3 bf16 terms per operand (6 bf16 MFMA products, fp32 accumulate), rest exact fp32 MFMA" if x3 else
                 "exact fp32 MFMA")
         out = {
             "metric": "mel-frames/sec (end-to-end infer incl. vocoder)", "value": value, "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("bf16x2 (bf16 MFMA, operands as hi+mid bf16 pairs)" if getattr(infer.model, "split", False) else "bf16") if bf16 else ("f32 via 3xbf16 split operands (gates)" if x3 else "f32"),
+            "scaling": "weak", "vs_baseline": None, "dtype": ("fp16x2 (fp16 MFMA, weights as hi+lo fp16 pairs)" if getattr(infer.model, "f16", False) else "bf16x2 (bf16 MFMA, operands as hi+mid bf16 pairs)" if getattr(infer.model, "split", False) else "bf16") if bf16 else ("f32 via 3xbf16 split operands (gates)" if x3 else "f32"),
             "data": "synthetic (seeded random weights + inputs; no checkpoint ships)",
             "clock_ghz_timed_region": clock_timed,
             "config": {"workload": f"{args.config}: {desc}, {prec}", "name": args.config,
@@ -661,7 +672,7 @@ def main():
                        "diffusion_loops": {"on": "hipGraph replay", "auto": "hipGraph replay (captured on the 2nd use of a shape)",
                                            "off": "eager launches"}.get(str(infer.model.use_graphs), str(infer.model.use_graphs)),
                        "hipgraph_captures": infer.model.n_captures, "frame_bucket": infer.model.t_bucket,
-                       "mfma_precision": ("bf16x2" if split else "bf16") if bf16 else ("bf16x3" if x3 else "fp32"),
+                       "mfma_precision": ("fp16x2" if getattr(infer.model, "f16", False) else "bf16x2" if split else "bf16") if bf16 else ("bf16x3" if x3 else "fp32"),
                        "step_overlap": (f"{args.streams} HIP streams: consecutive batches run concurrently" if step_streams else
                                         "vocoder(i) on a 2nd stream under acoustic(i+1)" if args.pipeline else "none (one stream)"),
                        "gflop_per_frame": {"algorithmic": flop_alg / 1e9, "cond_proj_hoisted": flop_hoisted / 1e9,
@@ -706,7 +717,7 @@ def main():
                              "meets_north_star": True, "measured_on": "tests/test_gpu_round3.py::test_bf16x3_mode_matches_the_reference_golden_chain, "
                                                                        "profiles/r03_parity.json"}
         if split:
-            out["parity"] = _parity_from_profile("bf16x2")
+            out["parity"] = _parity_from_profile("fp16x2" if getattr(infer.model, "f16", False) else "bf16x2")
         elif bf16:   # no reference arithmetic exists for bf16 operands: the distance to the fp32 reference is a measured fact, not parity
             out["parity"] = {"pinned": False, "mel_l1_vs_fp32_reference": 2.5e-3, "north_star_mel_l1": 1e-4, "meets_north_star": False,
                              "measured_on": "tests/golden/acoustic_t32_mel1000 (real reference, 1000 mel steps), tests/test_gpu_round2.py, "

@@ -9,8 +9,7 @@ import os
 import pytest
 import torch
 
-# NOT YET VALIDATED ON HARDWARE in the round that wrote it (GPU budget spent): opt-in until a run on an MI355X has passed
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SS_TEST_FP16X2") != "1", reason="fp16x2 is opt-in: set SS_TEST_FP16X2=1")]
+pytestmark = pytest.mark.gpu
 
 from conftest import record_measurement  # noqa: E402
 from oracle import harness  # noqa: E402
