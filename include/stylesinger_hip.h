@@ -282,7 +282,8 @@ typedef struct ss_gemm_bf16_args {
   /* split = 2 ("fp16x2" precision: BASELINE config 4 at parity with TWO products instead of three): the same pair layouts with FP16 terms, and
    * only the WEIGHTS are read as pairs - W holds (hi, lo) = ss_split_f16 of w * 2^s, the A operand's hi term alone feeds the matrix cores
    * (v_mfma_f32_32x32x16_f16: a*hi + a*lo), and the fp32 accumulator is multiplied by out_scale = 2^-s before bias / addend / residual are added.
-   * Outputs: GATE writes (fp16(g), 0); RESX reads and writes the stream as a true fp16 pair (22 significant bits). Why two products suffice:
+   * The A operand's second plane is never fetched. Outputs: GATE writes fp16(g) into the hi slots and leaves the second plane of its output rows
+   * untouched; RESX reads and writes the stream as a true fp16 pair (22 significant bits). Why two products suffice:
    * over 1000 reverse steps the weight rounding is the coherent error, the activation rounding averages out, and fp16's is 8x smaller than
    * bf16's (oracle/bf16x2_numerics.py: 1.9e-5 vs the reference's 1000-step golden, bar 1e-4). */
   float out_scale;

@@ -17,6 +17,12 @@ Measured (round 4, this container), mel L1 vs the reference:
     cond fp32; dil, out, skip W-split (2 products) . 1.55e-4      -> two products are NOT enough
     cond fp32; dil W-split; out, skip 3 products ... 5.7e-5       (inside the bar, margin 1.75x: not adopted)
     cond fp32; dil, out, skip 3 products ........... 2.4e-6       = the mode as built (oracle.set_matmul_rounding("bf16x2"); on the GPU 2.2e-6)
+
+    python -m oracle.bf16x2_numerics --fp16     the same sites with FP16 terms (11 significand bits: the activation rounding is 8x smaller)
+    cond fp32; dil, out, skip plain fp16 (1 product) 1.94e-4      all sites plain incl. cond 2.9e-4
+    cond fp32; dil, out, skip W-split (2 products) . 1.89e-5      = the "fp16x2" mode (oracle.set_matmul_rounding("fp16x2"); on the GPU 1.5e-5)
+    cond W-split too ............................... 1.60e-4      (the hoisted projection must stay exact here as well)
+    cond fp32; dil plain, out / skip W-split ....... 6.8e-5       (1.5 products on average: inside the bar, margin 1.5x - not adopted)
 """
 import os
 import sys
@@ -32,9 +38,12 @@ from stylesinger_amd import synth  # noqa: E402
 P3, P1, PA, PW = [(0, 0), (0, 1), (1, 0)], [(0, 0)], [(0, 0), (1, 0)], [(0, 0), (0, 1)]
 
 
+TERM = torch.bfloat16   # --fp16: torch.float16
+
+
 def split2(x):
-    hi = x.bfloat16().float()
-    return hi, (x - hi).bfloat16().float()
+    hi = x.to(TERM).float()
+    return hi, (x - hi).to(TERM).float()
 
 
 def make_conv(site_pairs, names):
@@ -90,7 +99,19 @@ VARIANTS = {
 }
 
 
+VARIANTS_FP16 = {
+    "fp16: cond fp32; dil, out, skip plain (1 product)": dict(cond=None, dil=P1, out=P1, skip=P1),
+    "fp16: all sites plain incl. cond": dict(cond=P1, dil=P1, out=P1, skip=P1),
+    "fp16: cond fp32; dil, out, skip W-split (= fp16x2)": dict(cond=None, dil=PW, out=PW, skip=PW),
+    "fp16: all sites W-split incl. cond": dict(cond=PW, dil=PW, out=PW, skip=PW),
+    "fp16: cond fp32; dil plain; out, skip W-split": dict(cond=None, dil=P1, out=PW, skip=PW),
+}
+
+
 if __name__ == "__main__":
+    if "--fp16" in sys.argv[1:]:
+        TERM = torch.float16
+        VARIANTS = VARIANTS_FP16
     for label, sp in VARIANTS.items():
         t0 = time.time()
         l1, mx = run("acoustic_t32_mel1000", sp)

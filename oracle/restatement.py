@@ -65,7 +65,7 @@ _ROUND = None
 # subnormals; it is undone in fp32 after the accumulation), the product a*hi + a*lo: 2 matrix products instead of 3. Why that is enough
 # (oracle/bf16x2_numerics.py): the WEIGHT rounding is the coherent error that adds up over 1000 steps, the activation rounding averages out,
 # and fp16's 11 significand bits make the latter 8x smaller than bf16's. The residual stream lives as the fp16 pair of x + dstep_l (22 bits);
-# the conditioner projection stays exact fp32. Pinned like bf16x2: 1.9e-5 vs the reference's 1000-step golden (bar 1e-4).
+# the conditioner projection stays exact fp32; the two f0 denoisers stay in the bf16x2 form. Pinned like bf16x2: 1.9e-5 vs the reference's 1000-step golden (bar 1e-4).
 FP16_WSHIFT = 8
 
 
@@ -376,7 +376,14 @@ def ddiffnet(sd, hp, f0, uv, t, cond, prefix):
     e = sd[prefix + ".uv_embed.weight"][uv]
     h = torch.cat([a, e], dim=-1)
     demb = step_embedding(sd, prefix, t, C)
-    h = residual_stack(sd, prefix, h, cond, demb, hp["f0_residual_layers"], hp["f0_dilation_cycle_length"])
+    global _ROUND
+    saved = _ROUND
+    if saved == "fp16x2":   # the f0 denoisers keep the three-product bf16 form in this mode (their outputs feed discrete voicing decisions)
+        _ROUND = "bf16x2"
+    try:
+        h = residual_stack(sd, prefix, h, cond, demb, hp["f0_residual_layers"], hp["f0_dilation_cycle_length"])
+    finally:
+        _ROUND = saved
     return conv1d_cl(h, sd[prefix + ".output_projection.weight"], sd[prefix + ".output_projection.bias"])
 
 

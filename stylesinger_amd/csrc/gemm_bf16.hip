@@ -49,7 +49,7 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(fl
 
 // SPLIT = 1 ("bf16x2"): operands are (hi, mid) bf16 pairs interleaved by 32 channels - a 128-byte K chunk holds 32 channels of BOTH planes
 // (slots 0-3 hi, 4-7 mid), the fetch / staging code is the same, and a chunk feeds 2 k-steps x 3 products (mid*hi, hi*mid, hi*hi) instead of 4 x 1.
-// SPLIT = 2 ("fp16x2"): the same layouts with fp16 terms; the A operand's second plane is not read (2 products: hi*lo, hi*hi) and the
+// SPLIT = 2 ("fp16x2"): the same layouts with fp16 terms; the A operand's second plane is neither fetched nor read (2 products: hi*lo, hi*hi) and the
 // accumulator is scaled by args.out_scale (the weights carry a power-of-two shift, pair16.h) before anything is added to it.
 template <int BM, int BN, int EPI, int SPLIT>
 __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles) {
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     b_lds[i] = lds_off(st_row + i * 32, st_slot);
   }
   const int lda2 = a.lda * 2;
+  [[maybe_unused]] const int a_lo_dead = (W2 && st_slot >= 4) ? (int)0x80000000 : 0;   // SPLIT = 2: the A operand's second plane is never read - not fetched either (zeros)
 
   // chunk c = (tap, k0): SGPR byte offsets of the A fetch (tap row shift + channel offset) and of the W fetch
   auto a_soff = [&](int c) {
@@ -123,7 +124,10 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
     if (c > 1) return;
 #endif
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ra[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[i] + so) | dead, 0, 0);
+    for (int i = 0; i < AP; ++i) {
+      if constexpr (W2) ra[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[i] + so) | dead | a_lo_dead, 0, 0);
+      else ra[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[i] + so) | dead, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[ST][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i] | dead, c * (BKH * 2), 0);
   };
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
 #endif
           const uint16_t gh = ss_f2t<W2>(g);
           __builtin_amdgcn_raw_buffer_store_b16(gh, rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
-          // second term 32 elements further; fp16x2: the gate output is only ever a matrix-core A operand (hi term), its second term is 0
-          if constexpr (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(W2 ? (uint16_t)0 : f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, 64, 0);
+          // second term 32 elements further; fp16x2: the gate output is only ever a matrix-core A operand (hi term), its second term is not written
+          if constexpr (SPLIT == 1) __builtin_amdgcn_raw_buffer_store_b16(f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, 64, 0);
         }
       }
     }

@@ -51,7 +51,7 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ds
 // fragment reads per k-step - 1.5x the matrix work per byte staged. Outputs leave as (hi, mid) pairs in the same interleaved layout.
 // SPLIT = 2 ("fp16x2"): the same image with fp16 terms; the A operand's second plane is staged but never read, a step runs 2 k-steps x 2
 // products (hi*hi, hi*lo) = 32 MFMAs from 8 + 8 fragment reads (step_w2), the accumulators are scaled by args.out_scale in the epilogue and the
-// output pair is (fp16(g), 0).
+// output is fp16(g) in the hi slots only (the second plane of the output rows is left untouched).
 template <class F, int... I>
 __device__ __forceinline__ void unrolled_steps(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -110,16 +110,19 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
   const int a_voff = ((t0 - HALO + r0) * a.lda + slot0 * 8) * 2;   // may be negative: >= 2^31 as unsigned -> out of range -> zeros
   const int b_voff = ((n0 + r0) * ldw + slot0 * 8) * 2;
   const int a_tail_dead = wave < 2 ? 0 : (int)0x80000000;          // piece w + 32 = rows 256 + 8 w ..: only rows < 272 exist
+  // SPLIT = 2: the A operand's second plane (logical slots 4-7) is never read by the matrix cores - its lanes fetch nothing (out of range: the
+  // DMA writes zeros), which halves the A traffic from L2 / HBM
+  const int a_lo_dead = (W2 && slot0 >= 4) ? (int)0x80000000 : 0;
   auto dma_a = [&](char* buf, int cc, int dead) {
 #pragma unroll
     for (int j = 0; j < 5; ++j)
       // the row offset of piece j goes into the VGPR offset (one add), NOT the SGPR offset: for the rows before the item (t0 - 8 + r < 0)
       // the per-lane offset is negative, i.e. >= 2^31 as unsigned, and the hardware adds the SGPR offset without wrapping - a positive
       // SGPR part would leave valid rows of later pieces out of range
-      glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | dead | (j == 4 ? a_tail_dead : 0), cc * (BKH * 2));
+      glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | dead | (j == 4 ? a_tail_dead : 0) | a_lo_dead, cc * (BKH * 2));
   };
   auto piece_a = [&](char* buf, int cc, int j) {
-    glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | (j == 4 ? a_tail_dead : 0), cc * (BKH * 2));
+    glds16(rsrc_a, buf + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | (j == 4 ? a_tail_dead : 0) | a_lo_dead, cc * (BKH * 2));
   };
   auto piece_b = [&](char* buf, int cc, int tap, int j) {
     glds16(rsrc_w, buf + (wave + 8 * j) * 8 * ROWB, b_voff, (tap * CCS + cc) * (BKH * 2) + 64 * j * ldw * 2);
@@ -435,8 +438,8 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
       if (t0 + 128 * wm + 32 * q + 4 * lh + rr >= row_lim) g = 0.f;
       const uint16_t gh = ss_f2t<W2>(g);
       *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW) = gh;
-      // second term; fp16x2: the gate output only ever feeds the matrix cores' A operand (hi term) - its second term is written as 0
-      if constexpr (SPLIT) *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW + 64) = W2 ? (uint16_t)0 : f2bf(g - __builtin_bit_cast(float, (uint32_t)gh << 16));
+      // second term; fp16x2: the gate output only ever feeds the matrix cores' A operand (hi term) - its second term is not written at all
+      if constexpr (SPLIT == 1) *reinterpret_cast<uint16_t*>(OUT + o_wr + rr * OROW + 64) = f2bf(g - __builtin_bit_cast(float, (uint32_t)gh << 16));
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my staging writes are done
     __builtin_amdgcn_s_barrier();         // the staging tile is complete; everyone finished reading addend quarter q
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gate256_kernel(const ss_gemm_bf16_args
         const int k = p >> 5, c16 = p & 31;
         const int grow = t0 + 128 * (k >> 5) + 32 * q + (k & 31);
         const uint4 v = *reinterpret_cast<const uint4*>(OUT + p * 16);
-        const bool ok = (n0 >> 1) + 32 * (c16 >> 3) < a.N;   // N is a multiple of 32 (checked by the launcher)
+        const bool ok = (n0 >> 1) + 32 * (c16 >> 3) < a.N && !(W2 && (c16 & 4));   // N is a multiple of 32 (checked by the launcher); W2: the hi halves only
         const int off = ok ? grow * a.ldc * 2 + n0 * 2 + c16 * 16 : (int)0x80000000;   // logical channel n0/2 sits at physical element n0
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_c, off, 0, 0);
       }

@@ -12,7 +12,7 @@
 //     stream / the fp32 outputs move as 16-byte vectors, full lines per wave instruction.
 // Arithmetic contract = gemm_bf16_kernel<..., SPLIT>: hi*hi + hi*mid + mid*hi of (hi, mid) bf16 pairs interleaved by 32 channels, fp32
 // accumulation (the order of the K products inside an accumulator differs: results agree to fp32 rounding).
-// W2 (ss_gemm_bf16_args.split = 2, "fp16x2"): fp16 terms, the A operand's second plane is staged but not read, two products hi*hi + hi*lo per
+// W2 (ss_gemm_bf16_args.split = 2, "fp16x2"): fp16 terms, the A operand's second plane is neither fetched (dead DMA lanes write zeros) nor read, two products hi*hi + hi*lo per
 // k-step (32 MFMAs per step, the 16 of the second k-step deferred), accumulators scaled by args.out_scale where the epilogue first touches them.
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
@@ -75,9 +75,10 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   const int slot0 = (lane & 7) ^ ((r0 >> 1) & 7);
   const int a_voff = ((t0 + r0) * a.lda + slot0 * 8) * 2;   // rows >= len are out of range: the DMA writes zeros
   const int b_voff = (r0 * ldw + slot0 * 8) * 2;            // packed weight rows >= Np read zeros
+  const int a_lo_dead = (W2 && slot0 >= 4) ? (int)0x80000000 : 0;   // W2: the A operand's second plane is never read - its lanes fetch nothing (zeros)
   auto piece = [&](char* Ab, char* Bb, int c, int i) {     // i = 0..3: A pieces, 4..7: B pieces of chunk c
     const int j = i & 3;
-    if (i < 4) glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, a_voff + 64 * j * a.lda * 2, c * ROWB);
+    if (i < 4) glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | a_lo_dead, c * ROWB);
     else glds16(rsrc_w, Bb + (wave + 8 * j) * 8 * ROWB, b_voff, c * ROWB + 64 * j * ldw * 2);
   };
 

@@ -249,9 +249,11 @@ class StyleSingerHIP(torch.nn.Module):
     # treat subnormal inputs for any weight that matters. oracle/restatement.py uses the same constant.
     FP16_WSHIFT = 8
 
-    def _split_w(self, w):
-        """packed fp32 weight -> split 16-bit pack of the precision mode (pairs interleaved by 32 along every row)"""
-        if not self.f16:
+    def _split_w(self, w, f0=False):
+        """packed fp32 weight -> split 16-bit pack of the precision mode (pairs interleaved by 32 along every row). The two f0 denoisers keep the
+        three-product bf16 form in "fp16x2" mode: their outputs feed DISCRETE voicing decisions (one flipped in 11 250 at T = 5625 with two
+        products, none with three) and their 200 steps are ~1 % of a C4 batch."""
+        if not self.f16 or f0:
             return L.split_bf16(w)
         if float(w.abs().max()) * 2.0 ** self.FP16_WSHIFT >= 32768.0:
             raise ValueError("mfma_precision=fp16x2: a hidden-layer weight exceeds 128 in magnitude (fp16 range after the 2^8 shift)")
@@ -324,7 +326,7 @@ class StyleSingerHIP(torch.nn.Module):
                 if self.x3 and self._wino_form(C, cycle) == 4:
                     t[f"w_dil_x3.{l}"] = L.split3_weights(t[f"w_dil_wino.{l}"], dil.Kp)
             if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
-                to_h = self._split_w if self.split else L.to_bf16   # split: pairs interleaved by 32 along every row
+                to_h = (lambda w_: self._split_w(w_, f0)) if self.split else L.to_bf16   # split: pairs interleaved by 32 along every row
                 t[f"w_dil_h.{l}"] = to_h(dil.W)
                 t[f"w_out_h.{l}"] = to_h(out.W)
             wc_rows.append(cnd.W)
@@ -347,7 +349,7 @@ class StyleSingerHIP(torch.nn.Module):
         t["b_cond"] = torch.cat(bc_rows, 0).contiguous()
         if self.bf16_hbm:
             t["w_cond_h"] = L.to_bf16(t["w_cond"])     # (unused in split mode: the hoisted projection runs in fp32 there)
-            t["w_skipall_h"] = (self._split_w if self.split else L.to_bf16)(t["w_skipall"])
+            t["w_skipall_h"] = self._split_w(t["w_skipall"], f0) if self.split else L.to_bf16(t["w_skipall"])
         skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
         fin = self._pack_conv(prefix + ".output_projection.weight", prefix + ".output_projection.bias")
         t["w_skip"], t["b_skip"], t["w_final"], t["b_final"] = skip.W, skip.bias, fin.W, fin.bias
@@ -412,8 +414,8 @@ class StyleSingerHIP(torch.nn.Module):
                 setattr(net, key, ptr_)
                 setattr(net, "gs_" + key, gs)
         net.mfma_bf16 = 1 if self.bf16 else 0
-        net.mfma_split = (2 if self.f16 else 1) if self.split else 0
-        net.mfma_out_scale = 2.0 ** -self.FP16_WSHIFT if self.f16 else 1.0
+        net.mfma_split = (2 if (self.f16 and not f0) else 1) if self.split else 0
+        net.mfma_out_scale = 2.0 ** -self.FP16_WSHIFT if (self.f16 and not f0) else 1.0
         net.skipall_folded = 1 if self.fold_skip else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):
