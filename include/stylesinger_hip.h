@@ -48,7 +48,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * "wino_v1" = 0|1 (F(2,3) gate: column tile, round-1 kernel); "voc_wino_max_mb" = 1..2048: vocoder items whose stage panel reaches this many MiB
  * take the direct conv kernel instead of the grouped-Winograd one (32-bit offsets; default 2048 = the real limit, tests lower it); "e16" = 0|1
  * the fp32 denoiser loops hand the 16x16x4 gate its conditioner addend in fetch order (ss_gate16_tile_addend once per forward; default 1);
- * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch */
+ * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch;
+ * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 0 until measured) */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -301,6 +302,12 @@ int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
  * say so; same arithmetic contract, results equal up to the K summation order. */
 int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* args);
+/* The same launch for split = 2 ("fp16x2") operands on 256 x 128 tiles with TWO workgroups per CU (4 waves, 80 KB of LDS each: the A image is
+ * compact - only the hi plane of the A operand is staged - and half the columns halve the weight tile), so that one workgroup's MFMAs run under
+ * the other's epilogue and barrier waits. Same arithmetic and summation order as ss_gemm_bf16_gate256. ss_gemm_bf16 dispatches here when the
+ * "gate128" tuning knob is 1 (default 0: not yet measured on hardware) and ss_gemm_bf16_gate128_ok(args). */
+int ss_gemm_bf16_gate128(const ss_gemm_bf16_args* args, void* stream);
+int ss_gemm_bf16_gate128_ok(const ss_gemm_bf16_args* args);
 /* The split-operand 1-tap forms of ss_gemm_bf16 for many-round launches (BASELINE config 4 in bf16x2 precision): SS_HEPI_RESX on the pair-only
  * stream (X = NULL) and SS_HEPI_STORE (the K = L*C skip GEMM), N <= 256, K a multiple of 64. 256 rows x all columns per workgroup, 8 waves, both
  * operands by LDS-DMA, epilogues through LDS as 16-byte vectors. ss_gemm_bf16 dispatches here when ss_gemm_bf16_tile256_ok(args) (and the

@@ -3,12 +3,15 @@ matches the C structs, the parameter/hparams contract matches the reference dump
 deterministic, and the product refuses to run without a GPU instead of falling back."""
 import json
 import os
+import subprocess
 
 import numpy as np
 import pytest
 import torch
 
 from stylesinger_amd import config, lib, spec, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_loads_and_exports_header_symbols():
@@ -363,3 +366,15 @@ def test_launch_planning_functions_of_the_library_run_without_a_gpu():
         assert l.ss_set_tuning(key, before) == 0
     assert l.ss_set_tuning(b"htile", 96) != 0 and b"htile" in l.ss_last_error()
     assert l.ss_get_tuning(b"nope") < 0
+
+
+def test_gate128_index_math_against_a_tagged_lds_image(tmp_path):
+    """gate128_kernel (the fp16x2 gate on 256 x 128 tiles, two workgroups per CU) takes all of its DMA / fragment / epilogue addresses from
+    stylesinger_amd/csrc/gate128_layout.h; tools/layout_check_gate128.cpp compiles the SAME header on the host, replays every LDS-DMA piece
+    into a tagged image and looks every access of the kernel up in it (coverage, right element, no bank conflicts, right output channel)."""
+    exe = str(tmp_path / "layout_check_gate128")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "stylesinger_amd", "csrc"), os.path.join(ROOT, "tools", "layout_check_gate128.cpp"),
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:]
