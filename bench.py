@@ -248,7 +248,9 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     peak = PEAK_BF16_MFMA if (bf16 or x3) else PEAK_FP32_MFMA
     # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
     g256 = hbm and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
-    hbm_name = ("gate256_kernel<8, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x256 tiles by LDS-DMA, direct" if g256 and f16 else
+    g128 = hbm and f16 and L.load().ss_get_tuning(b"gate128") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 128) >= 2048   # ss_gemm_bf16_gate128_ok's shape rule
+    hbm_name = ("gate128_kernel (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if g128 else
+                "gate256_kernel<8, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x256 tiles by LDS-DMA, direct" if g256 and f16 else
                 "gemm_bf16_kernel<GATE, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, direct" if f16 else
                 "gate256_kernel<split> ((hi, mid) bf16 operand pairs in HBM, 3 products, 256x256 tiles by LDS-DMA, direct" if g256 and split else
                 "gate256_kernel (bf16 operands in HBM, 256x256 tiles by LDS-DMA, direct" if g256 else

