@@ -49,7 +49,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * take the direct conv kernel instead of the grouped-Winograd one (32-bit offsets; default 2048 = the real limit, tests lower it); "e16" = 0|1
  * the fp32 denoiser loops hand the 16x16x4 gate its conditioner addend in fetch order (ss_gate16_tile_addend once per forward; default 1);
  * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch;
- * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1) */
+ * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "tile128" = 0|1 the
+ * fp16x2 residual projection of many tiles on ss_gemm_bf16_tile128 (default 0 until measured) */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -315,6 +316,12 @@ int ss_gemm_bf16_gate128_ok(const ss_gemm_bf16_args* args);
  * "gate256" knob) say so; same arithmetic contract, results equal up to the K summation order. */
 int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
+/* SS_HEPI_RESX on the pair-only stream for split = 2 ("fp16x2") operands on 128-row tiles with TWO workgroups per CU (4 waves, 80 KB of LDS:
+ * compact A image as in ss_gemm_bf16_gate128), so that one workgroup's stream traffic (epilogue) runs under the other's operand traffic (loop).
+ * Same arithmetic and summation order as ss_gemm_bf16_tile256. ss_gemm_bf16 dispatches here when the "tile128" tuning knob is 1 (default 0:
+ * not yet measured on hardware) and ss_gemm_bf16_tile128_ok(args). */
+int ss_gemm_bf16_tile128(const ss_gemm_bf16_args* args, void* stream);
+int ss_gemm_bf16_tile128_ok(const ss_gemm_bf16_args* args);
 /* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
