@@ -50,7 +50,7 @@ int ss_struct_sizes(int64_t* out, int n);
  * the fp32 denoiser loops hand the 16x16x4 gate its conditioner addend in fetch order (ss_gate16_tile_addend once per forward; default 1);
  * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch;
  * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "tile128" = 0|1 the
- * fp16x2 residual projection of many tiles on ss_gemm_bf16_tile128 (default 0 until measured) */
+ * fp16x2 residual projection of many tiles on ss_gemm_bf16_tile128 (default 0: measured, not faster than the 256-row kernel) */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -318,8 +318,9 @@ int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
 /* SS_HEPI_RESX on the pair-only stream for split = 2 ("fp16x2") operands on 128-row tiles with TWO workgroups per CU (4 waves, 80 KB of LDS:
  * compact A image as in ss_gemm_bf16_gate128), so that one workgroup's stream traffic (epilogue) runs under the other's operand traffic (loop).
- * Same arithmetic and summation order as ss_gemm_bf16_tile256. ss_gemm_bf16 dispatches here when the "tile128" tuning knob is 1 (default 0:
- * not yet measured on hardware) and ss_gemm_bf16_tile128_ok(args). */
+ * Same arithmetic and summation order as ss_gemm_bf16_tile256: bit-identical results (tests/test_gpu_fp16x2.py). Measured at the BASELINE
+ * config 4 shape: 131.9 us against the 256-row kernel's 128.9 us - the launch is HBM-bound either way - so ss_gemm_bf16 dispatches here only
+ * when the "tile128" tuning knob is set to 1 (default 0) and ss_gemm_bf16_tile128_ok(args). */
 int ss_gemm_bf16_tile128(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_tile128_ok(const ss_gemm_bf16_args* args);
 /* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights

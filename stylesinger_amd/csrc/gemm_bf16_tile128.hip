@@ -10,6 +10,10 @@
 // 16 MFMAs deferred past the next barrier and the next step's DMA pieces (2 A + 8 B per wave) issued between them, the epilogue in four
 // LDS-staged passes (here of 32 rows) with the stream's pairs as 16-byte vectors. Index math: gate128_layout.h (namespace t128), checked on the
 // host by tools/layout_check_gate128.cpp. Arithmetic and summation order = tile256s_kernel<RESX, true>: bit-identical results.
+// MEASURED (profiles/r04_kbench_tile128.log, BASELINE config 4 shape, back to back): 131.9 us against the 256-row kernel's 128.9 us. The
+// hypothesis above is wrong for this launch: it is HBM-bound as a whole (461 MB at 3.6 TB/s with reads and writes mixed), not phase-bound, and
+// the second workgroup only re-streams the 256 KB of weights once more per 128 rows. Kept behind the "tile128" knob (default 0) as the
+// two-workgroup skeleton for 1-tap GEMMs that DO have matrix or epilogue time to hide.
 #include "common.h"
 #include "../../include/stylesinger_hip.h"
 #include "pair16.h"
