@@ -72,6 +72,17 @@ def main():
         s = timeit(fr, a.iters)
         res.append(("residual projection K=256 N=256" + (" fp16x2" if a.f16 else " split x3" if a.split else " bf16") + (" pair-only stream" if po else ""), s,
                     nprod * 2.0 * B * T * C * C, B * T * (sp * 2.0 * C + (sp * 2.0 * C if po else 4.0 * C + 4.0 * C) + sp * 2.0 * C)))
+    if a.which == "skip":   # the K = L*C skip GEMM (STORE + ReLU) on the layer-slot operand of all 20 layers
+        GA = to_h(torch.randn(B, T, Lyr * C, device=d))
+        wsk = torch.randn(C, Lyr * C, 1, device=d) / math.sqrt(Lyr * C)
+        Wsk = to_w(L.pack_conv_weight(wsk))
+        S = torch.empty(B, T, C, device=d)
+        bsk = torch.randn(C, device=d)
+        def fs():
+            L.gemm_bf16(GA, Wsk, B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=Wsk.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=bsk, **skw)
+        s = timeit(fs, a.iters)
+        res.append(("skip GEMM K=5120 N=256" + (" fp16x2" if a.f16 else " split x3" if a.split else " bf16"), s, nprod * 2.0 * B * T * Lyr * C * C,
+                    B * T * ((1 if a.f16 else sp) * 2.0 * Lyr * C + 4.0 * C)))
     for name, s, fl, by in res:
         print(f"{name:40s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.1f} TF/s ({fl / s / 2.5e15 * 100:4.1f}% of bf16 peak)  {by / s / 1e12:5.2f} TB/s algorithmic HBM")
 
