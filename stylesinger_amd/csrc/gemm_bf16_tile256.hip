@@ -315,6 +315,10 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
 // Here the A chunks live in a ring of THREE buffers and chunk c+2 is issued in step c (after the weight tile of chunk c+1, which comes from L2
 // and stays one step ahead): twice the A bytes in flight, one counted s_waitcnt (the youngest four DMA instructions of a wave are A(c+1) when
 // step c starts). LDS: 3 x 32 KB A + 2 x 32 KB B = the CU's 160 KB. Same products, same order inside every accumulator: bit-identical results.
+// MEASURED (profiles/r04_kbench_skip_deep.log, back to back): 1070.9 -> 1053.1 us. The hypothesis above is refuted: twice the A bytes in flight
+// buy 1.7 %. What the three 16-bit many-round kernels of config 4 have in common is their matrix rate - 0.88-1.09 PFLOP/s whatever their
+// structure (this launch 0.88-1.03, the gates 0.85-1.09) - i.e. the rate the chip sustains on dense 16-bit MFMA under its power limit
+// (1.5-1.9 GHz while they run). Kept behind the "skip_deep" knob (default 0).
 __global__ __launch_bounds__(512, 2) void tile256s_deep_store_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int kchunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_t256d[];   // 160 KB: [A0][A1][A2][B0][B1] of 32 KB; epilogue: 2 x 64 KB staging
   char* const Abase = smem_t256d;
