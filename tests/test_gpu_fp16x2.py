@@ -217,7 +217,6 @@ def test_fp16x2_mode_meets_north_star_on_the_1000_step_golden():
         assert uv == 0 and d.mean().item() <= 6e-5
 
 
-@pytest.mark.skipif(os.environ.get("SS_TEST_FP16X2_LONG") != "1", reason="a minute of CPU oracle at T = 5625: set SS_TEST_FP16X2_LONG=1")
 def test_fp16x2_mode_at_the_c4_shape_matches_the_fp32_oracle():
     """The C4 SHAPE (one 30 s item, T = 5625: gate256_kernel<8, 2> and tile256s_kernel<., true> run here) with 100 + 2 x 100 step chains in
     fp16x2 mode against the fp32 oracle on this box."""
