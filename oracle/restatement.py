@@ -69,9 +69,33 @@ _ROUND = None
 FP16_WSHIFT = 8
 
 
+# "fp16q4" (NOT built on the GPU yet - the arithmetic contract of the next precision mode): fp16x2 with its SECOND product on
+# MXFP4 operands - a*hi on fp16 terms as before, plus q4(a)*q4(lo) where q4 = e2m1 elements with one power-of-two (E8M0) scale per 32 channels
+# (what v_mfma_scale_f32_32x32x64_f8f6f4 consumes at 3.7x the fp16 issue rate, tools/ubench/mfma_mx_layout.hip): 1.27 products instead of 2.
+# lo is a correction of relative size 2^-12, two significant bits of it are enough: 3.5e-5 / 4.4e-5 on the reference's 1000- / 100-step goldens.
+_FP4_GRID = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+_FP4_MID = (_FP4_GRID[1:] + _FP4_GRID[:-1]) / 2
+
+
+def mxfp4(x, dim):
+    """x -> its MXFP4 value: blocks of 32 along `dim` share the scale 2^(floor(log2(max |x|)) - 2) (the block's largest element lands in [4, 8),
+    the e2m1 grid's top is 6), elements round to the nearest grid point (ties to the smaller magnitude)."""
+    xs = x.movedim(dim, -1).contiguous()
+    shp = xs.shape
+    K = shp[-1]
+    pad = (-K) % 32
+    if pad:
+        xs = F.pad(xs, (0, pad))
+    b = xs.reshape(*xs.shape[:-1], -1, 32)
+    s = torch.exp2(torch.floor(torch.log2(b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30))) - 2)
+    idx = torch.bucketize((b / s).abs().clamp(max=6.0).contiguous(), _FP4_MID)
+    q = (_FP4_GRID[idx] * b.sign() * s).reshape(*xs.shape)[..., :K].reshape(shp)
+    return q.movedim(-1, dim)
+
+
 def set_matmul_rounding(mode):
     global _ROUND
-    assert mode in (None, "fp32", "bf16", "bf16x2", "fp16x2")
+    assert mode in (None, "fp32", "bf16", "bf16x2", "fp16x2", "fp16q4")
     _ROUND = None if mode in (None, "fp32") else mode
 
 
@@ -99,6 +123,15 @@ def conv1d_cl(x, w, b, dilation=1, rounded=False):
         (xh, xm), (wh, wm) = _split2(xt), _split2(w)
         y = F.conv1d(xm, wh, None, padding=pad, dilation=dilation) + F.conv1d(xh, wm, None, padding=pad, dilation=dilation)
         y = y + F.conv1d(xh, wh, None, padding=pad, dilation=dilation)
+        if b is not None:
+            y = y + b.view(1, -1, 1)
+        return y.transpose(1, 2)
+    if rounded is True and _ROUND == "fp16q4":
+        xh = xt.half().float()
+        ws = w * float(2 ** FP16_WSHIFT)
+        wh = ws.half().float()
+        y = F.conv1d(mxfp4(xt, 1), mxfp4(ws - wh, 1), None, padding=pad, dilation=dilation) + F.conv1d(xh, wh, None, padding=pad, dilation=dilation)
+        y = y * float(2.0 ** -FP16_WSHIFT)
         if b is not None:
             y = y + b.view(1, -1, 1)
         return y.transpose(1, 2)
@@ -346,7 +379,7 @@ def residual_stack(sd, prefix, x, cond, demb, L, cycle):
             hi, mid = _split2(xin)
             xin = hi + mid
             x = xin - ds
-        if _ROUND == "fp16x2":   # ... as the fp16 pair (22 significant bits); the matrix cores read its hi term only
+        if _ROUND in ("fp16x2", "fp16q4"):   # ... as the fp16 pair (22 significant bits); the matrix cores read its hi term only
             hi, lo = _split2h(xin)
             xin = hi + lo
             x = xin - ds
@@ -378,7 +411,7 @@ def ddiffnet(sd, hp, f0, uv, t, cond, prefix):
     demb = step_embedding(sd, prefix, t, C)
     global _ROUND
     saved = _ROUND
-    if saved == "fp16x2":   # the f0 denoisers keep the three-product bf16 form in this mode (their outputs feed discrete voicing decisions)
+    if saved in ("fp16x2", "fp16q4"):   # the f0 denoisers keep the three-product bf16 form in these modes (their outputs feed discrete voicing decisions)
         _ROUND = "bf16x2"
     try:
         h = residual_stack(sd, prefix, h, cond, demb, hp["f0_residual_layers"], hp["f0_dilation_cycle_length"])
