@@ -79,7 +79,8 @@ _FP4_MID = (_FP4_GRID[1:] + _FP4_GRID[:-1]) / 2
 
 def mxfp4(x, dim):
     """x -> its MXFP4 value: blocks of 32 along `dim` share the scale 2^(floor(log2(max |x|)) - 2) (the block's largest element lands in [4, 8),
-    the e2m1 grid's top is 6), elements round to the nearest grid point (ties to the smaller magnitude)."""
+    the e2m1 grid's top is 6), elements round to the nearest grid point, ties to the even mantissa (0.25 -> 0, 0.75 -> 1, 1.25 -> 1, 1.75 -> 2,
+    2.5 -> 2, 3.5 -> 4, 5 -> 4) and saturate at 6: what v_cvt_scalef32_pk_fp4_f16 does (profiles/r04_ubench_cvt_fp4_probe.log)."""
     xs = x.movedim(dim, -1).contiguous()
     shp = xs.shape
     K = shp[-1]
@@ -88,7 +89,8 @@ def mxfp4(x, dim):
         xs = F.pad(xs, (0, pad))
     b = xs.reshape(*xs.shape[:-1], -1, 32)
     s = torch.exp2(torch.floor(torch.log2(b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30))) - 2)
-    idx = torch.bucketize((b / s).abs().clamp(max=6.0).contiguous(), _FP4_MID)
+    v = (b / s).abs().clamp(max=6.0).contiguous()
+    idx = torch.bucketize(v, _FP4_MID) + ((v == 0.75) | (v == 1.75) | (v == 3.5)).long()   # bucketize sends ties down; these three go up (even mantissa)
     q = (_FP4_GRID[idx] * b.sign() * s).reshape(*xs.shape)[..., :K].reshape(shp)
     return q.movedim(-1, dim)
 
