@@ -9,6 +9,9 @@
 #   pmc-gate         PMC passes on the dominant kernel launch (one counter block per pass, --kernel-trace --pmc only)
 #   pmc-gate-c4x2    the same for the split-operand (bf16x2) 256x256 gate kernel at the C4 shape (tools/pmc_split.sh)
 #   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs direct vs grouped F(4,3))
+#   kbench-c4        the 16-bit many-round launches at the BASELINE config 4 shape: fp16x2 gate on gate256 / gate128, residual projection on
+#                    tile256 / tile128, skip GEMM with and without the deep A prefetch (tools/kbench_h.py)
+#   c4-streams       BASELINE config 4 with two batches in flight (the first experiment of the next round)
 #   ablate-gate16    timing ablations of the 16x16-tile gate kernel (debug builds: tools/ablate_g16.sh build, in the container)
 #   ablate-res16     the same for the residual-projection kernel (tools/ablate_r16.sh build, in the container)
 #   ubench           micro-benchmarks behind DESIGN.md §3.0 (VALU beside fp32 MFMA, 16x16x4 issue rate, DPP / LDS-DMA probes)
@@ -40,12 +43,22 @@ case "$sec" in
     python tools/kbench.py --which wino43_16 --iters 60 --mt=-1,3,2
     python tools/kbench.py --which res16 --iters 60 --mt 6
     python tools/kbench.py --which voc --iters 30 ;;
+  kbench-c4)
+    SS_GATE128=0 python tools/kbench_h.py --which gate --f16
+    python tools/kbench_h.py --which gate --f16 --gate128
+    python tools/kbench_h.py --which res --f16 --pair-only
+    SS_TILE128=1 python tools/kbench_h.py --which res --f16 --pair-only
+    python tools/kbench_h.py --which skip --f16
+    SS_SKIP_DEEP=1 python tools/kbench_h.py --which skip --f16 ;;
+  c4-streams)
+    python bench.py --config c4 --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline | tail -1 | cut -c1-400
+    python bench.py --config c4 --streams 2 --steps 2 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline | tail -1 | cut -c1-400 ;;
   ablate-gate16)
     bash tools/ablate_g16.sh run ;;
   ablate-res16)
     bash tools/ablate_r16.sh run ;;
   ubench)
-    for f in mfma_valu mfma16 glds_probe l2bw soffset_probe; do
+    for f in mfma_valu mfma16 glds_probe l2bw soffset_probe mfma_mx_layout cvt_fp4_probe; do
       hipcc --offload-arch=gfx950 -O3 tools/ubench/$f.hip -o /tmp/$f 2>/dev/null && /tmp/$f
     done ;;
   *) echo "unknown section '$sec'"; sed -n 2,15p $0; exit 2 ;;
