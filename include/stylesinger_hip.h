@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 13 /* 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 14 /* 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -291,7 +291,12 @@ typedef struct ss_gemm_bf16_args {
    * over 1000 reverse steps the weight rounding is the coherent error, the activation rounding averages out, and fp16's is 8x smaller than
    * bf16's (oracle/bf16x2_numerics.py: 1.9e-5 vs the reference's 1000-step golden, bar 1e-4). */
   float out_scale;
-  int32_t reserved_[2];
+  /* split = 3 ("fp16q4", SS_HEPI_GATE through ss_gemm_bf16_gate128q only - written at the end of round 4, not yet run on hardware): split = 2
+   * with the second product a * lo on the block-scaled fp4 matrix instruction. W is a ss_split_f16 pack whose lo plane has been replaced by
+   * the fp4 terms of lo in the kernel's lane order + their E8M0 block scales (stylesinger_amd.lib.pack_gate_q4, layout: csrc/gate128_layout.h
+   * g128q); the kernel converts its own fp16 A fragments to fp4 with the fixed power-of-two scale q_scale: q = fp4(a / q_scale). */
+  float q_scale;
+  int32_t reserved_;
   /* RESX with split operands and X == NULL ("pair-only residual stream"): the stream lives ONLY as the (hi, mid) pair Y = x + cur_bias (16
    * significand bits - measured harmless on the reference's 1000-step golden: 2.4e-6 either way, oracle/bf16x2_numerics.py). The epilogue reads
    * its element of Y, recovers x = hi + mid - cur_bias, and writes Y = pair(x_new + next_bias) in place: 3 instead of 4 KB per row of traffic. */
@@ -312,6 +317,13 @@ int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* args);
  * launches of >= 2048 such tiles (BASELINE config 4: 360 -> 333 us back to back, batch 11.9 -> 11.2 s). */
 int ss_gemm_bf16_gate128(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_gate128_ok(const ss_gemm_bf16_args* args);
+/* ss_gemm_bf16_gate128 for split = 3 ("fp16q4") operands: per pair of 32-channel steps 32 fp16 MFMAs (a * hi) + 8 block-scaled fp4 ones
+ * (a_q * lo_q, v_mfma_scale_f32_32x32x64_f8f6f4) instead of 64. NOT YET RUN ON HARDWARE; nothing dispatches to it.
+ * ss_gate128q_kindex(out): the K index (tap * 256 + channel) of element e of lane half h in step pair p, out[(p * 2 + h) * 32 + e], 12 pairs -
+ * the order the weights' fp4 lo terms are packed in (returns the number of entries written: 768). */
+int ss_gemm_bf16_gate128q(const ss_gemm_bf16_args* args, void* stream);
+int ss_gemm_bf16_gate128q_ok(const ss_gemm_bf16_args* args);
+int ss_gate128q_kindex(int32_t* out, int n);
 /* The split-operand 1-tap forms of ss_gemm_bf16 for many-round launches (BASELINE config 4 in bf16x2 precision): SS_HEPI_RESX on the pair-only
  * stream (X = NULL) and SS_HEPI_STORE (the K = L*C skip GEMM), N <= 256, K a multiple of 64. 256 rows x all columns per workgroup, 8 waves, both
  * operands by LDS-DMA, epilogues through LDS as 16-byte vectors. ss_gemm_bf16 dispatches here when ss_gemm_bf16_tile256_ok(args) (and the

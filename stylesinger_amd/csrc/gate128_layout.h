@@ -105,3 +105,32 @@ G128_HD int item_row(int p) { return p >> 5; }
 G128_HD int item_col0(int p) { return (p & 31) * 8; }
 
 }  // namespace t128
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// gate128q_kernel (gemm_bf16_gate128q.hip): gate128_kernel with its SECOND product (activation x weight-lo) on the block-scaled fp4 matrix
+// instruction. Steps S = 3 cc + tap are paired in issue order: pair p = steps (2 p, 2 p + 1). Over a pair, lane (row, h) of the fp16 product
+// holds in its four A fragments the 32 values element e = 16 (S & 1) + 8 ks + t  <->  K index of step S, channel 16 ks + 8 h + t (t < 8); it
+// converts them to fp4 in registers. v_mfma_scale_f32_32x32x64_f8f6f4 pairs lane (i, h) of A with lane (j, h) of B element by element
+// (tools/ubench/mfma_mx_layout.hip), so the weights' lo plane is packed ONCE in that element order: for packed column j, pair p, lane half h
+// the 32 nibbles sit in logical slot 4 + h of the weight line of the pair's ODD step (element e in nibble e & 1 of byte e >> 1) and their E8M0
+// block scale in byte h of logical slot 6 of the same line. Lines of even steps carry nothing in slots 4-7.
+namespace g128q {
+
+constexpr int CCS = 8;          // chunks of 32 channels per tap (K = 256)
+constexpr int STEPS = 3 * CCS;  // 24
+constexpr int PAIRS = STEPS / 2;
+
+G128_HD int step_tap(int S) { return S % 3; }
+G128_HD int step_chunk(int S) { return S / 3; }
+// weight line (128 bytes) of step S inside a packed row: the rows are tap-major
+G128_HD int step_line(int S) { return step_tap(S) * CCS + step_chunk(S); }
+// K index (tap * K + channel) of element e of lane half h in pair p
+G128_HD int q_kindex(int p, int h, int e, int K) {
+  const int S = 2 * p + (e >> 4), ks = (e >> 3) & 1, t = e & 7;
+  return step_tap(S) * K + 32 * step_chunk(S) + 16 * ks + 8 * h + t;
+}
+// where the operand register r (0..3) of the A-side conversion comes from: step parity r >> 1, k-step r & 1
+G128_HD int q_reg_parity(int r) { return r >> 1; }
+G128_HD int q_reg_ks(int r) { return r & 1; }
+
+}  // namespace g128q

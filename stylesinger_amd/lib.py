@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 13  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 14  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -79,7 +79,7 @@ class GemmBf16Args(C.Structure):
         ("gate_mode", C.c_int32), ("e_batch_stride", C.c_int64), ("X", _vp), ("x_batch_stride", C.c_int64), ("ldx", C.c_int32),
         ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
         ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
-        ("split", C.c_int32), ("out_scale", C.c_float), ("reserved_", C.c_int32 * 2), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
+        ("split", C.c_int32), ("out_scale", C.c_float), ("q_scale", C.c_float), ("reserved_", C.c_int32), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
     ]
 
 
@@ -452,6 +452,63 @@ def split_f16(x, bias=None, lens=None, scale=1.0):
     return y
 
 
+_FP4_GRID = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
+
+
+def fp4_rne(v):
+    """|v| <= 6 (float tensor) -> (code 0..7, value) of the nearest e2m1 magnitude, ties to the even mantissa (0.25 -> 0, 0.75 -> 1, 1.25 -> 1,
+    1.75 -> 2, 2.5 -> 2, 3.5 -> 4, 5 -> 4): what v_cvt_scalef32_pk_fp4_f16 does (profiles/r04_ubench_cvt_fp4_probe.log)."""
+    grid = torch.tensor(_FP4_GRID, device=v.device, dtype=v.dtype)
+    mid = (grid[1:] + grid[:-1]) / 2
+    a = v.abs().clamp(max=6.0).contiguous()
+    idx = torch.bucketize(a, mid) + ((a == 0.75) | (a == 1.75) | (a == 3.5)).long()
+    return idx, grid[idx]
+
+
+def gate128q_kindex():
+    """[12 pairs][2 lane halves][32 elements] -> K index (tap * 256 + channel): the element order of the fp16q4 gate's block-scaled second
+    product (csrc/gate128_layout.h, g128q::q_kindex - the same function the kernel's layout is checked against)."""
+    out = (C.c_int32 * 768)()
+    n = load().ss_gate128q_kindex(out, 768)
+    if n != 768:
+        raise StyleSingerHipError(f"ss_gate128q_kindex: {last_error()}")
+    return torch.tensor(list(out), dtype=torch.long).view(12, 2, 32)
+
+
+def pack_gate_q4(Wp, *, shift=8):
+    """Packed fp32 gate weight [Np][3 * 256] (ss_pack_conv_weight, gate-interleaved rows, tap-major) -> the operand of ss_gemm_bf16_gate128q
+    (ss_gemm_bf16_args.split = 3): the ss_split_f16 pack of w * 2^shift whose LO plane is replaced by the fp4 (e2m1) terms of
+    lo = w * 2^shift - fp16(w * 2^shift) in the kernel's lane order with one E8M0 scale per 32-element block (block = lane half h of step pair p).
+    Returns (pack [Np][2 * 768] fp16 bits, lo_q [Np][768] fp32 = the values the matrix cores will see for lo, in K order - for references)."""
+    Np, K3 = Wp.shape
+    assert K3 == 768, "the fp16q4 gate is built for K = 256, three taps"
+    dev = Wp.device
+    ws = Wp.float() * float(2 ** shift)
+    pack = split_f16(Wp, scale=float(2 ** shift))
+    lo = ws - ws.half().float()
+    tab = gate128q_kindex().to(dev)                                   # [12][2][32]
+    blocks = lo[:, tab.reshape(-1)].view(Np, 12, 2, 32)
+    amax = blocks.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -120))) - 2      # the block's largest element lands in [4, 8): the grid's top is 6
+    e = torch.where(amax > 0, e, torch.full_like(e, -120.0))
+    scale = torch.exp2(e)
+    idx, mag = fp4_rne(blocks / scale)
+    code = idx | ((blocks < 0).long() << 3)
+    nib = code.view(Np, 12, 2, 16, 2)
+    qbytes = (nib[..., 0] | (nib[..., 1] << 4)).to(torch.uint8)       # element e in nibble e & 1 of byte e >> 1
+    sbyte = (e.squeeze(-1) + 127).clamp(0, 254).to(torch.uint8)       # [Np][12][2]
+    wb = pack.view(torch.uint8).view(Np, 24, 128)
+    wb[:, :, 64:] = 0                                                 # nothing in the second half of any line ...
+    S_odd = torch.arange(12, device=dev) * 2 + 1
+    line = (S_odd % 3) * 8 + S_odd // 3                               # ... except the odd step of every pair: g128q::step_line
+    for h in range(2):
+        wb[:, line, 64 + 16 * h:64 + 16 * h + 16] = qbytes[:, :, h]
+        wb[:, line, 96 + h] = sbyte[:, :, h]
+    lo_q = torch.zeros_like(lo)
+    lo_q[:, tab.reshape(-1)] = (mag * torch.sign(blocks) * scale).view(Np, -1)
+    return pack, lo_q
+
+
 def split_planes(y):
     """[..., 2C] pairs-interleaved-by-32 bf16 / fp16 -> (hi [..., C], mid [..., C]) as float (host-side view for tests / debugging)."""
     v = y.float().reshape(*y.shape[:-1], y.shape[-1] // 64, 2, 32)
@@ -460,7 +517,7 @@ def split_planes(y):
 
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
               next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False,
-              split=0, cur_bias=None, out_scale=1.0):
+              split=0, cur_bias=None, out_scale=1.0, q_scale=0.0):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -481,7 +538,11 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.mask_rows = int(mask_rows)
     a.split = split
     a.out_scale = out_scale
+    a.q_scale = q_scale
     a.cur_bias = ptr(cur_bias)
+    if gate256 == 128 and epi == HEPI_GATE and split == 3:   # ... with the second product on the block-scaled fp4 instruction
+        check(load().ss_gemm_bf16_gate128q(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate128q")
+        return
     if gate256 == 128 and epi == HEPI_GATE:   # the fp16x2 gate on 256 x 128 tiles, two workgroups per CU
         check(load().ss_gemm_bf16_gate128(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate128")
         return

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--which", default="all")
     ap.add_argument("--split", action="store_true", help="bf16x2: (hi, mid) operand pairs, three products (ss_gemm_bf16_args.split)")
     ap.add_argument("--f16", action="store_true", help="fp16x2: fp16 terms, weights-only split, two products (ss_gemm_bf16_args.split = 2); implies --split")
+    ap.add_argument("--q4", action="store_true", help="with --f16: the gate on ss_gemm_bf16_gate128q (fp16q4: second product on the block-scaled fp4 instruction; NOT yet validated)")
     ap.add_argument("--gate128", action="store_true", help="with --f16: the gate on ss_gemm_bf16_gate128 (256 x 128 tiles, two workgroups per CU)")
     ap.add_argument("--pair-only", action="store_true", help="res with --split: the pair-only residual stream (X = NULL, Y read + rewritten in place)")
     ap.add_argument("--no-e", action="store_true", help="gate without the conditioner addend (what-if: how much of the launch is the addend?)")
@@ -36,12 +37,16 @@ def main():
     hdt = torch.float16 if a.f16 else torch.bfloat16
     skw = dict(split=2, out_scale=1.0 / 256.0) if a.f16 else dict(split=int(a.split))
     nprod = 2.0 if a.f16 else 3.0 if a.split else 1.0
+    skw_gate = skw
     Xh = to_h(torch.randn(B, T, C, device=d))
     E = torch.randn(B, T, 4 * 2 * C, device=d)   # 4 layer slabs are enough to defeat the L2
     El = torch.randn(4, B, T, 2 * C, device=d)
     Gh = torch.empty(B, T, C * sp, device=d, dtype=hdt)
     w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
     Wh = to_w(L.pack_conv_weight(w, interleave_half=C))
+    if a.q4:
+        Wh = L.pack_gate_q4(L.pack_conv_weight(w, interleave_half=C))[0]
+        skw_gate = dict(split=3, out_scale=1.0 / 256.0, q_scale=4.0)
     wo = torch.randn(C, C, 1, device=d) / math.sqrt(C)
     Woh = to_w(L.pack_conv_weight(wo))
     X = torch.randn(B, T, C, device=d)
@@ -60,9 +65,9 @@ def main():
                 L.gemm_bf16(Xh, Wh, B=B, T=T, K=C, taps=(-2, 0, 2), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, out=Gh, **skw)
                 return
             L.gemm_bf16(Xh, Wh, B=B, T=T, K=C, taps=(-2, 0, 2), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
-                        E=E[:, :, layer[0] * 2 * C:], lde=4 * 2 * C, e_bs=T * 4 * 2 * C, out=Gh, gate256=128 if a.gate128 else False, **skw)
+                        E=E[:, :, layer[0] * 2 * C:], lde=4 * 2 * C, e_bs=T * 4 * 2 * C, out=Gh, gate256=128 if (a.gate128 or a.q4) else False, **skw_gate)
         s = timeit(fg, a.iters)
-        res.append(("gate K=768 N=512" + (" fp16x2 (2 products)" + (" gate128" if a.gate128 else "") if a.f16 else " split x3" if a.split else " bf16"), s, nprod * 2.0 * B * T * 3 * C * 2 * C,
+        res.append(("gate K=768 N=512" + (" fp16q4 (fp16 + block-scaled fp4 product) gate128q" if a.q4 else " fp16x2 (2 products)" + (" gate128" if a.gate128 else "") if a.f16 else " split x3" if a.split else " bf16"), s, nprod * 2.0 * B * T * 3 * C * 2 * C,
                     B * T * (sp * 2.0 * C + 4.0 * 2 * C + sp * 2.0 * C)))
     if a.which in ("res", "all"):
         po = a.split and a.pair_only

@@ -186,6 +186,24 @@ int main() {
     }
     CHECK(stored == 64 * 64, "OUT: %d of %d values stored", stored, 64 * 64);   // 64 rows x 64 output channels per pass
   }
+  // ================================================================== gate128q_kernel: element order of the block-scaled second product
+  {
+    using namespace g128q;
+    std::vector<int> seen(3 * 256, 0);
+    for (int p = 0; p < PAIRS; ++p)
+      for (int h = 0; h < 2; ++h)
+        for (int e = 0; e < 32; ++e) {
+          const int k = q_kindex(p, h, e, 256);
+          CHECK(k >= 0 && k < 768, "g128q K index range");
+          ++seen[k];
+          // element e sits in operand register e >> 3 (8 fp4 per register); the kernel fills register 2 * (S & 1) + ks from the fragment of step S,
+          // k-step ks, whose lane half h holds channels 16 ks + 8 h + t (the A fragment check above: logical slot 2 ks + lh = channels 8 (2 ks + lh) ..)
+          const int r = e >> 3, t = e & 7, S = 2 * p + q_reg_parity(r), ks = q_reg_ks(r);
+          CHECK(k == step_tap(S) * 256 + 32 * step_chunk(S) + 8 * (2 * ks + h) + t, "g128q element (p=%d h=%d e=%d) != fragment (S=%d ks=%d t=%d)", p, h, e, S, ks, t);
+        }
+    for (int k = 0; k < 768; ++k) CHECK(seen[k] == 1, "g128q: K index %d covered %d times", k, seen[k]);
+    for (int S = 0; S < STEPS; ++S) CHECK(step_line(S) == (S % 3) * CCS + S / 3 && step_line(S) < 24, "g128q weight line of step %d", S);
+  }
   // ================================================================== tile128_resx_kernel (namespace t128)
   {
     using namespace t128;
