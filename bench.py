@@ -50,6 +50,8 @@ CONFIGS = {
     "c4bf16x2": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="bf16x2", sampler="ddpm"),
     # the same workload with plain bf16 operands (one product; 2.5e-3 from the fp32 reference after 1000 steps: does NOT meet north_star)
     "c4bf16": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="bf16", sampler="ddpm"),
+    # EXPERIMENTAL, its gate kernel has not run on hardware yet: fp16x2 with the mel gate's second product on the block-scaled fp4 instruction
+    "c4q": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16q4", sampler="ddpm"),
     # (the name the round-4 records of the fp16x2 mode were taken under: same as c4)
     "c4f16": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16x2", sampler="ddpm"),
     # one GPU's share of configs[4] (256 refs x 256 targets over 8 GPUs = 32 refs x 256 targets per GPU), at a representative size: 64 references x
@@ -657,7 +659,7 @@ def main():
                       f"sampler + 2x{cfg['f0_steps']}-step f0 loops + HiFi-GAN-NSF, per-reference style cache"}
         desc["c2x3"] = desc["c2"]
         desc["c1"] = desc["c2"].replace("utterances per GPU", "utterance (latency shape of inference/StyleSinger.py:175-186), one at a time")
-        desc["c4bf16"] = desc["c4f16"] = desc["c4bf16x2"] = desc["c4"]
+        desc["c4bf16"] = desc["c4f16"] = desc["c4bf16x2"] = desc["c4q"] = desc["c4"]
         desc = desc[args.config]
         x3 = getattr(infer.model, "x3", False)
         split = bool(getattr(infer.model, "split", False))
@@ -669,7 +671,7 @@ def main():
         out = {
             "metric": "mel-frames/sec (end-to-end infer incl. vocoder)", "value": value, "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("fp16x2 (fp16 MFMA, weights as hi+lo fp16 pairs)" if getattr(infer.model, "f16", False) else "bf16x2 (bf16 MFMA, operands as hi+mid bf16 pairs)" if getattr(infer.model, "split", False) else "bf16") if bf16 else ("f32 via 3xbf16 split operands (gates)" if x3 else "f32"),
+            "scaling": "weak", "vs_baseline": None, "dtype": ("fp16q4 (EXPERIMENTAL: fp16 MFMA + block-scaled fp4 MFMA for the weights' lo terms)" if getattr(infer.model, "q4", False) else "fp16x2 (fp16 MFMA, weights as hi+lo fp16 pairs)" if getattr(infer.model, "f16", False) else "bf16x2 (bf16 MFMA, operands as hi+mid bf16 pairs)" if getattr(infer.model, "split", False) else "bf16") if bf16 else ("f32 via 3xbf16 split operands (gates)" if x3 else "f32"),
             "data": "synthetic (seeded random weights + inputs; no checkpoint ships)",
             "clock_ghz_timed_region": clock_timed,
             "config": {"workload": f"{args.config}: {desc}, {prec}", "name": args.config,
@@ -722,7 +724,11 @@ def main():
                              "meets_north_star": True, "measured_on": "tests/test_gpu_round3.py::test_bf16x3_mode_matches_the_reference_golden_chain, "
                                                                        "profiles/r03_parity.json"}
         if split:
-            out["parity"] = _parity_from_profile("fp16x2" if getattr(infer.model, "f16", False) else "bf16x2")
+            if getattr(infer.model, "q4", False):   # experimental mode: no GPU parity record exists yet - never inherit fp16x2's
+                out["parity"] = {"pinned": False, "meets_north_star": None, "north_star_mel_l1": 1e-4,
+                                 "note": "fp16q4 is experimental: only its CPU restatement is pinned (4.3e-5 on the reference's 100-step golden, tests/test_oracle_golden.py)"}
+            else:
+                out["parity"] = _parity_from_profile("fp16x2" if getattr(infer.model, "f16", False) else "bf16x2")
         elif bf16:   # no reference arithmetic exists for bf16 operands: the distance to the fp32 reference is a measured fact, not parity
             out["parity"] = {"pinned": False, "mel_l1_vs_fp32_reference": 2.5e-3, "north_star_mel_l1": 1e-4, "meets_north_star": False,
                              "measured_on": "tests/golden/acoustic_t32_mel1000 (real reference, 1000 mel steps), tests/test_gpu_round2.py, "

@@ -521,6 +521,14 @@ typedef struct ss_wavenet {
    * term read by the matrix cores, the stream a true fp16 pair), two products per GEMM (ss_gemm_bf16_args.split = 2);
    * mfma_out_scale = 2^-s (every ss_gemm_bf16 launch of the stack passes it as out_scale) */
   float mfma_out_scale;
+  /* optional, with mfma_split = 2 ("fp16q4" precision; the kernel behind it has not run on hardware yet): per layer the dilated-conv weights as
+   * stylesinger_amd.lib.pack_gate_q4 packs (hi plane fp16, lo plane as block-scaled fp4 in the lane order of ss_gemm_bf16_gate128q). Layers that
+   * have one run their gate launch with split = 3 / q_scale = q_scale_gate when ss_gemm_bf16_gate128q_ok says so; every other launch of the mode
+   * is fp16x2's. gs in 16-bit elements. */
+  const uint16_t* w_dil_q[SS_MAX_LAYERS];
+  int64_t gs_w_dil_q;
+  float q_scale_gate; /* power of two: the fixed fp4 scale of the gate's A operand (the stream x + dstep: 2.0 in the numerics study) */
+  int32_t reserved3_;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -208,7 +208,19 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     g.C = w.GAh + (int64_t)l * C * pl;
     g.ldc = L * C * pl;
     g.c_batch_stride = (int64_t)T * L * C * pl;
-    SS_PROPAGATE(ss_gemm_bf16(&g, stream));
+    bool gate_done = false;
+    if (sp == 2 && net->w_dil_q[l] && net->q_scale_gate > 0.f) {   // "fp16q4": this layer's gate with its second product on the fp4 instruction, when the launch qualifies
+      ss_gemm_bf16_args q = g;
+      q.split = 3;
+      q.W = net->w_dil_q[l];
+      q.w_group_stride = net->gs_w_dil_q;
+      q.q_scale = net->q_scale_gate;
+      if (ss_gemm_bf16_gate128q_ok(&q)) {
+        SS_PROPAGATE(ss_gemm_bf16_gate128q(&q, stream));
+        gate_done = true;
+      }
+    }
+    if (!gate_done) SS_PROPAGATE(ss_gemm_bf16(&g, stream));
     // the residual stream of the LAST layer is never read (only the skip sum leaves the stack, net.py:120-127): no projection for it
     if (l + 1 == L) break;
     ss_gemm_bf16_args o = base_args_h(net, B, T, lens);

@@ -68,7 +68,8 @@ class WaveNet(C.Structure):
            ("gs_w_dil_h", C.c_int64), ("gs_w_out_h", C.c_int64), ("gs_w_skipall_h", C.c_int64), ("gs_w_cond_h", C.c_int64),
            ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS),
            ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64), ("w_skipall_x3", _vp), ("gs_w_skipall_x3", C.c_int64),
-           ("mfma_split", C.c_int32), ("mfma_out_scale", C.c_float)]
+           ("mfma_split", C.c_int32), ("mfma_out_scale", C.c_float),
+           ("w_dil_q", _vp * SS_MAX_LAYERS), ("gs_w_dil_q", C.c_int64), ("q_scale_gate", C.c_float), ("reserved3_", C.c_int32)]
 
 
 class GemmBf16Args(C.Structure):

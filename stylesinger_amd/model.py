@@ -176,8 +176,8 @@ class StyleSingerHIP(torch.nn.Module):
         # per-layer output projection = residual half only; skip sum of all layers as one K = L*C GEMM per step
         self.defer_skip = os.environ.get("SS_DEFER_SKIP", "1") not in ("0", "off", "false")
         prec = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32"))
-        if prec not in ("fp32", "bf16", "bf16x2", "fp16x2", "bf16x3"):
-            raise ValueError(f"mfma_precision={prec!r}: expected fp32 | bf16 | bf16x2 | fp16x2 | bf16x3")
+        if prec not in ("fp32", "bf16", "bf16x2", "fp16x2", "fp16q4", "bf16x3"):
+            raise ValueError(f"mfma_precision={prec!r}: expected fp32 | bf16 | bf16x2 | fp16x2 | fp16q4 | bf16x3")
         # "bf16x2" (BASELINE config 4 at fp32-grade parity): the bf16 mode's data path (hidden GEMMs on the bf16 matrix cores, operands bf16
         # in HBM) with every operand a (hi, mid) PAIR of bf16 terms and three products hi*hi + hi*mid + mid*hi per GEMM; the step-invariant
         # conditioner projection in exact fp32, skip_projection folded into the K = L*C skip GEMM as in fp32 mode. Measured on the reference's
@@ -186,9 +186,12 @@ class StyleSingerHIP(torch.nn.Module):
         # GEMM instead of three. Over 1000 steps the weight rounding is the coherent error, the activation rounding averages out and fp16's is
         # 8x smaller than bf16's: 1.9e-5 on the same golden (oracle/bf16x2_numerics.py; plain fp16 operands 1.9e-4, bf16 with these two
         # products 1.6e-4). The residual stream is a true fp16 pair (22 bits).
-        self.f16 = prec == "fp16x2"
-        self.split = prec in ("bf16x2", "fp16x2")
-        self.bf16 = prec in ("bf16", "bf16x2", "fp16x2")
+        # "fp16q4" (experimental: its gate kernel has not run on hardware yet): fp16x2 with the mel gate's second product on the block-scaled fp4
+        # matrix instruction where the launch qualifies (ss_gemm_bf16_gate128q); oracle contract set_matmul_rounding("fp16q4")
+        self.q4 = prec == "fp16q4"
+        self.f16 = prec in ("fp16x2", "fp16q4")
+        self.split = prec in ("bf16x2", "fp16x2", "fp16q4")
+        self.bf16 = prec in ("bf16", "bf16x2", "fp16x2", "fp16q4")
         # opt-in "bf16x3": fp32 products of the F(4,3) gate from operands split into three bf16 terms on the bf16 matrix cores
         # (ss_wino43_gate16x; fp32-grade results, oracle/bf16x3_numerics.py); everything else as the fp32 mode
         self.x3 = prec == "bf16x3"
@@ -329,6 +332,8 @@ class StyleSingerHIP(torch.nn.Module):
                 to_h = (lambda w_: self._split_w(w_, f0)) if self.split else L.to_bf16   # split: pairs interleaved by 32 along every row
                 t[f"w_dil_h.{l}"] = to_h(dil.W)
                 t[f"w_out_h.{l}"] = to_h(out.W)
+                if self.q4 and not f0 and C == 256:   # the fp4 lo plane in the lane order of ss_gemm_bf16_gate128q
+                    t[f"w_dil_q.{l}"] = L.pack_gate_q4(dil.W, shift=self.FP16_WSHIFT)[0]
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
         if self.defer_skip:  # skip halves of all output projections side by side: [C][L*C], column l*C + ci
@@ -416,6 +421,11 @@ class StyleSingerHIP(torch.nn.Module):
         net.mfma_bf16 = 1 if self.bf16 else 0
         net.mfma_split = (2 if (self.f16 and not f0) else 1) if self.split else 0
         net.mfma_out_scale = 2.0 ** -self.FP16_WSHIFT if (self.f16 and not f0) else 1.0
+        if self.q4 and not f0:
+            for l in range(Lyr):
+                if f"w_dil_q.{l}" in packs[0]:
+                    net.w_dil_q[l], net.gs_w_dil_q = place(f"w_dil_q.{l}")
+            net.q_scale_gate = 2.0   # the stream x + dstep on a fixed fp4 scale (oracle/second_product_numerics.py)
         net.skipall_folded = 1 if self.fold_skip else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):
