@@ -485,7 +485,12 @@ def pack_gate_q4(Wp, *, shift=8):
     assert K3 == 768, "the fp16q4 gate is built for K = 256, three taps"
     dev = Wp.device
     ws = Wp.float() * float(2 ** shift)
-    pack = split_f16(Wp, scale=float(2 ** shift))
+    if Wp.is_cuda:
+        pack = split_f16(Wp, scale=float(2 ** shift))
+    else:   # host form of ss_split_f16 (pairs interleaved by 32), so that the packer can be checked without a GPU
+        hi = ws.half()
+        lo16 = (ws - hi.float()).half()
+        pack = torch.stack([hi.view(Np, 24, 32), lo16.view(Np, 24, 32)], dim=2).reshape(Np, 2 * K3).contiguous()
     lo = ws - ws.half().float()
     tab = gate128q_kindex().to(dev)                                   # [12][2][32]
     blocks = lo[:, tab.reshape(-1)].view(Np, 12, 2, 32)
@@ -508,6 +513,27 @@ def pack_gate_q4(Wp, *, shift=8):
     lo_q = torch.zeros_like(lo)
     lo_q[:, tab.reshape(-1)] = (mag * torch.sign(blocks) * scale).view(Np, -1)
     return pack, lo_q
+
+
+def unpack_gate_q4(pack):
+    """What ss_gemm_bf16_gate128q reads from a pack_gate_q4 pack, decoded the way the kernel addresses it (csrc/gate128_layout.h): for packed
+    column n, step pair p, lane half h the 16 bytes at logical slot 4 + h of the weight line of step 2 p + 1 are 32 e2m1 nibbles (element e in
+    nibble e & 1 of byte e >> 1), byte h of slot 6 their E8M0 scale. Returns (hi [Np][768] fp32 in K order, lo_q [Np][768] fp32 in K order)."""
+    Np = pack.shape[0]
+    wb = pack.contiguous().view(torch.uint8).view(Np, 24, 128)
+    hi = pack.view(Np, 24, 64)[:, :, :32].float().reshape(Np, 768)
+    tab = gate128q_kindex().to(pack.device)
+    grid = torch.tensor(_FP4_GRID, device=pack.device)
+    lo_q = torch.zeros(Np, 768, device=pack.device)
+    for p in range(12):
+        S = 2 * p + 1
+        line = (S % 3) * 8 + S // 3
+        for h in range(2):
+            by = wb[:, line, 64 + 16 * h:64 + 16 * h + 16].long()                  # [Np][16]
+            nib = torch.stack([by & 15, by >> 4], dim=-1).reshape(Np, 32)             # element e = 2 * byte + nibble
+            val = grid[nib & 7] * torch.where((nib & 8) != 0, -1.0, 1.0) * torch.exp2(wb[:, line, 96 + h].float() - 127.0).unsqueeze(-1)
+            lo_q[:, tab[p, h]] = val
+    return hi, lo_q
 
 
 def split_planes(y):

@@ -378,3 +378,30 @@ def test_gate128_index_math_against_a_tagged_lds_image(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:]
+
+
+def test_fp16q4_weight_pack_round_trips_through_the_kernel_side_decoder():
+    """lib.pack_gate_q4 (the operand of ss_gemm_bf16_gate128q: hi plane fp16 of w * 2^8, lo plane as block-scaled fp4 in the kernel's lane
+    order) against lib.unpack_gate_q4, which reads the pack the way the kernel addresses it (weight line of the pair's odd step, slots 4 + h
+    and 6): every term lands where the kernel looks for it, the fp4 image is within half a grid step of lo, even lines carry nothing."""
+    g = torch.Generator().manual_seed(5)
+    Wp = torch.randn(64, 768, generator=g) * 0.05
+    Wp[3] = 0.0                                   # an all-zero row: scale byte must not produce NaN / inf
+    pack, lo_q = lib.pack_gate_q4(Wp, shift=8)
+    assert pack.dtype == torch.float16 and pack.shape == (64, 1536)
+    hi, lo_dec = lib.unpack_gate_q4(pack)
+    ws = Wp * 256.0
+    assert torch.equal(hi, ws.half().float())
+    assert torch.equal(lo_dec, lo_q), "the decoder (kernel's view) and the packer's own dequantised values agree exactly"
+    lo = ws - ws.half().float()
+    blocks = lib.gate128q_kindex()
+    for p in (0, 5, 11):
+        for h in (0, 1):
+            idx = blocks[p, h]
+            amax = lo[:, idx].abs().amax(dim=1)
+            err = (lo_q[:, idx] - lo[:, idx]).abs().amax(dim=1)
+            assert bool((err <= 0.26 * amax + 1e-30).all())   # half the grid's largest step (4 -> 6) relative to a block maximum in [4, 8)
+    wb = pack.view(torch.uint8).view(64, 24, 128)
+    even_lines = [(S % 3) * 8 + S // 3 for S in range(0, 24, 2)]
+    assert int(wb[:, even_lines, 64:].max()) == 0
+    assert torch.isfinite(lo_dec).all() and float(lo_dec[3].abs().max()) == 0.0
