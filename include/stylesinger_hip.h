@@ -324,6 +324,12 @@ int ss_gemm_bf16_gate128_ok(const ss_gemm_bf16_args* args);
 int ss_gemm_bf16_gate128q(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_gate128q_ok(const ss_gemm_bf16_args* args);
 int ss_gate128q_kindex(int32_t* out, int n);
+/* The long-K STORE GEMM (the skip GEMM) of ss_gemm_bf16_tile256 for split = 3 ("fp16q4") operands: the same second product on the block-scaled
+ * fp4 instruction, pairs = consecutive 32-channel chunks, A scale q_scale (gate outputs: 2^-2). NOT YET RUN ON HARDWARE; nothing dispatches
+ * to it. ss_tile256q_kindex(out, n_pairs): K index of element e of lane half h in chunk pair p, out[(p * 2 + h) * 32 + e] (returns the count). */
+int ss_gemm_bf16_tile256q(const ss_gemm_bf16_args* args, void* stream);
+int ss_gemm_bf16_tile256q_ok(const ss_gemm_bf16_args* args);
+int ss_tile256q_kindex(int32_t* out, int n_pairs);
 /* The split-operand 1-tap forms of ss_gemm_bf16 for many-round launches (BASELINE config 4 in bf16x2 precision): SS_HEPI_RESX on the pair-only
  * stream (X = NULL) and SS_HEPI_STORE (the K = L*C skip GEMM), N <= 256, K a multiple of 64. 256 rows x all columns per workgroup, 8 waves, both
  * operands by LDS-DMA, epilogues through LDS as 16-byte vectors. ss_gemm_bf16 dispatches here when ss_gemm_bf16_tile256_ok(args) (and the
@@ -528,7 +534,11 @@ typedef struct ss_wavenet {
   const uint16_t* w_dil_q[SS_MAX_LAYERS];
   int64_t gs_w_dil_q;
   float q_scale_gate; /* power of two: the fixed fp4 scale of the gate's A operand (the stream x + dstep: 2.0 in the numerics study) */
-  int32_t reserved3_;
+  float q_scale_z;    /* ... of the skip GEMM's A operand (gate outputs in (-1, 1): 0.25) */
+  /* optional, as w_dil_q: the folded skip-all weights as a stylesinger_amd.lib.pack_skip_q4 pack; the K = L*C skip GEMM then runs on
+   * ss_gemm_bf16_tile256q (split = 3, q_scale = q_scale_z) when ss_gemm_bf16_tile256q_ok says so. gs in 16-bit elements. */
+  const uint16_t* w_skipall_q;
+  int64_t gs_w_skipall_q;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -274,6 +274,14 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     k.act = SS_ACT_RELU;
     k.C = w.G;
   }
+  if (sp == 2 && net->w_skipall_q && net->q_scale_z > 0.f) {   // "fp16q4": the second product on the fp4 instruction, when the launch qualifies
+    ss_gemm_bf16_args q = k;
+    q.split = 3;
+    q.W = net->w_skipall_q;
+    q.w_group_stride = net->gs_w_skipall_q;
+    q.q_scale = net->q_scale_z;
+    if (ss_gemm_bf16_tile256q_ok(&q)) return ss_gemm_bf16_tile256q(&q, stream);
+  }
   return ss_gemm_bf16(&k, stream);
 }
 

@@ -134,3 +134,7 @@ G128_HD int q_reg_parity(int r) { return r >> 1; }
 G128_HD int q_reg_ks(int r) { return r & 1; }
 
 }  // namespace g128q
+
+// tile256q_store_kernel (gemm_bf16_tile256q.hip): the same pairing for a 1-tap GEMM - pair p = chunks (2 p, 2 p + 1); element e of lane half h:
+// chunk 2 p + (e >> 4), k-step (e >> 3) & 1, channel 16 ks + 8 h + (e & 7) of it. The fp4 terms sit in the weight line of chunk 2 p + 1.
+G128_HD int t128q_kindex(int p, int h, int e) { return 32 * (2 * p + (e >> 4)) + 16 * ((e >> 3) & 1) + 8 * h + (e & 7); }

@@ -69,7 +69,8 @@ class WaveNet(C.Structure):
            ("w_dil_x3", _vp * SS_MAX_LAYERS), ("gs_w_dil_x3", C.c_int64), ("w_dil_wino16", _vp * SS_MAX_LAYERS),
            ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64), ("w_skipall_x3", _vp), ("gs_w_skipall_x3", C.c_int64),
            ("mfma_split", C.c_int32), ("mfma_out_scale", C.c_float),
-           ("w_dil_q", _vp * SS_MAX_LAYERS), ("gs_w_dil_q", C.c_int64), ("q_scale_gate", C.c_float), ("reserved3_", C.c_int32)]
+           ("w_dil_q", _vp * SS_MAX_LAYERS), ("gs_w_dil_q", C.c_int64), ("q_scale_gate", C.c_float), ("q_scale_z", C.c_float),
+           ("w_skipall_q", _vp), ("gs_w_skipall_q", C.c_int64)]
 
 
 class GemmBf16Args(C.Structure):
@@ -476,13 +477,19 @@ def gate128q_kindex():
     return torch.tensor(list(out), dtype=torch.long).view(12, 2, 32)
 
 
-def pack_gate_q4(Wp, *, shift=8):
-    """Packed fp32 gate weight [Np][3 * 256] (ss_pack_conv_weight, gate-interleaved rows, tap-major) -> the operand of ss_gemm_bf16_gate128q
-    (ss_gemm_bf16_args.split = 3): the ss_split_f16 pack of w * 2^shift whose LO plane is replaced by the fp4 (e2m1) terms of
-    lo = w * 2^shift - fp16(w * 2^shift) in the kernel's lane order with one E8M0 scale per 32-element block (block = lane half h of step pair p).
-    Returns (pack [Np][2 * 768] fp16 bits, lo_q [Np][768] fp32 = the values the matrix cores will see for lo, in K order - for references)."""
-    Np, K3 = Wp.shape
-    assert K3 == 768, "the fp16q4 gate is built for K = 256, three taps"
+def tile256q_kindex(n_pairs):
+    """[n_pairs][2][32] -> K index: the element order of the fp16q4 skip GEMM's block-scaled second product (csrc/gate128_layout.h t128q_kindex)."""
+    out = (C.c_int32 * (n_pairs * 64))()
+    if load().ss_tile256q_kindex(out, n_pairs) != n_pairs * 64:
+        raise StyleSingerHipError(f"ss_tile256q_kindex: {last_error()}")
+    return torch.tensor(list(out), dtype=torch.long).view(n_pairs, 2, 32)
+
+
+def _pack_q4(Wp, tab, odd_lines, shift):
+    """shared by pack_gate_q4 / pack_skip_q4: the ss_split_f16 pack of w * 2^shift with its lo plane replaced by block-scaled fp4 terms; tab
+    [pairs][2][32] = K index of every element, odd_lines [pairs] = the 64-element weight line that carries pair p's terms"""
+    Np, K = Wp.shape
+    nl = K // 32
     dev = Wp.device
     ws = Wp.float() * float(2 ** shift)
     if Wp.is_cuda:
@@ -490,29 +497,65 @@ def pack_gate_q4(Wp, *, shift=8):
     else:   # host form of ss_split_f16 (pairs interleaved by 32), so that the packer can be checked without a GPU
         hi = ws.half()
         lo16 = (ws - hi.float()).half()
-        pack = torch.stack([hi.view(Np, 24, 32), lo16.view(Np, 24, 32)], dim=2).reshape(Np, 2 * K3).contiguous()
+        pack = torch.stack([hi.view(Np, nl, 32), lo16.view(Np, nl, 32)], dim=2).reshape(Np, 2 * K).contiguous()
     lo = ws - ws.half().float()
-    tab = gate128q_kindex().to(dev)                                   # [12][2][32]
-    blocks = lo[:, tab.reshape(-1)].view(Np, 12, 2, 32)
+    npairs = tab.shape[0]
+    tab = tab.to(dev)
+    blocks = lo[:, tab.reshape(-1)].view(Np, npairs, 2, 32)
     amax = blocks.abs().amax(dim=-1, keepdim=True)
     e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -120))) - 2      # the block's largest element lands in [4, 8): the grid's top is 6
     e = torch.where(amax > 0, e, torch.full_like(e, -120.0))
     scale = torch.exp2(e)
     idx, mag = fp4_rne(blocks / scale)
     code = idx | ((blocks < 0).long() << 3)
-    nib = code.view(Np, 12, 2, 16, 2)
+    nib = code.view(Np, npairs, 2, 16, 2)
     qbytes = (nib[..., 0] | (nib[..., 1] << 4)).to(torch.uint8)       # element e in nibble e & 1 of byte e >> 1
-    sbyte = (e.squeeze(-1) + 127).clamp(0, 254).to(torch.uint8)       # [Np][12][2]
-    wb = pack.view(torch.uint8).view(Np, 24, 128)
+    sbyte = (e.squeeze(-1) + 127).clamp(0, 254).to(torch.uint8)       # [Np][pairs][2]
+    wb = pack.view(torch.uint8).view(Np, nl, 128)
     wb[:, :, 64:] = 0                                                 # nothing in the second half of any line ...
-    S_odd = torch.arange(12, device=dev) * 2 + 1
-    line = (S_odd % 3) * 8 + S_odd // 3                               # ... except the odd step of every pair: g128q::step_line
+    line = torch.as_tensor(odd_lines, device=dev, dtype=torch.long)   # ... except the line that closes every pair
     for h in range(2):
         wb[:, line, 64 + 16 * h:64 + 16 * h + 16] = qbytes[:, :, h]
         wb[:, line, 96 + h] = sbyte[:, :, h]
     lo_q = torch.zeros_like(lo)
     lo_q[:, tab.reshape(-1)] = (mag * torch.sign(blocks) * scale).view(Np, -1)
     return pack, lo_q
+
+
+def pack_skip_q4(Wp, *, shift=8):
+    """Packed fp32 1-tap weight [Np][K] (K a multiple of 64) -> the operand of ss_gemm_bf16_tile256q (split = 3): as pack_gate_q4, pairs =
+    consecutive 32-channel chunks, the pair's fp4 terms in the line of its odd chunk. Returns (pack [Np][2 K] fp16 bits, lo_q [Np][K] fp32)."""
+    Np, K = Wp.shape
+    assert K % 64 == 0
+    return _pack_q4(Wp, tile256q_kindex(K // 64), [2 * p + 1 for p in range(K // 64)], shift)
+
+
+def pack_gate_q4(Wp, *, shift=8):
+    """Packed fp32 gate weight [Np][3 * 256] (ss_pack_conv_weight, gate-interleaved rows, tap-major) -> the operand of ss_gemm_bf16_gate128q
+    (ss_gemm_bf16_args.split = 3): the ss_split_f16 pack of w * 2^shift whose LO plane is replaced by the fp4 (e2m1) terms of
+    lo = w * 2^shift - fp16(w * 2^shift) in the kernel's lane order with one E8M0 scale per 32-element block (block = lane half h of step pair p).
+    Returns (pack [Np][2 * 768] fp16 bits, lo_q [Np][768] fp32 = the values the matrix cores will see for lo, in K order - for references)."""
+    Np, K3 = Wp.shape
+    assert K3 == 768, "the fp16q4 gate is built for K = 256, three taps"
+    S_odd = [2 * p + 1 for p in range(12)]
+    return _pack_q4(Wp, gate128q_kindex(), [(S % 3) * 8 + S // 3 for S in S_odd], shift)   # g128q::step_line of the pair's odd step
+
+
+def unpack_skip_q4(pack):
+    """the ss_gemm_bf16_tile256q view of a pack_skip_q4 pack: (hi [Np][K], lo_q [Np][K]) in K order"""
+    Np, K = pack.shape[0], pack.shape[1] // 2
+    nl = K // 32
+    wb = pack.contiguous().view(torch.uint8).view(Np, nl, 128)
+    hi = pack.view(Np, nl, 64)[:, :, :32].float().reshape(Np, K)
+    tab = tile256q_kindex(K // 64).to(pack.device)
+    grid = torch.tensor(_FP4_GRID, device=pack.device)
+    lo_q = torch.zeros(Np, K, device=pack.device)
+    for p in range(K // 64):
+        for h in range(2):
+            by = wb[:, 2 * p + 1, 64 + 16 * h:64 + 16 * h + 16].long()
+            nib = torch.stack([by & 15, by >> 4], dim=-1).reshape(Np, 32)
+            lo_q[:, tab[p, h]] = grid[nib & 7] * torch.where((nib & 8) != 0, -1.0, 1.0) * torch.exp2(wb[:, 2 * p + 1, 96 + h].float() - 127.0).unsqueeze(-1)
+    return hi, lo_q
 
 
 def unpack_gate_q4(pack):
@@ -567,6 +610,9 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.out_scale = out_scale
     a.q_scale = q_scale
     a.cur_bias = ptr(cur_bias)
+    if gate256 and epi == HEPI_STORE and split == 3:   # the fp16q4 skip GEMM
+        check(load().ss_gemm_bf16_tile256q(C.byref(a), stream_ptr()), "ss_gemm_bf16_tile256q")
+        return
     if gate256 == 128 and epi == HEPI_GATE and split == 3:   # ... with the second product on the block-scaled fp4 instruction
         check(load().ss_gemm_bf16_gate128q(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate128q")
         return

@@ -355,6 +355,8 @@ class StyleSingerHIP(torch.nn.Module):
         if self.bf16_hbm:
             t["w_cond_h"] = L.to_bf16(t["w_cond"])     # (unused in split mode: the hoisted projection runs in fp32 there)
             t["w_skipall_h"] = self._split_w(t["w_skipall"], f0) if self.split else L.to_bf16(t["w_skipall"])
+            if self.q4 and not f0 and t["w_skipall"].shape[1] % 64 == 0:   # the fp4 lo plane in the lane order of ss_gemm_bf16_tile256q
+                t["w_skipall_q"] = L.pack_skip_q4(t["w_skipall"], shift=self.FP16_WSHIFT)[0]
         skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
         fin = self._pack_conv(prefix + ".output_projection.weight", prefix + ".output_projection.bias")
         t["w_skip"], t["b_skip"], t["w_final"], t["b_final"] = skip.W, skip.bias, fin.W, fin.bias
@@ -426,6 +428,9 @@ class StyleSingerHIP(torch.nn.Module):
                 if f"w_dil_q.{l}" in packs[0]:
                     net.w_dil_q[l], net.gs_w_dil_q = place(f"w_dil_q.{l}")
             net.q_scale_gate = 2.0   # the stream x + dstep on a fixed fp4 scale (oracle/second_product_numerics.py)
+            if "w_skipall_q" in packs[0]:
+                net.w_skipall_q, net.gs_w_skipall_q = place("w_skipall_q")
+                net.q_scale_z = 0.25   # gate outputs in (-1, 1)
         net.skipall_folded = 1 if self.fold_skip else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):

@@ -108,3 +108,38 @@ def test_fp16q4_mode_stays_close_to_fp16x2_at_the_c4_shape():
     print(f"fp16q4 vs fp16x2 at B=32 x T=5625, {S} steps: mel L1 {d.mean().item():.3e} max {d.max().item():.3e}")
     assert d.mean().item() > 0, "the two modes must not be the same code path at this shape"
     assert d.mean().item() <= 1e-4
+
+
+@pytest.mark.parametrize("T,K", [(5600, 512), (777, 1024)])
+def test_tile256q_store_matches_float64_of_the_same_terms(T, K):
+    """ss_gemm_bf16_tile256q (the fp16q4 skip GEMM: STORE + ReLU, A = gate outputs in the pair layout, hi term only) against float64 of the terms
+    the matrix cores see: a (fp16) x w_hi (fp16) + fp4(a / 2^-2) x block-scaled fp4 (w_lo), scaled by 2^-8, + bias, ReLU."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(T + K)
+    B, N, qs = 3, 256, 0.25
+    sc, osc = float(2 ** WS), float(2.0 ** -WS)
+    lens_l = [T, T - 37, 5]
+    lens = torch.tensor(lens_l, dtype=torch.int32, device=dev)
+    a = (torch.rand(B, T, K, generator=g) * 2 - 1).to(dev)          # gate outputs live in (-1, 1)
+    for b in range(B):
+        a[b, lens_l[b]:] = 0
+    As = L.split_f16(a)
+    ah = a.to(torch.float16).float()
+    idx, mag = L.fp4_rne(ah / qs)
+    aq = mag * torch.sign(ah) * qs
+    w = (torch.randn(N, K, 1, generator=g) / K ** 0.5).to(dev)
+    Wp = L.pack_conv_weight(w)
+    pack, lo_q = L.pack_skip_q4(Wp, shift=WS)
+    hi = (Wp * sc).to(torch.float16).float()
+    bias = (torch.randn(N, generator=g) * 0.1).to(dev)
+    ref = torch.relu((ah.double() @ hi.double().t() + aq.double() @ lo_q.double().t())[..., :N] * osc + bias.double()).float()
+    exact = torch.relu((a.double() @ Wp.double().t())[..., :N] + bias.double()).float()
+    for b in range(B):
+        ref[b, lens_l[b]:] = 0
+        exact[b, lens_l[b]:] = 0
+    S = torch.empty(B, T, N, device=dev)
+    L.gemm_bf16(As, pack, B=B, T=T, K=K, taps=(0,), N=N, Np=Wp.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, lda=2 * K, split=3,
+                out_scale=osc, q_scale=qs, bias=L.pack_bias(bias), gate256=True)
+    e_same, e_exact = (S - ref).abs().max().item(), (S - exact).abs().max().item()
+    print(f"tile256q T={T} K={K}: vs float64 of the same terms {e_same:.2e}, vs exact operands {e_exact:.2e}")
+    assert e_same <= 2e-5 * K ** 0.5 and e_exact <= 5e-3

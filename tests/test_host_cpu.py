@@ -405,3 +405,22 @@ def test_fp16q4_weight_pack_round_trips_through_the_kernel_side_decoder():
     even_lines = [(S % 3) * 8 + S // 3 for S in range(0, 24, 2)]
     assert int(wb[:, even_lines, 64:].max()) == 0
     assert torch.isfinite(lo_dec).all() and float(lo_dec[3].abs().max()) == 0.0
+
+
+def test_fp16q4_skip_weight_pack_round_trips_through_the_kernel_side_decoder():
+    """lib.pack_skip_q4 (operand of ss_gemm_bf16_tile256q: pairs of consecutive 32-channel chunks) against lib.unpack_skip_q4, the kernel's view."""
+    g = torch.Generator().manual_seed(6)
+    Wp = torch.randn(32, 512, generator=g) * 0.03
+    pack, lo_q = lib.pack_skip_q4(Wp, shift=8)
+    hi, lo_dec = lib.unpack_skip_q4(pack)
+    ws = Wp * 256.0
+    assert torch.equal(hi, ws.half().float()) and torch.equal(lo_dec, lo_q)
+    lo = ws - ws.half().float()
+    tab = lib.tile256q_kindex(8)
+    assert sorted(tab.reshape(-1).tolist()) == list(range(512))
+    for p in (0, 7):
+        for h in (0, 1):
+            idx = tab[p, h]
+            assert bool(((lo_q[:, idx] - lo[:, idx]).abs().amax(dim=1) <= 0.26 * lo[:, idx].abs().amax(dim=1) + 1e-30).all())
+    wb = pack.view(torch.uint8).view(32, 16, 128)
+    assert int(wb[:, 0::2, 64:].max()) == 0     # even chunks carry nothing in their second half

@@ -203,6 +203,16 @@ int main() {
         }
     for (int k = 0; k < 768; ++k) CHECK(seen[k] == 1, "g128q: K index %d covered %d times", k, seen[k]);
     for (int S = 0; S < STEPS; ++S) CHECK(step_line(S) == (S % 3) * CCS + S / 3 && step_line(S) < 24, "g128q weight line of step %d", S);
+    // tile256q_store_kernel: pairs of consecutive chunks of a 1-tap GEMM (K = 5120: 80 pairs)
+    std::vector<int> seen1(5120, 0);
+    for (int p = 0; p < 80; ++p)
+      for (int h = 0; h < 2; ++h)
+        for (int e = 0; e < 32; ++e) {
+          const int k = t128q_kindex(p, h, e), r = e >> 3, t = e & 7, c = 2 * p + (r >> 1), ks = r & 1;
+          CHECK(k == 32 * c + 8 * (2 * ks + h) + t && k >= 0 && k < 5120, "t128q element (p=%d h=%d e=%d)", p, h, e);
+          ++seen1[k];
+        }
+    for (int k = 0; k < 5120; ++k) CHECK(seen1[k] == 1, "t128q: K index %d covered %d times", k, seen1[k]);
   }
   // ================================================================== tile128_resx_kernel (namespace t128)
   {
