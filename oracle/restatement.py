@@ -69,10 +69,14 @@ _ROUND = None
 FP16_WSHIFT = 8
 
 
-# "fp16q4" (NOT built on the GPU yet - the arithmetic contract of the next precision mode): fp16x2 with its SECOND product on
-# MXFP4 operands - a*hi on fp16 terms as before, plus q4(a)*q4(lo) where q4 = e2m1 elements with one power-of-two (E8M0) scale per 32 channels
-# (what v_mfma_scale_f32_32x32x64_f8f6f4 consumes at 3.7x the fp16 issue rate, tools/ubench/mfma_mx_layout.hip): 1.27 products instead of 2.
-# lo is a correction of relative size 2^-12, two significant bits of it are enough: 3.5e-5 / 4.4e-5 on the reference's 1000- / 100-step goldens.
+# "fp16q4" (kernels written, not yet run - the arithmetic contract of the next precision mode as it is WIRED): fp16x2 with
+# the SECOND product of the dilated conv and of the skip GEMM on fp4 (e2m1) operands - a*hi on fp16 terms as before, plus q4(a)*q4(lo) on
+# v_mfma_scale_f32_32x32x64_f8f6f4 (3.7x the fp16 issue rate, tools/ubench/mfma_mx_layout.hip): the activation on a FIXED power-of-two scale
+# (the stream x + dstep: 2, gate outputs / the skip GEMM's operand: 2^-2 - the kernels convert their own fragment registers, no block maximum),
+# the weights' lo terms with one E8M0 scale per 32-element block. The output projection (HBM-bound on the GPU) keeps fp16x2's two fp16 products.
+# lo is a correction of relative size 2^-12, two significant bits of it are enough: 3.4e-5 / 4.2e-5 on the reference's 1000- / 100-step goldens
+# (oracle/second_product_numerics.py). (The GPU's blocks are the 32 elements a lane holds over a step pair, not 32 consecutive channels, and its
+# skip GEMM is the folded K = L*C form: the same arithmetic class, not the same bits.)
 _FP4_GRID = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
 _FP4_MID = (_FP4_GRID[1:] + _FP4_GRID[:-1]) / 2
 
@@ -93,6 +97,16 @@ def mxfp4(x, dim):
     idx = torch.bucketize(v, _FP4_MID) + ((v == 0.75) | (v == 1.75) | (v == 3.5)).long()   # bucketize sends ties down; these three go up (even mantissa)
     q = (_FP4_GRID[idx] * b.sign() * s).reshape(*xs.shape)[..., :K].reshape(shp)
     return q.movedim(-1, dim)
+
+
+def fp4_fixed(x, scale):
+    """x -> fp4(x / scale) * scale: e2m1 on a fixed power-of-two scale, ties to the even mantissa, saturating at 6 (v_cvt_scalef32_pk_fp4_f16)"""
+    v = (x / scale).abs().clamp(max=6.0).contiguous()
+    idx = torch.bucketize(v, _FP4_MID) + ((v == 0.75) | (v == 1.75) | (v == 3.5)).long()
+    return _FP4_GRID[idx] * x.sign() * scale
+
+
+FP4_SCALE = {"dil": 2.0, "skip": 0.25}   # the fixed activation scales of the fp16q4 mode (ss_wavenet.q_scale_gate / q_scale_z)
 
 
 def set_matmul_rounding(mode):
@@ -116,11 +130,14 @@ def _split2h(x):
 
 
 def conv1d_cl(x, w, b, dilation=1, rounded=False):
-    """'same' Conv1d on channels-last input; w is the torch [Cout, Cin, k] parameter. rounded: True = a GEMM the HIP path runs on the bf16
-    matrix cores in the bf16 modes; "hoisted" = the same, but step-invariant (exact fp32 in bf16x2 mode)."""
+    """'same' Conv1d on channels-last input; w is the torch [Cout, Cin, k] parameter. rounded: True or a site name ("dil" | "out" | "skip") = a GEMM
+    the HIP path runs on the 16-bit matrix cores in those modes; "hoisted" = the same, but step-invariant (exact fp32 in the split modes)."""
     k = w.shape[-1]
     pad = (k - 1) // 2 * dilation
     xt = x.transpose(1, 2)
+    site = rounded if rounded in ("dil", "out", "skip") else None
+    if site is not None:
+        rounded = True
     if rounded is True and _ROUND == "bf16x2":
         (xh, xm), (wh, wm) = _split2(xt), _split2(w)
         y = F.conv1d(xm, wh, None, padding=pad, dilation=dilation) + F.conv1d(xh, wm, None, padding=pad, dilation=dilation)
@@ -128,16 +145,16 @@ def conv1d_cl(x, w, b, dilation=1, rounded=False):
         if b is not None:
             y = y + b.view(1, -1, 1)
         return y.transpose(1, 2)
-    if rounded is True and _ROUND == "fp16q4":
+    if rounded is True and _ROUND == "fp16q4" and site in FP4_SCALE:
         xh = xt.half().float()
         ws = w * float(2 ** FP16_WSHIFT)
         wh = ws.half().float()
-        y = F.conv1d(mxfp4(xt, 1), mxfp4(ws - wh, 1), None, padding=pad, dilation=dilation) + F.conv1d(xh, wh, None, padding=pad, dilation=dilation)
+        y = F.conv1d(fp4_fixed(xh, FP4_SCALE[site]), mxfp4(ws - wh, 1), None, padding=pad, dilation=dilation) + F.conv1d(xh, wh, None, padding=pad, dilation=dilation)
         y = y * float(2.0 ** -FP16_WSHIFT)
         if b is not None:
             y = y + b.view(1, -1, 1)
         return y.transpose(1, 2)
-    if rounded is True and _ROUND == "fp16x2":
+    if rounded is True and _ROUND in ("fp16x2", "fp16q4"):
         xh = xt.half().float()
         wh, wl = _split2h(w * float(2 ** FP16_WSHIFT))
         y = F.conv1d(xh, wl, None, padding=pad, dilation=dilation) + F.conv1d(xh, wh, None, padding=pad, dilation=dilation)
@@ -385,13 +402,13 @@ def residual_stack(sd, prefix, x, cond, demb, L, cycle):
             hi, lo = _split2h(xin)
             xin = hi + lo
             x = xin - ds
-        y = conv1d_cl(xin, sd[p + ".dilated_conv.weight"], sd[p + ".dilated_conv.bias"], dilation=d, rounded=True) + c
+        y = conv1d_cl(xin, sd[p + ".dilated_conv.weight"], sd[p + ".dilated_conv.bias"], dilation=d, rounded="dil") + c
         y = torch.sigmoid(y[..., :C]) * torch.tanh(y[..., C:])
-        y = conv1d_cl(y, sd[p + ".output_projection.weight"], sd[p + ".output_projection.bias"], rounded=True)
+        y = conv1d_cl(y, sd[p + ".output_projection.weight"], sd[p + ".output_projection.bias"], rounded="out")
         x = (x + y[..., :C]) / math.sqrt(2.0)
         skip = skip + y[..., C:]
     h = skip / math.sqrt(L)
-    h = conv1d_cl(h, sd[prefix + ".skip_projection.weight"], sd[prefix + ".skip_projection.bias"], rounded=True)
+    h = conv1d_cl(h, sd[prefix + ".skip_projection.weight"], sd[prefix + ".skip_projection.bias"], rounded="skip")
     return F.relu(h)
 
 
