@@ -8,6 +8,7 @@
 #   profile [args]   rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary [args]`
 #   pmc-gate         PMC passes on the dominant kernel launch (one counter block per pass, --kernel-trace --pmc only)
 #   pmc-gate-c4x2    the same for the split-operand (bf16x2) 256x256 gate kernel at the C4 shape (tools/pmc_split.sh)
+#   pmc-gate128 [--q4]  the same for the fp16x2 gate on 256x128 tiles, two workgroups per CU (tools/pmc_gate128.sh)
 #   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs direct vs grouped F(4,3))
 #   kbench-c4        the 16-bit many-round launches at the BASELINE config 4 shape: fp16x2 gate on gate256 / gate128, residual projection on
 #                    tile256 / tile128, skip GEMM with and without the deep A prefetch (tools/kbench_h.py)
@@ -39,6 +40,8 @@ case "$sec" in
     bash tools/pmc.sh g16_tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -- $K ;;
   pmc-gate-c4x2)
     bash tools/pmc_split.sh ;;
+  pmc-gate128)
+    bash tools/pmc_gate128.sh "$@" ;;
   kbench)
     python tools/kbench.py --which wino43_16 --iters 60 --mt=-1,3,2
     python tools/kbench.py --which res16 --iters 60 --mt 6
