@@ -721,6 +721,16 @@ def emotion_forward(esd, frames):
     return e / e.norm(dim=1, keepdim=True)
 
 
+def speaker_embed(ssd, frames):
+    """resemblyzer.VoiceEncoder (un-vendored dependency of the reference, requirements.txt: resemblyzer==0.1.1.dev0; used at
+    inference/StyleSinger.py:100,104): forward = ReLU(linear(h_last)) L2-normalised per partial - the architecture of the emotion encoder -
+    and embed_utterance's tail = L2-normalised mean of the partial embeddings. PARITY UNPINNED: the package and its weights are not in
+    /root/reference; this restates its published algorithm."""
+    partial = emotion_forward(ssd, frames)
+    raw = partial.mean(0)
+    return raw / raw.norm(2), partial
+
+
 # ------------------------------------------------------------------------------------------------
 # HiFi-GAN-NSF (modules/hifigan/hifigan_nsf.py:105-169, modules/parallel_wavegan/models/source.py:311-531)
 # ------------------------------------------------------------------------------------------------

@@ -424,3 +424,20 @@ def test_fp16q4_skip_weight_pack_round_trips_through_the_kernel_side_decoder():
             assert bool(((lo_q[:, idx] - lo[:, idx]).abs().amax(dim=1) <= 0.26 * lo[:, idx].abs().amax(dim=1) + 1e-30).all())
     wb = pack.view(torch.uint8).view(32, 16, 128)
     assert int(wb[:, 0::2, 64:].max()) == 0     # even chunks carry nothing in their second half
+
+
+def test_speaker_encoder_partial_slicing_known_answers():
+    """stylesinger_amd.speaker.compute_partial_slices = resemblyzer.VoiceEncoder.compute_partial_slices (un-vendored dependency of the reference,
+    inference/StyleSinger.py:100-104): rate 1.3 partials per second -> one every round(16000 / 1.3 / 160) = 77 frames; hand-computed cases."""
+    from stylesinger_amd import speaker
+    w, m = speaker.compute_partial_slices(48000)                 # 3 s: n_frames 301, steps 219 -> starts 0, 77, 154; last coverage 0.9125
+    assert [(s.start, s.stop) for s in m] == [(0, 160), (77, 237), (154, 314)]
+    assert (w[-1].start, w[-1].stop) == (24640, 50240)
+    _, m = speaker.compute_partial_slices(16000)                 # 1 s: a single (padded) partial
+    assert [(s.start, s.stop) for s in m] == [(0, 160)]
+    _, m = speaker.compute_partial_slices(16000 * 2 + 1000)      # n_frames 207, steps 125 -> starts 0, 77; last coverage (33000 - 12320) / 25600 = 0.81
+    assert [(s.start, s.stop) for s in m] == [(0, 160), (77, 237)]
+    _, m = speaker.compute_partial_slices(16000 * 2 - 2000)      # n_frames 188, steps 106 -> starts 0, 77; last coverage (30000 - 12320) / 25600 = 0.69 < 0.75: dropped
+    assert [(s.start, s.stop) for s in m] == [(0, 160)]
+    _, m = speaker.compute_partial_slices(16000 * 2 - 2000, min_coverage=0.5)
+    assert len(m) == 2
