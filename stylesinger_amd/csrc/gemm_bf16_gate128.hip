@@ -285,6 +285,10 @@ extern "C" int ss_gemm_bf16_gate128_ok(const ss_gemm_bf16_args* a) {
   if (a->K != 256 || (a->Np % BN) != 0 || (a->lda % 8) != 0 || (a->N % 32) != 0 || (a->ldc % 8) != 0 || (a->lde % 4) != 0) return 0;
   if (a->lda < 2 * a->K || a->ldc < 2 * a->N || 2 * a->N > a->Np || !(a->out_scale > 0.f && a->out_scale <= 1.f)) return 0;
   if ((int64_t)a->T * a->lda * 2 >= (1ll << 31) || (int64_t)a->T * a->lde * 4 >= (1ll << 31) || (int64_t)a->T * a->ldc * 2 >= (1ll << 31)) return 0;
+  // everything the launcher insists on: a launch that misses one of these falls back to the other kernels instead of failing
+  if ((((uintptr_t)a->A) & 15) != 0 || (((uintptr_t)a->W) & 15) != 0 || (a->a_batch_stride & 7) != 0 || !a->C) return 0;
+  if (a->E && ((((uintptr_t)a->E) & 15) != 0 || (a->e_batch_stride & 3) != 0)) return 0;
+  if ((int64_t)a->Np * 3 * a->K * 4 >= (1ll << 31)) return 0;
   const long tiles = (long)ss_cdiv(a->T, BM) * a->B * (a->Np / BN);
   return tiles >= 2048 ? 1 : 0;
 }
