@@ -473,7 +473,7 @@ def gate128q_kindex():
     out = (C.c_int32 * 768)()
     n = load().ss_gate128q_kindex(out, 768)
     if n != 768:
-        raise StyleSingerHipError(f"ss_gate128q_kindex: {last_error()}")
+        raise StyleSingerHipError("ss_gate128q_kindex: " + load().ss_last_error().decode(errors="replace"))
     return torch.tensor(list(out), dtype=torch.long).view(12, 2, 32)
 
 
@@ -481,7 +481,7 @@ def tile256q_kindex(n_pairs):
     """[n_pairs][2][32] -> K index: the element order of the fp16q4 skip GEMM's block-scaled second product (csrc/gate128_layout.h t128q_kindex)."""
     out = (C.c_int32 * (n_pairs * 64))()
     if load().ss_tile256q_kindex(out, n_pairs) != n_pairs * 64:
-        raise StyleSingerHipError(f"ss_tile256q_kindex: {last_error()}")
+        raise StyleSingerHipError("ss_tile256q_kindex: " + load().ss_last_error().decode(errors="replace"))
     return torch.tensor(list(out), dtype=torch.long).view(n_pairs, 2, 32)
 
 
