@@ -337,37 +337,59 @@ def mel_loop_in_run(infer, B, T, S_mel, executed_flop_per_frame_step, peak):
             "executed_mfma_frac": executed_flop_per_frame_step * S_mel * B * T / (ms * 1e-3) / peak, "frames": B * T}
 
 
+PARITY_FILES = ("r04_parity.json", "r05_parity.json")   # written by the GPU tests through tests/conftest.py::record_measurement; later wins
+
+
 def _parity_record(name):
-    pj = os.path.join(ROOT, "profiles", "r04_parity.json")
-    try:
-        rec = json.load(open(pj))
-        return rec.get("measurements", rec).get(name)
-    except (OSError, ValueError):
-        return None
+    rec = None
+    for fn in PARITY_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            rec = d.get("measurements", d).get(name) or rec
+        except (OSError, ValueError):
+            pass
+    return rec
 
 
-def _parity_from_profile(mode):
-    """Parity block of a precision mode, read from the round's committed measurement record (profiles/r04_parity.json, written by the GPU tests
-    through tests/conftest.py::record_measurement) - never a constant in this file."""
-    rec = {}
-    for fn in ("r04_parity.json",):
-        pj = os.path.join(ROOT, "profiles", fn)
-        if os.path.exists(pj):
-            try:
-                rec = json.load(open(pj))
-            except (ValueError, OSError):
-                rec = {}
-    rec = rec.get("measurements", rec)
-    a = rec.get(f"c4_{mode}_t32_1000steps_vs_fp32_reference") or {}
-    b = rec.get(f"c4_shape_t5625_100steps_{mode}_vs_fp32_oracle") or {}
-    l1 = [v for v in (a.get("mel_l1"), b.get("mel_l1")) if v is not None]
-    return {"pinned": True, "north_star_mel_l1": 1e-4,
-            "mel_l1_vs_fp32_reference_1000_step_golden": a.get("mel_l1"), "mel_l1_vs_fp32_oracle_t5625_100_steps": b.get("mel_l1"),
-            "meets_north_star": (max(l1) <= 1e-4) if len(l1) == 2 else None,
-            "measured_on": ("tests/test_gpu_fp16x2.py" if mode == "fp16x2" else "tests/test_gpu_round4.py") +
-                           " (acoustic_t32_mel1000 = the real reference's 1000-step golden; T=5625 item vs the oracle), profiles/r04_parity.json",
-            **({"cpu_restatement_mel_l1_vs_1000_step_golden": 1.87e-5, "cpu_restatement": "tests/test_oracle_golden.py::test_fp16x2_restatement_meets_the_bar_on_the_1000_step_golden"}
-               if mode == "fp16x2" else {})}
+def measure_parity_on_1000_step_golden(mode, dev):
+    """Parity of a precision mode MEASURED IN THIS RUN (outside the timed region, ~2 s): the real reference's 1000-step golden
+    `tests/golden/acoustic_t32_mel1000.pt` (a committed fixture generated from the unmodified reference by oracle/gen_golden.py; reading it is not
+    using the oracle) through `StyleSingerHIP.forward` in `mode` on the reference's own noise tape -> mel L1 / max / voicing flips."""
+    import torch
+    from stylesinger_amd import config, synth
+    from stylesinger_amd.model import StyleSingerHIP
+    case = torch.load(os.path.join(ROOT, "tests", "golden", "acoustic_t32_mel1000.pt"), weights_only=False)
+    meta, gold = case["meta"], case["out"]
+    hp = config.make_hparams(dict(timesteps=meta["steps_mel"], K_step=meta["steps_mel"], f0_timesteps=meta["steps_f0"], mfma_precision=mode,
+                                  **meta.get("hp_over", {})))
+    sd = synth.synth_acoustic_state_dict(hp, meta["seed"])
+    b = {k: v.to(dev) for k, v in synth.synth_batch(meta["B"], meta["T"], meta["Tp"], meta["Tr"], hp, meta["seed"]).items()}
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(meta["tape_seed"]), meta["B"], meta["T"], meta["steps_f0"], meta["steps_mel"])
+    m = StyleSingerHIP(None, hparams=hp)
+    m.load_state_dict(sd)
+    m.eval().to(dev)
+    got = m(b["txt_tokens"], mel2ph=b["mel2ph"], spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"], ref_f0=b["ref_f0"],
+            global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"], noise=noise)
+    d = (got["mel_out"].cpu() - gold["mel_out"]).abs()
+    uv = int(((got["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).sum())
+    return {"golden": "tests/golden/acoustic_t32_mel1000.pt (the REAL reference, fp32, 1000 mel steps)", "mel_l1": d.mean().item(),
+            "mel_max": d.max().item(), "voicing_flips": uv}
+
+
+def parity_block(mode, dev):
+    """`parity` of a 16-bit precision mode: (1) measured in this run on the reference's 1000-step golden, (2) the round's committed GPU-test
+    records for the sizes a bench run cannot afford (BASELINE configs[3] as specified: one T = 5625 item x 1000 steps against the real
+    reference's output, tests/test_gpu_round5.py) - labelled as such, never constants in this file."""
+    live = measure_parity_on_1000_step_golden(mode, dev)
+    spec = _parity_record(f"c4_as_specified_t5625_1000steps_{mode}_vs_fp32_reference") or {}
+    shape = _parity_record(f"c4_shape_t5625_100steps_{mode}_vs_fp32_oracle") or {}
+    vals = [v for v in (live["mel_l1"], spec.get("mel_l1")) if v is not None]
+    return {"pinned": True, "north_star_mel_l1": 1e-4, "measured_in_this_run": live,
+            "mel_l1_vs_fp32_reference_1000_step_golden": live["mel_l1"],
+            "from_committed_gpu_tests": {"c4_as_specified_t5625_x_1000_steps_vs_the_real_reference": spec or None,
+                                         "t5625_x_100_steps_vs_fp32_oracle": shape or None,
+                                         "files": ["profiles/" + f for f in PARITY_FILES], "tests": "tests/test_gpu_round5.py, tests/test_gpu_fp16x2.py, tests/test_gpu_round4.py"},
+            "meets_north_star": bool(vals) and max(vals) <= 1e-4}
 
 
 def secondary_configs():
@@ -377,7 +399,7 @@ def secondary_configs():
     reports value, ms_per_step, dtype and its own live roofline block; c4 (fp16x2: meets north_star) and c4bf16 (plain bf16 operands: does not) carry
     their parity status, c5 its style-cache accounting, c1 is the B = 1 latency shape (`c1_gpu`)."""
     out = {}
-    for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4bf16", 1, 1), ("c2x3", 6, 3)):
+    for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4bf16x2", 1, 1), ("c4bf16", 1, 1), ("c2x3", 6, 3)):
         # (c5: a step is a whole 2048-pair sweep, ~45 s: no untimed warm-up sweep - the first timed step carries the one-off graph captures, ~2 s)
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "0" if name == "c5" else "1" if streams == 1 else "3",
                "--streams", str(streams), "--no-cpu-baseline", "--no-secondary"]
@@ -406,7 +428,61 @@ def secondary_configs():
             out[name]["style_cache"] = d["style_cache"]
         if "one_batch_at_a_time" in d:
             out[name]["one_batch_at_a_time"] = d["one_batch_at_a_time"]
+    out["c3_emulated"] = c3_emulated()
     return out
+
+
+def emulate_gather(shard_out, shard_events, B, T, W, ssd):
+    """What `gather_mels` + `run_sharded` do on W ranks, replayed on one device from the W shards' results: every shard's payload
+    [B, T, 80 mel + f0 + bit-cast len], the rank-major buffer the all-gather delivers, and the item order restored through
+    `dist.gathered_order`; checks that item g of the restored batch is item g // W of shard g % W, bit for bit."""
+    import torch
+    t0 = time.perf_counter()
+    pay = []
+    for r in range(W):
+        mel, f0, lens = shard_out[r]
+        p_ = torch.empty(B, T, mel.shape[2] + 2, device=mel.device, dtype=torch.float32)
+        p_[:, :, :mel.shape[2]] = mel
+        p_[:, :, mel.shape[2]] = f0
+        p_[:, :, mel.shape[2] + 1] = lens.to(torch.int32).view(torch.float32)[:, None]
+        pay.append(p_)
+    allg = torch.cat(pay, 0)                                     # rank-major, as all_gather_into_tensor lays it out
+    order = ssd.gathered_order(B * W, W)
+    rows = sorted((g, r) for r, g in enumerate(order) if g >= 0)
+    sel = torch.tensor([r for _, r in rows], device=allg.device)
+    restored = allg[sel]
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    ok = all(torch.equal(restored[g, :, :80], shard_out[g % W][0][g // W]) for g in range(B * W))
+    lens_ok = torch.equal(restored[:, 0, 81].contiguous().view(torch.int32).cpu(),
+                          torch.stack([shard_out[g % W][2][g // W].to(torch.int32).cpu() for g in range(B * W)]))
+    per = {}
+    for r, (a, b) in shard_events:
+        per.setdefault(r, []).append(a.elapsed_time(b))
+    ms = [sum(v) / len(v) for _, v in sorted(per.items())]
+    return {"shards": W, "items": B * W, "per_shard_ms": [round(v, 2) for v in ms], "spread_ms": round(max(ms) - min(ms), 2),
+            "spread_frac": round((max(ms) - min(ms)) / (sum(ms) / len(ms)), 4), "payload_bytes_per_rank": B * T * 82 * 4,
+            "gather_layout_and_order_restore_ms": round(build_ms, 2), "item_order_restored": bool(ok and lens_ok),
+            "note": "8 shards of BASELINE configs[2] back to back on ONE device (one stream): exercises rank::W sharding, the payload and the order "
+                    "restore of the C3 host path; it measures nothing about RCCL / xGMI - the 1->8 GPU curve remains unmeasured"}
+
+
+def c3_emulated():
+    """BASELINE configs[2] (64 utterances over 8 GPUs) emulated on ONE device: the 8 shards `rank::8` run back to back through the real step, each
+    shard's all-gather payload is built, the 8 payloads are laid out as the collective would deliver them and the item order is restored
+    (`--emulate-ranks 8`). It measures NOTHING about xGMI / RCCL - it exercises the C3 host path (sharding rule, payload, order) on the
+    driver's box and reports the per-shard time spread a real 8-GPU run would see as tail imbalance."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "c2", "--emulate-ranks", "8", "--steps", "2", "--warmup", "1", "--streams", "1",
+           "--no-cpu-baseline", "--no-secondary", "--no-roofline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        d = json.loads(line[-1])
+    except (subprocess.TimeoutExpired, ValueError) as e:
+        return {"error": repr(e)[:400]}
+    return dict(d.get("emulated") or {}, ms_per_step_all_shards=d["ms_per_step"], value_one_device=d["value"], unit=d["unit"])
 
 
 def cpu_baseline(hp_over, extra_threads):
@@ -546,6 +622,7 @@ def main():
     step_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     gather_events = []
     last = {}
+    shard_out, shard_events = {}, []
 
     def step(i, r=None):
         r = rank if r is None else r
@@ -563,6 +640,8 @@ def main():
         gather_events.append((e0, e1))
         own = slice(r * B, (r + 1) * B) if world > 1 else slice(None)   # the gathered buffer is rank-major: rows of shard r
         last["mel"], last["r"] = mel, r
+        if n_emul > 1:
+            shard_out[r] = (mel, f0, lens)
         if voc_stream is None:
             return infer.vocode(mel[own], f0[own], lens[own], seed=4321 + i)
         ready = torch.cuda.Event()
@@ -598,7 +677,13 @@ def main():
     mel_items = []
     for i in range(args.steps):
         for r in batches:
+            if n_emul > 1:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             wav = run_step(i, r)
+            if n_emul > 1:
+                ev[1].record()
+                shard_events.append((r, ev))
             frames_local += last["frames"] if sweep_mode else B * T
             if args.checksum and i == args.steps - 1 and not sweep_mode:
                 mel_items.append(last["mel"])   # summed after the final sync (the step may still be running on its own stream)
@@ -695,6 +780,7 @@ def main():
         }
         if single is not None:
             out["one_batch_at_a_time"] = single
+            out["config"]["one_batch_at_a_time"] = single   # the driver's record keeps `config`: the strict batch-at-a-time figure rides there too
         if sweep_mode and last.get("sweep_stats"):
             out["style_cache"] = dict(last["sweep_stats"], note="per step: every reference is encoded once (style_encodes) and served from the "
                                                                 "cache for each further target (style_cache_hits)")
@@ -704,6 +790,8 @@ def main():
                              "pin": "eta=1, stride 1 reproduces the reference's ancestral chain (golden acoustic_t64_s100)",
                              "measured_on": "profiles/r04_parity.json: ddim_eta1_vs_reference_golden_t64_s100",
                              "mel_l1_eta1_vs_reference_golden": (_parity_record("ddim_eta1_vs_reference_golden_t64_s100") or {}).get("mel_l1")}
+        if n_emul > 1 and shard_out:
+            out["emulated"] = emulate_gather(shard_out, shard_events, B, T, n_emul, ssd)
         if world > 1:
             out["dist"] = {"ranks": dist.get_world_size(), "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
                            "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "collective": "all_gather_into_tensor, once per step",
@@ -728,12 +816,11 @@ def main():
                 out["parity"] = {"pinned": False, "meets_north_star": None, "north_star_mel_l1": 1e-4,
                                  "note": "fp16q4 is experimental: only its CPU restatement is pinned (3.9e-5 on the reference's 100-step golden, tests/test_oracle_golden.py)"}
             else:
-                out["parity"] = _parity_from_profile("fp16x2" if getattr(infer.model, "f16", False) else "bf16x2")
+                out["parity"] = parity_block("fp16x2" if getattr(infer.model, "f16", False) else "bf16x2", dev)
         elif bf16:   # no reference arithmetic exists for bf16 operands: the distance to the fp32 reference is a measured fact, not parity
-            out["parity"] = {"pinned": False, "mel_l1_vs_fp32_reference": 2.5e-3, "north_star_mel_l1": 1e-4, "meets_north_star": False,
-                             "measured_on": "tests/golden/acoustic_t32_mel1000 (real reference, 1000 mel steps), tests/test_gpu_round2.py, "
-                                            "profiles/r03_parity.json",
-                             "fp32_mode_same_case": 1.0e-6}
+            live = measure_parity_on_1000_step_golden("bf16", dev)
+            out["parity"] = {"pinned": False, "measured_in_this_run": live, "mel_l1_vs_fp32_reference": live["mel_l1"], "north_star_mel_l1": 1e-4,
+                             "meets_north_star": live["mel_l1"] <= 1e-4}
         if world == 1 and n_emul == 1 and args.config == "c2" and not args.no_secondary and not (args.batch or args.frames or args.diff_steps):
             torch.cuda.empty_cache()
             out["secondary"] = secondary_configs()

@@ -55,7 +55,9 @@ def build_reference(steps_mel, steps_f0, seed=1234, hp_over=None):
     return model, hp, sd
 
 
-def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True, seed=1234, keep_stages=True, hp_over=None):
+def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True, seed=1234, keep_stages=True, hp_over=None,
+                      keep_keys=None):
+    """`keep_keys`: store only these outputs (the full-size C4 case keeps the fixture at ~2 MB)."""
     model, hp, sd = build_reference(steps_mel, steps_f0, seed, hp_over)
     batch = synth.synth_batch(B, T, Tp, Tr, hp, seed)
     tape = synth.NoiseTape(seed + 1)
@@ -78,7 +80,7 @@ def run_acoustic_case(name, B, T, Tp, Tr, steps_mel, steps_f0, give_mel2ph=True,
                     infer=True, note=batch["note"], note_dur=batch["note_dur"], note_type=batch["note_type"])
     for h in hooks:
         h.remove()
-    keys = ["mel2ph", "style", "pitch_pred", "f0_denorm", "decoder_inp", "mel_out", "dur"]
+    keys = keep_keys or ["mel2ph", "style", "pitch_pred", "f0_denorm", "decoder_inp", "mel_out", "dur"]
     out = {k: ret[k].detach().clone() for k in keys if k in ret and torch.is_tensor(ret[k])}
     if "dur_choice" in ret:
         out["dur_choice"] = ret["dur_choice"].clone()
@@ -227,8 +229,18 @@ def round3_cases():
     run_pitch_case("norm_interp_f0")
 
 
+def round5_cases():
+    # BASELINE configs[3] AS SPECIFIED, one item: T = 5625 (30 s) AND 1000 mel steps (+ 2 x 100 f0 steps), the REAL reference in fp32.
+    # ~1.5e14 flop on the CPU (tens of minutes); only the outputs the C4 parity test compares are kept.
+    run_acoustic_case("acoustic_t5625_mel1000", B=1, T=5625, Tp=105, Tr=1500, steps_mel=1000, steps_f0=100, keep_stages=False,
+                      keep_keys=["mel_out", "pitch_pred", "f0_denorm"])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--round5" in sys.argv:
+        round5_cases()
+        return
     if "--only-plms" in sys.argv:
         run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)
         run_plms_case("plms_t24_k12_i4", T=24, steps_mel=12, interval=4)

@@ -622,7 +622,9 @@ __global__ __launch_bounds__(256) void f0_tail_kernel(const SkipSrc src, int64_t
   const SsPhilox rng(seed + (seed_dev ? seed_dev[0] : 0ull));
   float f0v = f0[i];
   int32_t uvv = uv[i];
-  f0_update_row(a0 + bf[0], a1 + bf[1], a2 + bf[2], i, b, t, T, f0v, uvv, lo[i], hi[i], noise, gumbel_u, rng, step, k);
+  // padded frames: eps / logits = 0 as the row-masked projection GEMM wrote them before this kernel replaced it (not 0 + b_final)
+  f0_update_row(masked ? 0.f : a0 + bf[0], masked ? 0.f : a1 + bf[1], masked ? 0.f : a2 + bf[2], i, b, t, T, f0v, uvv, lo[i], hi[i], noise, gumbel_u, rng,
+                step, k);
   if (j == 0) {
     f0[i] = f0v;
     uv[i] = uvv;
@@ -772,7 +774,7 @@ static int mel_input_proj(const ss_wavenet* net, const float* x_in, const int32_
 // The tail of a mel network evaluation for SMALL launches (one short utterance: the B = 1 latency shape) in ONE launch: output projection
 // (C -> M), the DDPM posterior step on x (shallow_diffusion_tts.py:130-162; same tape / Philox counters as the SS_EPI_DDPM epilogue) and the
 // NEXT evaluation's input projection relu(W_in x + b) - two 16-20 us MFMA launches of 24-48 workgroups become one ~8 us VALU launch. Exact
-// fp32 FMAs; only the summation order over K differs from the matrix-core form. 8 frames per workgroup.
+// fp32 FMAs; only the summation order over K differs from the matrix-core form. MTR = 2 frames per workgroup.
 constexpr int MTR = 2;
 __global__ __launch_bounds__(256) void mel_tail_kernel(const SkipSrc src, const float* __restrict__ Wf, const float* __restrict__ bf,
                                                        float* __restrict__ x, const float* __restrict__ noise, uint64_t seed,

@@ -329,13 +329,15 @@ __global__ __launch_bounds__(256, (BM >= 128 ? 2 : 3)) void gemm_bf16_kernel(con
           if constexpr (W2) g = act(fmaf(acc[m][n][r], osc, b0 + pe0[m][n / 2][r]), m0, s0, h0) * act(fmaf(acc[m][n + 1][r], osc, b1 + pe1[m][n / 2][r]), m1, s1, h1);
           else g = act(acc[m][n][r] + b0 + pe0[m][n / 2][r], m0, s0, h0) * act(acc[m][n + 1][r] + b1 + pe1[m][n / 2][r], m1, s1, h1);
           if (row0 + rr >= row_lim) g = 0.f;
-#if SS_HABL == 4
-          if (g == 12345.678f)
-#endif
           const uint16_t gh = ss_f2t<W2>(g);
-          __builtin_amdgcn_raw_buffer_store_b16(gh, rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
-          // second term 32 elements further; fp16x2: the gate output is only ever a matrix-core A operand (hi term), its second term is not written
-          if constexpr (SPLIT == 1) __builtin_amdgcn_raw_buffer_store_b16(f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, 64, 0);
+#if SS_HABL == 4
+          if (g == 12345.678f)   // ablation build (tools/ablate_h.sh): no output stores
+#endif
+          {
+            __builtin_amdgcn_raw_buffer_store_b16(gh, rsrc_c, coff + rr * ldc2, 0, 0);   // rows >= T: out of range, dropped
+            // second term 32 elements further; fp16x2: the gate output is only ever a matrix-core A operand (hi term), its second term is not written
+            if constexpr (SPLIT == 1) __builtin_amdgcn_raw_buffer_store_b16(f2bf(g - bf2f(gh)), rsrc_c, coff + rr * ldc2, 64, 0);
+          }
         }
       }
     }
@@ -546,8 +548,10 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
   SS_CHECK_ARG(a.K > 0 && (a.K % (a.split ? 32 : BKH)) == 0 && (a.lda % 8) == 0, "ss_gemm_bf16: K=%d must be a multiple of 64 (32 when split), lda=%d of 8", a.K, a.lda);
   SS_CHECK_ARG((a.Np & 31) == 0 && (a.epi == SS_HEPI_GATE ? (a.Np & 63) == 0 && 2 * a.N <= a.Np : a.Np >= a.N), "ss_gemm_bf16: bad Np=%d for N=%d", a.Np, a.N);
   SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16: A/W must be 16-byte aligned");
+  // 32-bit buffer offsets per item: the output element is 2 bytes for the GATE epilogue (16-bit terms), 4 for STORE; RESX writes X (fp32) and Y (terms)
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.T * a.lde * 4 < (1ll << 31) && (int64_t)a.T * a.ldx * 4 < (1ll << 31) &&
-                   (int64_t)a.T * a.ldc * 4 < (1ll << 31), "ss_gemm_bf16: item too large for 32-bit offsets");
+                   (int64_t)a.T * a.ldc * (a.epi == SS_HEPI_GATE ? 2 : 4) < (1ll << 31) && (int64_t)a.T * a.ldy * 2 < (1ll << 31),
+               "ss_gemm_bf16: item too large for 32-bit offsets");
   SS_CHECK_ARG(a.split >= 0 && a.split <= 2, "ss_gemm_bf16: split=%d", a.split);
   SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16: split = 2 needs 0 < out_scale <= 1 (got %g)", (double)a.out_scale);
   if (a.split) {   // pairs interleaved by 32: physical rows hold 2 x the logical channels

@@ -290,7 +290,7 @@ extern "C" int ss_gemm_bf16_gate128_ok(const ss_gemm_bf16_args* a) {
   if (a->E && ((((uintptr_t)a->E) & 15) != 0 || (a->e_batch_stride & 3) != 0)) return 0;
   if ((int64_t)a->Np * 3 * a->K * 4 >= (1ll << 31)) return 0;
   const long tiles = (long)ss_cdiv(a->T, BM) * a->B * (a->Np / BN);
-  return tiles >= 2048 ? 1 : 0;
+  return tiles >= 8l * ss_n_cu() ? 1 : 0;   // four rounds of two workgroups per CU (2048 tiles on the 256 CUs of an MI355X)
 }
 
 extern "C" int ss_gemm_bf16_gate128(const ss_gemm_bf16_args* args, void* stream) {

@@ -4,9 +4,10 @@
 (inference/StyleSinger.py:41-63: run the model, drop all-zero frames, clip the mel to
 [mel_vmin, mel_vmax], vocode with the predicted f0).  `infer_batch` is the batched, device-resident
 form the benchmark and the data-parallel driver use.  The feature extractors of `preprocess_input`
-(:94-137) are wired in as far as their models are vendored: `preprocess_batch` computes the reference mel, the emotion
-embedding and the normalised f0 contour on the device; the speaker embedding (resemblyzer) and the f0
-tracker (parselmouth) are un-vendored third-party models and stay inputs.
+(:94-137) run on the device: `preprocess_batch` computes the reference mel, the emotion embedding, the speaker
+embedding (resemblyzer's published algorithm on the emotion encoder's kernels, `speaker.py`; parity unpinned: un-vendored package),
+the f0 contour (Praat's autocorrelation method, `f0track.py`; parity unpinned: parselmouth is un-vendored) and its normalisation.
+Only `trim_long_silences` (webrtcvad, a fixed-point GMM whose tables are not in the reference tree) stays with the caller.
 """
 import numpy as np
 import torch
@@ -19,9 +20,11 @@ from .vocoder import get_vocoder_cls
 
 class StyleSingerInfer:
     def __init__(self, hparams=None, device=None, model_state=None, vocoder_state=None, vocoder_config=None, dictionary=None,
-                 emotion_state=None):
+                 emotion_state=None, speaker_state=None):
         """`emotion_state`: state_dict of the reference's emotion encoder checkpoint (`EmotionEncoder.load_model`,
-        inference/StyleSinger.py:101) - enables the emotion branch of `preprocess_batch`."""
+        inference/StyleSinger.py:101) - enables the emotion branch of `preprocess_batch`.
+        `speaker_state`: `model_state` of resemblyzer's `pretrained.pt` (`VoiceEncoder()`, inference/StyleSinger.py:100) - enables the
+        speaker branch."""
         self.hparams = make_hparams(hparams)
         self._front_hparams = hparams
         if device is None:
@@ -43,6 +46,10 @@ class StyleSingerInfer:
         if emotion_state is not None:
             from .emotion import EmotionEncoderHIP
             self.emotion_encoder = EmotionEncoderHIP(emotion_state, device=self.device)
+        self.speaker_encoder = None
+        if speaker_state is not None:
+            from .speaker import SpeakerEncoderHIP
+            self.speaker_encoder = SpeakerEncoderHIP(speaker_state, device=self.device)
 
     @classmethod
     def from_checkpoints(cls, hparams, exp_dir, vocoder_dir, device=None, dictionary=None):
@@ -156,22 +163,17 @@ class StyleSingerInfer:
             f0 = np.concatenate([f0, [f0[-1]] * delta], 0)
         return f0[:n_mel]
 
-    @torch.no_grad()
-    def embed_emotion_batch(self, wavs, lens):
-        """`Embed_utterance(wav, using_partials=True)` (data_gen/tts/emotion/inference.py:111-151) for a batch of PREPROCESSED
-        waveforms (`preprocess_wav` output, zero beyond lens[b]; lens are host ints): per item zero-pad to the last partial's end,
-        40-mel power spectrogram (EmotionMelFrontendHIP), the partial windows of ALL items through the LSTM in one pass, mean + L2
-        norm per item. -> [B, 256] on the device."""
-        from .emotion import compute_partial_slices
+    def _partials_batch(self, wavs, lens, slicer):
+        """Shared front half of the two utterance encoders: per item zero-pad to the end of its last partial window, 40-mel power
+        spectrogram of the whole batch (EmotionMelFrontendHIP: the same librosa.feature.melspectrogram parameters in both packages),
+        gather the 160-frame partial windows of ALL items. -> (frames [sum P_b, 160, 40], counts [P_b])"""
         from .frontend import EmotionMelFrontendHIP
-        if self.emotion_encoder is None:
-            raise L.StyleSingerHipError("embed_emotion_batch: construct StyleSingerInfer(..., emotion_state=<emotion encoder state_dict>)")
         if self._emo_frontend is None:
             self._emo_frontend = EmotionMelFrontendHIP(self.device)
         lens = [int(v) for v in lens]
         B = len(lens)
-        slices = [compute_partial_slices(n) for n in lens]
-        need = [max(n, ws[-1].stop) for n, (ws, _) in zip(lens, slices)]   # `if max_wave_length >= len(wav): pad` (:129-131)
+        slices = [slicer(n) for n in lens]
+        need = [max(n, ws[-1].stop) for n, (ws, _) in zip(lens, slices)]   # `if max_wave_length >= len(wav): pad` (inference.py:129-131)
         buf = torch.zeros(B, max(need), device=self.device, dtype=torch.float32)
         buf[:, :wavs.shape[1]] = wavs.to(self.device).float()[:, :max(need)]
         mel40, _ = self._emo_frontend.wav2mel(buf, need)
@@ -185,13 +187,51 @@ class StyleSingerInfer:
         ib = torch.cat(idx_b).to(self.device)
         it = torch.cat(idx_t).to(self.device)
         frames = mel40[ib, it].reshape(sum(counts), 160, mel40.shape[-1]).contiguous()
-        part = self.emotion_encoder.embed_frames_batch(frames)
-        out = torch.empty(B, part.shape[1], device=self.device, dtype=torch.float32)
+        return frames, counts
+
+    def _mean_l2norm_per_item(self, part, counts):
+        out = torch.empty(len(counts), part.shape[1], device=self.device, dtype=torch.float32)
         lib, o = L.load(), 0
         for b, c in enumerate(counts):
             L.check(lib.ss_mean_l2norm(L.ptr(part[o:o + c]), L.ptr(out[b]), c, part.shape[1], L.stream_ptr()), "ss_mean_l2norm")
             o += c
         return out
+
+    @torch.no_grad()
+    def embed_emotion_batch(self, wavs, lens):
+        """`Embed_utterance(wav, using_partials=True)` (data_gen/tts/emotion/inference.py:111-151) for a batch of PREPROCESSED
+        waveforms (`preprocess_wav` output, zero beyond lens[b]; lens are host ints): per item zero-pad to the last partial's end,
+        40-mel power spectrogram (EmotionMelFrontendHIP), the partial windows of ALL items through the LSTM in one pass, mean + L2
+        norm per item. -> [B, 256] on the device."""
+        from .emotion import compute_partial_slices
+        if self.emotion_encoder is None:
+            raise L.StyleSingerHipError("embed_emotion_batch: construct StyleSingerInfer(..., emotion_state=<emotion encoder state_dict>)")
+        frames, counts = self._partials_batch(wavs, lens, compute_partial_slices)
+        return self._mean_l2norm_per_item(self.emotion_encoder.embed_frames_batch(frames), counts)
+
+    @torch.no_grad()
+    def embed_speaker_batch(self, wavs, lens, rate=1.3, min_coverage=0.75):
+        """`VoiceEncoder().embed_utterance(wav)` (inference/StyleSinger.py:100,104; resemblyzer 0.1.1.dev0, un-vendored: parity UNPINNED,
+        `speaker.py`) for a batch of waveforms [B, L] (zero beyond lens[b]): partial windows of 160 frames every round(16000 / rate / 160)
+        frames of the 40-mel, VoiceEncoder.forward on all of them in one pass (3 x LSTM, ReLU(Linear), L2 norm per partial), L2-normalised
+        mean per item. The reference hands it the 48 kHz samples of `process_audio` rounded to float16 (:87,104) and the package reads
+        them as 16 kHz audio - `preprocess_batch` reproduces exactly that. -> [B, 256] on the device."""
+        from .speaker import compute_partial_slices as spk_slices
+        if self.speaker_encoder is None:
+            raise L.StyleSingerHipError("embed_speaker_batch: construct StyleSingerInfer(..., speaker_state=<resemblyzer model_state>)")
+        frames, counts = self._partials_batch(wavs, lens, lambda n: spk_slices(n, rate, min_coverage))
+        return self._mean_l2norm_per_item(self.speaker_encoder.forward(frames), counts)
+
+    def process_audio_wav(self, ref_wavs, frames):
+        """The waveform `process_audio` returns next to the mel (inference/StyleSinger.py:86-88): the audio zero-padded to
+        n_mel * hop samples (utils/audios/__init__.py:76-78) and rounded to float16. -> ([B, max n_mel * hop] fp32 holding
+        float16-representable values, zero beyond each item's length; lengths as host ints)"""
+        hop = int(self.hparams["hop_size"])
+        lens = [int(f) * hop for f in frames]
+        out = torch.zeros(ref_wavs.shape[0], max(lens), device=self.device, dtype=torch.float32)
+        n = min(out.shape[1], ref_wavs.shape[1])
+        out[:, :n] = ref_wavs[:, :n].to(self.device).half().float()
+        return out, lens
 
     @torch.no_grad()
     def preprocess_batch(self, ref_wavs, ref_lens, spk_embed, f0_hz, txt_tokens, note, note_dur, note_type, mel2ph=None,
@@ -203,8 +243,9 @@ class StyleSingerInfer:
           emo_wavs [B, Le] `preprocess_wav` output for the emotion encoder (zero beyond emo_lens[b])  -> emo_embed (Embed_utterance, :104)
                    default: the reference audio itself, volume-normalised on the device; `trim_long_silences` needs the un-vendored
                    webrtcvad and is the caller's step. Pass `emo_embed` [B, 256] instead to skip this branch.
-          spk_embed [B, 256] stays an input: its model (resemblyzer VoiceEncoder, :100-103) is un-vendored, as is the f0 tracker
-                   (parselmouth, :125-127)."""
+          spk_embed [B, 256], or None -> `VoiceEncoder().embed_utterance(wav)` (:100,104) on the device (`embed_speaker_batch`;
+                   needs `speaker_state`) from what the reference hands it: `process_audio`'s waveform, i.e. the reference audio
+                   zero-padded to n_mel * hop samples and rounded to float16 (:87; utils/audios/__init__.py:76-78)."""
         from .frontend import MelFrontendHIP
         from .pitch import norm_interp_f0_device
         d = self.device
@@ -226,6 +267,10 @@ class StyleSingerInfer:
                 emo_wavs = self._emo_frontend.normalize_volume(ref_wavs, torch.tensor(ref_lens_h))
                 emo_lens = ref_lens_h
             emo_embed = self.embed_emotion_batch(emo_wavs, emo_lens)
+        if spk_embed is None:
+            hop = int(self.hparams["hop_size"])
+            wav16, wav16_lens = self.process_audio_wav(ref_wavs, [n // hop + 1 for n in ref_lens_h])   # frames of a centred STFT
+            spk_embed = self.embed_speaker_batch(wav16, wav16_lens)
         batch = dict(txt_tokens=txt_tokens.to(d), note=note.to(d), note_dur=note_dur.to(d).float(), note_type=note_type.to(d),
                      spk_embed=spk_embed.to(d).float(), emo_embed=emo_embed.to(d).float(), ref_mels=ref_mels, ref_f0=ref_f0)
         if mel2ph is not None:

@@ -350,6 +350,10 @@ class StyleSingerHIP(torch.nn.Module):
                 t["w_skipall_x3"] = L.split3_gemm16_weights(t["w_skipall"], t["w_skipall"].shape[1])
             t["b_skipall"] = L.pack_bias(bsk.contiguous())
         t["dstep"] = dstep
+        if self.f16 and not f0 and float(dstep.abs().max()) >= 16384.0:
+            # activation-range contract of the fp16 modes: the stream enters every layer as fp16(x + dstep_l); a step embedding this large
+            # leaves no headroom below 65504 (the bf16 modes have the fp32 exponent range)
+            raise ValueError("mfma_precision=fp16x2: a diffusion-step embedding exceeds 16384 in magnitude - fp16 activations would overflow; use bf16x2")
         t["w_cond"] = torch.cat(wc_rows, 0).contiguous()
         t["b_cond"] = torch.cat(bc_rows, 0).contiguous()
         if self.bf16_hbm:
@@ -1053,6 +1057,11 @@ class StyleSingerHIP(torch.nn.Module):
         else:
             self._run_mel(pl)
         xm = pl.xm
+        if self.f16 and pl.uses <= 1 and not torch.isfinite(xm).all():
+            # fp16 terms carry the residual stream x + dstep and the gate outputs inside the stack: unlike the bf16 modes they overflow beyond
+            # 65504. Checked on the first forward of every plan (one host sync); a checkpoint that trips it needs mfma_precision="bf16x2".
+            raise L.StyleSingerHipError("mfma_precision=fp16x2: non-finite mel after the diffusion loop - the residual stream of this checkpoint "
+                                        "leaves the fp16 range (|x + dstep| > 65504); use mfma_precision='bf16x2' (fp32 exponent range)")
         mel_out = torch.empty(B, T, M, **f32)
         # the reference does not mask padded frames here (shallow_diffusion_tts.py:305-306); with per-item
         # lengths the frames past lens[b] are not part of the utterance, so they are written as 0.
