@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 14 /* 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 15 /* 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params; 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -668,6 +668,32 @@ int ss_reflect_pad(const float* x, const int32_t* lens, float* y, int B, int Lx,
  * between voiced neighbours on unvoiced ones (flat beyond the first/last voiced frame, 0 when nothing is voiced);
  * uv [B][T] = 1.0 on unvoiced frames. Frames >= lens[b] (NULL = T) are written as 0. Inputs and outputs must not alias. */
 int ss_norm_interp_f0(const float* f0_hz, const int32_t* lens, float* out, float* uv, int B, int T, void* stream);
+
+/* f0 tracker (input producer; replaces inference/StyleSinger.py:125-127:
+ *   parselmouth.Sound(wav, sr).to_pitch_ac(time_step, voicing_threshold=0.6, pitch_floor=80, pitch_ceiling=800).selected_array['frequency']
+ * and the padding onto the mel frame grid of :128-135). parselmouth / Praat are un-vendored: the kernels follow the published algorithm
+ * (Boersma 1993; Hanning window of three floor periods) - PARITY UNPINNED, oracle/praat_pitch.py is the CPU restatement. float64 throughout.
+ * Geometry (host side: stylesinger_amd/f0track.py::geometry, the paper's / the manual's formulas): */
+typedef struct ss_f0track_params {
+  double sample_rate, time_step /* s */, pitch_floor, pitch_ceiling, voicing_threshold, silence_threshold, octave_cost, octave_jump_cost,
+      voiced_unvoiced_cost;
+  int32_t nsamp_window;     /* even: 2 * halfnsamp_window */
+  int32_t halfnsamp_window; /* floor(3 / floor / dx) / 2 - 1 */
+  int32_t nsamp_period;     /* floor(1 / dx / floor) */
+  int32_t halfnsamp_period; /* nsamp_period / 2 + 1 */
+  int32_t maximum_lag;      /* min(floor(nsamp_window / 3) + 2, nsamp_window) */
+  int32_t nlag;             /* floor(nsamp_window / 2): lags 0 .. nlag are kept per frame (< 1024) */
+  int32_t hop;              /* time_step in samples (must be an integer) */
+  int32_t reserved_;
+} ss_f0track_params;
+int64_t ss_f0track_workspace_bytes(int B, int max_frames, int nlag);
+/* wav [B][wav_stride] fp32 (zero beyond n_samples[b]); n_frames[b] analysis frames of item b, frame i centred between samples
+ * left0[b] + i * hop and left0[b] + i * hop + 1 (0-based); window [nsamp_window] = the Hanning window, window_r [nlag + 1] = its normalised
+ * autocorrelation (float64, device). f0_out [B][ld_out] fp32 <- 0 everywhere, then the selected frequency of frame i (0 = unvoiced) at
+ * column lpad + i (the reference pads the contour by 2 * pad_size frames on the left and zeros on the right, :128-130). */
+int ss_f0track(const float* wav, int64_t wav_stride, const int32_t* n_samples, const int32_t* n_frames, const int32_t* left0, int B, int max_frames,
+               const ss_f0track_params* prm, const double* window, const double* window_r, float* f0_out, int ld_out, int lpad, void* workspace,
+               int64_t workspace_bytes, void* stream);
 
 /* Emotion encoder (input producer; data_gen/tts/emotion/model.py:11-78 = nn.LSTM(40, 256, 3) + Linear, inference.py:39-53,
  * 139-151). One LSTM layer's recurrence as a persistent launch (one workgroup per sequence):

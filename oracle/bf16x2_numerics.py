@@ -23,6 +23,8 @@ Measured (round 4, this container), mel L1 vs the reference:
     cond fp32; dil, out, skip W-split (2 products) . 1.89e-5      = the "fp16x2" mode (oracle.set_matmul_rounding("fp16x2"); on the GPU 1.5e-5)
     cond W-split too ............................... 1.60e-4      (the hoisted projection must stay exact here as well)
     cond fp32; dil plain, out / skip W-split ....... 6.8e-5       (1.5 products on average: inside the bar, margin 1.5x - not adopted)
+
+    python -m oracle.bf16x2_numerics --eslab    round 5: fp16x2 with the exact fp32 conditioner slab E STORED in fewer bits (see the results in DESIGN.md 3.1j)
 """
 import os
 import sys
@@ -54,6 +56,15 @@ def make_conv(site_pairs, names):
         key = names.get(id(w), "")
         site = ("cond" if "conditioner" in key else "dil" if "dilated" in key else "out" if "residual_layers" in key else
                 "skip" if "skip_projection" in key else None)
+        if rounded and key.startswith("postdiff") and isinstance(site_pairs.get(site), str):
+            # round-5 question (C4: half of the gate launch's bytes are the fp32 conditioner slab E): the EXACT fp32 projection, STORED in fewer bits
+            y = F.conv1d(xt, w, b, padding=pad, dilation=dilation)
+            hi = y.to(TERM).float()
+            if site_pairs[site] == "store16":            # one 16-bit term per element (2 of 4 bytes)
+                y = hi
+            elif site_pairs[site] == "store16+8":        # 16-bit term + an e4m3 correction of (y - hi) * 2^11 (3 of 4 bytes)
+                y = hi + ((y - hi) * 2048.0).to(torch.float8_e4m3fn).float() / 2048.0
+            return y.transpose(1, 2)
         if not rounded or site_pairs.get(site) is None or not key.startswith("postdiff"):
             return F.conv1d(xt, w, b, padding=pad, dilation=dilation).transpose(1, 2)
         xs, ws = split2(xt), split2(w)
@@ -108,7 +119,16 @@ VARIANTS_FP16 = {
 }
 
 
+VARIANTS_ESLAB = {   # --eslab (fp16 terms): fp16x2 with the hoisted conditioner projection computed in fp32 but STORED narrower
+    "fp16x2, E stored as one fp16 term (2 B)": dict(cond="store16", dil=PW, out=PW, skip=PW),
+    "fp16x2, E stored as fp16 + e4m3 correction (3 B)": dict(cond="store16+8", dil=PW, out=PW, skip=PW),
+}
+
+
 if __name__ == "__main__":
+    if "--eslab" in sys.argv[1:]:
+        TERM = torch.float16
+        VARIANTS = VARIANTS_ESLAB
     if "--fp16" in sys.argv[1:]:
         TERM = torch.float16
         VARIANTS = VARIANTS_FP16

@@ -40,7 +40,15 @@ __device__ __forceinline__ void unrolled_steps(F&& f, std::integer_sequence<int,
   (f(std::integral_constant<int, I>{}), ...);
 }
 
-__global__ __launch_bounds__(256, 2) void gate128_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int d) {
+__global__ __launch_bounds__(256, 2) void gate128_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int d,
+                                                          unsigned long long* clock_probe) {
+  // ss_set_clock_probe: workgroup 0 reports the shader cycles and 100 MHz ticks its first wave lived (-> the clock the launch sustained)
+  const bool probing = clock_probe != nullptr && blockIdx.x == 0;
+  unsigned long long probe_c0 = 0, probe_r0 = 0;
+  if (probing) {
+    probe_c0 = __builtin_readcyclecounter();
+    probe_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_g128[];   // 80 KB: two workgroups per CU
   // [A0 20 K][B0 16 K][A1 20 K][B1 16 K]: the operands of the LAST step live in A1 / B1, so the first 36 KB are free while it runs
   char* const A0 = smem_g128;
@@ -272,6 +280,10 @@ __global__ __launch_bounds__(256, 2) void gate128_kernel(const ss_gemm_bf16_args
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_c, off, 0, 0);   // rows >= T dropped
     }
   }
+  if (probing && tid == 0) {
+    atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
+    atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
+  }
 }
 
 }  // namespace
@@ -316,7 +328,7 @@ extern "C" int ss_gemm_bf16_gate128(const ss_gemm_bf16_args* args, void* stream)
     ss_set_error("ss_gemm_bf16_gate128: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
     return SS_ERR_HIP;
   }
-  hipLaunchKernelGGL(gate128_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, n_tiles, a.tap_off[2]);
+  hipLaunchKernelGGL(gate128_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, n_tiles, a.tap_off[2], g_ss_tuning.clock_probe);
   SS_CHECK_LAUNCH("ss_gemm_bf16_gate128");
   return SS_OK;
 }

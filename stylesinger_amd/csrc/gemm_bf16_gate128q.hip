@@ -41,7 +41,15 @@ __device__ __forceinline__ void unrolled_steps(F&& f, std::integer_sequence<int,
   (f(std::integral_constant<int, I>{}), ...);
 }
 
-__global__ __launch_bounds__(256, 2) void gate128q_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int d) {
+__global__ __launch_bounds__(256, 2) void gate128q_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int n_tiles, int d,
+                                                          unsigned long long* clock_probe) {
+  // ss_set_clock_probe: workgroup 0 reports the shader cycles and 100 MHz ticks its first wave lived (-> the clock the launch sustained)
+  const bool probing = clock_probe != nullptr && blockIdx.x == 0;
+  unsigned long long probe_c0 = 0, probe_r0 = 0;
+  if (probing) {
+    probe_c0 = __builtin_readcyclecounter();
+    probe_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_g128q[];   // 80 KB: two workgroups per CU
   // [A0 20 K][B0 16 K][A1 20 K][B1 16 K]: the operands of the LAST step live in A1 / B1, so the first 36 KB are free while it runs
   char* const A0 = smem_g128q;
@@ -323,6 +331,10 @@ __global__ __launch_bounds__(256, 2) void gate128q_kernel(const ss_gemm_bf16_arg
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_c, off, 0, 0);   // rows >= T dropped
     }
   }
+  if (probing && tid == 0) {
+    atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
+    atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
+  }
 }
 
 }  // namespace
@@ -336,8 +348,11 @@ extern "C" int ss_gemm_bf16_gate128q_ok(const ss_gemm_bf16_args* a) {
   if (a->K != 256 || (a->Np % BN) != 0 || (a->lda % 8) != 0 || (a->N % 32) != 0 || (a->ldc % 8) != 0 || (a->lde % 4) != 0) return 0;
   if (a->lda < 2 * a->K || a->ldc < 2 * a->N || 2 * a->N > a->Np || !(a->out_scale > 0.f && a->out_scale <= 1.f) || !(a->q_scale > 0.f)) return 0;
   if ((int64_t)a->T * a->lda * 2 >= (1ll << 31) || (int64_t)a->T * a->lde * 4 >= (1ll << 31) || (int64_t)a->T * a->ldc * 2 >= (1ll << 31)) return 0;
+  // everything the launcher insists on: a launch that misses one of these falls back to the fp16x2 kernels instead of failing
+  if ((((uintptr_t)a->A) & 15) != 0 || (((uintptr_t)a->W) & 15) != 0 || (a->a_batch_stride & 7) != 0 || !a->C) return 0;
+  if (a->E && ((((uintptr_t)a->E) & 15) != 0 || (a->e_batch_stride & 3) != 0)) return 0;
   const long tiles = (long)ss_cdiv(a->T, BM) * a->B * (a->Np / BN);
-  return tiles >= 2048 ? 1 : 0;
+  return (g_ss_tuning.q4_force || tiles >= 8l * ss_n_cu()) ? 1 : 0;   // four rounds of two workgroups per CU
 }
 
 extern "C" int ss_gemm_bf16_gate128q(const ss_gemm_bf16_args* args, void* stream) {
@@ -368,7 +383,7 @@ extern "C" int ss_gemm_bf16_gate128q(const ss_gemm_bf16_args* args, void* stream
     ss_set_error("ss_gemm_bf16_gate128q: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
     return SS_ERR_HIP;
   }
-  hipLaunchKernelGGL(gate128q_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, n_tiles, a.tap_off[2]);
+  hipLaunchKernelGGL(gate128q_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, n_tiles, a.tap_off[2], g_ss_tuning.clock_probe);
   SS_CHECK_LAUNCH("ss_gemm_bf16_gate128q");
   return SS_OK;
 }

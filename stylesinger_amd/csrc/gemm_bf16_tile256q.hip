@@ -243,7 +243,7 @@ extern "C" int ss_gemm_bf16_tile256q_ok(const ss_gemm_bf16_args* a) {
   if ((a->N % 4) != 0 || (a->ldc % 4) != 0 || (a->act != SS_ACT_NONE_ && a->act != SS_ACT_RELU_)) return 0;
   if (a->N > BN || (a->K % 64) != 0 || a->lda < 2 * a->K || (a->lda % 8) != 0 || !(a->out_scale > 0.f && a->out_scale <= 1.f) || !(a->q_scale > 0.f)) return 0;
   if ((int64_t)a->T * a->lda * 2 >= (1ll << 31) || (int64_t)a->T * a->ldc * 4 >= (1ll << 31) || (int64_t)a->Np * a->K * 4 >= (1ll << 31)) return 0;
-  return (long)ss_cdiv(a->T, BM) * a->B >= 2L * ss_n_cu() ? 1 : 0;
+  return (g_ss_tuning.q4_force || (long)ss_cdiv(a->T, BM) * a->B >= 2L * ss_n_cu()) ? 1 : 0;
 }
 
 extern "C" int ss_gemm_bf16_tile256q(const ss_gemm_bf16_args* args, void* stream) {

@@ -239,7 +239,9 @@ class StyleSingerInfer:
         """Batched device form of `preprocess_input` + `input_to_batch` (inference/StyleSinger.py:94-172): from reference audio to
         the dict `infer_batch` takes, with no host round trip of the data.
           ref_wavs [B, L] fp32 48 kHz reference audio (zero beyond ref_lens[b]; ref_lens host ints)   -> ref_mels  (process_audio, :106-118)
-          f0_hz    [B, Tr] tracker contour in Hz aligned to the mel frames (align_f0_to_mel), 0 = unvoiced -> ref_f0 (norm_interp_f0, :152)
+          f0_hz    [B, Tr] tracker contour in Hz aligned to the mel frames (align_f0_to_mel), 0 = unvoiced -> ref_f0 (norm_interp_f0, :152);
+                   None -> tracked on the device from `process_audio`'s waveform as :112-135 does with parselmouth (`f0track.py`: Praat's
+                   published autocorrelation method, 80-800 Hz, voicing threshold 0.6; parity UNPINNED - parselmouth is un-vendored)
           emo_wavs [B, Le] `preprocess_wav` output for the emotion encoder (zero beyond emo_lens[b])  -> emo_embed (Embed_utterance, :104)
                    default: the reference audio itself, volume-normalised on the device; `trim_long_silences` needs the un-vendored
                    webrtcvad and is the caller's step. Pass `emo_embed` [B, 256] instead to skip this branch.
@@ -255,6 +257,13 @@ class StyleSingerInfer:
         ref_wavs = ref_wavs.to(d).float()
         ref_mels, frames = self._mel_frontend.wav2mel(ref_wavs, torch.tensor(ref_lens_h, dtype=torch.int64))
         Tr = ref_mels.shape[1]
+        hop = int(self.hparams["hop_size"])
+        wav16 = None
+        if f0_hz is None or spk_embed is None:   # the waveform the reference hands both third-party producers (:87)
+            wav16, wav16_lens = self.process_audio_wav(ref_wavs, [n // hop + 1 for n in ref_lens_h])   # frames of a centred STFT
+        if f0_hz is None:
+            from .f0track import track_f0_device
+            f0_hz = track_f0_device(wav16, wav16_lens, Tr, sr=int(self.hparams["audio_sample_rate"]), hop_size=hop)
         f0_hz = f0_hz.to(d).float()
         if f0_hz.shape[1] != Tr:
             raise ValueError(f"preprocess_batch: f0_hz has {f0_hz.shape[1]} frames, the reference mel {Tr} (use align_f0_to_mel)")
@@ -268,8 +277,6 @@ class StyleSingerInfer:
                 emo_lens = ref_lens_h
             emo_embed = self.embed_emotion_batch(emo_wavs, emo_lens)
         if spk_embed is None:
-            hop = int(self.hparams["hop_size"])
-            wav16, wav16_lens = self.process_audio_wav(ref_wavs, [n // hop + 1 for n in ref_lens_h])   # frames of a centred STFT
             spk_embed = self.embed_speaker_batch(wav16, wav16_lens)
         batch = dict(txt_tokens=txt_tokens.to(d), note=note.to(d), note_dur=note_dur.to(d).float(), note_type=note_type.to(d),
                      spk_embed=spk_embed.to(d).float(), emo_embed=emo_embed.to(d).float(), ref_mels=ref_mels, ref_f0=ref_f0)

@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 14  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 15  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -103,6 +103,12 @@ class HifiGan(C.Structure):
     ]
 
 
+class F0TrackParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("sample_rate", "time_step", "pitch_floor", "pitch_ceiling", "voicing_threshold", "silence_threshold",
+                                          "octave_cost", "octave_jump_cost", "voiced_unvoiced_cost")] \
+        + [(n, C.c_int32) for n in ("nsamp_window", "halfnsamp_window", "nsamp_period", "halfnsamp_period", "maximum_lag", "nlag", "hop", "reserved_")]
+
+
 _CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "uint32_t": C.c_uint32,
           "float": C.c_float, "void": None}
 
@@ -156,15 +162,15 @@ def load():
         fn.argtypes = argtypes
     if lib.ss_abi_version() != ABI_VERSION:
         raise StyleSingerHipError(f"libstylesinger_hip.so has ABI {lib.ss_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
-    sizes = (C.c_int64 * 4)()
-    if lib.ss_struct_sizes(sizes, 4) != 0:
+    sizes = (C.c_int64 * 5)()
+    if lib.ss_struct_sizes(sizes, 5) != 0:
         raise StyleSingerHipError("ss_struct_sizes failed")
-    mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan), C.sizeof(GemmBf16Args))
+    mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan), C.sizeof(GemmBf16Args), C.sizeof(F0TrackParams))
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
     for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE16_KS", b"gate16_ks"), ("SS_GATE256", b"gate256"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile"), ("SS_E16", b"e16"), ("SS_MEL_TAIL", b"mel_tail"), ("SS_HTILE", b"htile"),
-                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_TILE128", b"tile128"), ("SS_SKIP_DEEP", b"skip_deep")):
+                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_TILE128", b"tile128"), ("SS_SKIP_DEEP", b"skip_deep"), ("SS_Q4_FORCE", b"q4_force")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")

@@ -1,13 +1,11 @@
 """Speaker encoder (`resemblyzer.VoiceEncoder().embed_utterance`, inference/StyleSinger.py:100-104) on the kernels of the emotion
 encoder, against the oracle's restatement of the package's published algorithm (parity UNPINNED: the package is an un-vendored dependency).
-Written after the round's GPU budget was spent - every launch is one tests/test_gpu_round2.py::test_emotion_encoder_matches_reference_golden
-already exercises, only the host-side slicing / composition is new: opt-in until it has run once (SS_TEST_SPEAKER=1)."""
-import os
-
+Every launch is one tests/test_gpu_round2.py::test_emotion_encoder_matches_reference_golden already exercises, only the host-side slicing /
+composition is new. First run on an MI355X in round 5 (profiles/r05_session1_tests.log: partial embeds 6.7e-8, utterance embed 2.2e-8)."""
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SS_TEST_SPEAKER") != "1", reason="not yet run on hardware: set SS_TEST_SPEAKER=1")]
+pytestmark = pytest.mark.gpu
 
 from oracle import restatement as R  # noqa: E402
 from stylesinger_amd import synth  # noqa: E402
