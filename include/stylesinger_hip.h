@@ -669,6 +669,15 @@ int ss_reflect_pad(const float* x, const int32_t* lens, float* y, int B, int Lx,
  * uv [B][T] = 1.0 on unvoiced frames. Frames >= lens[b] (NULL = T) are written as 0. Inputs and outputs must not alias. */
 int ss_norm_interp_f0(const float* f0_hz, const int32_t* lens, float* out, float* uv, int B, int T, void* stream);
 
+/* EXPERIMENT (round 5; csrc/fused_gate_res.hip): the F(4,3) gate launch (ss_wino43_gate16w, mt = 2, addend in fetch order) and the residual-half
+ * projection (ss_gemm16_resw, mt = 6) of ONE layer of the mel denoiser as ONE launch: a dataflow grid in which a projection workgroup starts when
+ * the gate workgroups of its row tile(s) have published (agent-scope release / acquire on per-row-tile counters) instead of at a kernel boundary.
+ * Bit-identical to the two launches. counters: one ZEROED uint32 per gate row tile (ss_fused_gate_res_counters); error: int32, set to 1 if a
+ * bounded wait gave up (results are then undefined). Not used by the loop drivers: DESIGN.md 7 has the measurement and why. */
+int ss_fused_gate_res_counters(int B, int T, int dilation);
+int ss_fused_gate_res(const ss_conv_gemm_args* gate, const float* W16g, int dilation, const ss_conv_gemm_args* res, const float* W16r, uint32_t* counters,
+                      int32_t* error, void* stream);
+
 /* f0 tracker (input producer; replaces inference/StyleSinger.py:125-127:
  *   parselmouth.Sound(wav, sr).to_pitch_ac(time_step, voicing_threshold=0.6, pitch_floor=80, pitch_ceiling=800).selected_array['frequency']
  * and the padding onto the mel frame grid of :128-135). parselmouth / Praat are un-vendored: the kernels follow the published algorithm

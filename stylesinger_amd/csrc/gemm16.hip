@@ -54,18 +54,20 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, float* lds_d
 
 // WL = weight layout: false = packed rows [Np][Kp]; true = the lane-contiguous repack of ss_pack_gemm16_weights
 // ([n tile][wave][K chunk][half][lane][4 floats]): one fetch instruction of a wave = 1 KB contiguous instead of 16 columns x 64 B
+// The kernel body as a device function of (workgroup id, LDS base of 3 * 16 MT * LD floats): the __global__ wrapper below passes blockIdx.x and its
+// static LDS; the dataflow experiment of fused_gate_res.hip (round 5) calls the same body from a launch that also holds the gate's workgroups.
 template <int MT, int KCH, bool WL>
-__global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int m_tiles_per_item,
-                                                                           int m_tiles, int n_tiles) {
+__device__ __forceinline__ void gemm16_res_body(const ss_conv_gemm_args& a, const float* __restrict__ W16, int m_tiles_per_item, int m_tiles, int n_tiles,
+                                                const int block_id, float* __restrict__ lds_) {
   constexpr int BM = 16 * MT;
   constexpr int GROUPS = BM / 8;                 // DMA instructions per chunk (8 rows x 128 B each)
   constexpr int DPW = (GROUPS + 3) / 4;          // ... per wave
   static_assert(GROUPS % 4 == 0, "row groups must split evenly over the 4 waves");
-  __shared__ __attribute__((aligned(16))) float As0[BM * LD];
-  __shared__ __attribute__((aligned(16))) float As1[BM * LD];
-  __shared__ __attribute__((aligned(16))) float As2[BM * LD];
+  float* const As0 = static_cast<float*>(__builtin_assume_aligned(lds_, 16));
+  float* const As1 = As0 + BM * LD;
+  float* const As2 = As1 + BM * LD;
 
-  const int id = blockIdx.x;
+  const int id = block_id;
   const int grp = id / (8 * n_tiles);
   const int rem = id % (8 * n_tiles);
   const int mt = grp * 8 + (rem & 7);
@@ -241,6 +243,13 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(cons
       if (SS_R16_ABL == 5 && o != 123456.789f) continue;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsrc_c, c_base, (16 * m + r) * a.ldc * 4, 0);
     }
+}
+
+template <int MT, int KCH, bool WL>
+__global__ __launch_bounds__(256, (MT >= 8 ? 2 : 3)) void gemm16_res_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int m_tiles_per_item,
+                                                                           int m_tiles, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float As[3 * 16 * MT * LD];
+  gemm16_res_body<MT, KCH, WL>(a, W16, m_tiles_per_item, m_tiles, n_tiles, (int)blockIdx.x, As);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -457,6 +466,8 @@ __global__ void pack_gemm16_kernel(const float* __restrict__ src, float* __restr
 
 }  // namespace
 
+#ifndef SS_FUSED_TU   // fused_gate_res.hip includes this file for the kernel bodies above only
+
 // row-tile count (16*mt rows per workgroup) for a launch of B items x T rows x N columns: fewest workgroup layers per CU x rows per tile
 extern "C" int ss_gemm16_pick(int B, int T, int N) {
   const int n_tiles = ss_cdiv(N, BN);
@@ -569,3 +580,4 @@ extern "C" int ss_gemm16_ksplit_pick(int B, int T, int N, int K) {
   if (s > 16) s = 16;
   return s < 1 ? 1 : s;
 }
+#endif  // SS_FUSED_TU

@@ -57,28 +57,31 @@ __device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { retur
 // WL = weight layout: false = the packed rows of ss_pack_conv_weight ([Np][6][Kp], shared with the 32x32x2 kernel); true = the
 // lane-contiguous repack of ss_pack_gate16_weights ([n tile][wave][K chunk][component][half][lane][4 floats]): one fetch instruction of
 // a wave is 1 KB contiguous (8 cache lines) instead of 16 columns x 64 B (16 lines).
+// The kernel body as a device function of (workgroup id, LDS base): the __global__ wrapper below passes blockIdx.x and its dynamic LDS; the
+// dataflow experiment of fused_gate_res.hip (round 5) calls the same body from a launch that also holds the residual projection's workgroups.
+// Returns false for the padding workgroups of the XCD-aligned grid (no tile).
 template <int MT, bool KS, bool WL>
-__global__ __launch_bounds__(256, (MT <= 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int q_tiles_per_item,
-                                                               int q_tiles, int n_tiles, int log2d, unsigned long long* clock_probe) {
+__device__ __forceinline__ bool wino43_gate16_body(const ss_conv_gemm_args& a, const float* __restrict__ W16, int q_tiles_per_item, int q_tiles, int n_tiles,
+                                                   int log2d, unsigned long long* clock_probe, const int block_id, float* __restrict__ smem_) {
   constexpr int BQ = 16 * MT;
   constexpr int NFULL = BQ / 32;             // staging passes of 32 rows x 8 sixteen-byte slots
   constexpr bool HALF = (BQ % 32) != 0;      // + one pass of 16 rows x 16 eight-byte half slots
-  const bool probing = clock_probe != nullptr && blockIdx.x == 0;
+  const bool probing = clock_probe != nullptr && block_id == 0;
   unsigned long long probe_c0 = 0, probe_r0 = 0;
   if (probing) {
     probe_c0 = __builtin_readcyclecounter();
     probe_r0 = __builtin_amdgcn_s_memrealtime();
   }
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* smem = static_cast<float*>(__builtin_assume_aligned(smem_, 16));
   float* As = smem;  // [2][BQ][LD]; KS: [2][6][BQ][LD] (all six components of a K chunk staged at once)
   constexpr int SZC = BQ * LD;  // floats of one staged component
 
-  const int id = blockIdx.x;
+  const int id = block_id;
   const int grp = id / (8 * n_tiles);
   const int rem = id % (8 * n_tiles);
   const int qt = grp * 8 + (rem & 7);
   const int nt = rem >> 3;
-  if (qt >= q_tiles) return;
+  if (qt >= q_tiles) return false;
   // block-uniform by construction; telling the compiler so makes lens[b] a scalar load instead of a vector load + vmcnt(0) in front of
   // the first row fetch
   const int b = __builtin_amdgcn_readfirstlane(qt / q_tiles_per_item);
@@ -496,6 +499,14 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : 2)) void wino43_gate16_kernel(c
     atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
     atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
   }
+  return true;
+}
+
+template <int MT, bool KS, bool WL>
+__global__ __launch_bounds__(256, (MT <= 2 ? 3 : 2)) void wino43_gate16_kernel(const ss_conv_gemm_args a, const float* __restrict__ W16, int q_tiles_per_item,
+                                                               int q_tiles, int n_tiles, int log2d, unsigned long long* clock_probe) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wino43_gate16_body<MT, KS, WL>(a, W16, q_tiles_per_item, q_tiles, n_tiles, log2d, clock_probe, (int)blockIdx.x, smem);
 }
 
 template <int MT, bool KS, bool WL>
@@ -519,6 +530,8 @@ int launch16(const ss_conv_gemm_args& a, const float* W16, int dilation, int log
 }
 
 }  // namespace
+
+#ifndef SS_FUSED_TU   // fused_gate_res.hip includes this file for the kernel bodies above only
 
 // Workgroups a tiling of `quads` rows launches, and the model used to pick one: a launch costs (work per wave tile) x (workgroup
 // layers per CU). MT = 0 in the return value means "the 32x32x2 kernel (wino43_gate.hip) is the better fit".
@@ -676,3 +689,4 @@ extern "C" int ss_gate16_tile_addend(const float* E, int lde, int64_t e_batch_st
   SS_CHECK_LAUNCH("ss_gate16_tile_addend");
   return SS_OK;
 }
+#endif  // SS_FUSED_TU

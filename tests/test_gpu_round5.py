@@ -214,3 +214,62 @@ def test_preprocess_batch_speaker_branch_equals_hand_assembly_and_the_oracle():
     assert worst["embed"] <= 2e-5 and worst["partial"] <= 2e-5 and worst["norm"] <= 1e-5, worst
     res = inf.infer_batch(batch, seed=3, vocode=False)
     assert torch.isfinite(res["mel"]).all()
+
+
+def _sung_wave(n, f_lo, f_hi, seed):
+    """a sung-note-like test signal: harmonic complex with vibrato and a glide, an unvoiced (noise) stretch and a silent one"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 48000.0
+    inst = np.linspace(f_lo, f_hi, n) * (1 + 0.02 * np.sin(2 * np.pi * 5.0 * t))
+    ph = 2 * np.pi * np.cumsum(inst) / 48000.0
+    w = sum(0.25 / h * np.sin(h * ph + 0.3 * h) for h in range(1, 9)) + 0.002 * rng.standard_normal(n)
+    a, b = n // 3, n // 3 + n // 8
+    w[a:b] = 0.02 * rng.standard_normal(b - a)          # unvoiced consonant-like noise
+    w[b:b + n // 10] = 0.0                              # a short rest
+    return w.astype(np.float32)
+
+
+def test_f0_tracker_matches_the_praat_restatement_and_feeds_preprocess_batch():
+    """`ss_f0track` (csrc/f0track.hip: Praat's autocorrelation method as published, float64 on the device) against oracle/praat_pitch.py on a
+    ragged batch of sung-note-like signals - same voicing decision on every frame, frequencies to 1e-3 Hz (both sides compute in float64; the
+    device returns fp32) - and `preprocess_batch(f0_hz=None)` against the same contour handed in by the caller. PARITY UNPINNED: parselmouth is an
+    un-vendored dependency of the reference (inference/StyleSinger.py:125-127); the restatement is held to analytic known answers on the CPU
+    (tests/test_f0track_cpu.py)."""
+    from oracle import praat_pitch as P
+    from stylesinger_amd.f0track import track_f0_device
+    from stylesinger_amd.infer import StyleSingerInfer
+    dev = torch.device("cuda:0")
+    n_mel = [150, 121]
+    lens = [m * 256 for m in n_mel]
+    wav = torch.zeros(2, max(lens))
+    wav[0, :lens[0]] = torch.from_numpy(_sung_wave(lens[0], 180.0, 260.0, 1))
+    wav[1, :lens[1]] = torch.from_numpy(_sung_wave(lens[1], 420.0, 330.0, 2))
+    wav16 = wav.half().float()                                   # what the reference hands the tracker (:87)
+    got = track_f0_device(wav16.to(dev), lens, max(n_mel)).cpu().numpy()
+    worst, flips, voiced = 0.0, 0, 0
+    for b in range(2):
+        ref = P.reference_f0(wav16[b, :lens[b]].numpy().astype(np.float64), n_mel[b])
+        g = got[b, :n_mel[b]]
+        flips += int(((g > 0) != (ref > 0)).sum())
+        both = (g > 0) & (ref > 0)
+        voiced += int(both.sum())
+        worst = max(worst, float(np.abs(g[both] - ref[both]).max()))
+        assert (got[b, n_mel[b]:] == 0).all()
+    print(f"f0 tracker vs the Praat restatement: {voiced} voiced frames, max |df| {worst:.3e} Hz, voicing flips {flips}")
+    record_measurement("f0_tracker_device_vs_praat_restatement", pinned=False, voiced_frames=voiced, max_abs_df_hz=worst, voicing_flips=flips)
+    assert voiced > 100 and flips == 0 and worst <= 1e-3
+    # the wired producer: reference audio in, nothing else from the host
+    hp = config.make_hparams(dict(timesteps=3, K_step=3, f0_timesteps=3))
+    esd, ssd = synth.synth_emotion_state_dict(5), synth.synth_emotion_state_dict(6)
+    inf = StyleSingerInfer(hp, device=dev, model_state=synth.synth_acoustic_state_dict(hp, 5), vocoder_state=synth.synth_vocoder_state_dict(None, 5),
+                           emotion_state=esd, speaker_state=ssd)
+    it = synth.synth_batch(2, 48, 6, 8, hp, 5)
+    args = dict(txt_tokens=it["txt_tokens"], note=it["note"], note_dur=it["note_dur"], note_type=it["note_type"], mel2ph=it["mel2ph"])
+    raw_lens = [lens[0] - 256, lens[1] - 100]                    # process_audio pads them back to n_mel * hop
+    auto = inf.preprocess_batch(wav[:, :max(raw_lens)].to(dev) * torch.tensor([[1.0], [1.0]], device=dev), raw_lens, None, None, **args)
+    w16, w16_lens = inf.process_audio_wav(wav[:, :max(raw_lens)].to(dev), [n // 256 + 1 for n in raw_lens])
+    f0_hand = track_f0_device(w16, w16_lens, auto["ref_mels"].shape[1])
+    hand = inf.preprocess_batch(wav[:, :max(raw_lens)].to(dev), raw_lens, auto["spk_embed"], f0_hand, **args)
+    assert torch.equal(auto["ref_f0"], hand["ref_f0"]) and torch.equal(auto["ref_mels"], hand["ref_mels"])
+    res = inf.infer_batch(auto, seed=3, vocode=True)
+    assert torch.isfinite(res["mel"]).all() and torch.isfinite(res["wav"]).all()

@@ -1,0 +1,112 @@
+"""Round-5 experiment: one layer's F(4,3) gate + residual projection of the mel denoiser as ONE dataflow launch (ss_fused_gate_res: per-row-tile
+counters, agent-scope release / acquire) against the two dependent launches the loop uses, at BASELINE configs[1]'s shape (B = 8 x T = 1500).
+Prints: bit-identity of the 20-layer chain's outputs, us per layer of (gate, projection) as 40 launches vs 20 fused launches (+ one memset of
+the counters), both replayed from a hipGraph.
+    python tools/kbench_fused.py [--B 8] [--T 1500] [--iters 30]
+"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stylesinger_amd import lib as L  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--T", type=int, default=1500)
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, T, C, Lyr = a.B, a.T, 256, 20
+    g = torch.Generator().manual_seed(7)
+    lens = torch.full((B,), T, device=dev, dtype=torch.int32)
+    lens[-1] = T - 37
+    X0 = torch.randn(B, T, C, generator=g).to(dev)
+    for b in range(B):
+        X0[b, int(lens[b]):] = 0
+    E = (torch.randn(B, T, Lyr * 2 * C, generator=g) * 0.5).to(dev)
+    dstep = (torch.randn(Lyr, C, generator=g) * 0.1).to(dev)
+    lib = L.load()
+    packs = []
+    for l in range(Lyr):
+        d = 1 << (l % 4)
+        w = (torch.randn(2 * C, C, 3, generator=g) / math.sqrt(3 * C)).to(dev)
+        wt = L.pack_conv_weight(L.wino43_weight(w), interleave_half=C)
+        wo = (torch.randn(2 * C, C, 1, generator=g) / math.sqrt(C)).to(dev)
+        wop = L.pack_conv_weight(wo)
+        bo = L.pack_bias((torch.randn(2 * C, generator=g) * 0.1).to(dev))
+        packs.append(dict(d=d, wt=wt, wt16=L.pack_gate16_weights(wt, C), wo=wop, wo16=L.pack_gemm16_weights(wop[:C].contiguous(), wop.shape[1]), bo=bo,
+                          e16=L.gate16_tile_addend(E[:, :, l * 2 * C:], B=B, T=T, Np=2 * C, lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, dilation=d, mt=2)))
+    ncnt = [lib.ss_fused_gate_res_counters(B, T, p["d"]) for p in packs]
+    counters = torch.zeros(sum(ncnt), device=dev, dtype=torch.int32)
+    coff = [sum(ncnt[:l]) for l in range(Lyr)]
+    err = torch.zeros(1, device=dev, dtype=torch.int32)
+
+    def kws(l, X, GA):
+        p = packs[l]
+        gk = dict(A=X, W=p["wt"], out=GA[:, :, l * C:], W16=p["wt16"], B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lens=lens, a_bias=dstep[l], epi=L.EPI_GATE,
+                  E=p["e16"], e_tiled=True, lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, ldc=Lyr * C, c_bs=T * Lyr * C, mask_rows=True)
+        rk = dict(A=GA[:, :, l * C:], W=p["wo"], out=X, W16=p["wo16"], R=X, B=B, T=T, Cin=C, N=C, Np=2 * C, Kp=C, lda=Lyr * C, a_bs=T * Lyr * C, lens=lens,
+                  bias=p["bo"], ldr=C, ldc=C, post_scale=0.70710678)
+        return gk, rk
+
+    def two_launch(X, GA):
+        for l in range(Lyr):
+            gk, rk = kws(l, X, GA)
+            g2 = {k: v for k, v in gk.items() if k not in ("A", "W", "out", "W16")}
+            L.wino43_gate16(gk["A"], gk["W"], gk["out"], dilation=packs[l]["d"], mt=2, W16=gk["W16"], **g2)
+            r2 = {k: v for k, v in rk.items() if k not in ("A", "W", "out", "W16")}
+            L.gemm16_res(rk["A"], rk["W"], rk["out"], mt=6, W16=rk["W16"], **r2)
+
+    def fused(X, GA):
+        counters.zero_()
+        for l in range(Lyr):
+            gk, rk = kws(l, X, GA)
+            L.fused_gate_res(gk, rk, dilation=packs[l]["d"], counters=counters[coff[l]:], error=err)
+
+    outs = []
+    for fn in (two_launch, fused):
+        X = X0.clone()
+        GA = torch.zeros(B, T, Lyr * C, device=dev)
+        fn(X, GA)
+        torch.cuda.synchronize()
+        outs.append((X, GA))
+    same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    print(f"fused vs two launches after {Lyr} layers: bit-identical {same}; max |dX| {(outs[0][0] - outs[1][0]).abs().max().item():.3e}, "
+          f"max |dG| {(outs[0][1] - outs[1][1]).abs().max().item():.3e}; wait gave up: {int(err.item())}")
+    assert torch.isfinite(outs[0][0]).all()
+
+    def timed(fn):
+        X = X0.clone()
+        GA = torch.zeros(B, T, Lyr * C, device=dev)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            fn(X, GA)
+            st.synchronize()
+            with torch.cuda.graph(gr, stream=st):
+                fn(X, GA)
+            gr.replay()
+            st.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(a.iters):
+                gr.replay()
+            e1.record(st)
+            st.synchronize()
+        torch.cuda.current_stream().wait_stream(st)
+        return e0.elapsed_time(e1) * 1e3 / (a.iters * Lyr)
+    for rep in range(2):
+        t2 = timed(two_launch)
+        tf = timed(fused)
+        print(f"B={B} T={T}: per layer, two launches (gate, projection) {t2:.2f} us; one dataflow launch {tf:.2f} us ({(tf / t2 - 1) * 100:+.1f} %); wait gave up: {int(err.item())}")
+
+
+if __name__ == "__main__":
+    main()
