@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 15 /* 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params; 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 15 /* 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_fused_gate_res (experiment), knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -49,10 +49,10 @@ int ss_struct_sizes(int64_t* out, int n);
  * take the direct conv kernel instead of the grouped-Winograd one (32-bit offsets; default 2048 = the real limit, tests lower it); "e16" = 0|1
  * the fp32 denoiser loops hand the 16x16x4 gate its conditioner addend in fetch order (ss_gate16_tile_addend once per forward; default 1);
  * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch;
- * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "tile128" = 0|1 the
- * fp16x2 residual projection of many tiles on ss_gemm_bf16_tile128 (default 0: measured, not faster than the 256-row kernel); "skip_deep" =
- * 0|1 the fp16x2 long-K STORE GEMM (K >= 512: the skip GEMM) of ss_gemm_bf16_tile256 prefetches its A operand two chunks ahead (three A
- * buffers, 160 KB of LDS; default 0: measured 1071 -> 1053 us back to back at the BASELINE config 4 shape - the launch is not latency-bound) */
+ * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "q4_force" = 0|1 the
+ * fp16q4 kernels (ss_gemm_bf16_gate128q / _tile256q) take any launch they can compute, not only those that fill the chip (default 0; the parity
+ * tests run one 30 s item through them). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
+ * forwards SS_* variables once at load). */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
 int ss_get_tuning(const char* key);
@@ -336,13 +336,6 @@ int ss_tile256q_kindex(int32_t* out, int n_pairs);
  * "gate256" knob) say so; same arithmetic contract, results equal up to the K summation order. */
 int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
-/* SS_HEPI_RESX on the pair-only stream for split = 2 ("fp16x2") operands on 128-row tiles with TWO workgroups per CU (4 waves, 80 KB of LDS:
- * compact A image as in ss_gemm_bf16_gate128), so that one workgroup's stream traffic (epilogue) runs under the other's operand traffic (loop).
- * Same arithmetic and summation order as ss_gemm_bf16_tile256: bit-identical results (tests/test_gpu_fp16x2.py). Measured at the BASELINE
- * config 4 shape: 131.9 us against the 256-row kernel's 128.9 us - the launch is HBM-bound either way - so ss_gemm_bf16 dispatches here only
- * when the "tile128" tuning knob is set to 1 (default 0) and ss_gemm_bf16_tile128_ok(args). */
-int ss_gemm_bf16_tile128(const ss_gemm_bf16_args* args, void* stream);
-int ss_gemm_bf16_tile128_ok(const ss_gemm_bf16_args* args);
 /* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,

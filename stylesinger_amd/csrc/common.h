@@ -64,7 +64,7 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   q4_force: 0 (default) = the fp16q4 kernels take only launches that fill the chip (their _ok rules); 1 = any launch they can compute (parity tests run
 //     one 30 s item through them).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
-                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int tile128; int skip_deep; int q4_force; };
+                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; };
 extern SsTuning g_ss_tuning;
 // compute units of the current device (cached per device; 256 when no device can be queried): the tiling picks model a launch as
 // workgroup layers per CU, so the count must be the device's, not MI355X's

@@ -75,38 +75,6 @@ G128_HD int out_store_tile_row(int p, int q) {
 }  // namespace g128
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
-// tile128_resx_kernel (gemm_bf16_tile128.hip): the fp16x2 residual projection on the pair-only stream, 128 rows x all N <= 256 columns per
-// workgroup, 4 waves (wave wn owns columns 64 wn .. +64, wave tile 128 x 64), two workgroups per CU. Same compact A image and pair B image.
-namespace t128 {
-
-constexpr int BM = 128;
-constexpr int BN = 256;
-constexpr int WAVES = 4;
-constexpr int A_ROWB = 64;
-constexpr int B_ROWB = 128;
-constexpr int A_PIECES = BM * A_ROWB / 1024;   // 8 per 32-channel chunk; wave w issues pieces w, w + 4
-constexpr int B_PIECES = BN * B_ROWB / 1024;   // 32; wave w issues pieces w + 4 j, j < 8
-constexpr int ST_ROWB = BN * 4;                // staged accumulator row: 256 fp32
-
-G128_HD int a_swz(int row) { return g128::a_swz(row); }
-G128_HD int a_dma_row(int piece, int lane) { return g128::a_dma_row(piece, lane); }
-G128_HD int a_dma_slot(int piece, int lane) { return g128::a_dma_slot(piece, lane); }
-G128_HD int a_frag_row(int m, int l31) { return 32 * m + l31; }
-G128_HD int a_frag_lds(int row, int ks, int lh) { return row * A_ROWB + (((2 * ks + lh) ^ a_swz(row)) << 4); }
-G128_HD int b_swz(int row) { return g128::b_swz(row); }
-G128_HD int b_dma_row(int piece, int lane) { return g128::b_dma_row(piece, lane); }
-G128_HD int b_dma_slot(int piece, int lane) { return g128::b_dma_slot(piece, lane); }
-G128_HD int b_frag_row(int wn, int n, int l31) { return 64 * wn + 32 * n + l31; }
-G128_HD int b_frag_lds(int row, int plane, int ks, int lh) { return row * B_ROWB + (((4 * plane + 2 * ks + lh) ^ b_swz(row)) << 4); }
-// staging of accumulator block q (tile rows 32 q + (0..31)): element r of wave wn, lane (l31, lh), column block n
-G128_HD int st_write(int wn, int n, int l31, int lh, int r) { return (4 * lh + g128::acc_rr(r)) * ST_ROWB + (64 * wn + 32 * n + l31) * 4; }
-// epilogue item p = tid + 256 j (j < 4): staged row p >> 5, channels 8 (p & 31) .. + 8
-G128_HD int item_row(int p) { return p >> 5; }
-G128_HD int item_col0(int p) { return (p & 31) * 8; }
-
-}  // namespace t128
-
-// ------------------------------------------------------------------------------------------------------------------------------------------
 // gate128q_kernel (gemm_bf16_gate128q.hip): gate128_kernel with its SECOND product (activation x weight-lo) on the block-scaled fp4 matrix
 // instruction. Steps S = 3 cc + tap are paired in issue order: pair p = steps (2 p, 2 p + 1). Over a pair, lane (row, h) of the fp16 product
 // holds in its four A fragments the 32 values element e = 16 (S & 1) + 8 ks + t  <->  K index of step S, channel 16 ks + 8 h + t (t < 8); it

@@ -573,8 +573,7 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
       return launch_tiles<SS_HEPI_GATE>(a, stream);
     case SS_HEPI_RESX:
       SS_CHECK_ARG(a.X != nullptr || (a.split && a.Y && a.cur_bias), "ss_gemm_bf16: RESX needs X (or, with split operands, Y + cur_bias: the pair-only stream)");
-      // fp16x2 pair-only stream, many tiles: 128-row tiles, two workgroups per CU ("tile128" knob: off - measured 131.9 vs 128.9 us, HBM-bound either way)
-      if (g_ss_tuning.tile128 && ss_gemm_bf16_tile128_ok(&a)) return ss_gemm_bf16_tile128(&a, stream_);
+      // (a 128-row / two-workgroups-per-CU form of this launch measured 131.9 vs 128.9 us in round 4 - HBM-bound either way - and was removed in round 5)
       if (g_ss_tuning.gate256 && ss_gemm_bf16_tile256_ok(&a)) return ss_gemm_bf16_tile256(&a, stream_);
       return launch_tiles<SS_HEPI_RESX>(a, stream);
     default: break;

@@ -308,181 +308,8 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   }
 }
 
-// ---- the long-K STORE GEMM (K = L*C skip GEMM) of the fp16x2 mode with the A operand prefetched TWO chunks ahead.
-// tile256s_kernel<STORE, true> at the BASELINE config 4 shape: 917 us for 377 us of matrix time and 1.85 GB of A (2.0 TB/s). Its 160 steps wait
-// on their DMA: a step is ~1 us of MFMAs, the next chunk is issued one step ahead, an HBM round trip under load is ~2 us. By Little's law the A
-// bytes in flight bound the launch: 256 CUs x 16 KB (the hi plane of one 32-channel chunk of 256 rows) / 2 us = 2 TB/s - what is measured.
-// Here the A chunks live in a ring of THREE buffers and chunk c+2 is issued in step c (after the weight tile of chunk c+1, which comes from L2
-// and stays one step ahead): twice the A bytes in flight, one counted s_waitcnt (the youngest four DMA instructions of a wave are A(c+1) when
-// step c starts). LDS: 3 x 32 KB A + 2 x 32 KB B = the CU's 160 KB. Same products, same order inside every accumulator: bit-identical results.
-// MEASURED (profiles/r04_kbench_skip_deep.log, back to back): 1070.9 -> 1053.1 us. The hypothesis above is refuted: twice the A bytes in flight
-// buy 1.7 %. What the three 16-bit many-round kernels of config 4 have in common is their matrix rate - 0.88-1.09 PFLOP/s whatever their
-// structure (this launch 0.88-1.03, the gates 0.85-1.09) - i.e. the rate the chip sustains on dense 16-bit MFMA under its power limit
-// (1.5-1.9 GHz while they run). Kept behind the "skip_deep" knob (default 0).
-__global__ __launch_bounds__(512, 2) void tile256s_deep_store_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int kchunks) {
-  extern __shared__ __attribute__((aligned(16))) char smem_t256d[];   // 160 KB: [A0][A1][A2][B0][B1] of 32 KB; epilogue: 2 x 64 KB staging
-  char* const Abase = smem_t256d;
-  char* const Bbase = smem_t256d + 3 * BM * ROWB;
-
-  const int mt = blockIdx.x;
-  if (mt >= m_tiles) return;
-  const int b = mt / m_tiles_per_item;
-  const int t0 = (mt % m_tiles_per_item) * BM;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int len = ss_uniform_len(a.lens, b, a.T);
-  const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
-  const int ldw = 2 * a.K;
-
-  auto uniform_ptr = [](const void* p) {
-    const uint64_t v = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
-  };
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(a.A + (int64_t)b * a.a_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * a.lda * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(a.W + (int64_t)grp_w * a.w_group_stride), 0, __builtin_amdgcn_readfirstlane(a.Np * ldw * 2), 0x00020000);
-
-  // DMA roles and fragment addresses: tile256s_kernel's (pair-layout images, the A operand's second plane not fetched)
-  const int r0 = 8 * wave + (lane >> 3);
-  const int slot0 = (lane & 7) ^ ((r0 >> 1) & 7);
-  const int a_voff = (((t0 + r0) * a.lda + slot0 * 8) * 2) | (slot0 >= 4 ? (int)0x80000000 : 0);
-  const int b_voff = (r0 * ldw + slot0 * 8) * 2;
-  auto piece_a = [&](char* Ab, int c, int j) { glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, a_voff + 64 * j * a.lda * 2, c * ROWB); };
-  auto piece_b = [&](char* Bb, int c, int j) { glds16(rsrc_w, Bb + (wave + 8 * j) * 8 * ROWB, b_voff, c * ROWB + 64 * j * ldw * 2); };
-  const int a_base = (128 * wm + l31) * ROWB, a_swz = (((128 * wm + l31) >> 1) & 7) ^ lh;
-  const int b_base = (64 * wn + l31) * ROWB, b_swz = (((64 * wn + l31) >> 1) & 7) ^ lh;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  bf16x8 p_ah[4], p_bh[2], p_bm[2];
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) p_ah[m][e] = (__bf16)0.f;
-#pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      p_bh[n][e] = (__bf16)0.f;
-      p_bm[n][e] = (__bf16)0.f;
-    }
-  auto mfma8 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2]) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) acc[m][n] = ss_mfma_32x32x16<true>(fa[m], fb[n], acc[m][n]);
-  };
-  // issue order: A(0), B(0), A(1) | step c: B(c+1), A(c+2). At the top of step c everything but the youngest group - A(c+1), when it exists - has
-  // to have landed.
-#pragma unroll
-  for (int j = 0; j < 4; ++j) piece_a(Abase, 0, j);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) piece_b(Bbase, 0, j);
-  if (kchunks > 1) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) piece_a(Abase + BM * ROWB, 1, j);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  int ia = 0;   // ring slot of chunk c's A image
-  for (int c = 0; c < kchunks; ++c) {
-    const char* Ac = Abase + ia * (BM * ROWB);
-    const char* Bc = Bbase + (c & 1) * (BN * ROWB);
-    char* Bn = Bbase + ((c + 1) & 1) * (BN * ROWB);
-    const int ia2 = ia == 0 ? 2 : ia - 1;          // (c + 2) % 3 == (c - 1) % 3: the slot chunk c-1 has just left
-    char* An2 = Abase + ia2 * (BM * ROWB);
-    const bool more_b = c + 1 < kchunks, more_a = c + 2 < kchunks;
-    if (more_b) wait_vmcnt<4>();       // A(c+1), the youngest four, may still be in flight
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();      // everyone's pieces of chunk c have landed; everyone finished reading chunk c-1's buffers
-    auto rd_a = [&](int slot, bf16x8 (&f)[4]) {
-      const int ao = a_base + ((slot ^ a_swz) << 4);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) f[m] = *reinterpret_cast<const bf16x8*>(Ac + ao + m * 32 * ROWB);
-    };
-    auto rd_b = [&](int slot, bf16x8 (&f)[2]) {
-      const int bo = b_base + ((slot ^ b_swz) << 4);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) f[n] = *reinterpret_cast<const bf16x8*>(Bc + bo + n * 32 * ROWB);
-    };
-    bf16x8 ah0[4], bh0[2];
-    rd_a(0, ah0);
-    rd_b(0, bh0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {    // the 16 MFMAs deferred by the previous step; B(c+1) after the first four, A(c+2) after the next four
-      const int m = (i >> 1) & 3, n = i & 1;
-      acc[m][n] = ss_mfma_32x32x16<true>(p_ah[m], i < 8 ? p_bm[n] : p_bh[n], acc[m][n]);
-      if (i < 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (i < 4) {
-          if (more_b) piece_b(Bn, c + 1, i);        // wave-uniform branches
-        } else {
-          if (more_a) piece_a(An2, c + 2, i - 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8 bm0[2];
-    rd_b(4, bm0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(ah0, bh0);
-    __builtin_amdgcn_sched_barrier(0);
-    rd_a(2, p_ah);
-    rd_b(2, p_bh);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(ah0, bm0);
-    __builtin_amdgcn_sched_barrier(0);
-    rd_b(6, p_bm);
-    __builtin_amdgcn_sched_barrier(0);
-    ia = ia == 2 ? 0 : ia + 1;
-  }
-  mfma8(p_ah, p_bm);
-  mfma8(p_ah, p_bh);
-
-  // ---- epilogue: tile256s_kernel<STORE, true>'s
-  const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
-  const float* biasg = a.bias ? a.bias + (int64_t)grp_w * a.bias_group_stride : nullptr;
-  __builtin_amdgcn_s_barrier();   // everyone is done reading the operand buffers
-  const int st_wr = (32 * wm + 4 * lh) * (BN * 4) + (64 * wn + l31) * 4;   // + rr * BN * 4 (+ 128 for n = 1)
-  float* Cb = (float*)a.C + (int64_t)b * a.c_batch_stride;
-  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Cb), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldc * 4)), 0x00020000);
-  const int c4 = (tid & 63) * 4;
-  const int dead = c4 < a.N ? 0 : (int)0x80000000;
-  float bs[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) bs[e] = (biasg && !dead) ? biasg[c4 + e] : 0.f;
-  const bool relu = a.act == SS_ACT_RELU;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    char* St = smem_t256d + (q & 1) * 64 * 1024;
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(St + st_wr + ((r & 3) + 8 * (r >> 2)) * (BN * 4) + n * 128) = acc[q][n][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = (tid >> 6) + 8 * j;
-      const int grow = t0 + 128 * (k >> 5) + 32 * q + (k & 31);
-      float4 v = *reinterpret_cast<const float4*>(St + k * (BN * 4) + c4 * 4);
-      v = make_float4(fmaf(v.x, a.out_scale, bs[0]), fmaf(v.y, a.out_scale, bs[1]), fmaf(v.z, a.out_scale, bs[2]), fmaf(v.w, a.out_scale, bs[3]));
-      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      if (grow >= row_lim) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_c, (grow * a.ldc + c4) * 4 | dead, 0, 0);
-    }
-  }
-}
+// (round 4 measured a variant of the long-K STORE GEMM with its A operand prefetched two chunks ahead - three A buffers, 160 KB of LDS: 1070.9 ->
+// 1053.1 us back to back, profiles/r04_kbench_skip_deep.log; not latency-bound. Removed in round 5 together with its "skip_deep" knob.)
 
 }  // namespace
 
@@ -521,17 +348,6 @@ extern "C" int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream)
   if (a.epi == SS_HEPI_STORE) {
     SS_CHECK_ARG(a.C && (a.N % 4) == 0 && (a.ldc % 4) == 0 && (int64_t)a.T * a.ldc * 4 < (1ll << 31) && (a.act == SS_ACT_NONE_ || a.act == SS_ACT_RELU_),
                  "ss_gemm_bf16_tile256: STORE needs C, N %% 4 == 0, ldc %% 4 == 0, act none | relu");
-    if (a.split == 2 && g_ss_tuning.skip_deep != 0 && a.K >= 512) {   // long K (the skip GEMM): A prefetched two chunks ahead, 160 KB of LDS
-      const size_t lds_deep = (size_t)160 * 1024;
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile256s_deep_store_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_deep);
-      if (e != hipSuccess) {
-        ss_set_error("ss_gemm_bf16_tile256: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds_deep, hipGetErrorString(e));
-        return SS_ERR_HIP;
-      }
-      hipLaunchKernelGGL(tile256s_deep_store_kernel, dim3(m_tiles), dim3(512), lds_deep, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, a.K / 32);
-      SS_CHECK_LAUNCH("ss_gemm_bf16_tile256");
-      return SS_OK;
-    }
     SS_PROPAGATE(a.split == 2 ? go(&tile256s_kernel<SS_HEPI_STORE, true>) : go(&tile256s_kernel<SS_HEPI_STORE, false>));
   } else {
     SS_CHECK_ARG(a.epi == SS_HEPI_RESX && a.X == nullptr && a.Y && a.cur_bias && (a.N % 32) == 0 && a.ldy >= 2 * a.N && (a.ldy % 8) == 0 &&

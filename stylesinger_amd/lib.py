@@ -170,7 +170,7 @@ def load():
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
     for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE16_KS", b"gate16_ks"), ("SS_GATE256", b"gate256"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile"), ("SS_E16", b"e16"), ("SS_MEL_TAIL", b"mel_tail"), ("SS_HTILE", b"htile"),
-                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_TILE128", b"tile128"), ("SS_SKIP_DEEP", b"skip_deep"), ("SS_Q4_FORCE", b"q4_force")):
+                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_Q4_FORCE", b"q4_force")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")
@@ -636,9 +636,6 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
         return
     if gate256 == 128 and epi == HEPI_GATE:   # the fp16x2 gate on 256 x 128 tiles, two workgroups per CU
         check(load().ss_gemm_bf16_gate128(C.byref(a), stream_ptr()), "ss_gemm_bf16_gate128")
-        return
-    if gate256 == 128 and epi == HEPI_RESX and X is None:   # the fp16x2 residual projection on 128-row tiles, two workgroups per CU
-        check(load().ss_gemm_bf16_tile128(C.byref(a), stream_ptr()), "ss_gemm_bf16_tile128")
         return
     if gate256:   # the 256-row LDS-DMA kernels directly (ss_gemm_bf16 picks them by itself for many-round launches)
         if epi == HEPI_GATE:

@@ -214,95 +214,10 @@ int main() {
         }
     for (int k = 0; k < 5120; ++k) CHECK(seen1[k] == 1, "t128q: K index %d covered %d times", k, seen1[k]);
   }
-  // ================================================================== tile128_resx_kernel (namespace t128)
-  {
-    using namespace t128;
-    std::vector<Tag> img(t128::BM * t128::A_ROWB / 16);
-    for (int w = 0; w < t128::WAVES; ++w)
-      for (int j = 0; j < 2; ++j)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int p = w + 4 * j;
-          CHECK(t128::a_dma_row(p, lane) == t128::a_dma_row(w, lane) + 64 * j && t128::a_dma_slot(p, lane) == t128::a_dma_slot(w, lane), "t128 A piece identity");
-          const int row = t128::a_dma_row(p, lane), slot = t128::a_dma_slot(p, lane), byte = p * 1024 + lane * 16;
-          CHECK(row < t128::BM && byte == row * t128::A_ROWB + ((slot ^ t128::a_swz(row)) << 4), "t128 A dma lands off its swizzled slot");
-          Tag& t = img[byte >> 4];
-          CHECK(t.row < 0, "t128 A image unit written twice");
-          t.row = row;
-          t.slot = slot;
-        }
-    for (const Tag& t : img) CHECK(t.row >= 0, "t128 A image unit never written");
-    CHECK(t128::A_PIECES == 8 && t128::B_PIECES == 32, "t128 piece counts");
-    for (int m = 0; m < 4; ++m)
-      for (int ks = 0; ks < 2; ++ks) {
-        int byte[64];
-        for (int lane = 0; lane < 64; ++lane) {
-          const int l31 = lane & 31, lh = lane >> 5;
-          const int row0 = t128::a_frag_row(0, l31);
-          const int a_base = row0 * t128::A_ROWB, a_sw = t128::a_swz(row0) ^ lh;
-          byte[lane] = a_base + (((2 * ks) ^ a_sw) << 4) + m * 32 * t128::A_ROWB;   // the kernel's rd_a
-          const Tag& t = img[byte[lane] >> 4];
-          CHECK(t.row == 32 * m + l31 && t.slot == 2 * ks + lh, "t128 A fragment m=%d ks=%d lane=%d reads (row %d, slot %d)", m, ks, lane, t.row, t.slot);
-        }
-        check_b128_conflicts(byte, "t128 A fragment");
-      }
-    std::vector<Tag> imgb(t128::BN * t128::B_ROWB / 16);
-    for (int w = 0; w < t128::WAVES; ++w)
-      for (int j = 0; j < 8; ++j)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int p = w + 4 * j;
-          CHECK(t128::b_dma_row(p, lane) == t128::b_dma_row(w, lane) + 32 * j && t128::b_dma_slot(p, lane) == t128::b_dma_slot(w, lane), "t128 B piece identity");
-          const int row = t128::b_dma_row(p, lane), slot = t128::b_dma_slot(p, lane), byte = p * 1024 + lane * 16;
-          CHECK(row < t128::BN && byte == row * t128::B_ROWB + ((slot ^ t128::b_swz(row)) << 4), "t128 B dma lands off its swizzled slot");
-          Tag& t = imgb[byte >> 4];
-          CHECK(t.row < 0, "t128 B image unit written twice");
-          t.row = row;
-          t.slot = slot;
-        }
-    for (const Tag& t : imgb) CHECK(t.row >= 0, "t128 B image unit never written");
-    for (int wn = 0; wn < 4; ++wn)
-      for (int n = 0; n < 2; ++n)
-        for (int slot4 : {0, 2, 4, 6}) {
-          int byte[64];
-          for (int lane = 0; lane < 64; ++lane) {
-            const int l31 = lane & 31, lh = lane >> 5;
-            const int row0 = t128::b_frag_row(wn, 0, l31);
-            const int b_base = row0 * t128::B_ROWB, b_sw = t128::b_swz(row0) ^ lh;
-            byte[lane] = b_base + ((slot4 ^ b_sw) << 4) + n * 32 * t128::B_ROWB;   // the kernel's rd_b
-            const Tag& t = imgb[byte[lane] >> 4];
-            CHECK(t.row == 64 * wn + 32 * n + l31 && t.slot == slot4 + lh, "t128 B fragment wn=%d n=%d slot=%d lane=%d reads (row %d, slot %d)", wn, n, slot4, lane, t.row, t.slot);
-          }
-          check_b128_conflicts(byte, "t128 B fragment");
-        }
-    // staging [32][256] fp32: written per accumulator element, read per item (row, 8 channels)
-    struct S { int row = -1, col = -1; };
-    std::vector<S> st(32 * 256);
-    for (int wn = 0; wn < 4; ++wn)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int n = 0; n < 2; ++n)
-          for (int r = 0; r < 16; ++r) {
-            const int l31 = lane & 31, lh = lane >> 5;
-            const int byte = t128::st_write(wn, 0, l31, lh, 0) + acc_rr(r) * t128::ST_ROWB + n * 128;   // the kernel: st_wr + rr * ST_ROWB + n * 128
-            CHECK(byte == t128::st_write(wn, n, l31, lh, r), "t128 staging write expression");
-            S& e = st[byte >> 2];
-            CHECK(e.row < 0, "t128 staging element written twice");
-            e.row = 4 * lh + acc_rr(r);        // row inside the accumulator block (C/D layout of the 32x32 MFMA)
-            e.col = 64 * wn + 32 * n + l31;
-          }
-    for (const S& e : st) CHECK(e.row >= 0, "t128 staging element never written");
-    for (int tid = 0; tid < 256; ++tid)
-      for (int j = 0; j < 4; ++j) {
-        const int p = tid + 256 * j, k = t128::item_row(p), col0 = t128::item_col0(tid);
-        CHECK(t128::item_col0(p) == col0 && k == (tid >> 5) + 8 * j && k < 32, "t128 item mapping");
-        for (int e = 0; e < 8; ++e) {
-          const S& v = st[(k * t128::ST_ROWB + col0 * 4 + e * 4) >> 2];
-          CHECK(v.row == k && v.col == col0 + e, "t128 item (row %d, col %d) reads (row %d, col %d)", k, col0 + e, v.row, v.col);
-        }
-      }
-  }
   if (fails) {
     std::printf("layout_check_gate128: %d check(s) FAILED\n", fails);
     return 1;
   }
-  std::printf("layout_check_gate128: all checks passed (A 20 pieces / 96 fragment reads x 4 dilations, B 16 / 8, addend 32 x 4 quarters, 4096 x 4 staged outputs; tile128: A 8 / B 32 pieces, 8 + 32 fragment reads, 8192 staged accumulators)\n");
+  std::printf("layout_check_gate128: all checks passed (A 20 pieces / 96 fragment reads x 4 dilations, B 16 / 8, addend 32 x 4 quarters, 4096 x 4 staged outputs)\n");
   return 0;
 }

@@ -11,7 +11,7 @@
 #   pmc-gate128 [--q4]  the same for the fp16x2 gate on 256x128 tiles, two workgroups per CU (tools/pmc_gate128.sh)
 #   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs direct vs grouped F(4,3))
 #   kbench-c4        the 16-bit many-round launches at the BASELINE config 4 shape: fp16x2 gate on gate256 / gate128, residual projection on
-#                    tile256 / tile128, skip GEMM with and without the deep A prefetch (tools/kbench_h.py)
+#                    tile256 (tools/kbench_h.py)
 #   c4-streams       BASELINE config 4 with two batches in flight (the first experiment of the next round)
 #   ablate-gate16    timing ablations of the 16x16-tile gate kernel (debug builds: tools/ablate_g16.sh build, in the container)
 #   ablate-res16     the same for the residual-projection kernel (tools/ablate_r16.sh build, in the container)
