@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void f0t_autocorr_kernel(const float* __restri
   double* f = f0t_smem;          // [nw]
   double* red = f0t_smem + nw;   // [256]
   const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
-  if (i >= n_frames[b]) return;
+  if (i >= n_frames[b] || i >= max_frames) return;
   const float* x = wav + (int64_t)b * stride;
   const int64_t row = (int64_t)b * max_frames + i;
   double* r = R + row * (nlag + 1);
@@ -267,9 +267,8 @@ __global__ __launch_bounds__(64) void f0t_viterbi_kernel(const double* __restric
                                                          double octave_jump_cost, double voiced_unvoiced_cost, uint8_t* __restrict__ psi,
                                                          float* __restrict__ f0_out, int ld_out, int lpad) {
   __shared__ double dprev[F0T_MAXC], fprev[F0T_MAXC], dcur[F0T_MAXC];
-  __shared__ int place_s;
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int n = n_frames[b];
+  const int n = n_frames[b] < max_frames ? n_frames[b] : max_frames;
   float* out = f0_out + (int64_t)b * ld_out;
   for (int t = lane; t < ld_out; t += 64) out[t] = 0.f;
   if (n <= 0) return;
@@ -277,7 +276,8 @@ __global__ __launch_bounds__(64) void f0t_viterbi_kernel(const double* __restric
   int nprev = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t row = (int64_t)b * max_frames + i;
-    const int nc = n_cand[row];
+    int nc = n_cand[row];
+    nc = nc < 1 ? 1 : (nc > F0T_MAXC ? F0T_MAXC : nc);
     double f2 = 0.0, d2 = 0.0;
     bool v2 = false;
     if (lane < nc) {

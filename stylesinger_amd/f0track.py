@@ -109,10 +109,13 @@ def track_f0_device(wavs, n_samples, n_out, sr=48000, hop_size=256, pitch_floor=
     lib = L.load()
     wsb = lib.ss_f0track_workspace_bytes(B, max_frames, g["nlag"])
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-    i32 = lambda v: torch.tensor(v, dtype=torch.int32).to(dev)
+    # ONE int32 table [3][B] that stays referenced until the launches are queued (three temporaries would be freed - and their memory handed to
+    # the next one - before the kernels read them)
+    meta = torch.tensor([ns, [nf for nf, _ in grid], [lf for _, lf in grid]], dtype=torch.int32).to(dev)
     out = torch.empty(B, int(n_out), device=dev, dtype=torch.float32)
     import ctypes
-    L.check(lib.ss_f0track(L.ptr(wavs), wavs.shape[1], L.ptr(i32(ns)), L.ptr(i32([nf for nf, _ in grid])), L.ptr(i32([lf for _, lf in grid])), B,
+    L.check(lib.ss_f0track(L.ptr(wavs), wavs.shape[1], L.ptr(meta[0]), L.ptr(meta[1]), L.ptr(meta[2]), B,
                            max_frames, ctypes.byref(prm), L.ptr(win), L.ptr(win_r), L.ptr(out), int(n_out), 2 * pad_size, L.ptr(ws), wsb,
                            L.stream_ptr()), "ss_f0track")
+    meta.record_stream(torch.cuda.current_stream(dev))
     return out
