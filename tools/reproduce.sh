@@ -12,7 +12,10 @@
 #   kbench           back-to-back timings of the hot launches (gate tilings, residual projection, vocoder convs direct vs grouped F(4,3))
 #   kbench-c4        the 16-bit many-round launches at the BASELINE config 4 shape: fp16x2 gate on gate256 / gate128, residual projection on
 #                    tile256 (tools/kbench_h.py)
-#   c4-streams       BASELINE config 4 with two batches in flight (the first experiment of the next round)
+#   c4-streams       BASELINE config 4 with two batches in flight (measured in round 5: slower)
+#   fused            round 5: gate + residual projection of one layer as one dataflow launch vs two launches (DESIGN.md 7 lead 1)
+#   c4q / c3-emulated  the fp16q4 line of config 4 / configs[2]'s 8 shards emulated on one device
+#   pmc-gate128      PMC passes on gate128_kernel at the config-4 shape (profiles/r05_pmc_gate128.json)
 #   ablate-gate16    timing ablations of the 16x16-tile gate kernel (debug builds: tools/ablate_g16.sh build, in the container)
 #   ablate-res16     the same for the residual-projection kernel (tools/ablate_r16.sh build, in the container)
 #   ubench           micro-benchmarks behind DESIGN.md §3.0 (VALU beside fp32 MFMA, 16x16x4 issue rate, DPP / LDS-DMA probes)
@@ -49,10 +52,18 @@ case "$sec" in
   kbench-c4)
     SS_GATE128=0 python tools/kbench_h.py --which gate --f16
     python tools/kbench_h.py --which gate --f16 --gate128
+    python tools/kbench_h.py --which gate --f16 --q4
     python tools/kbench_h.py --which res --f16 --pair-only
-    SS_TILE128=1 python tools/kbench_h.py --which res --f16 --pair-only
-    python tools/kbench_h.py --which skip --f16
-    SS_SKIP_DEEP=1 python tools/kbench_h.py --which skip --f16 ;;
+    python tools/kbench_h.py --which skip --f16 ;;
+  fused)
+    # round 5: one residual layer as ONE dataflow launch (gate + projection, per-row-tile counters) vs the two launches, bit-identity checked
+    python tools/kbench_fused.py
+    python tools/kbench_fused.py --B 32 --T 1500
+    python tools/kbench_fused.py --B 1 --T 750 ;;
+  c4q)
+    python bench.py --config c4q --streams 1 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary | tail -1 | cut -c1-600 ;;
+  c3-emulated)
+    python bench.py --config c2 --emulate-ranks 8 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-secondary --no-roofline | tail -1 | cut -c1-900 ;;
   c4-streams)
     python bench.py --config c4 --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline | tail -1 | cut -c1-400
     python bench.py --config c4 --streams 2 --steps 2 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline | tail -1 | cut -c1-400 ;;
