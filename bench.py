@@ -144,12 +144,17 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     hbm = bf16 and getattr(infer.model, "bf16_hbm", False)
     split = bool(getattr(infer.model, "split", False))
     f16 = bool(getattr(infer.model, "f16", False))   # "fp16x2": fp16 terms, weights-only split, 2 products
+    q4 = bool(getattr(infer.model, "q4", False)) and all(f"w_dil_q.{l}" in packs for l in range(Lyr))   # "fp16q4": 2nd product on the fp4 instruction
     if hbm:  # bf16 operands in HBM (ss_gemm_bf16): the operand X + dstep is already rounded by the producing epilogue
         Xh = L.split_f16(X) if f16 else L.split_bf16(X) if split else L.to_bf16(X)
         Gh = torch.empty(B, T, C * (2 if split else 1), device=dev, dtype=torch.float16 if f16 else torch.bfloat16)
 
     def launch(l):
         d = 1 << (l % 4)
+        if hbm and q4:   # what run_residual_stack launches in fp16q4 mode when the launch fills the chip (ss_gemm_bf16_gate128q)
+            L.gemm_bf16(Xh, packs[f"w_dil_q.{l}"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
+                        E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, out=Gh, split=3, out_scale=2.0 ** -infer.model.FP16_WSHIFT, q_scale=2.0, gate256=128)
+            return
         if hbm:
             L.gemm_bf16(Xh, packs[f"w_dil_h.{l}"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
                         E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, out=Gh, split=2 if f16 else int(split),
@@ -248,12 +253,15 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     if probing:
         L.check(L.load().ss_set_clock_probe(None), "ss_set_clock_probe")
     flops = 2.0 * B * T * (3 * C) * (2 * C)
-    executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 2.0 if f16 else 3.0 if split else 1.0)   # x3: six bf16 products each; bf16x2: three; fp16x2: two
+    # x3: six bf16 products each; bf16x2: three; fp16x2: two; fp16q4: one fp16 product + one fp4 product of the same shape (counted as two products:
+    # the fp4 instruction does 4x the work per issue, so its pipe time is a quarter - `frac` is flops over the FP16 peak and overstates pipe time)
+    executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 2.0 if f16 else 3.0 if split else 1.0)
     peak = PEAK_BF16_MFMA if (bf16 or x3) else PEAK_FP32_MFMA
     # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
     g256 = hbm and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
     g128 = hbm and f16 and L.load().ss_get_tuning(b"gate128") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 128) >= 2048   # ss_gemm_bf16_gate128_ok's shape rule
-    hbm_name = ("gate128_kernel (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if g128 else
+    hbm_name = ("gate128q_kernel (fp16 operands in HBM, weights = fp16 hi terms + block-scaled fp4 lo terms: 16 fp16 MFMAs + 4 fp4 ones per step, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if (g128 and q4) else
+                "gate128_kernel (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if g128 else
                 "gate256_kernel<8, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x256 tiles by LDS-DMA, direct" if g256 and f16 else
                 "gemm_bf16_kernel<GATE, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, direct" if f16 else
                 "gate256_kernel<split> ((hi, mid) bf16 operand pairs in HBM, 3 products, 256x256 tiles by LDS-DMA, direct" if g256 and split else
@@ -268,8 +276,8 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
     traffic = None
     pmc_src = None
-    form = (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
-    for fn in ("r05_pmc_gate128.json", "r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
+    form = (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16q4" if q4 else "fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
+    for fn in ("r05_pmc_gate128.json", "r05_pmc_gate.json", "r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj):
             continue
@@ -284,7 +292,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # above runs the kernel back to back, where the chip clocks down; in the loop it alternates with the projections): average duration of
     # the C2 launches and the executed-MFMA fraction that follows from it. null when no such profile exists for this kernel / shape.
     in_loop = None
-    csv_path = os.path.join(ROOT, "profiles", "r04_bench_c2_1stream_kernel_stats.csv")
+    csv_path = os.path.join(ROOT, "profiles", "r05_bench_c2_1stream_kernel_stats.csv")
     if wino_m == 4 and mt and not x3 and B * T == 12000 and os.path.exists(csv_path):
         try:
             import csv
@@ -292,7 +300,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                 if f"wino43_gate16_kernel<{mt}" in row["Name"]:
                     us = float(row["AverageNs"]) * 1e-3
                     in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak,
-                               "source": "profiles/r04_bench_c2_1stream_kernel_stats.csv"}
+                               "source": "profiles/r05_bench_c2_1stream_kernel_stats.csv"}
                     break
         except (KeyError, ValueError, OSError):
             in_loop = None
