@@ -697,6 +697,15 @@ int ss_f0track(const float* wav, int64_t wav_stride, const int32_t* n_samples, c
                const ss_f0track_params* prm, const double* window, const double* window_r, float* f0_out, int ld_out, int lpad, void* workspace,
                int64_t workspace_bytes, void* stream);
 
+/* trim_long_silences (data_gen/tts/emotion/audio.py:58-100; called by preprocess_wav :38) AROUND the caller's voice-activity flags: the decision
+ * itself is webrtcvad's (an un-vendored C library, no published text to restate); the reference's windowing, smoothing, dilation and compaction
+ * run here. wav [B][wav_stride] fp32, n_samples[b] valid samples; flags [B][flags_stride] uint8, one per window of samples_per_window samples
+ * (floor(n_samples / samples_per_window) of them are read). A window is kept iff, after a moving average of avg_width windows rounded half to even
+ * (more than half of the neighbourhood voiced), any window within max_silence / 2 of it (binary_dilation with ones(max_silence + 1)) is voiced.
+ * out [B][out_stride] <- the kept windows back to back, zeros behind; out_lens[b] = kept samples; win_dst [B][max_windows] int32 scratch. */
+int ss_vad_trim(const float* wav, int64_t wav_stride, const int32_t* n_samples, const uint8_t* flags, int flags_stride, int B, int max_windows,
+                int samples_per_window, int avg_width, int max_silence, float* out, int64_t out_stride, int32_t* out_lens, int32_t* win_dst, void* stream);
+
 /* Emotion encoder (input producer; data_gen/tts/emotion/model.py:11-78 = nn.LSTM(40, 256, 3) + Linear, inference.py:39-53,
  * 139-151). One LSTM layer's recurrence as a persistent launch (one workgroup per sequence):
  *   xproj  [P][n][H][4] = x_t . W_ih^T + b_ih + b_hh for every step, gate-interleaved (i,f,g,o per hidden unit) - one

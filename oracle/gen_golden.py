@@ -229,6 +229,50 @@ def round3_cases():
     run_pitch_case("norm_interp_f0")
 
 
+def run_vad_trim_case(name="vad_trim", seed=1234):
+    """The reference's own `trim_long_silences` (data_gen/tts/emotion/audio.py:58-100) with the third-party decision INJECTED: `webrtcvad` is stubbed
+    by a Vad whose `is_speech` replays preset flags (and checks the PCM window it is handed), so everything around the decision - window cut,
+    moving average + np.round, binary_dilation, compaction - is the real code. Cases: random flags at several densities, all voiced, all unvoiced,
+    isolated voiced windows, lengths that are not a multiple of the 480-sample window."""
+    import numpy as np
+    refimport.load()
+    import webrtcvad
+
+    class Vad:
+        flags, seen = [], []
+
+        def __init__(self, mode=3):
+            assert mode == 3
+            self.i = 0
+
+        def is_speech(self, buf, sample_rate):
+            assert sample_rate == 16000 and len(buf) == 960
+            v = Vad.flags[self.i]
+            self.i += 1
+            return bool(v)
+    webrtcvad.Vad = Vad
+    from data_gen.tts.emotion import audio as A
+    rng = np.random.default_rng(seed)
+    cases = {}
+
+    def add(key, n, flags_fn):
+        wav = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        nw = n // 480
+        Vad.flags = [int(v) for v in flags_fn(nw)]
+        out = A.trim_long_silences(wav)
+        cases[key] = dict(wav=torch.from_numpy(wav), flags=torch.tensor(Vad.flags, dtype=torch.uint8), out=torch.from_numpy(np.ascontiguousarray(out)))
+    add("dense", 16000 * 2 + 123, lambda nw: rng.random(nw) > 0.3)
+    add("half", 16000 * 3, lambda nw: rng.random(nw) > 0.5)
+    add("sparse", 16000 * 3 + 479, lambda nw: rng.random(nw) > 0.85)
+    add("runs", 16000 * 4, lambda nw: (np.arange(nw) // 9) % 3 == 0)
+    add("all_voiced", 480 * 20 + 7, lambda nw: np.ones(nw))
+    add("all_unvoiced", 480 * 20, lambda nw: np.zeros(nw))
+    add("one_voiced_run", 480 * 40, lambda nw: (np.arange(nw) >= 15) & (np.arange(nw) < 21))
+    add("short", 480 * 3 + 100, lambda nw: np.ones(nw))
+    torch.save(dict(meta=dict(seed=seed, window=480, avg_width=8, max_silence=6), cases=cases), os.path.join(GOLD, name + ".pt"))
+    print(f"[gen_golden] {name}: " + ", ".join(f"{k} {len(v['wav'])}->{len(v['out'])}" for k, v in cases.items()))
+
+
 def round5_cases():
     # BASELINE configs[3] AS SPECIFIED, one item: T = 5625 (30 s) AND 1000 mel steps (+ 2 x 100 f0 steps), the REAL reference in fp32.
     # ~1.5e14 flop on the CPU (tens of minutes); only the outputs the C4 parity test compares are kept.
@@ -238,8 +282,12 @@ def round5_cases():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--vad" in sys.argv:
+        run_vad_trim_case()
+        return
     if "--round5" in sys.argv:
         round5_cases()
+        run_vad_trim_case()
         return
     if "--only-plms" in sys.argv:
         run_plms_case("plms_t40_k20_i3", T=40, steps_mel=20, interval=3)

@@ -171,3 +171,82 @@ extern "C" int ss_reflect_pad(const float* x, const int32_t* lens, float* y, int
   SS_CHECK_LAUNCH("ss_reflect_pad");
   return SS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// trim_long_silences (data_gen/tts/emotion/audio.py:58-100) around the caller's VAD decisions. The reference asks webrtcvad (an un-vendored C
+// library: a fixed-point GMM, no published text to restate) for one flag per 30 ms window; everything AROUND that decision is restated here and
+// pinned against the real function run with injected flags (tests/golden/vad_trim.pt): the waveform cut to whole windows, the flags smoothed by
+// a moving average of `avg_width` (zero padded (w - 1) / 2 left, w / 2 right; np.round = half to even, so a window stays voiced iff MORE than
+// half of its neighbourhood is), dilated by `max_silence` windows to both sides (binary_dilation with ones(max_silence + 1), origin centred),
+// the kept windows compacted. Integer logic + copies: bit-exact.
+namespace {
+
+__global__ __launch_bounds__(256) void vad_mask_kernel(const uint8_t* __restrict__ flags, int flags_stride, const int32_t* __restrict__ n_samples,
+                                                       int spw, int avg_width, int dil, int max_windows, int32_t* __restrict__ win_dst,
+                                                       int32_t* __restrict__ out_lens) {
+  extern __shared__ int32_t vad_smem[];   // [max_windows] smoothed mask, then [max_windows] kept mask
+  int32_t* m1 = vad_smem;
+  int32_t* m2 = vad_smem + max_windows;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint8_t* f = flags + (int64_t)b * flags_stride;
+  const int nw = n_samples[b] / spw < max_windows ? n_samples[b] / spw : max_windows;
+  const int lpad = (avg_width - 1) / 2, rpad = avg_width / 2;
+  for (int i = tid; i < nw; i += 256) {
+    int cnt = 0;
+    for (int j = i - lpad; j <= i + rpad; ++j) cnt += (j >= 0 && j < nw && f[j]) ? 1 : 0;
+    m1[i] = 2 * cnt > avg_width ? 1 : 0;   // np.round(cnt / width): exactly one half rounds to the even 0
+  }
+  __syncthreads();
+  const int o = (dil + 1) / 2;   // structure ones(dil + 1), origin at its centre (scipy.ndimage.binary_dilation's default)
+  for (int i = tid; i < nw; i += 256) {
+    int any = 0;
+    // binary_dilation: out[i] = OR_k structure[k] & in[i - k + origin], k = 0 .. dil
+    for (int k = 0; k <= dil; ++k) {
+      const int j = i - k + o;
+      any |= (j >= 0 && j < nw) ? m1[j] : 0;
+    }
+    m2[i] = any;
+  }
+  __syncthreads();
+  if (tid == 0) {   // windows per item are a few hundred: a serial prefix is cheaper than its own launch
+    int kept = 0;
+    for (int i = 0; i < nw; ++i) {
+      win_dst[(int64_t)b * max_windows + i] = m2[i] ? kept : -1;
+      kept += m2[i];
+    }
+    for (int i = nw; i < max_windows; ++i) win_dst[(int64_t)b * max_windows + i] = -1;
+    out_lens[b] = kept * spw;
+  }
+}
+
+__global__ __launch_bounds__(256) void vad_copy_kernel(const float* __restrict__ wav, int64_t wav_stride, const int32_t* __restrict__ win_dst, int max_windows,
+                                                       int spw, float* __restrict__ out, int64_t out_stride, const int32_t* __restrict__ out_lens) {
+  const int b = blockIdx.y, w = blockIdx.x;
+  if (w < max_windows) {
+    const int dst = win_dst[(int64_t)b * max_windows + w];
+    if (dst >= 0)
+      for (int i = threadIdx.x; i < spw; i += 256) out[(int64_t)b * out_stride + (int64_t)dst * spw + i] = wav[(int64_t)b * wav_stride + (int64_t)w * spw + i];
+  }
+  // zero the tail [out_lens[b], out_stride): block w owns the slice w, w + gridDim.x, ... of it
+  const int64_t n = out_lens[b];
+  for (int64_t i = n + (int64_t)w * 256 + threadIdx.x; i < out_stride; i += (int64_t)gridDim.x * 256) out[(int64_t)b * out_stride + i] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int ss_vad_trim(const float* wav, int64_t wav_stride, const int32_t* n_samples, const uint8_t* flags, int flags_stride, int B, int max_windows,
+                           int samples_per_window, int avg_width, int max_silence, float* out, int64_t out_stride, int32_t* out_lens, int32_t* win_dst,
+                           void* stream_) {
+  SS_CHECK_ARG(wav && n_samples && flags && out && out_lens && win_dst, "ss_vad_trim: null argument");
+  SS_CHECK_ARG(B > 0 && max_windows > 0 && samples_per_window > 0 && avg_width > 0 && max_silence >= 0 && flags_stride >= max_windows &&
+                   out_stride >= (int64_t)max_windows * samples_per_window && wav_stride >= (int64_t)max_windows * samples_per_window,
+               "ss_vad_trim: bad dims (B=%d windows=%d spw=%d)", B, max_windows, samples_per_window);
+  SS_CHECK_ARG((size_t)max_windows * 8 <= 64 * 1024, "ss_vad_trim: more than 8192 windows per item (%d)", max_windows);
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(vad_mask_kernel, dim3(B), dim3(256), (size_t)max_windows * 8, stream, flags, flags_stride, n_samples, samples_per_window, avg_width,
+                     max_silence, max_windows, win_dst, out_lens);
+  SS_CHECK_LAUNCH("vad_mask_kernel");
+  hipLaunchKernelGGL(vad_copy_kernel, dim3(max_windows, B), dim3(256), 0, stream, wav, wav_stride, win_dst, max_windows, samples_per_window, out, out_stride, out_lens);
+  SS_CHECK_LAUNCH("vad_copy_kernel");
+  return SS_OK;
+}

@@ -235,7 +235,7 @@ class StyleSingerInfer:
 
     @torch.no_grad()
     def preprocess_batch(self, ref_wavs, ref_lens, spk_embed, f0_hz, txt_tokens, note, note_dur, note_type, mel2ph=None,
-                         emo_embed=None, emo_wavs=None, emo_lens=None):
+                         emo_embed=None, emo_wavs=None, emo_lens=None, emo_vad_flags=None):
         """Batched device form of `preprocess_input` + `input_to_batch` (inference/StyleSinger.py:94-172): from reference audio to
         the dict `infer_batch` takes, with no host round trip of the data.
           ref_wavs [B, L] fp32 48 kHz reference audio (zero beyond ref_lens[b]; ref_lens host ints)   -> ref_mels  (process_audio, :106-118)
@@ -243,8 +243,10 @@ class StyleSingerInfer:
                    None -> tracked on the device from `process_audio`'s waveform as :112-135 does with parselmouth (`f0track.py`: Praat's
                    published autocorrelation method, 80-800 Hz, voicing threshold 0.6; parity UNPINNED - parselmouth is un-vendored)
           emo_wavs [B, Le] `preprocess_wav` output for the emotion encoder (zero beyond emo_lens[b])  -> emo_embed (Embed_utterance, :104)
-                   default: the reference audio itself, volume-normalised on the device; `trim_long_silences` needs the un-vendored
-                   webrtcvad and is the caller's step. Pass `emo_embed` [B, 256] instead to skip this branch.
+                   default: the reference audio itself, volume-normalised on the device. `trim_long_silences` (audio.py:58-100) runs on the
+                   device AROUND the caller's decisions: pass `emo_vad_flags` [B, nW] = webrtcvad's `is_speech` per 30 ms window of the
+                   volume-normalised 16-bit PCM (the decision itself is an un-vendored fixed-point GMM: `vadtrim.py`); without flags the
+                   audio goes untrimmed. Pass `emo_embed` [B, 256] instead to skip this branch.
           spk_embed [B, 256], or None -> `VoiceEncoder().embed_utterance(wav)` (:100,104) on the device (`embed_speaker_batch`;
                    needs `speaker_state`) from what the reference hands it: `process_audio`'s waveform, i.e. the reference audio
                    zero-padded to n_mel * hop samples and rounded to float16 (:87; utils/audios/__init__.py:76-78)."""
@@ -275,6 +277,10 @@ class StyleSingerInfer:
                     self._emo_frontend = EmotionMelFrontendHIP(d)
                 emo_wavs = self._emo_frontend.normalize_volume(ref_wavs, torch.tensor(ref_lens_h))
                 emo_lens = ref_lens_h
+                if emo_vad_flags is not None:   # preprocess_wav's second step (audio.py:38), around the caller's VAD flags
+                    from .vadtrim import trim_long_silences_device
+                    emo_wavs, kept = trim_long_silences_device(emo_wavs, emo_lens, emo_vad_flags)
+                    emo_lens = [int(v) for v in kept.cpu()]   # the partial slicing below is host arithmetic on the lengths
             emo_embed = self.embed_emotion_batch(emo_wavs, emo_lens)
         if spk_embed is None:
             spk_embed = self.embed_speaker_batch(wav16, wav16_lens)

@@ -82,3 +82,19 @@ def test_frame_grid_for_lengths_that_are_not_a_multiple_of_the_hop(n):
         ws, ms, me = P.frame_start(g, i)
         assert ws == left + i * 256 + 1 - d["halfnsamp_window"] and ms == left + i * 256 + 1 - d["nsamp_period"]
         assert ws >= 0 and ws + d["nsamp_window"] <= n and ms >= 0 and me <= n
+
+
+def test_vad_trim_host_mirror_equals_the_real_function_with_injected_flags(golden_dir):
+    """`stylesinger_amd.vadtrim.window_mask` (the integer logic of the device kernel) against the REAL `trim_long_silences`
+    (data_gen/tts/emotion/audio.py:58-100) run with its webrtcvad decision injected (tests/golden/vad_trim.pt, oracle/gen_golden.py --vad):
+    the kept samples must be exactly the reference's."""
+    import os
+    import torch
+    from stylesinger_amd import vadtrim
+    g = torch.load(os.path.join(golden_dir, "vad_trim.pt"), weights_only=False)
+    for key, c in g["cases"].items():
+        wav, flags = c["wav"].numpy(), c["flags"].numpy()
+        nw = len(wav) // 480
+        mask = vadtrim.window_mask(flags[:nw])
+        out = wav[:nw * 480].reshape(nw, 480)[mask].reshape(-1)
+        assert out.shape == tuple(c["out"].shape) and (out == c["out"].numpy()).all(), key

@@ -273,3 +273,26 @@ def test_f0_tracker_matches_the_praat_restatement_and_feeds_preprocess_batch():
     assert torch.equal(auto["ref_f0"], hand["ref_f0"]) and torch.equal(auto["ref_mels"], hand["ref_mels"])
     res = inf.infer_batch(auto, seed=3, vocode=True)
     assert torch.isfinite(res["mel"]).all() and torch.isfinite(res["wav"]).all()
+
+
+def test_vad_trim_on_the_device_equals_the_real_function_with_injected_flags(golden_dir):
+    """`ss_vad_trim` (windowing, moving average + round, dilation, compaction around the caller's webrtcvad flags) against the REAL
+    `trim_long_silences` (data_gen/tts/emotion/audio.py:58-100) run with injected flags (tests/golden/vad_trim.pt): bit-exact, as a ragged batch."""
+    from stylesinger_amd.vadtrim import trim_long_silences_device
+    g = torch.load(os.path.join(golden_dir, "vad_trim.pt"), weights_only=False)
+    keys = list(g["cases"])
+    cs = [g["cases"][k] for k in keys]
+    Lmax = max(len(c["wav"]) for c in cs)
+    Wmax = max(len(c["flags"]) for c in cs)
+    wav = torch.zeros(len(cs), Lmax)
+    flags = torch.zeros(len(cs), Wmax, dtype=torch.uint8)
+    for i, c in enumerate(cs):
+        wav[i, :len(c["wav"])] = c["wav"]
+        flags[i, :len(c["flags"])] = c["flags"]
+    out, lens = trim_long_silences_device(wav.cuda(), [len(c["wav"]) for c in cs], flags)
+    out, lens = out.cpu(), lens.cpu()
+    for i, (k, c) in enumerate(zip(keys, cs)):
+        n = int(lens[i])
+        assert n == len(c["out"]), (k, n, len(c["out"]))
+        assert torch.equal(out[i, :n], c["out"]), k
+        assert (out[i, n:] == 0).all(), k
