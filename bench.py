@@ -305,7 +305,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         except (KeyError, ValueError, OSError):
             in_loop = None
     csv_c4 = os.path.join(ROOT, "profiles", "r05_bench_c4_fp16x2_20steps_kernel_stats.csv")
-    if g128 and B * T == 180000 and os.path.exists(csv_c4):   # the C4 dominant kernel inside the graph-replayed loop (rocprofv3 --kernel-trace --stats)
+    if g128 and not q4 and B * T == 180000 and os.path.exists(csv_c4):   # the C4 dominant kernel inside the graph-replayed loop (rocprofv3 --kernel-trace --stats)
         try:
             import csv
             for row in csv.DictReader(open(csv_c4)):
