@@ -697,6 +697,13 @@ int ss_f0track(const float* wav, int64_t wav_stride, const int32_t* n_samples, c
                const ss_f0track_params* prm, const double* window, const double* window_r, float* f0_out, int ld_out, int lpad, void* workspace,
                int64_t workspace_bytes, void* stream);
 
+/* audio.normalize_volume(wav, target_dbfs, increase_only=True) (data_gen/tts/emotion/audio.py:109-115, as preprocess_wav applies it) per item of a
+ * zero-padded batch wav [B][L]: out = wav * 10^(change / 20) with change = target_dbfs - 10 log10(mean over the item's lens[b] samples of wav^2)
+ * when change >= 0, else out = wav. In place allowed. */
+int ss_normalize_volume(const float* wav, const int32_t* lens, float* out, int B, int L, float target_dbfs, void* stream);
+/* y[b][t] = fp32(fp16_rne(x[b][t])) for t < min(n_out[b], Lx), 0 for the rest of the ldy columns: the waveform `process_audio` returns
+ * (inference/StyleSinger.py:86-88: padded to n_mel * hop samples, `.astype(np.float16)`), which the reference hands resemblyzer and parselmouth. */
+int ss_round_f16_rows(const float* x, int64_t ldx, int Lx, const int32_t* n_out, float* y, int64_t ldy, int B, void* stream);
 /* trim_long_silences (data_gen/tts/emotion/audio.py:58-100; called by preprocess_wav :38) AROUND the caller's voice-activity flags: the decision
  * itself is webrtcvad's (an un-vendored C library, no published text to restate); the reference's windowing, smoothing, dilation and compaction
  * run here. wav [B][wav_stride] fp32, n_samples[b] valid samples; flags [B][flags_stride] uint8, one per window of samples_per_window samples

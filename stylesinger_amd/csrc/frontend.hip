@@ -250,3 +250,68 @@ extern "C" int ss_vad_trim(const float* wav, int64_t wav_stride, const int32_t* 
   SS_CHECK_LAUNCH("vad_copy_kernel");
   return SS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Two element-wise producers of `preprocess_input` that used to be torch expressions on the host side of the binding:
+//   ss_normalize_volume : audio.normalize_volume(wav, -30 dBFS, increase_only=True) (data_gen/tts/emotion/audio.py:109-115) per item of a zero-padded
+//                         batch: gain = 10^((target - 10 log10(mean(wav^2))) / 20) when that change is >= 0, else 1 (mean over the item's own samples,
+//                         accumulated in float64);
+//   ss_round_f16_rows   : what `process_audio` hands the speaker encoder and the f0 tracker (inference/StyleSinger.py:86-88): the waveform zero-padded
+//                         to n_out[b] samples and rounded to float16 (`.astype(np.float16)`, RNE), returned as fp32 values.
+namespace {
+
+__global__ __launch_bounds__(256) void normalize_volume_kernel(const float* __restrict__ wav, const int32_t* __restrict__ lens, float* __restrict__ out, int L,
+                                                               float target_dbfs) {
+  __shared__ double red[256];
+  __shared__ float gain_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* x = wav + (int64_t)b * L;
+  int n = lens ? lens[b] : L;
+  n = n < 0 ? 0 : (n > L ? L : n);
+  double s = 0.0;
+  for (int i = tid; i < n; i += 256) s += (double)x[i] * (double)x[i];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double ms = red[0] / (n > 0 ? n : 1);
+    const double change = (double)target_dbfs - 10.0 * log10(ms);
+    gain_s = (ms > 0.0 && change >= 0.0) ? (float)pow(10.0, change / 20.0) : 1.0f;
+  }
+  __syncthreads();
+  const float g = gain_s;
+  for (int i = tid; i < L; i += 256) out[(int64_t)b * L + i] = x[i] * g;
+}
+
+__global__ void round_f16_rows_kernel(const float* __restrict__ x, int64_t ldx, int Lx, const int32_t* __restrict__ n_out, float* __restrict__ y, int64_t ldy,
+                                      int B) {
+  const int64_t total = (int64_t)B * ldy;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ldy);
+    const int64_t t = i % ldy;
+    float v = 0.f;
+    if (t < n_out[b] && t < Lx) v = (float)(_Float16)x[(int64_t)b * ldx + t];   // fp32 -> fp16 conversion rounds to nearest even (v_cvt_f16_f32)
+    y[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int ss_normalize_volume(const float* wav, const int32_t* lens, float* out, int B, int L, float target_dbfs, void* stream) {
+  SS_CHECK_ARG(wav && out && B > 0 && L > 0, "ss_normalize_volume: bad arguments");
+  hipLaunchKernelGGL(normalize_volume_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, wav, lens, out, L, target_dbfs);
+  SS_CHECK_LAUNCH("normalize_volume_kernel");
+  return SS_OK;
+}
+
+extern "C" int ss_round_f16_rows(const float* x, int64_t ldx, int Lx, const int32_t* n_out, float* y, int64_t ldy, int B, void* stream) {
+  SS_CHECK_ARG(x && n_out && y && B > 0 && Lx > 0 && ldx >= Lx && ldy > 0, "ss_round_f16_rows: bad arguments");
+  const int64_t total = (int64_t)B * ldy;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(round_f16_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, Lx, n_out, y, ldy, B);
+  SS_CHECK_LAUNCH("round_f16_rows_kernel");
+  return SS_OK;
+}

@@ -96,12 +96,15 @@ class MelFrontendHIP:
             wav = torch.nn.functional.pad(wav, (0, R * hop - Ls))
         wav = wav.contiguous()
         n = torch.full((B,), Ls, device=self.device, dtype=torch.int64) if lens is None else lens.to(self.device).to(torch.int64)
-        if lens is not None:  # samples past an item's length are not part of it
-            wav = wav * (torch.arange(R * hop, device=self.device)[None, :] < n[:, None])
+        lib = L.load()
+        if lens is not None:  # samples past an item's length are not part of it: zeroed (the row-mask kernel on the [B][R * hop][1] view)
+            n32 = n.to(torch.int32).contiguous()
+            masked = torch.empty_like(wav)
+            L.check(lib.ss_add_bcast_mask(L.ptr(wav), None, None, None, None, L.ptr(masked), B, R * hop, 1, L.ptr(n32), L.stream_ptr()), "wav mask")
+            wav = masked
         rows = ((n + hop - 1) // hop).to(torch.int32)
         frames = (n // hop + 1).to(torch.int32)
         T = Ls // hop + 1
-        lib = L.load()
         S = torch.empty(B, T, 2 * self.nb_pad, device=self.device, dtype=torch.float32)
         L.conv_gemm(wav, self.W_dft, S, B=B, T=T, Cin=hop, N=2 * self.nb_pad, Np=self.W_dft.shape[0], Kp=self.W_dft.shape[1] // taps,
                     lda=hop, a_bs=R * hop, taps=tuple(j - taps // 2 for j in range(taps)), lens=rows, mask_rows=False)
@@ -111,7 +114,8 @@ class MelFrontendHIP:
         L.conv_gemm(P, self.W_mel, mel, B=B, T=T, Cin=self.nb_pad, N=self.n_mels, Np=self.W_mel.shape[0], Kp=self.W_mel.shape[1],
                     mask_rows=False)
         L.check(lib.ss_log10_floor(L.ptr(mel), L.ptr(mel), mel.numel(), self.eps, L.stream_ptr()), "log10")
-        mel.masked_fill_((torch.arange(T, device=self.device)[None, :] >= frames[:, None])[:, :, None], 0.0)
+        frames = frames.contiguous()
+        L.check(lib.ss_add_bcast_mask(L.ptr(mel), None, None, None, None, L.ptr(mel), B, T, self.n_mels, L.ptr(frames), L.stream_ptr()), "mel mask")
         return mel, frames
 
 
@@ -151,11 +155,13 @@ class EmotionMelFrontendHIP:
     def normalize_volume(self, wav, lens, target_dbfs=-30.0):
         """audio.normalize_volume(increase_only=True) per item of a zero-padded batch [B, L]: scale by 10^(change/20) when
         change = target - 10 log10(mean(wav^2)) >= 0 (mean over the item's own samples), else leave untouched."""
-        n = lens.to(self.device).to(torch.float32).clamp_min(1.0)
-        ms = (wav.float() ** 2).sum(dim=1) / n
-        change = target_dbfs - 10.0 * torch.log10(ms)
-        gain = torch.where(change < 0, torch.ones_like(change), 10.0 ** (change / 20.0))
-        return wav * gain[:, None]
+        wav = wav.to(self.device).float().contiguous()
+        out = torch.empty_like(wav)
+        n = torch.as_tensor(lens).to(device=self.device, dtype=torch.int32).contiguous()
+        L.check(L.load().ss_normalize_volume(L.ptr(wav), L.ptr(n), L.ptr(out), wav.shape[0], wav.shape[1], float(target_dbfs), L.stream_ptr()),
+                "ss_normalize_volume")
+        n.record_stream(torch.cuda.current_stream(self.device))
+        return out
 
     @torch.no_grad()
     def wav2mel(self, wav, lens=None):

@@ -228,9 +228,12 @@ class StyleSingerInfer:
         float16-representable values, zero beyond each item's length; lengths as host ints)"""
         hop = int(self.hparams["hop_size"])
         lens = [int(f) * hop for f in frames]
-        out = torch.zeros(ref_wavs.shape[0], max(lens), device=self.device, dtype=torch.float32)
-        n = min(out.shape[1], ref_wavs.shape[1])
-        out[:, :n] = ref_wavs[:, :n].to(self.device).half().float()
+        x = ref_wavs.to(self.device).float().contiguous()
+        out = torch.empty(x.shape[0], max(lens), device=self.device, dtype=torch.float32)
+        n_out = torch.tensor(lens, dtype=torch.int32).to(self.device)
+        L.check(L.load().ss_round_f16_rows(L.ptr(x), x.shape[1], x.shape[1], L.ptr(n_out), L.ptr(out), out.shape[1], x.shape[0], L.stream_ptr()),
+                "ss_round_f16_rows")
+        n_out.record_stream(torch.cuda.current_stream(self.device))
         return out, lens
 
     @torch.no_grad()
