@@ -668,8 +668,10 @@ int ss_norm_interp_f0(const float* f0_hz, const int32_t* lens, float* out, float
  * Bit-identical to the two launches. counters: one ZEROED uint32 per gate row tile (ss_fused_gate_res_counters); error: int32, set to 1 if a
  * bounded wait gave up (results are then undefined). Not used by the loop drivers: DESIGN.md 7 has the measurement and why. */
 int ss_fused_gate_res_counters(int B, int T, int dilation);
+/* write_through: 0 = plain stores + release fence / acquire fence; 1 = the gate stores its outputs sc1 (write-through) and the projection reads them
+ * sc1, no fences (the cheaper valid publish form) */
 int ss_fused_gate_res(const ss_conv_gemm_args* gate, const float* W16g, int dilation, const ss_conv_gemm_args* res, const float* W16r, uint32_t* counters,
-                      int32_t* error, void* stream);
+                      int32_t* error, int write_through, void* stream);
 
 /* f0 tracker (input producer; replaces inference/StyleSinger.py:125-127:
  *   parselmouth.Sound(wav, sr).to_pitch_ac(time_step, voicing_threshold=0.6, pitch_floor=80, pitch_ceiling=800).selected_array['frequency']

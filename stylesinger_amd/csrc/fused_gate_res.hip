@@ -26,7 +26,10 @@ namespace fz_r {
 namespace {
 
 // MT = 2 gate tiles (32 quads = 128 frames, 48 KB of LDS, K-staged, weights in fetch order) + 96-row projection tiles (36 KB): BASELINE configs[1]
-template <int GMT, int RMT, int KCH>
+// WT = false: plain stores + agent-scope release fence / acquire fence (form 1). WT = true: the gate writes its outputs THROUGH (sc1 stores), waits for
+// them (every wave's s_waitcnt vmcnt(0) inside __syncthreads) and raises the counter; the projection polls and reads the gate outputs with sc1
+// loads - no fence on either side (the guide's cheaper valid form: "sc1 loads may replace the acquire only when the producer stored sc1").
+template <int GMT, int RMT, int KCH, bool WT>
 __global__ __launch_bounds__(256, 3) void fused_gate_res_kernel(const ss_conv_gemm_args g, const float* __restrict__ W16g, int q_tiles_per_item, int q_tiles,
                                                                 int n_tiles_g, int log2d, const ss_conv_gemm_args r, const float* __restrict__ W16r,
                                                                 int m_tiles_per_item, int m_tiles, int n_tiles_r, int n_gate_blocks,
@@ -34,13 +37,13 @@ __global__ __launch_bounds__(256, 3) void fused_gate_res_kernel(const ss_conv_ge
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = (int)blockIdx.x;
   if (bid < n_gate_blocks) {
-    const bool real = fz_g::wino43_gate16_body<GMT, true, true>(g, W16g, q_tiles_per_item, q_tiles, n_tiles_g, log2d, nullptr, bid, smem);
+    const bool real = fz_g::wino43_gate16_body<GMT, true, true, WT ? 16 : 0>(g, W16g, q_tiles_per_item, q_tiles, n_tiles_g, log2d, nullptr, bid, smem);
     if (!real) return;
     __syncthreads();   // every wave's stores are issued
     if (threadIdx.x == 0) {
       const int grp = bid / (8 * n_tiles_g), rem = bid % (8 * n_tiles_g);
       const int qt = grp * 8 + (rem & 7);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if constexpr (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(counters + qt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -67,11 +70,11 @@ __global__ __launch_bounds__(256, 3) void fused_gate_res_kernel(const ss_conv_ge
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if constexpr (!WT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
   }
-  fz_r::gemm16_res_body<RMT, KCH, true>(r, W16r, m_tiles_per_item, m_tiles, n_tiles_r, rb, smem);
+  fz_r::gemm16_res_body<RMT, KCH, true, WT ? 16 : 0>(r, W16r, m_tiles_per_item, m_tiles, n_tiles_r, rb, smem);
 }
 
 }  // namespace
@@ -84,7 +87,7 @@ extern "C" int ss_fused_gate_res_counters(int B, int T, int dilation) {
 // gate args / res args exactly as ss_wino43_gate16w / ss_gemm16_resw take them (the gate's output C must be the projection's A); mt_gate = 2,
 // mt_res = 6 only. counters: one zeroed uint32 per gate row tile (ceil(quads / 32) * B); error: one int32, set to 1 if a wait gave up.
 extern "C" int ss_fused_gate_res(const ss_conv_gemm_args* gate, const float* W16g, int dilation, const ss_conv_gemm_args* res, const float* W16r,
-                                 uint32_t* counters, int32_t* error, void* stream_) {
+                                 uint32_t* counters, int32_t* error, int write_through, void* stream_) {
   SS_CHECK_ARG(gate && res && W16g && W16r && counters && error, "ss_fused_gate_res: null argument");
   const ss_conv_gemm_args& g = *gate;
   const ss_conv_gemm_args& r = *res;
@@ -105,8 +108,12 @@ extern "C" int ss_fused_gate_res(const ss_conv_gemm_args* gate, const float* W16
   const int n_tiles_r = ss_cdiv(r.N, 64);
   const int n_res = ss_cdiv(m_tiles, 8) * 8 * n_tiles_r;
   const size_t lds = (size_t)12 * 16 * GMT * 32 * sizeof(float);   // the gate's K-staged image (48 KB) >= the projection's ring (36 KB)
-  hipLaunchKernelGGL((fused_gate_res_kernel<GMT, RMT, KCH>), dim3(n_gate + n_res), dim3(256), lds, (hipStream_t)stream_, g, W16g, q_tiles_per_item, q_tiles,
-                     n_tiles_g, log2d, r, W16r, m_tiles_per_item, m_tiles, n_tiles_r, n_gate, counters, (unsigned)n_tiles_g, error);
+  if (write_through)
+    hipLaunchKernelGGL((fused_gate_res_kernel<GMT, RMT, KCH, true>), dim3(n_gate + n_res), dim3(256), lds, (hipStream_t)stream_, g, W16g, q_tiles_per_item,
+                       q_tiles, n_tiles_g, log2d, r, W16r, m_tiles_per_item, m_tiles, n_tiles_r, n_gate, counters, (unsigned)n_tiles_g, error);
+  else
+    hipLaunchKernelGGL((fused_gate_res_kernel<GMT, RMT, KCH, false>), dim3(n_gate + n_res), dim3(256), lds, (hipStream_t)stream_, g, W16g, q_tiles_per_item,
+                       q_tiles, n_tiles_g, log2d, r, W16r, m_tiles_per_item, m_tiles, n_tiles_r, n_gate, counters, (unsigned)n_tiles_g, error);
   SS_CHECK_LAUNCH("fused_gate_res_kernel");
   return SS_OK;
 }

@@ -48,15 +48,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 // LDS-DMA of 64 x 16 bytes: lane i's 16 bytes land at lds_dst + 16 i (wave-uniform destination, per-lane source offset).
 // (A __device__ helper on purpose: with the builtin written directly inside the templated __global__ body, the host pass of hipcc
 //  (ROCm 7.2) silently drops the kernel's launch stub and the library no longer links.)
+template <int AUX = 0>   // cache-policy bits (0 in the product; 16 = sc1: reads past this CU's L1, for operands another workgroup published write-through)
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voffset, int soffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, AUX);
 }
 
 // WL = weight layout: false = packed rows [Np][Kp]; true = the lane-contiguous repack of ss_pack_gemm16_weights
 // ([n tile][wave][K chunk][half][lane][4 floats]): one fetch instruction of a wave = 1 KB contiguous instead of 16 columns x 64 B
 // The kernel body as a device function of (workgroup id, LDS base of 3 * 16 MT * LD floats): the __global__ wrapper below passes blockIdx.x and its
 // static LDS; the dataflow experiment of fused_gate_res.hip (round 5) calls the same body from a launch that also holds the gate's workgroups.
-template <int MT, int KCH, bool WL>
+template <int MT, int KCH, bool WL, int A_AUX = 0>
 __device__ __forceinline__ void gemm16_res_body(const ss_conv_gemm_args& a, const float* __restrict__ W16, int m_tiles_per_item, int m_tiles, int n_tiles,
                                                 const int block_id, float* __restrict__ lds_) {
   constexpr int BM = 16 * MT;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void gemm16_res_body(const ss_conv_gemm_args& a, cons
   auto dma = [&](float* buf, int c) {
 #pragma unroll
     for (int j = 0; j < DPW; ++j)
-      glds16(rsrc_a, buf + (wave + 4 * j) * 8 * LD, a_voff[j], c * (BK * 4));
+      glds16<A_AUX>(rsrc_a, buf + (wave + 4 * j) * 8 * LD, a_voff[j], c * (BK * 4));
   };
   int a_rd[MT][2];
 #pragma unroll

@@ -60,7 +60,8 @@ __device__ __forceinline__ float2 vsub(const float2& a, const float2& b) { retur
 // The kernel body as a device function of (workgroup id, LDS base): the __global__ wrapper below passes blockIdx.x and its dynamic LDS; the
 // dataflow experiment of fused_gate_res.hip (round 5) calls the same body from a launch that also holds the residual projection's workgroups.
 // Returns false for the padding workgroups of the XCD-aligned grid (no tile).
-template <int MT, bool KS, bool WL>
+// ST_AUX: cache-policy bits of the output stores (0 in the product; 16 = sc1, write-through to memory: the publish form of the dataflow experiment)
+template <int MT, bool KS, bool WL, int ST_AUX = 0>
 __device__ __forceinline__ bool wino43_gate16_body(const ss_conv_gemm_args& a, const float* __restrict__ W16, int q_tiles_per_item, int q_tiles, int n_tiles,
                                                    int log2d, unsigned long long* clock_probe, const int block_id, float* __restrict__ smem_) {
   constexpr int BQ = 16 * MT;
@@ -484,8 +485,8 @@ __device__ __forceinline__ bool wino43_gate16_body(const ss_conv_gemm_args& a, c
           if (ta >= row_lim) ga = 0.f;
           if (ta + d >= row_lim) gb = 0.f;
         }
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ga), rsrc_c, c_base, dr * ldc4, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb), rsrc_c, c_base, (dr + d) * ldc4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ga), rsrc_c, c_base, dr * ldc4, ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb), rsrc_c, c_base, (dr + d) * ldc4, ST_AUX);
       }
     }
   };

@@ -63,22 +63,34 @@ def main():
             r2 = {k: v for k, v in rk.items() if k not in ("A", "W", "out", "W16")}
             L.gemm16_res(rk["A"], rk["W"], rk["out"], mt=6, W16=rk["W16"], **r2)
 
-    def fused(X, GA):
-        counters.zero_()
-        for l in range(Lyr):
-            gk, rk = kws(l, X, GA)
-            L.fused_gate_res(gk, rk, dilation=packs[l]["d"], counters=counters[coff[l]:], error=err)
+    def make_fused(wt):
+        def fused(X, GA):
+            counters.zero_()
+            for l in range(Lyr):
+                gk, rk = kws(l, X, GA)
+                L.fused_gate_res(gk, rk, dilation=packs[l]["d"], counters=counters[coff[l]:], error=err, write_through=wt)
+        return fused
+    fused, fused_wt = make_fused(False), make_fused(True)
 
     outs = []
-    for fn in (two_launch, fused):
+    for fn in (two_launch, fused, fused_wt):
         X = X0.clone()
         GA = torch.zeros(B, T, Lyr * C, device=dev)
         fn(X, GA)
         torch.cuda.synchronize()
         outs.append((X, GA))
-    same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    print(f"fused vs two launches after {Lyr} layers: bit-identical {same}; max |dX| {(outs[0][0] - outs[1][0]).abs().max().item():.3e}, "
-          f"max |dG| {(outs[0][1] - outs[1][1]).abs().max().item():.3e}; wait gave up: {int(err.item())}")
+    for name, o in (("release / acquire fences", outs[1]), ("write-through stores + sc1 loads", outs[2])):
+        same = torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+        print(f"dataflow launch ({name}) vs two launches after {Lyr} layers: bit-identical {same}; max |dX| {(outs[0][0] - o[0]).abs().max().item():.3e}, "
+              f"max |dG| {(outs[0][1] - o[1]).abs().max().item():.3e}; wait gave up: {int(err.item())}")
+    # the write-through form has no fence to fall back on: repeat it under load and compare every time (staleness would show as a mismatch)
+    bad = 0
+    for rep in range(10):
+        X = X0.clone()
+        GA = torch.zeros(B, T, Lyr * C, device=dev)
+        fused_wt(X, GA)
+        bad += int(not (torch.equal(outs[0][0], X) and torch.equal(outs[0][1], GA)))
+    print(f"write-through form repeated 10x: {bad} mismatching runs")
     assert torch.isfinite(outs[0][0]).all()
 
     def timed(fn):
@@ -105,7 +117,9 @@ def main():
     for rep in range(2):
         t2 = timed(two_launch)
         tf = timed(fused)
-        print(f"B={B} T={T}: per layer, two launches (gate, projection) {t2:.2f} us; one dataflow launch {tf:.2f} us ({(tf / t2 - 1) * 100:+.1f} %); wait gave up: {int(err.item())}")
+        tw = timed(fused_wt)
+        print(f"B={B} T={T}: per layer, two launches (gate, projection) {t2:.2f} us; one dataflow launch with fences {tf:.2f} us ({(tf / t2 - 1) * 100:+.1f} %), "
+              f"with write-through stores / sc1 loads {tw:.2f} us ({(tw / t2 - 1) * 100:+.1f} %); wait gave up: {int(err.item())}")
 
 
 if __name__ == "__main__":
