@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 15 /* 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_fused_gate_res (experiment), knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 15 /* 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -661,17 +661,6 @@ int ss_reflect_pad(const float* x, const int32_t* lens, float* y, int B, int Lx,
  * between voiced neighbours on unvoiced ones (flat beyond the first/last voiced frame, 0 when nothing is voiced);
  * uv [B][T] = 1.0 on unvoiced frames. Frames >= lens[b] (NULL = T) are written as 0. Inputs and outputs must not alias. */
 int ss_norm_interp_f0(const float* f0_hz, const int32_t* lens, float* out, float* uv, int B, int T, void* stream);
-
-/* EXPERIMENT (round 5; csrc/fused_gate_res.hip): the F(4,3) gate launch (ss_wino43_gate16w, mt = 2, addend in fetch order) and the residual-half
- * projection (ss_gemm16_resw, mt = 6) of ONE layer of the mel denoiser as ONE launch: a dataflow grid in which a projection workgroup starts when
- * the gate workgroups of its row tile(s) have published (agent-scope release / acquire on per-row-tile counters) instead of at a kernel boundary.
- * Bit-identical to the two launches. counters: one ZEROED uint32 per gate row tile (ss_fused_gate_res_counters); error: int32, set to 1 if a
- * bounded wait gave up (results are then undefined). Not used by the loop drivers: DESIGN.md 7 has the measurement and why. */
-int ss_fused_gate_res_counters(int B, int T, int dilation);
-/* write_through: 0 = plain stores + release fence / acquire fence; 1 = the gate stores its outputs sc1 (write-through) and the projection reads them
- * sc1, no fences (the cheaper valid publish form) */
-int ss_fused_gate_res(const ss_conv_gemm_args* gate, const float* W16g, int dilation, const ss_conv_gemm_args* res, const float* W16r, uint32_t* counters,
-                      int32_t* error, int write_through, void* stream);
 
 /* f0 tracker (input producer; replaces inference/StyleSinger.py:125-127:
  *   parselmouth.Sound(wav, sr).to_pitch_ac(time_step, voicing_threshold=0.6, pitch_floor=80, pitch_ceiling=800).selected_array['frequency']

@@ -300,18 +300,6 @@ def gemm16_res(A, W, out, *, mt=0, W16=None, **kw):
     check(load().ss_gemm16_res(C.byref(a), int(mt), stream_ptr()), "ss_gemm16_res")
 
 
-def fused_gate_res(gate_kw, res_kw, *, dilation, counters, error, write_through=False):
-    """EXPERIMENT (ss_fused_gate_res): one layer's F(4,3) gate + residual projection as one dataflow launch. gate_kw / res_kw: dicts with A, W, out,
-    W16 and the keyword arguments of wino43_gate16 / gemm16_res."""
-    g = dict(gate_kw)
-    r = dict(res_kw)
-    g.setdefault("epi", EPI_GATE)
-    ga = _fill_args(g.pop("A"), g.pop("W"), g.pop("out"), **{k: v for k, v in g.items() if k != "W16"})
-    ra = _fill_args(r.pop("A"), r.pop("W"), r.pop("out"), **{k: v for k, v in r.items() if k != "W16"})
-    check(load().ss_fused_gate_res(C.byref(ga), ptr(gate_kw["W16"]), int(dilation), C.byref(ra), ptr(res_kw["W16"]), ptr(counters), ptr(error),
-                                   int(bool(write_through)), stream_ptr()), "ss_fused_gate_res")
-
-
 def gemm16_store(A, W, out, *, mt=0, **kw):
     """C = act(A.W^T + bias) on 16x16x4 tiles with both operands streamed by LDS-DMA (ss_gemm16_store)."""
     a = _fill_args(A, W, out, **kw)

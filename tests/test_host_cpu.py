@@ -37,14 +37,13 @@ def test_argument_errors_are_reported_not_crashed():
     assert l.ss_conv_gemm(None, None) != 0
     assert b"null args" in l.ss_last_error()
     assert l.ss_layernorm(None, None, None, None, 1, 1, 8, 8, 8, 8, 8, 1e-5, None, 0, None) != 0
-    # round-5 entry points: the input producers and the dataflow experiment refuse bad arguments before touching a device
+    # round-5 entry points: the input producers refuse bad arguments before touching a device
     assert l.ss_f0track(None, 0, None, None, None, 1, 1, None, None, None, None, 1, 0, None, 0, None) != 0 and b"ss_f0track" in l.ss_last_error()
     assert l.ss_f0track_workspace_bytes(2, 143, 899) > 2 * 143 * 900 * 8 and l.ss_f0track_workspace_bytes(0, 1, 1) == 0
     assert l.ss_vad_trim(None, 0, None, None, 0, 1, 1, 480, 8, 6, None, 0, None, None, None) != 0 and b"ss_vad_trim" in l.ss_last_error()
     assert l.ss_normalize_volume(None, None, None, 1, 1, -30.0, None) != 0
     assert l.ss_round_f16_rows(None, 0, 0, None, None, 0, 1, None) != 0
-    assert l.ss_fused_gate_res(None, None, 1, None, None, None, None, 0, None) != 0 and b"ss_fused_gate_res" in l.ss_last_error()
-    assert l.ss_fused_gate_res_counters(8, 1500, 1) == 96 and l.ss_fused_gate_res_counters(8, 1500, 8) == 96
+    assert not hasattr(l, "ss_fused_gate_res")   # the dataflow-launch experiment is built from tools/experiments/, not shipped in the library
     assert l.ss_set_tuning(b"q4_force", 1) == 0 and l.ss_get_tuning(b"q4_force") == 1 and l.ss_set_tuning(b"q4_force", 0) == 0
     assert l.ss_set_tuning(b"tile128", 1) != 0 and l.ss_set_tuning(b"skip_deep", 1) != 0      # removed in round 5
 

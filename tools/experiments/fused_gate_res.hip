@@ -11,17 +11,30 @@
 // Same bodies, same arithmetic, same order: the results are bit-identical to the two-launch form (tools/kbench.py --which fused checks it).
 // What it prices: one kernel boundary (1.7-1.9 us) and the drain of the gate grid against a release per gate workgroup, a poll + acquire per
 // projection workgroup, and the projection running with the gate's register / LDS footprint. Measured: DESIGN.md 7 (round 5).
+// NOT part of libstylesinger_hip.so: an experiment lives under tools/ and is built into its own shared object by tools/kbench_fused.py
+// (hipcc, a few seconds); the product library ships no kernel its default paths cannot reach.
 #define SS_FUSED_TU 1
-#include "common.h"
+#include "../../stylesinger_amd/csrc/common.h"
 #include "../../include/stylesinger_hip.h"
+#include <stdarg.h>
 #include <type_traits>
 
 namespace fz_g {
-#include "wino43_gate16.hip"
+#include "../../stylesinger_amd/csrc/wino43_gate16.hip"
 }
 namespace fz_r {
-#include "gemm16.hip"
+#include "../../stylesinger_amd/csrc/gemm16.hip"
 }
+
+// the product library's error sink, local to this object (common.h declares it; the SS_CHECK_* macros call it)
+static char g_fz_error[512];
+void ss_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_fz_error, sizeof(g_fz_error), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ssx_fused_last_error(void) { return g_fz_error; }
 
 namespace {
 
@@ -79,22 +92,22 @@ __global__ __launch_bounds__(256, 3) void fused_gate_res_kernel(const ss_conv_ge
 
 }  // namespace
 
-extern "C" int ss_fused_gate_res_counters(int B, int T, int dilation) {
+extern "C" int ssx_fused_gate_res_counters(int B, int T, int dilation) {
   if (B <= 0 || T <= 0 || dilation <= 0) return 0;
   return ss_cdiv(ss_cdiv(T, 4 * dilation) * dilation, 32) * B;
 }
 
 // gate args / res args exactly as ss_wino43_gate16w / ss_gemm16_resw take them (the gate's output C must be the projection's A); mt_gate = 2,
 // mt_res = 6 only. counters: one zeroed uint32 per gate row tile (ceil(quads / 32) * B); error: one int32, set to 1 if a wait gave up.
-extern "C" int ss_fused_gate_res(const ss_conv_gemm_args* gate, const float* W16g, int dilation, const ss_conv_gemm_args* res, const float* W16r,
+extern "C" int ssx_fused_gate_res(const ss_conv_gemm_args* gate, const float* W16g, int dilation, const ss_conv_gemm_args* res, const float* W16r,
                                  uint32_t* counters, int32_t* error, int write_through, void* stream_) {
-  SS_CHECK_ARG(gate && res && W16g && W16r && counters && error, "ss_fused_gate_res: null argument");
+  SS_CHECK_ARG(gate && res && W16g && W16r && counters && error, "ssx_fused_gate_res: null argument");
   const ss_conv_gemm_args& g = *gate;
   const ss_conv_gemm_args& r = *res;
-  SS_CHECK_ARG(dilation >= 1 && dilation <= 32 && (dilation & (dilation - 1)) == 0, "ss_fused_gate_res: dilation must be a power of two <= 32");
+  SS_CHECK_ARG(dilation >= 1 && dilation <= 32 && (dilation & (dilation - 1)) == 0, "ssx_fused_gate_res: dilation must be a power of two <= 32");
   SS_CHECK_ARG(g.B == r.B && g.T == r.T && g.Kp == 256 && r.Kp == 256 && g.Np == 512 && r.N == 256 && g.epi == SS_EPI_GATE && g.e_tiled,
-               "ss_fused_gate_res: the mel denoiser's layer shape only (C = 256, addend in fetch order)");
-  SS_CHECK_ARG(g.group_size == 0 && r.group_size == 0 && g.C == r.A && g.ldc == r.lda, "ss_fused_gate_res: the gate's output must be the projection's operand");
+               "ssx_fused_gate_res: the mel denoiser's layer shape only (C = 256, addend in fetch order)");
+  SS_CHECK_ARG(g.group_size == 0 && r.group_size == 0 && g.C == r.A && g.ldc == r.lda, "ssx_fused_gate_res: the gate's output must be the projection's operand");
   int log2d = 0;
   while ((1 << log2d) < dilation) ++log2d;
   constexpr int GMT = 2, RMT = 6, KCH = 8;

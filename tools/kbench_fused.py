@@ -1,4 +1,4 @@
-"""Round-5 experiment: one layer's F(4,3) gate + residual projection of the mel denoiser as ONE dataflow launch (ss_fused_gate_res: per-row-tile
+"""Round-5 experiment: one layer's F(4,3) gate + residual projection of the mel denoiser as ONE dataflow launch (tools/experiments/fused_gate_res.hip, its own shared object: per-row-tile
 counters, agent-scope release / acquire) against the two dependent launches the loop uses, at BASELINE configs[1]'s shape (B = 8 x T = 1500).
 Prints: bit-identity of the 20-layer chain's outputs, us per layer of (gate, projection) as 40 launches vs 20 fused launches (+ one memset of
 the counters), both replayed from a hipGraph.
@@ -11,8 +11,39 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from stylesinger_amd import lib as L  # noqa: E402
+
+EXP_SRC = os.path.join(ROOT, "tools", "experiments", "fused_gate_res.hip")
+EXP_SO = os.path.join(ROOT, "tools", "experiments", "libfused_gate_res.so")
+
+
+def load_experiment():
+    """The experiment is NOT in libstylesinger_hip.so: build its own shared object (hipcc, ~20 s) unless a current one travelled with the tree."""
+    deps = [EXP_SRC, os.path.join(ROOT, "stylesinger_amd", "csrc", "wino43_gate16.hip"), os.path.join(ROOT, "stylesinger_amd", "csrc", "gemm16.hip")]
+    if not os.path.exists(EXP_SO) or os.path.getmtime(EXP_SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", EXP_SRC, "-o", EXP_SO], check=True)
+    x = ctypes.CDLL(EXP_SO)
+    x.ssx_fused_last_error.restype = ctypes.c_char_p
+    x.ssx_fused_gate_res_counters.argtypes = [ctypes.c_int] * 3
+    x.ssx_fused_gate_res.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int, ctypes.c_void_p]
+    return x
+
+
+def fused_gate_res(x, gate_kw, res_kw, *, dilation, counters, error, write_through):
+    g, r = dict(gate_kw), dict(res_kw)
+    g.setdefault("epi", L.EPI_GATE)
+    ga = L._fill_args(g.pop("A"), g.pop("W"), g.pop("out"), **{k: v for k, v in g.items() if k != "W16"})
+    ra = L._fill_args(r.pop("A"), r.pop("W"), r.pop("out"), **{k: v for k, v in r.items() if k != "W16"})
+    rc = x.ssx_fused_gate_res(ctypes.byref(ga), L.ptr(gate_kw["W16"]), int(dilation), ctypes.byref(ra), L.ptr(res_kw["W16"]), L.ptr(counters), L.ptr(error),
+                              int(bool(write_through)), L.stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"ssx_fused_gate_res failed ({rc}): {x.ssx_fused_last_error().decode(errors='replace')}")
 
 
 def main():
@@ -32,6 +63,7 @@ def main():
     E = (torch.randn(B, T, Lyr * 2 * C, generator=g) * 0.5).to(dev)
     dstep = (torch.randn(Lyr, C, generator=g) * 0.1).to(dev)
     lib = L.load()
+    exp = load_experiment()
     packs = []
     for l in range(Lyr):
         d = 1 << (l % 4)
@@ -42,7 +74,7 @@ def main():
         bo = L.pack_bias((torch.randn(2 * C, generator=g) * 0.1).to(dev))
         packs.append(dict(d=d, wt=wt, wt16=L.pack_gate16_weights(wt, C), wo=wop, wo16=L.pack_gemm16_weights(wop[:C].contiguous(), wop.shape[1]), bo=bo,
                           e16=L.gate16_tile_addend(E[:, :, l * 2 * C:], B=B, T=T, Np=2 * C, lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, dilation=d, mt=2)))
-    ncnt = [lib.ss_fused_gate_res_counters(B, T, p["d"]) for p in packs]
+    ncnt = [exp.ssx_fused_gate_res_counters(B, T, p["d"]) for p in packs]
     counters = torch.zeros(sum(ncnt), device=dev, dtype=torch.int32)
     coff = [sum(ncnt[:l]) for l in range(Lyr)]
     err = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -68,7 +100,7 @@ def main():
             counters.zero_()
             for l in range(Lyr):
                 gk, rk = kws(l, X, GA)
-                L.fused_gate_res(gk, rk, dilation=packs[l]["d"], counters=counters[coff[l]:], error=err, write_through=wt)
+                fused_gate_res(exp, gk, rk, dilation=packs[l]["d"], counters=counters[coff[l]:], error=err, write_through=wt)
         return fused
     fused, fused_wt = make_fused(False), make_fused(True)
 

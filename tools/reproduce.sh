@@ -56,7 +56,8 @@ case "$sec" in
     python tools/kbench_h.py --which res --f16 --pair-only
     python tools/kbench_h.py --which skip --f16 ;;
   fused)
-    # round 5: one residual layer as ONE dataflow launch (gate + projection, per-row-tile counters) vs the two launches, bit-identity checked
+    # round 5: one residual layer as ONE dataflow launch (gate + projection, per-row-tile counters; fences | write-through) vs the two launches, bit-identity
+    # checked. The experiment is not in the library: tools/kbench_fused.py builds tools/experiments/libfused_gate_res.so (hipcc) when it is missing / stale
     python tools/kbench_fused.py
     python tools/kbench_fused.py --B 32 --T 1500
     python tools/kbench_fused.py --B 1 --T 750 ;;
