@@ -186,8 +186,9 @@ class StyleSingerHIP(torch.nn.Module):
         # GEMM instead of three. Over 1000 steps the weight rounding is the coherent error, the activation rounding averages out and fp16's is
         # 8x smaller than bf16's: 1.9e-5 on the same golden (oracle/bf16x2_numerics.py; plain fp16 operands 1.9e-4, bf16 with these two
         # products 1.6e-4). The residual stream is a true fp16 pair (22 bits).
-        # "fp16q4" (experimental: its gate kernel has not run on hardware yet): fp16x2 with the mel gate's second product on the block-scaled fp4
-        # matrix instruction where the launch qualifies (ss_gemm_bf16_gate128q); oracle contract set_matmul_rounding("fp16q4")
+        # "fp16q4": fp16x2 with the second product of the mel gate and of the skip GEMM on the block-scaled fp4 matrix instruction where the launch
+        # fills the chip (ss_gemm_bf16_gate128q / _tile256q; validated on hardware in round 5: 2.6e-5 vs the real reference at T = 5625 x 1000 steps);
+        # oracle contract set_matmul_rounding("fp16q4")
         self.q4 = prec == "fp16q4"
         self.f16 = prec in ("fp16x2", "fp16q4")
         self.split = prec in ("bf16x2", "fp16x2", "fp16q4")
