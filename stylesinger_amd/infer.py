@@ -317,5 +317,51 @@ class StyleSingerInfer:
         f0_pred = f0_pred[mask]
         return self.vocoder.spec2wav(mel_pred, f0=f0_pred, noise=vocoder_noise)
 
-    def infer_once(self, inp):
-        return self.forward_model(inp)
+    @staticmethod
+    def _load_wav(path, want_sr):
+        """A reference-audio FILE: 16-bit PCM WAV at the model's sample rate (the reference resamples through librosa, un-vendored: other rates
+        are refused, not approximated). -> float32 mono in [-1, 1)."""
+        import wave
+        with wave.open(str(path), "rb") as wf:
+            if wf.getsampwidth() != 2 or wf.getframerate() != want_sr:
+                raise ValueError(f"{path}: need 16-bit PCM at {want_sr} Hz (got {8 * wf.getsampwidth()} bit, {wf.getframerate()} Hz)")
+            pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2").astype(np.float32).reshape(-1, wf.getnchannels())
+        return pcm.mean(axis=1) / 32768.0
+
+    @torch.no_grad()
+    def preprocess_input(self, inp, vad_flags=None):
+        """Mirror of `StyleSingerInfer.preprocess_input` (inference/StyleSinger.py:94-137) with every producer on the device: fills `mel`,
+        `spk_embed`, `emo_embed`, `f0` (the tracker's contour in Hz on the mel grid) and `item_name` / `wav_fn` from `inp['ref_audio']` (a float
+        waveform at the model's sample rate, or the path of a 16-bit PCM WAV at that rate). `inp['ph_token']` is used when present; otherwise
+        `inp['ph']` goes through `self.ph_encoder` (any object with the reference's `encode(str)`), which the caller sets. Needs `emotion_state` and
+        `speaker_state` (the two encoders' checkpoints). `vad_flags`: webrtcvad's decisions for `trim_long_silences` (vadtrim.py); None = untrimmed."""
+        sr, hop = int(self.hparams["audio_sample_rate"]), int(self.hparams["hop_size"])
+        audio = inp["ref_audio"]
+        wav = self._load_wav(audio, sr) if isinstance(audio, (str, bytes)) or hasattr(audio, "__fspath__") else np.asarray(audio, dtype=np.float32)
+        if "ph_token" not in inp:
+            enc = getattr(self, "ph_encoder", None)
+            if enc is None:
+                raise ValueError("preprocess_input: give inp['ph_token'] or set self.ph_encoder (the reference's build_token_encoder(phone_set.json))")
+            inp["ph_token"] = enc.encode(" ".join(inp["ph"]))
+        t = lambda x, dt: torch.as_tensor(np.asarray(x), dtype=dt)[None]
+        batch = self.preprocess_batch(torch.from_numpy(wav)[None], [len(wav)], None, None, t(inp["ph_token"], torch.long), t(inp["note"], torch.long),
+                                      t(inp["note_dur"], torch.float32), t(inp["note_type"], torch.long),
+                                      emo_vad_flags=None if vad_flags is None else np.asarray(vad_flags)[None])
+        n_mel = len(wav) // hop + 1
+        wav16, lens16 = self.process_audio_wav(torch.from_numpy(wav)[None], [n_mel])
+        from .f0track import track_f0_device
+        f0_hz = track_f0_device(wav16, lens16, n_mel, sr=sr, hop_size=hop)
+        inp.update(item_name=inp.get("name"), wav_fn=audio if isinstance(audio, str) else None, mel=batch["ref_mels"][0, :n_mel].cpu().numpy(),
+                   spk_embed=batch["spk_embed"][0].cpu().numpy(), emo_embed=batch["emo_embed"][0].cpu().numpy(),
+                   f0=f0_hz[0].double().cpu().numpy())
+        return inp
+
+    def postprocess_output(self, output):
+        return output
+
+    def infer_once(self, inp, vad_flags=None):
+        """inference/StyleSinger.py:175-179: preprocess_input -> forward_model -> postprocess_output. An `inp` that already carries the features
+        (`mel`, `spk_embed`, `emo_embed`, `f0`, `ph_token`) skips the preprocessing, as before."""
+        if not all(k in inp for k in ("mel", "spk_embed", "emo_embed", "f0", "ph_token")):
+            inp = self.preprocess_input(inp, vad_flags)
+        return self.postprocess_output(self.forward_model(inp))

@@ -296,3 +296,35 @@ def test_vad_trim_on_the_device_equals_the_real_function_with_injected_flags(gol
         assert n == len(c["out"]), (k, n, len(c["out"]))
         assert torch.equal(out[i, :n], c["out"]), k
         assert (out[i, n:] == 0).all(), k
+
+
+def test_infer_once_runs_from_reference_audio_like_the_reference_entry_point(tmp_path):
+    """`StyleSingerInfer.infer_once(inp)` with the reference's input dict (inference/StyleSinger.py:175-221: `ref_audio`, `ph` / `ph_token`, `note`,
+    `note_dur`, `note_type`): `preprocess_input` fills mel / spk_embed / emo_embed / f0 on the device - from a waveform array and from a 16-bit WAV
+    file - and the features equal what `preprocess_batch` makes of the same audio; a waveform comes out."""
+    import wave
+    from stylesinger_amd.infer import StyleSingerInfer
+    dev = torch.device("cuda:0")
+    hp = config.make_hparams(dict(timesteps=3, K_step=3, f0_timesteps=3))
+    inf = StyleSingerInfer(hp, device=dev, model_state=synth.synth_acoustic_state_dict(hp, 5), vocoder_state=synth.synth_vocoder_state_dict(None, 5),
+                           emotion_state=synth.synth_emotion_state_dict(5), speaker_state=synth.synth_emotion_state_dict(6))
+    n = 256 * 140
+    wav = _sung_wave(n, 200.0, 280.0, 3)
+    pcm = np.round(np.clip(wav, -1, 1) * 32767).astype("<i2")
+    path = tmp_path / "ref.wav"
+    with wave.open(str(path), "wb") as wf:
+        wf.setnchannels(1)
+        wf.setsampwidth(2)
+        wf.setframerate(48000)
+        wf.writeframes(pcm.tobytes())
+    it = synth.synth_batch(1, 40, 5, 8, hp, 5)
+    base = dict(name="t", ph_token=it["txt_tokens"][0].numpy(), note=it["note"][0].numpy(), note_dur=it["note_dur"][0].numpy(),
+                note_type=it["note_type"][0].numpy(), mel2ph=it["mel2ph"][0].numpy())   # (mel2ph: random weights predict degenerate durations)
+    a = inf.preprocess_input(dict(base, ref_audio=pcm.astype(np.float32) / 32768.0))
+    b = inf.preprocess_input(dict(base, ref_audio=str(path)))
+    for k in ("mel", "spk_embed", "emo_embed", "f0"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["mel"].shape == (141, 80) and a["f0"].shape == (141,) and (a["f0"][:4] == 0).all() and (a["f0"] > 0).sum() > 50
+    assert abs(float(np.linalg.norm(a["spk_embed"])) - 1.0) < 1e-5 and abs(float(np.linalg.norm(a["emo_embed"])) - 1.0) < 1e-5
+    out = inf.infer_once(dict(base, ref_audio=str(path)))
+    assert out.ndim == 1 and len(out) > 0 and np.isfinite(out).all()
