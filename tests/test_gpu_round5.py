@@ -328,3 +328,32 @@ def test_infer_once_runs_from_reference_audio_like_the_reference_entry_point(tmp
     assert abs(float(np.linalg.norm(a["spk_embed"])) - 1.0) < 1e-5 and abs(float(np.linalg.norm(a["emo_embed"])) - 1.0) < 1e-5
     out = inf.infer_once(dict(base, ref_audio=str(path)))
     assert out.ndim == 1 and len(out) > 0 and np.isfinite(out).all()
+
+
+def test_vad_trim_device_equals_the_host_mirror_on_random_flag_patterns():
+    """60 random items (lengths off the window grid, flag densities from 5 % to 95 %, bursts) in three ragged batches: `ss_vad_trim` against the host
+    mirror `vadtrim.window_mask`, itself pinned to the real function by the golden cases (tests/test_f0track_cpu.py)."""
+    from stylesinger_amd.vadtrim import trim_long_silences_device, window_mask
+    rng = np.random.default_rng(2025)
+    for batch in range(3):
+        items = []
+        for i in range(20):
+            n = int(rng.integers(480 * 2, 480 * 90)) + int(rng.integers(0, 480))
+            nw = n // 480
+            p = rng.uniform(0.05, 0.95)
+            f = (rng.random(nw) < p)
+            if i % 3 == 0:   # bursts
+                f = np.repeat(rng.random(nw // 5 + 1) < p, 5)[:nw]
+            items.append((rng.standard_normal(n).astype(np.float32), f.astype(np.uint8)))
+        Lmax, Wmax = max(len(w) for w, _ in items), max(len(f) for _, f in items)
+        wav = torch.zeros(len(items), Lmax)
+        flags = torch.zeros(len(items), Wmax, dtype=torch.uint8)
+        for i, (w, f) in enumerate(items):
+            wav[i, :len(w)] = torch.from_numpy(w)
+            flags[i, :len(f)] = torch.from_numpy(f)
+        out, lens = trim_long_silences_device(wav.cuda(), [len(w) for w, _ in items], flags)
+        out, lens = out.cpu().numpy(), lens.cpu().numpy()
+        for i, (w, f) in enumerate(items):
+            nw = len(w) // 480
+            ref = w[:nw * 480].reshape(nw, 480)[window_mask(f[:nw])].reshape(-1)
+            assert lens[i] == len(ref) and np.array_equal(out[i, :len(ref)], ref) and not out[i, len(ref):].any(), (batch, i)
