@@ -357,3 +357,35 @@ def test_vad_trim_device_equals_the_host_mirror_on_random_flag_patterns():
             nw = len(w) // 480
             ref = w[:nw * 480].reshape(nw, 480)[window_mask(f[:nw])].reshape(-1)
             assert lens[i] == len(ref) and np.array_equal(out[i, :len(ref)], ref) and not out[i, len(ref):].any(), (batch, i)
+
+
+def test_f0_tracker_on_harder_signals_matches_the_restatement():
+    """Device tracker vs oracle/praat_pitch.py where the candidate competition matters: a strong second harmonic (octave ambiguity), a breathy tone
+    whose voicing hovers around the threshold, a low-level tone on a DC offset, a fast glide across two octaves. Both sides decide from the same
+    float64 quantities (direct autocorrelation sums vs an FFT: ~1e-13 apart), so every frame must agree except on an exact tie of path costs."""
+    from oracle import praat_pitch as P
+    from stylesinger_amd.f0track import track_f0_device
+    rng = np.random.default_rng(7)
+    n_mel = 130
+    n = n_mel * 256
+    t = np.arange(n) / 48000.0
+    sigs = []
+    sigs.append(0.1 * np.sin(2 * np.pi * 170 * t) + 0.35 * np.sin(2 * np.pi * 340 * t + 0.7))
+    sigs.append(sum(0.08 / h * np.sin(2 * np.pi * 240 * h * t) for h in range(1, 6)) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t)) + 0.05 * rng.standard_normal(n))
+    sigs.append(0.004 * np.sin(2 * np.pi * 130 * t) + 0.2 + 0.0002 * rng.standard_normal(n))
+    f_inst = 110.0 * 2 ** (2.0 * t / t[-1])
+    sigs.append(0.3 * np.sin(2 * np.pi * np.cumsum(f_inst) / 48000.0) + 0.1 * np.sin(4 * np.pi * np.cumsum(f_inst) / 48000.0))
+    wav16 = torch.from_numpy(np.stack(sigs).astype(np.float32)).half().float()
+    got = track_f0_device(wav16.cuda(), [n] * len(sigs), n_mel).cpu().numpy()
+    flips, worst, voiced = 0, 0.0, 0
+    for b in range(len(sigs)):
+        ref = P.reference_f0(wav16[b].numpy().astype(np.float64), n_mel)
+        g = got[b]
+        flips += int(((g > 0) != (ref > 0)).sum())
+        both = (g > 0) & (ref > 0)
+        voiced += int(both.sum())
+        if both.any():
+            worst = max(worst, float(np.abs(g[both] - ref[both]).max()))
+    print(f"f0 tracker, harder signals: {voiced} voiced frames, max |df| {worst:.3e} Hz, voicing flips {flips}")
+    record_measurement("f0_tracker_device_vs_praat_restatement_hard_signals", pinned=False, voiced_frames=voiced, max_abs_df_hz=worst, voicing_flips=flips)
+    assert voiced > 200 and flips <= 1 and worst <= 2e-3
