@@ -83,10 +83,17 @@ def main():
         Wsk = to_w(L.pack_conv_weight(wsk))
         S = torch.empty(B, T, C, device=d)
         bsk = torch.randn(C, device=d)
-        def fs():
-            L.gemm_bf16(GA, Wsk, B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=Wsk.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=bsk, **skw)
+        if a.q4:   # fp16q4: the second product on the block-scaled fp4 instruction (ss_gemm_bf16_tile256q)
+            Wq = L.pack_skip_q4(L.pack_conv_weight(wsk))[0]
+
+            def fs():
+                L.gemm_bf16(GA, Wq, B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=L.round_up(C, 32), epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S,
+                            bias=bsk, split=3, out_scale=1.0 / 256.0, q_scale=0.25, gate256=True)
+        else:
+            def fs():
+                L.gemm_bf16(GA, Wsk, B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=Wsk.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=bsk, **skw)
         s = timeit(fs, a.iters)
-        res.append(("skip GEMM K=5120 N=256" + (" fp16x2" if a.f16 else " split x3" if a.split else " bf16"), s, nprod * 2.0 * B * T * Lyr * C * C,
+        res.append(("skip GEMM K=5120 N=256" + (" fp16q4" if a.q4 else " fp16x2" if a.f16 else " split x3" if a.split else " bf16"), s, nprod * 2.0 * B * T * Lyr * C * C,
                     B * T * ((1 if a.f16 else sp) * 2.0 * Lyr * C + 4.0 * C)))
     for name, s, fl, by in res:
         print(f"{name:40s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.1f} TF/s ({fl / s / 2.5e15 * 100:4.1f}% of bf16 peak)  {by / s / 1e12:5.2f} TB/s algorithmic HBM")
