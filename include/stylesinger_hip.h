@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 15 /* 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512; 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -51,7 +51,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch;
  * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "q4_force" = 0|1 the
  * fp16q4 kernels (ss_gemm_bf16_gate128q / _tile256q) take any launch they can compute, not only those that fill the chip (default 0; the parity
- * tests run one 30 s item through them). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
+ * tests run one 30 s item through them); "layer512" = 0|1 the fp16x2 mel stack as one ss_layer512 launch per layer when the shape qualifies
+ * (default 1; 0 = the gate + residual-projection launch pair). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
  * forwards SS_* variables once at load). */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
@@ -336,6 +337,46 @@ int ss_tile256q_kindex(int32_t* out, int n_pairs);
  * "gate256" knob) say so; same arithmetic contract, results equal up to the K summation order. */
 int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream);
 int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
+/* ONE launch per residual layer of the mel denoiser in "fp16x2" precision for many-round launches (BASELINE configs[3]); replaces the
+ * SS_HEPI_GATE launch + the SS_HEPI_RESX launch of a layer (modules/diff/net.py:66-78: dilated conv + conditioner addend -> sigmoid * tanh ->
+ * residual half of output_projection -> (x + r) / sqrt(2)). A workgroup owns 128 rows x all 512 pre-activation columns (C = 256 fixed): the
+ * gate output stays in LDS as the residual projection's operand and leaves the CU once (G, the skip GEMM's operand); persistent workgroups,
+ * weight fragments streamed L2 -> registers in the order ss_layer512_pack_gate / _pack_res lay them out, the conditioner addend in the
+ * accumulator order of ss_layer512_tile_addend. Same arithmetic contract as ss_gemm_bf16 with split = 2 (results equal up to the fp32
+ * summation order). The stream is DOUBLE BUFFERED: Yout must differ from Yin (a tile reads halo rows its neighbours rewrite).
+ * Yout == NULL: gate only (the last layer: its residual stream is never read). */
+typedef struct ss_layer512_args {
+  const uint16_t* Yin;      /* fp16 pair stream [B][T][ldy] = x + dstep_l (pairs interleaved by 32; only the hi plane feeds the conv) */
+  int64_t yin_batch_stride; /* elements */
+  int32_t ldy;              /* elements, >= 512, multiple of 8; also the row stride of Yout */
+  int32_t d;                /* dilation, 1..8: taps (-d, 0, d) */
+  uint16_t* Yout;           /* pair(x' + next_bias), or NULL */
+  int64_t yout_batch_stride;
+  const int32_t* lens;
+  int32_t B, T;
+  const uint16_t* Wg;       /* ss_layer512_pack_gate of the layer's ss_split_f16 dilated-conv pack (786 432 elements) */
+  const uint16_t* Wr;       /* ss_layer512_pack_res of the residual half of the ss_split_f16 output-projection pack (131 072 elements) */
+  const float* E512;        /* ss_layer512_tile_addend of this layer's 512 addend columns: ss_layer512_addend_floats(B, T) floats */
+  uint16_t* G;              /* gate output fp16 [B][T][ldg], hi slots of the pair layout (the second plane is not written) */
+  int64_t g_batch_stride;
+  int32_t ldg;
+  int32_t mask_rows;        /* rows >= lens[b]: G = 0, Yout = 0 */
+  const float* bias_r;      /* [256] residual half of the output-projection bias, or NULL */
+  const float* cur_bias;    /* [256] dstep_l: Yin = x + cur_bias */
+  const float* next_bias;   /* [256] dstep_{l+1}, or NULL */
+  float out_scale;          /* 2^-s of the weight packs */
+  float post_scale;         /* 1 / sqrt(2) */
+} ss_layer512_args;
+int ss_layer512(const ss_layer512_args* args, void* stream);
+/* 1 if the shape fits the kernel's fixed geometry and fills the chip (>= 4 rounds of 128-row tiles per CU) */
+int ss_layer512_ok(int B, int T, int C, int d_max, int ldy, int ldg);
+int64_t ss_layer512_addend_floats(int B, int T);
+/* E [B][T][lde] (the layer's 512 packed addend columns start at E) -> the tiled slab the kernel reads (once per forward and layer) */
+int ss_layer512_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* out, int B, int T, void* stream);
+/* ss_split_f16 pack [512][3 * 256 * 2] of the gate-interleaved dilated-conv weights -> fragment order (786 432 elements) */
+int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, void* stream);
+/* ss_split_f16 pack [>= 256][256 * 2] of the output projection (first 256 rows = residual half) -> fragment order (131 072 elements) */
+int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, void* stream);
 /* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
@@ -532,6 +573,11 @@ typedef struct ss_wavenet {
    * ss_gemm_bf16_tile256q (split = 3, q_scale = q_scale_z) when ss_gemm_bf16_tile256q_ok says so. gs in 16-bit elements. */
   const uint16_t* w_skipall_q;
   int64_t gs_w_skipall_q;
+  /* optional, with mfma_split = 2 and C = 256, one group: per layer the ss_layer512_pack_gate / _pack_res fragment-order packs of w_dil_h / w_out_h.
+   * When every layer has them, the "layer512" knob is on and ss_layer512_ok(B, T, ...) holds, the residual stack runs ONE ss_layer512 launch per
+   * layer (w_out_f of the last layer is unused). */
+  const uint16_t* w_dil_f[SS_MAX_LAYERS];
+  const uint16_t* w_out_f[SS_MAX_LAYERS];
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

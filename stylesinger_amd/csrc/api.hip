@@ -14,7 +14,7 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 1, 0};
+SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 1, 0, 1};
 
 namespace {
 struct Knob { const char* key; int* slot; bool (*ok)(int); };
@@ -32,7 +32,7 @@ const Knob* knobs(int* n) {
       {"res_tile", &g_ss_tuning.res_tile, ok_tile},    {"skip_tile", &g_ss_tuning.skip_tile, ok_tile}, {"htile", &g_ss_tuning.htile, ok_htile},
       {"wino_tn", &g_ss_tuning.wino_tn, ok_012},       {"wino_v1", &g_ss_tuning.wino_v1, ok_01},      {"voc_wino_max_mb", &g_ss_tuning.voc_wino_max_mb, ok_mb},
       {"e16", &g_ss_tuning.e16, ok_01},                {"mel_tail", &g_ss_tuning.mel_tail, ok_01},     {"gate128", &g_ss_tuning.gate128, ok_01},
-      {"q4_force", &g_ss_tuning.q4_force, ok_01},
+      {"q4_force", &g_ss_tuning.q4_force, ok_01},      {"layer512", &g_ss_tuning.layer512, ok_01},
   };
   *n = (int)(sizeof(k) / sizeof(k[0]));
   return k;
@@ -105,5 +105,6 @@ extern "C" int ss_struct_sizes(int64_t* out, int n) {
   out[2] = (int64_t)sizeof(ss_hifigan);
   if (n >= 4) out[3] = (int64_t)sizeof(ss_gemm_bf16_args);
   if (n >= 5) out[4] = (int64_t)sizeof(ss_f0track_params);
+  if (n >= 6) out[5] = (int64_t)sizeof(ss_layer512_args);
   return SS_OK;
 }

@@ -61,10 +61,12 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     the next input projection as one VALU launch (mel_tail_kernel); 0 = always the two matrix-core launches.
 //   voc_wino_max_mb: the vocoder's grouped-Winograd convs address an item with 32-bit byte offsets; items whose stage panel (+ halo) reaches
 //     this many MiB take the direct kernel instead (default 2048 = the real limit; tests lower it to force that fallback).
+//   layer512: 1 (default) = the fp16x2 mel stack runs ONE ss_layer512 launch per layer (gate + residual projection, G kept in LDS) when the
+//     net carries the fragment-order packs and ss_layer512_ok(B, T, ...) holds; 0 = the gate + residual-projection launch pair.
 //   q4_force: 0 (default) = the fp16q4 kernels take only launches that fill the chip (their _ok rules); 1 = any launch they can compute (parity tests run
 //     one 30 s item through them).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
-                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; };
+                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; int layer512; };
 extern SsTuning g_ss_tuning;
 // compute units of the current device (cached per device; 256 when no device can be queried): the tiling picks model a launch as
 // workgroup layers per CU, so the count must be the device's, not MI355X's

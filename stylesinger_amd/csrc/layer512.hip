@@ -1,0 +1,449 @@
+// ONE launch per residual layer of the mel denoiser in "fp16x2" precision for many-round launches (BASELINE configs[3]: 32 x 5625 rows):
+//   y = dilated_conv(x + dstep_l) + conditioner addend ; g = sigmoid(y[:C]) * tanh(y[C:]) ; x' = (x + W_res g + b) / sqrt(2)      (modules/diff/net.py:66-78)
+// A workgroup owns 128 rows x ALL 512 pre-activation columns: the gate output G (128 x 256 fp16 = 64 KB) stays in LDS, the 1x1 residual
+// projection runs from it, and only the skip operand (G, once) and the new residual stream leave the CU. Replaces gate128_kernel +
+// tile256s_kernel<RESX> per layer (profiles/r05_bench_c4_fp16x2_20steps_kernel_stats.csv: 262 + 125 us): the projection launch's 461 MB of
+// HBM traffic (G re-read, stream read + rewritten) and its 19 launches per step disappear.
+//
+// Shape of the kernel (what differs from the gate128 / gate256 family):
+//   * 8 waves, wave w owns packed columns 64 w .. 64 w + 63 (= output channels 32 w .. + 31, both gate operands) of all 128 rows:
+//     2 x 4 accumulator blocks of 32 x 32 (128 registers). The WEIGHT fragments of a wave are private to it, so they never touch LDS: they are
+//     packed once in fragment order (ss_layer512_pack_gate / _res: one k-step of a wave = 4 KB contiguous) and stream L2 -> VGPR through a
+//     register ring, 1 KB per instruction. Only the activations go through LDS.
+//   * The WHOLE activation tile (128 + 2 x 8 halo rows x 256 channels, hi plane only: 72 KB) is staged once by LDS-DMA, so the 48 k-steps
+//     (8 chunks x 3 taps x 2) run WITHOUT a barrier: the eight waves drift apart and each SIMD's two waves fill each other's issue gaps.
+//   * Operand roles are swapped with respect to gate128: the weights are the matrix instruction's A operand, the activations its B operand.
+//     An accumulator lane then holds ONE row and 16 channels in groups of 4 consecutive ones: G goes to LDS as 8-byte stores, the conditioner
+//     addend arrives as 16-byte loads from a slab laid out in exactly this order (ss_layer512_tile_addend, once per forward), and the residual
+//     epilogue reads / writes the stream's (hi, lo) fp16 pairs as 8-byte vectors straight from the accumulators (no staging pass).
+//   * Persistent workgroups (one per CU, 144 KB of LDS = two 72 KB regions): region r holds A(tile i), then G(tile i) over it; the A tile of
+//     tile i + 1 lands in the other region while tile i's epilogues run. Three barriers per tile.
+//   * The stream is double buffered in HBM (Yin -> Yout): a tile reads 8 halo rows of its neighbours, which another workgroup rewrites.
+// Arithmetic contract = ss_gemm_bf16 with split = 2: a * hi + a * lo of fp16 terms (weights = pairs of w * 2^s), fp32 accumulation scaled by
+// out_scale; G = fp16(g) in the hi slots of the pair layout; the stream a true fp16 pair. Results equal those of the two-launch form up to the
+// fp32 summation order (tests/test_gpu_layer512.py: both against float64 of the same terms).
+#include "common.h"
+#include "../../include/stylesinger_hip.h"
+#include "pair16.h"
+#include <type_traits>
+#include <utility>
+
+typedef ss_f32x16 f32x16;
+typedef ss_bf16x8 bf16x8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128;                    // rows per tile
+constexpr int HALO = 8;                    // dilations up to 8
+constexpr int AROWS = BM + 2 * HALO;       // 144 staged rows
+constexpr int ROWB = 512;                  // bytes per LDS row: 256 channels, hi plane (fp16)
+constexpr int REGION = AROWS * ROWB;       // 73 728 B; two regions
+constexpr int KSTEPS = 48;                 // 8 chunks x 3 taps x 2 k-steps of 16 channels
+constexpr int WG_STEP = 4096;              // bytes of gate weights per wave and k-step: (hi, lo) x 2 column blocks x 1 KB
+constexpr int WG_WAVE = KSTEPS * WG_STEP;  // 196 608 B per wave
+constexpr int RSTEPS = 16;                 // K = 256 of the residual projection
+constexpr int WR_STEP = 2048;              // (hi, lo) x 1 KB
+constexpr int WR_WAVE = RSTEPS * WR_STEP;  // 32 768 B per wave
+constexpr int E_TILE = BM * 512 * 4;       // 262 144 B of tiled addend per tile
+constexpr int NRING = 3;                   // weight fragments of NRING - 1 k-steps in flight
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+template <class F, int... I>
+__device__ __forceinline__ void unrolled_steps(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ bf16x8 ldw(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+__device__ __forceinline__ int acc_rr(int r) { return (r & 3) + 8 * (r >> 2); }
+
+template <bool FUSE>
+__global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args a, int tiles_per_item, int n_tiles, unsigned long long* clock_probe) {
+  const bool probing = clock_probe != nullptr && blockIdx.x == 0;
+  unsigned long long probe_c0 = 0, probe_r0 = 0;
+  if (probing) {
+    probe_c0 = __builtin_readcyclecounter();
+    probe_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem_l512[];   // 144 KB: two regions of 144 rows x 512 B
+
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int d = a.d;
+  const int ldy2 = a.ldy * 2;   // bytes per stream row
+
+  const __amdgpu_buffer_rsrc_t rsrc_wg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Wg + (int64_t)wave * WG_WAVE), 0, WG_WAVE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(FUSE ? (const char*)a.Wr + (int64_t)wave * WR_WAVE : (const char*)a.Wg), 0,
+                                                                         FUSE ? WR_WAVE : 0, 0x00020000);
+  auto tile_coords = [&](int tile, int& b, int& t0) {
+    b = tile / tiles_per_item;
+    t0 = (tile - b * tiles_per_item) * BM;
+  };
+  // ---- DMA of an activation tile: 72 pieces of 2 rows; wave w issues pieces w + 8 j (j < 9). Lane i of piece p lands at (row 2 p + (i >> 5),
+  // physical slot i & 31) and fetches logical slot (i & 31) ^ (row & 15) = channels 8 s .. of the HI plane: chunk s >> 2, bytes 16 (s & 3) of
+  // its 128-byte pair line. 16 j more rows leave the swizzle unchanged. Rows outside [0, len) are out of range: the DMA writes zeros (the
+  // conv's padding).
+  auto dma_tile = [&](int tile, char* region, int lane) {
+    int b, t0;
+    tile_coords(tile, b, t0);
+    const int len = ss_uniform_len(a.lens, b, a.T);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.Yin + (int64_t)b * a.yin_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * ldy2), 0x00020000);
+    const int dma_row = 2 * wave + (lane >> 5);
+    const int dma_slot = (lane & 31) ^ (dma_row & 15);
+    const int voff = (t0 - HALO + dma_row) * ldy2 + (dma_slot >> 2) * 128 + (dma_slot & 3) * 16;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) glds16(rsrc_a, region + (wave + 8 * j) * 1024, voff + 16 * j * ldy2, 0);
+  };
+
+  const float L2E = 1.44269504088896340736f;
+  auto sigm = [](float x, float mul) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * mul)); };
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) dma_tile(tile, smem_l512, tid0 & 63);
+  int it = 0;
+  for (; tile < n_tiles; tile += gridDim.x, ++it) {
+    // per-lane constants are recomputed per tile from an opaque copy of the thread id: hoisted out of this loop they would stay live across
+    // the 128-accumulator conv loop and spill
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int w_voff = lane * 16;
+    // ---- activation fragments (the matrix instruction's B operand): lane (l31, lh) reads channels 16 ks + 8 lh .. + 7 of LDS row
+    // HALO + (tap - 1) d + 32 m + l31; 16-byte slot s of row r sits at physical slot s ^ (r & 15): the 16 rows of a ds_read_b128 lane group
+    // touch 16 distinct 16-byte units. 32 m more rows leave the swizzle unchanged.
+    int a_off[3], a_sw[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int row = HALO + (j - 1) * d + l31;
+      a_off[j] = row * ROWB;
+      a_sw[j] = (row & 15) ^ lh;
+    }
+    // G tile (rows 0 .. 127 of the region, same swizzle): fragment reads of the residual projection and the epilogue's 8-byte writes
+    const int g_off = l31 * ROWB, g_sw = (l31 & 15) ^ lh;
+    const int gw_sw = l31 & 15;
+    char* const Rc = smem_l512 + (it & 1) * REGION;   // A(tile), then G(tile)
+    char* const Rn = smem_l512 + ((it & 1) ^ 1) * REGION;
+    int b, t0;
+    tile_coords(tile, b, t0);
+    const int len = ss_uniform_len(a.lens, b, a.T);
+    const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+
+    // ---- the dilated conv: 48 k-steps, no barrier. Weight ring: fragments of k-step S + NRING - 1 are requested before the MFMAs of step S.
+    bf16x8 wq[NRING][4];   // [plane * 2 + nb]
+    bf16x8 act[2][4];
+    auto load_w = [&](bf16x8 (&dst)[4], int S) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) dst[p] = ldw(rsrc_wg, w_voff + p * 1024, S * WG_STEP);
+    };
+    auto read_act = [&](bf16x8 (&dst)[4], int S) {
+      const int cc = S / 6, tap = (S / 2) % 3, ks = S & 1;
+      const int ao = a_off[tap] + (((4 * cc + 2 * ks) ^ a_sw[tap]) << 4);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + ao + m * 32 * ROWB);
+    };
+#pragma unroll
+    for (int s = 0; s < NRING - 1; ++s) load_w(wq[s], s);
+    wait_vmcnt<4 * (NRING - 1)>();   // my DMA pieces of this tile have landed (only the ring's loads are younger)
+    __builtin_amdgcn_s_barrier();    // [B1] everyone's pieces have
+    read_act(act[0], 0);
+    auto kstep = [&](auto stag) {
+      constexpr int S = decltype(stag)::value;
+      if constexpr (S + NRING - 1 < KSTEPS) load_w(wq[(S + NRING - 1) % NRING], S + NRING - 1);
+      if constexpr (S + 1 < KSTEPS) read_act(act[(S + 1) & 1], S + 1);
+      const bf16x8 (&w)[4] = wq[S % NRING];
+      const bf16x8 (&x)[4] = act[S & 1];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[n][m] = ss_mfma_32x32x16<true>(w[p * 2 + n], x[m], acc[n][m]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    unrolled_steps(kstep, std::make_integer_sequence<int, KSTEPS>{});
+
+    // ---- gate epilogue. Addend slab in accumulator order: block (nb, m), quarter q -> one 16-byte load per lane, 1 KB per wave instruction.
+    const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr((const char*)a.E512 + (int64_t)tile * E_TILE + (int64_t)wave * (E_TILE / 8)), 0, E_TILE / 8, 0x00020000);
+    f32x4 ev[2][2][4];
+    auto load_e = [&](f32x4 (&dst)[2][4], int m) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + m) * 4 + q) * 1024, 0));
+    };
+    load_e(ev[0], 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
+    __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
+    if (tile + (int)gridDim.x < n_tiles) dma_tile(tile + gridDim.x, Rn, lane);
+    const float m0 = -L2E, m1 = -2.0f * L2E;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m + 1 < 4) load_e(ev[(m + 1) & 1], m + 1);
+      const bool pad = t0 + 32 * m + l31 >= row_lim;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t pk[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int e = 2 * e2 + k, r = 4 * q + e;
+            const float v0 = fmaf(acc[0][m][r], a.out_scale, ev[m & 1][0][q][e]);
+            const float v1 = fmaf(acc[1][m][r], a.out_scale, ev[m & 1][1][q][e]);
+            float g = sigm(v0, m0) * fmaf(sigm(v1, m1), 2.0f, -1.0f);   // sigmoid(v0) * tanh(v1), net.py:72-73
+            if (pad) g = 0.f;
+            v |= (uint32_t)ss_f2t<true>(g) << (16 * k);
+          }
+          pk[e2] = v;
+        }
+        // channels 32 w + 8 q + 4 lh .. + 3 of row 32 m + l31: logical slot 4 w + q, bytes 8 lh .. of it
+        char* dst = Rc + (32 * m + l31) * ROWB + (((4 * wave + q) ^ gw_sw) << 4) + 8 * lh;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pk[0], pk[1]};
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // my G writes are done
+    __builtin_amdgcn_s_barrier();         // [B3] the G tile is complete
+
+    // ---- G -> HBM (the skip GEMM's operand): 128 rows x 32 slots of 16 B, eight per thread; the hi halves of the pair layout's 128-byte lines
+    {
+      const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.G + (int64_t)b * a.g_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldg * 2)), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int p = tid + 512 * j;
+        const int R = p >> 5, ps = p & 31;
+        const int s = ps ^ (R & 15);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Rc + p * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_g, (t0 + R) * a.ldg * 2 + (s >> 2) * 128 + (s & 3) * 16, 0, 0);   // rows >= T dropped
+      }
+    }
+    if constexpr (FUSE) {
+      // ---- residual projection from the G tile: out^T[channel][row], wave w owns channels 32 w .. + 31; 16 k-steps of 8 MFMAs
+      f32x16 acc2[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
+      bf16x8 wr[NRING][2];
+      bf16x8 gf[2][4];
+      auto load_wr = [&](bf16x8 (&dst)[2], int S) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) dst[p] = ldw(rsrc_wr, w_voff + p * 1024, S * WR_STEP);
+      };
+      auto read_g = [&](bf16x8 (&dst)[4], int S) {
+        const int go = g_off + (((2 * S) ^ g_sw) << 4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + go + m * 32 * ROWB);
+      };
+#pragma unroll
+      for (int s = 0; s < NRING - 1; ++s) load_wr(wr[s], s);
+      read_g(gf[0], 0);
+      // per-channel constants of this lane's 16 channels 32 w + 8 q + 4 lh + e
+      f32x4 bs[4], cb[4], nb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 32 * wave + 8 * q + 4 * lh;
+        bs[q] = a.bias_r ? *reinterpret_cast<const f32x4*>(a.bias_r + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        cb[q] = *reinterpret_cast<const f32x4*>(a.cur_bias + c0);
+        nb[q] = a.next_bias ? *reinterpret_cast<const f32x4*>(a.next_bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      auto rstep = [&](auto stag) {
+        constexpr int S = decltype(stag)::value;
+        if constexpr (S + NRING - 1 < RSTEPS) load_wr(wr[(S + NRING - 1) % NRING], S + NRING - 1);
+        if constexpr (S + 1 < RSTEPS) read_g(gf[(S + 1) & 1], S + 1);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc2[m] = ss_mfma_32x32x16<true>(wr[S % NRING][p], gf[S & 1][m], acc2[m]);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      unrolled_steps(rstep, std::make_integer_sequence<int, RSTEPS>{});
+
+      // ---- stream update on the (hi, lo) fp16 pairs: x = hi + lo - cur_bias ; x' = (x + acc * out_scale + b) * post_scale ; Y' = pair(x' + next_bias)
+      const __amdgpu_buffer_rsrc_t rsrc_yi = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.Yin + (int64_t)b * a.yin_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * ldy2)), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc_yo = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.Yout + (int64_t)b * a.yout_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * ldy2)), 0x00020000);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int grow = t0 + 32 * m + l31;
+        const bool pad = grow >= row_lim;
+        const int yo = grow * ldy2 + wave * 128 + 8 * lh;   // + 16 q (+ 64 for the lo plane)
+        u32x2 hv[4], lv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hv[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_yi, yo + 16 * q, 0, 0));
+          lv[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_yi, yo + 16 * q + 64, 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x2 ho, lo;
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            uint32_t hp = 0, lp = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int e = 2 * e2 + k;
+              const float hf = ss_t2f_packed<true>(hv[q][e2], k), mf = ss_t2f_packed<true>(lv[q][e2], k);
+              const float xn = (((hf + mf) - cb[q][e]) + fmaf(acc2[m][4 * q + e], a.out_scale, bs[q][e])) * a.post_scale;
+              const float yv = pad ? 0.f : xn + nb[q][e];
+              const uint16_t yh = ss_f2t<true>(yv);
+              const uint16_t yl = ss_f2t<true>(yv - ss_t2f<true>(yh));
+              hp |= (uint32_t)yh << (16 * k);
+              lp |= (uint32_t)yl << (16 * k);
+            }
+            ho[e2] = hp;
+            lo[e2] = lp;
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(ho, rsrc_yo, yo + 16 * q, 0, 0);   // rows >= T: out of range, dropped
+          __builtin_amdgcn_raw_buffer_store_b64(lo, rsrc_yo, yo + 16 * q + 64, 0, 0);
+        }
+      }
+    }
+    // (no barrier here: the next tile's [B1] is reached by a wave only after its reads of this G tile, and this region is next written by
+    // the DMA issued after the next tile's [B2])
+  }
+  if (probing && tid0 == 0) {
+    atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
+    atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);
+  }
+}
+
+// ---- packers (device -> device, once per checkpoint / forward)
+// gate weights: the ss_split_f16 pack of the interleaved dilated-conv weights, [512 packed columns][3 taps x 256 channels x (hi | lo)] with pairs
+// interleaved by 32 (line (tap * 8 + cc) of a row = 32 hi + 32 lo terms) -> fragment order [wave 8][k-step 48][plane 2][nb 2][lane 64][8]:
+// k-step S = (cc * 3 + tap) * 2 + ks; lane (l31, lh) holds channels 32 cc + 16 ks + 8 lh .. + 7 of packed column 64 wave + 32 nb + l31
+__global__ void pack_gate_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte fragment each: 8 * 48 * 4 * 64 = 98 304
+  if (i >= 8 * KSTEPS * 4 * 64) return;
+  const int lane = i & 63, pn = (i >> 6) & 3, S = (i >> 8) % KSTEPS, w = i / (256 * KSTEPS);
+  const int plane = pn >> 1, nb = pn & 1, l31 = lane & 31, lh = lane >> 5;
+  const int cc = S / 6, tap = (S / 2) % 3, ks = S & 1;
+  const int col = 64 * w + 32 * nb + l31;
+  const uint16_t* s = src + (int64_t)col * (3 * 256 * 2) + (tap * 8 + cc) * 64 + plane * 32 + 16 * ks + 8 * lh;
+  *reinterpret_cast<uint4*>(dst + (int64_t)i * 8) = *reinterpret_cast<const uint4*>(s);
+}
+// residual weights: [>= 256 rows][256 channels x (hi | lo)] pairs interleaved by 32 -> [wave 8][k-step 16][plane 2][lane 64][8]: lane (l31, lh)
+// holds channels 16 S + 8 lh .. + 7 of output channel 32 wave + l31
+__global__ void pack_res_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 8 * 16 * 2 * 64 = 16 384 fragments
+  if (i >= 8 * RSTEPS * 2 * 64) return;
+  const int lane = i & 63, plane = (i >> 6) & 1, S = (i >> 7) % RSTEPS, w = i / (128 * RSTEPS);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int row = 32 * w + l31, k = 16 * S + 8 * lh;
+  const uint16_t* s = src + (int64_t)row * (256 * 2) + (k >> 5) * 64 + plane * 32 + (k & 31);
+  *reinterpret_cast<uint4*>(dst + (int64_t)i * 8) = *reinterpret_cast<const uint4*>(s);
+}
+// conditioner addend E [B][T][lde] (this layer's 512 packed columns) -> [tile][wave 8][nb 2][m 4][q 4][lane 64][4]: lane (l31, lh) holds packed
+// columns 64 wave + 32 nb + 8 q + 4 lh .. + 3 of row 32 m + l31 of the tile; rows >= T are zero
+__global__ void tile_addend_kernel(const float* __restrict__ E, int lde, int64_t e_batch_stride, float* __restrict__ out, int T, int tiles_per_item, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 each
+  if (i >= n) return;
+  const int lane = (int)(i & 63), q = (int)(i >> 6) & 3, m = (int)(i >> 8) & 3, nb = (int)(i >> 10) & 1, w = (int)(i >> 11) & 7;
+  const int64_t tile = i >> 14;
+  const int b = (int)(tile / tiles_per_item), t = (int)(tile % tiles_per_item) * BM + 32 * m + (lane & 31);
+  const int col = 64 * w + 32 * nb + 8 * q + 4 * (lane >> 5);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < T) v = *reinterpret_cast<const float4*>(E + (int64_t)b * e_batch_stride + (int64_t)t * lde + col);
+  *reinterpret_cast<float4*>(out + i * 4) = v;
+}
+
+}  // namespace
+
+extern "C" int64_t ss_layer512_addend_floats(int B, int T) { return (int64_t)B * ss_cdiv(T, BM) * (E_TILE / 4); }
+
+extern "C" int ss_layer512_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* out, int B, int T, void* stream) {
+  SS_CHECK_ARG(E && out && B > 0 && T > 0 && (lde % 4) == 0 && lde >= 512 && (e_batch_stride % 4) == 0 && (((uintptr_t)E) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
+               "ss_layer512_tile_addend: E / out 16-byte aligned, lde %% 4 == 0 and >= 512");
+  const int tpi = ss_cdiv(T, BM);
+  const int64_t n = (int64_t)B * tpi * (E_TILE / 16);
+  hipLaunchKernelGGL(tile_addend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, E, lde, e_batch_stride, out, T, tpi, n);
+  SS_CHECK_LAUNCH("ss_layer512_tile_addend");
+  return SS_OK;
+}
+
+extern "C" int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, void* stream) {
+  SS_CHECK_ARG(w_pairs && out && (((uintptr_t)w_pairs) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "ss_layer512_pack_gate: 16-byte aligned pointers");
+  hipLaunchKernelGGL(pack_gate_kernel, dim3(8 * KSTEPS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w_pairs, out);
+  SS_CHECK_LAUNCH("ss_layer512_pack_gate");
+  return SS_OK;
+}
+
+extern "C" int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, void* stream) {
+  SS_CHECK_ARG(w_pairs && out && (((uintptr_t)w_pairs) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "ss_layer512_pack_res: 16-byte aligned pointers");
+  hipLaunchKernelGGL(pack_res_kernel, dim3(8 * RSTEPS * 2 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w_pairs, out);
+  SS_CHECK_LAUNCH("ss_layer512_pack_res");
+  return SS_OK;
+}
+
+// 1 if the fused layer launch can take this shape and is expected to pay: C = 256 (the kernel's fixed geometry), dilation <= 8, 32-bit offsets,
+// and at least four rounds of 128-row tiles per CU (below that the single-round kernels win)
+extern "C" int ss_layer512_ok(int B, int T, int C, int d_max, int ldy, int ldg) {
+  if (C != 256 || d_max < 1 || d_max > HALO || B < 1 || T < 1) return 0;
+  if (ldy < 512 || (ldy % 8) != 0 || ldg < 512 || (ldg % 8) != 0) return 0;
+  if ((int64_t)T * ldy * 2 >= (1ll << 31) || (int64_t)T * ldg * 2 >= (1ll << 31)) return 0;
+  return (long)ss_cdiv(T, BM) * B >= 4l * ss_n_cu() ? 1 : 0;
+}
+
+extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
+  SS_CHECK_ARG(args != nullptr, "ss_layer512: null args");
+  const ss_layer512_args& a = *args;
+  SS_CHECK_ARG(a.Yin && a.Wg && a.E512 && a.G, "ss_layer512: null Yin / Wg / E512 / G");
+  SS_CHECK_ARG(a.B > 0 && a.T > 0 && a.d >= 1 && a.d <= HALO, "ss_layer512: B, T > 0 and 1 <= d <= 8");
+  SS_CHECK_ARG(a.ldy >= 512 && (a.ldy % 8) == 0 && a.ldg >= 512 && (a.ldg % 8) == 0 && (a.yin_batch_stride % 8) == 0 && (a.g_batch_stride % 8) == 0,
+               "ss_layer512: ldy / ldg >= 512 and multiples of 8 (pair layout of 256 channels), batch strides multiples of 8");
+  SS_CHECK_ARG((int64_t)a.T * a.ldy * 2 < (1ll << 31) && (int64_t)a.T * a.ldg * 2 < (1ll << 31), "ss_layer512: item too large for 32-bit offsets");
+  SS_CHECK_ARG((((uintptr_t)a.Yin) & 15) == 0 && (((uintptr_t)a.Wg) & 15) == 0 && (((uintptr_t)a.E512) & 15) == 0 && (((uintptr_t)a.G) & 15) == 0,
+               "ss_layer512: Yin / Wg / E512 / G must be 16-byte aligned");
+  SS_CHECK_ARG(a.out_scale > 0.f && a.out_scale <= 1.f, "ss_layer512: 0 < out_scale <= 1");
+  const bool fuse = a.Yout != nullptr;
+  if (fuse) {
+    SS_CHECK_ARG(a.Wr && a.cur_bias && a.Yout != a.Yin && (a.yout_batch_stride % 8) == 0 && (((uintptr_t)a.Yout) & 15) == 0 && (((uintptr_t)a.Wr) & 15) == 0,
+                 "ss_layer512: the fused form needs Wr, cur_bias and a Yout buffer different from Yin (tiles read their neighbours' halo rows)");
+    SS_CHECK_ARG((((uintptr_t)a.cur_bias) & 15) == 0 && (!a.bias_r || (((uintptr_t)a.bias_r) & 15) == 0) && (!a.next_bias || (((uintptr_t)a.next_bias) & 15) == 0),
+                 "ss_layer512: bias vectors must be 16-byte aligned");
+  }
+  const int tpi = ss_cdiv(a.T, BM);
+  const int n_tiles = tpi * a.B;
+  const int grid = n_tiles < ss_n_cu() ? n_tiles : ss_n_cu();
+  const size_t lds = (size_t)2 * REGION;
+  auto go = [&](auto kern) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      ss_set_error("ss_layer512: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
+      return SS_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, tpi, n_tiles, g_ss_tuning.clock_probe);
+    return SS_OK;
+  };
+  SS_PROPAGATE(fuse ? go(&layer512_kernel<true>) : go(&layer512_kernel<false>));
+  SS_CHECK_LAUNCH("ss_layer512");
+  return SS_OK;
+}

@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 15  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 16  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -70,7 +70,8 @@ class WaveNet(C.Structure):
            ("w_out16", _vp * SS_MAX_LAYERS), ("gs_w_out16", C.c_int64), ("w_skipall_x3", _vp), ("gs_w_skipall_x3", C.c_int64),
            ("mfma_split", C.c_int32), ("mfma_out_scale", C.c_float),
            ("w_dil_q", _vp * SS_MAX_LAYERS), ("gs_w_dil_q", C.c_int64), ("q_scale_gate", C.c_float), ("q_scale_z", C.c_float),
-           ("w_skipall_q", _vp), ("gs_w_skipall_q", C.c_int64)]
+           ("w_skipall_q", _vp), ("gs_w_skipall_q", C.c_int64),
+           ("w_dil_f", _vp * SS_MAX_LAYERS), ("w_out_f", _vp * SS_MAX_LAYERS)]
 
 
 class GemmBf16Args(C.Structure):
@@ -86,6 +87,15 @@ class GemmBf16Args(C.Structure):
 
 
 HEPI_STORE, HEPI_GATE, HEPI_RESX = 0, 1, 2
+
+
+class Layer512Args(C.Structure):
+    _fields_ = [
+        ("Yin", _vp), ("yin_batch_stride", C.c_int64), ("ldy", C.c_int32), ("d", C.c_int32), ("Yout", _vp), ("yout_batch_stride", C.c_int64),
+        ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("Wg", _vp), ("Wr", _vp), ("E512", _vp), ("G", _vp), ("g_batch_stride", C.c_int64),
+        ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("cur_bias", _vp), ("next_bias", _vp), ("out_scale", C.c_float),
+        ("post_scale", C.c_float),
+    ]
 
 
 class HifiGan(C.Structure):
@@ -162,15 +172,15 @@ def load():
         fn.argtypes = argtypes
     if lib.ss_abi_version() != ABI_VERSION:
         raise StyleSingerHipError(f"libstylesinger_hip.so has ABI {lib.ss_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
-    sizes = (C.c_int64 * 5)()
-    if lib.ss_struct_sizes(sizes, 5) != 0:
+    sizes = (C.c_int64 * 6)()
+    if lib.ss_struct_sizes(sizes, 6) != 0:
         raise StyleSingerHipError("ss_struct_sizes failed")
-    mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan), C.sizeof(GemmBf16Args), C.sizeof(F0TrackParams))
+    mine = (C.sizeof(ConvGemmArgs), C.sizeof(WaveNet), C.sizeof(HifiGan), C.sizeof(GemmBf16Args), C.sizeof(F0TrackParams), C.sizeof(Layer512Args))
     if tuple(sizes) != mine:
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
     for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE16_KS", b"gate16_ks"), ("SS_GATE256", b"gate256"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile"), ("SS_E16", b"e16"), ("SS_MEL_TAIL", b"mel_tail"), ("SS_HTILE", b"htile"),
-                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_Q4_FORCE", b"q4_force")):
+                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_Q4_FORCE", b"q4_force"), ("SS_LAYER512", b"layer512")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")
@@ -632,6 +642,44 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
             check(load().ss_gemm_bf16_tile256(C.byref(a), stream_ptr()), "ss_gemm_bf16_tile256")
         return
     check(load().ss_gemm_bf16(C.byref(a), stream_ptr()), "ss_gemm_bf16")
+
+
+def layer512_pack_gate(w_pairs):
+    """ss_split_f16 pack [512][3*256*2] of the gate-interleaved dilated-conv weights -> the fragment order ss_layer512 streams (fp16 [786432])."""
+    assert w_pairs.dtype == torch.float16 and tuple(w_pairs.shape) == (512, 3 * 256 * 2) and w_pairs.is_contiguous(), tuple(w_pairs.shape)
+    out = torch.empty(8 * 48 * 4 * 64 * 8, device=w_pairs.device, dtype=torch.float16)
+    check(load().ss_layer512_pack_gate(ptr(w_pairs), ptr(out), stream_ptr()), "ss_layer512_pack_gate")
+    return out
+
+
+def layer512_pack_res(w_pairs):
+    """ss_split_f16 pack [>= 256][256*2] of the output projection (first 256 rows = residual half) -> fragment order (fp16 [131072])."""
+    assert w_pairs.dtype == torch.float16 and w_pairs.shape[0] >= 256 and w_pairs.shape[1] == 512 and w_pairs.is_contiguous(), tuple(w_pairs.shape)
+    out = torch.empty(8 * 16 * 2 * 64 * 8, device=w_pairs.device, dtype=torch.float16)
+    check(load().ss_layer512_pack_res(ptr(w_pairs), ptr(out), stream_ptr()), "ss_layer512_pack_res")
+    return out
+
+
+def layer512_tile_addend(E, *, B, T, lde=None, e_bs=None, out=None):
+    """E fp32 [B][T][lde] (the layer's 512 packed addend columns start at E) -> the tiled slab ss_layer512 reads."""
+    lde = lde if lde is not None else E.shape[-1]
+    n = load().ss_layer512_addend_floats(B, T)
+    out = torch.empty(n, device=E.device, dtype=torch.float32) if out is None else out
+    check(load().ss_layer512_tile_addend(ptr(E), lde, e_bs if e_bs is not None else T * lde, ptr(out), B, T, stream_ptr()), "ss_layer512_tile_addend")
+    return out
+
+
+def layer512(Yin, Wg, E512, G, *, B, T, d, lens=None, Yout=None, Wr=None, bias_r=None, cur_bias=None, next_bias=None, out_scale=1.0 / 256.0,
+             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True):
+    """ss_layer512: one launch per residual layer (gate + residual projection) of the fp16x2 mel denoiser; see include/stylesinger_hip.h."""
+    a = Layer512Args()
+    a.Yin = ptr(Yin); a.ldy = Yin.shape[-1]; a.yin_batch_stride = T * a.ldy; a.d = d
+    a.Yout = ptr(Yout); a.yout_batch_stride = T * a.ldy
+    a.lens = ptr(lens); a.B = B; a.T = T; a.Wg = ptr(Wg); a.Wr = ptr(Wr); a.E512 = ptr(E512)
+    a.G = ptr(G); a.ldg = ldg if ldg is not None else G.shape[-1]; a.g_batch_stride = g_bs if g_bs is not None else T * a.ldg
+    a.mask_rows = int(mask_rows); a.bias_r = ptr(bias_r); a.cur_bias = ptr(cur_bias); a.next_bias = ptr(next_bias)
+    a.out_scale = out_scale; a.post_scale = post_scale
+    check(load().ss_layer512(C.byref(a), stream_ptr()), "ss_layer512")
 
 
 def layernorm(x, gamma, beta, *, B, T, C_, out=None, lens=None, mask_rows=False, eps=1e-5):

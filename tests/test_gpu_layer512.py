@@ -1,0 +1,141 @@
+"""ss_layer512: ONE launch per residual layer of the fp16x2 mel denoiser (dilated conv + conditioner addend -> sigmoid * tanh -> residual half of
+output_projection -> (x + r) / sqrt(2), modules/diff/net.py:66-78) with the gate output kept in LDS. Checked against float64 math on the SAME
+fp16 terms (the contract of ss_gemm_bf16 with split = 2) and against the two-launch form it replaces (gate kernel + RESX on the pair-only stream)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import record_measurement  # noqa: E402
+from stylesinger_amd import lib as L  # noqa: E402
+
+WS = 8
+C = 256
+
+
+def _split_ref(x, scale=1.0):
+    v = x * scale
+    hi = v.to(torch.float16).float()
+    return hi, (v - hi).to(torch.float16).float()
+
+
+def _pack_e(E):
+    """[.., 2C] (sigmoid half | tanh half) -> the gate-interleaved packed column order (32-column blocks alternate)"""
+    Ep = torch.empty_like(E)
+    for p in range(C // 32):
+        Ep[..., 64 * p:64 * p + 32] = E[..., 32 * p:32 * p + 32]
+        Ep[..., 64 * p + 32:64 * p + 64] = E[..., C + 32 * p:C + 32 * p + 32]
+    return Ep
+
+
+def _case(B, T, lens_list, d, seed):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sc, osc = float(2 ** WS), float(2.0 ** -WS)
+    lens = torch.tensor(lens_list, dtype=torch.int32, device=dev)
+    x = torch.randn(B, T, C, generator=g).to(dev) * 2.0
+    cb = torch.randn(C, generator=g).to(dev)
+    nb = torch.randn(C, generator=g).to(dev)
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    y0 = x + cb
+    for b in range(B):
+        y0[b, lens[b]:] = 0
+    Yin = L.split_f16(y0)                                   # [B,T,2C] pair stream = x + cur_bias
+    yh, yl = L.split_planes(Yin)
+    w = (torch.randn(2 * C, C, 3, generator=g) / (3 * C) ** 0.5).to(dev)
+    Ws = L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=sc)     # [512][3*256*2]
+    wo = (torch.randn(2 * C, C, 1, generator=g) / C ** 0.5).to(dev)           # output_projection: residual half = rows [0, C)
+    Wos = L.split_f16(L.pack_conv_weight(wo), scale=sc)                      # [512][512]
+    E = (torch.randn(B, T, 2 * C, generator=g) * 0.5).to(dev)
+    Lyr = 3
+    Eall = torch.randn(B, T, Lyr * 2 * C, generator=g).to(dev)               # the layer's slab sits in the middle of a wider row
+    Eall[..., 2 * C:4 * C] = _pack_e(E)
+    return dict(dev=dev, B=B, T=T, lens=lens, d=d, sc=sc, osc=osc, x=x, cb=cb, nb=nb, bo=bo, Yin=Yin, yh=yh, yl=yl, w=w, Ws=Ws, wo=wo, Wos=Wos, E=E,
+                Eall=Eall, Lyr=Lyr)
+
+
+def _reference(c):
+    """float64 math on the terms the matrix cores see"""
+    d, osc, sc, lens, B = c["d"], c["osc"], c["sc"], c["lens"], c["B"]
+    wh, wl = _split_ref(c["w"], sc)
+    conv = lambda a, ww: torch.nn.functional.conv1d(a.double().transpose(1, 2), ww.double(), padding=d, dilation=d).transpose(1, 2)
+    z = (conv(c["yh"], wl) + conv(c["yh"], wh)) * osc + c["E"].double()
+    g_ref = (torch.sigmoid(z[..., :C]) * torch.tanh(z[..., C:])).float()
+    for b in range(B):
+        g_ref[b, lens[b]:] = 0
+    return g_ref
+
+
+def _stream_ref(c, g16):
+    """x' from the fp16 gate outputs the kernel itself produced (so that the projection is checked on its own operands)"""
+    osc, sc, lens, B = c["osc"], c["sc"], c["lens"], c["B"]
+    woh, wol = (t.double() for t in _split_ref(c["wo"][:C, :, 0], sc))
+    gh = g16.double()
+    proj = (gh @ wol.t() + gh @ woh.t()) * osc
+    x_in = (c["yh"] + c["yl"]) - c["cb"]
+    y_ref = ((x_in.double() + (proj + c["bo"].double())) * (0.5 ** 0.5)).float() + c["nb"]
+    for b in range(B):
+        y_ref[b, lens[b]:] = 0
+    return y_ref
+
+
+@pytest.mark.parametrize("B,T,lens,d", [(2, 300, [300, 190], 1), (3, 517, [517, 480, 5], 8), (1, 128, [128], 2), (2, 1000, [1000, 873], 4)])
+def test_layer512_matches_float64_of_the_same_terms(B, T, lens, d):
+    c = _case(B, T, lens, d, seed=T + d)
+    dev, Lyr = c["dev"], c["Lyr"]
+    Wg = L.layer512_pack_gate(c["Ws"])
+    Wr = L.layer512_pack_res(c["Wos"])
+    E512 = L.layer512_tile_addend(c["Eall"][..., 2 * C:], B=B, T=T, lde=Lyr * 2 * C)
+    GA = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.float16)
+    Yout = torch.full((B, T, 2 * C), 5.0, device=dev, dtype=torch.float16)
+    L.layer512(c["Yin"], Wg, E512, GA[..., 2 * C:], B=B, T=T, d=d, lens=c["lens"], Yout=Yout, Wr=Wr, bias_r=c["bo"], cur_bias=c["cb"], next_bias=c["nb"],
+               out_scale=c["osc"], ldg=2 * Lyr * C, g_bs=T * 2 * Lyr * C)
+    torch.cuda.synchronize()
+    gah, gal = L.split_planes(GA)
+    got = gah[..., C:2 * C]
+    g_ref = _reference(c)
+    eg = (got - g_ref).abs().max().item()
+    assert torch.all(gal == 7.0), "the gate output's second plane is not written"
+    assert torch.all(gah[..., :C] == 7.0) and torch.all(gah[..., 2 * C:] == 7.0), "the neighbouring layer slots are untouched"
+    assert eg <= 3e-4, eg           # one fp16 rounding of values in (-1, 1) + hardware exp / rcp
+    y_ref = _stream_ref(c, got)
+    y1h, y1l = L.split_planes(Yout)
+    ey = ((y1h + y1l) - y_ref).abs().max().item()
+    assert ey <= 1e-5, ey
+    assert torch.equal(y1h, (y1h + y1l).to(torch.float16).float()), "hi = RNE16(value): a true fp16 pair"
+    # gate-only form (the last layer): same G, no stream written
+    GA2 = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.float16)
+    L.layer512(c["Yin"], Wg, E512, GA2[..., 2 * C:], B=B, T=T, d=d, lens=c["lens"], out_scale=c["osc"], ldg=2 * Lyr * C, g_bs=T * 2 * Lyr * C)
+    assert torch.equal(GA.view(torch.int16), GA2.view(torch.int16))
+    # the two-launch form it replaces: generic gate kernel + RESX on the pair-only stream (in place)
+    GA3 = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.float16)
+    L.gemm_bf16(c["Yin"], c["Ws"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=c["lens"], E=c["Eall"][..., 2 * C:], lde=Lyr * 2 * C,
+                out=GA3[..., 2 * C:], ldc=2 * Lyr * C, c_bs=T * 2 * Lyr * C, lda=2 * C, split=2, out_scale=c["osc"])
+    Yp = c["Yin"].clone()
+    L.gemm_bf16(GA3[..., 2 * C:], c["Wos"], B=B, T=T, K=C, taps=(0,), N=C, Np=c["Wos"].shape[0], epi=L.HEPI_RESX, lens=c["lens"], bias=L.pack_bias(c["bo"]), X=None,
+                post_scale=0.5 ** 0.5, next_bias=c["nb"], Y=Yp, lda=2 * Lyr * C, a_bs=T * 2 * Lyr * C, split=2, out_scale=c["osc"], cur_bias=c["cb"])
+    g3 = L.split_planes(GA3)[0][..., C:2 * C]
+    y3h, y3l = L.split_planes(Yp)
+    dg = (got - g3).abs().max().item()
+    dy = ((y1h + y1l) - (y3h + y3l)).abs().max().item()
+    print(f"layer512 B={B} T={T} d={d}: G vs float64 {eg:.2e}, stream vs float64 {ey:.2e}; vs the two-launch form G {dg:.2e} stream {dy:.2e}")
+    assert dg <= 5e-4 and dy <= 2e-3   # a last-bit difference of a gate output is one fp16 ulp (2^-11 below 1); the projection spreads it
+    record_measurement("layer512_unit", B=B, T=T, d=d, G_vs_f64=eg, stream_vs_f64=ey, G_vs_two_launch=dg, stream_vs_two_launch=dy)
+
+
+def test_layer512_many_tiles_per_workgroup():
+    """more tiles than CUs: the persistent loop's region alternation, the next-tile DMA and the three barriers per tile"""
+    B, T = 6, 128 * 70 + 37
+    c = _case(B, T, [T, T - 1, 128 * 35, 4000, T - 129, 77], 2, seed=11)
+    dev, Lyr = c["dev"], c["Lyr"]
+    Wg, Wr = L.layer512_pack_gate(c["Ws"]), L.layer512_pack_res(c["Wos"])
+    E512 = L.layer512_tile_addend(c["Eall"][..., 2 * C:], B=B, T=T, lde=Lyr * 2 * C)
+    GA = torch.zeros((B, T, 2 * C), device=dev, dtype=torch.float16)
+    Yout = torch.zeros((B, T, 2 * C), device=dev, dtype=torch.float16)
+    L.layer512(c["Yin"], Wg, E512, GA, B=B, T=T, d=2, lens=c["lens"], Yout=Yout, Wr=Wr, bias_r=c["bo"], cur_bias=c["cb"], next_bias=c["nb"], out_scale=c["osc"])
+    got = L.split_planes(GA)[0]
+    eg = (got - _reference(c)).abs().max().item()
+    y1h, y1l = L.split_planes(Yout)
+    ey = ((y1h + y1l) - _stream_ref(c, got)).abs().max().item()
+    print(f"layer512 {B} x {T} ({B * ((T + 127) // 128)} tiles): G {eg:.2e} stream {ey:.2e}")
+    assert eg <= 3e-4 and ey <= 1e-5, (eg, ey)

@@ -1,0 +1,76 @@
+"""ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser) against the launch pair it replaces, at the BASELINE configs[3] shape.
+    python tools/kbench_layer512.py [--B 32] [--T 5625] [--iters 40]
+Every variant cycles through four addend slabs and alternates the two stream buffers, as the denoiser loop does."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stylesinger_amd import lib as L  # noqa: E402
+from tools.kbench import timeit  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=5625)
+    ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--which", default="all")
+    a = ap.parse_args()
+    d = torch.device("cuda:0")
+    B, T, C, NS = a.B, a.T, 256, 4
+    lens = torch.full((B,), T, device=d, dtype=torch.int32)
+    Y = [L.split_f16(torch.randn(B, T, C, device=d)), torch.empty(B, T, 2 * C, device=d, dtype=torch.float16)]
+    E = torch.randn(B, T, NS * 2 * C, device=d)
+    E512 = [L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C) for s in range(NS)]
+    GA = torch.empty(B, T, NS * 2 * C, device=d, dtype=torch.float16)
+    w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
+    Ws = L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=256.0)
+    wo = torch.randn(2 * C, C, 1, device=d) / math.sqrt(C)
+    Wos = L.split_f16(L.pack_conv_weight(wo), scale=256.0)
+    Wg, Wr = L.layer512_pack_gate(Ws), L.layer512_pack_res(Wos)
+    cb, nb, bo = (torch.randn(C, device=d) for _ in range(3))
+    bop = L.pack_bias(bo)
+    k = [0]
+    res = []
+    fl_gate = 2.0 * 2.0 * B * T * 3 * C * 2 * C
+    fl_res = 2.0 * 2.0 * B * T * C * C
+
+    def pair():
+        k[0] += 1
+        s = k[0] % NS
+        L.gemm_bf16(Y[0], Ws, B=B, T=T, K=C, taps=(-2, 0, 2), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, E=E[..., s * 2 * C:], lde=NS * 2 * C,
+                    out=GA[..., s * 2 * C:], ldc=NS * 2 * C, c_bs=T * NS * 2 * C, lda=2 * C, split=2, out_scale=1.0 / 256.0)
+        L.gemm_bf16(GA[..., s * 2 * C:], Wos, B=B, T=T, K=C, taps=(0,), N=C, Np=Wos.shape[0], epi=L.HEPI_RESX, lens=lens, bias=bop, X=None, post_scale=0.7071,
+                    next_bias=nb, Y=Y[0], lda=NS * 2 * C, a_bs=T * NS * 2 * C, split=2, out_scale=1.0 / 256.0, cur_bias=cb)
+
+    def gate_only_old():
+        k[0] += 1
+        s = k[0] % NS
+        L.gemm_bf16(Y[0], Ws, B=B, T=T, K=C, taps=(-2, 0, 2), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens, E=E[..., s * 2 * C:], lde=NS * 2 * C,
+                    out=GA[..., s * 2 * C:], ldc=NS * 2 * C, c_bs=T * NS * 2 * C, lda=2 * C, split=2, out_scale=1.0 / 256.0)
+
+    def fused():
+        k[0] += 1
+        s = k[0] % NS
+        L.layer512(Y[k[0] & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Yout=Y[(k[0] & 1) ^ 1], Wr=Wr, bias_r=bo, cur_bias=cb, next_bias=nb,
+                   ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+
+    def gate_only_new():
+        k[0] += 1
+        s = k[0] % NS
+        L.layer512(Y[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+
+    for name, fn, fl in (("gate128 + tile256 RESX (the launch pair)", pair, fl_gate + fl_res), ("gate128 alone", gate_only_old, fl_gate),
+                         ("layer512 fused (gate + residual projection)", fused, fl_gate + fl_res), ("layer512 gate only", gate_only_new, fl_gate)):
+        if a.which != "all" and a.which not in name:
+            continue
+        s = timeit(fn, a.iters)
+        print(f"{name:46s} {s * 1e6:9.1f} us  {fl / s / 1e12:7.1f} TF/s executed ({fl / s / 2.5e15 * 100:4.1f}% of the fp16 peak)")
+
+
+if __name__ == "__main__":
+    main()
