@@ -343,33 +343,43 @@ int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
  * gate output stays in LDS as the residual projection's operand and leaves the CU once (G, the skip GEMM's operand); persistent workgroups,
  * weight fragments streamed L2 -> registers in the order ss_layer512_pack_gate / _pack_res lay them out, the conditioner addend in the
  * accumulator order of ss_layer512_tile_addend. Same arithmetic contract as ss_gemm_bf16 with split = 2 (results equal up to the fp32
- * summation order). The stream is DOUBLE BUFFERED: Yout must differ from Yin (a tile reads halo rows its neighbours rewrite).
- * Yout == NULL: gate only (the last layer: its residual stream is never read). */
+ * summation order).
+ * The residual stream x + dstep_l lives in a layout of its own, written by ss_layer512_entry and by this launch only:
+ *   H  fp16 [B][T][ldh]: the hi term as plain rows (the conv's operand). DOUBLE BUFFERED: Hout must differ from Hin (a tile reads halo rows its
+ *      neighbours rewrite);
+ *   P  the (hi, lo) fp16 pair in accumulator order, ss_layer512_stream_bytes(B, T) bytes, updated in place:
+ *      [tile = b * ceil(T / 128) + t / 128][wave 8][m 4][q 4][lane 64] x 16 bytes {hi01, hi23, lo01, lo23}; lane (l31, lh) of (wave, m, q)
+ *      holds channels 32 wave + 8 q + 4 lh .. + 3 of row 32 m + l31 of the tile.
+ * Hout == NULL: gate only (the last layer: its residual stream is never read); P and Wr are then unused. */
 typedef struct ss_layer512_args {
-  const uint16_t* Yin;      /* fp16 pair stream [B][T][ldy] = x + dstep_l (pairs interleaved by 32; only the hi plane feeds the conv) */
-  int64_t yin_batch_stride; /* elements */
-  int32_t ldy;              /* elements, >= 512, multiple of 8; also the row stride of Yout */
+  const uint16_t* Hin;      /* fp16 [B][T][ldh] = hi term of x + dstep_l */
+  int64_t h_batch_stride;   /* elements; the same for Hout */
+  int32_t ldh;              /* elements, >= 256, multiple of 8; also the row stride of Hout */
   int32_t d;                /* dilation, 1..8: taps (-d, 0, d) */
-  uint16_t* Yout;           /* pair(x' + next_bias), or NULL */
-  int64_t yout_batch_stride;
+  uint16_t* Hout;           /* hi term of x' + next_bias, or NULL */
+  void* P;                  /* pair stream, read and rewritten in place */
   const int32_t* lens;
   int32_t B, T;
   const uint16_t* Wg;       /* ss_layer512_pack_gate of the layer's ss_split_f16 dilated-conv pack (786 432 elements) */
   const uint16_t* Wr;       /* ss_layer512_pack_res of the residual half of the ss_split_f16 output-projection pack (131 072 elements) */
   const float* E512;        /* ss_layer512_tile_addend of this layer's 512 addend columns: ss_layer512_addend_floats(B, T) floats */
-  uint16_t* G;              /* gate output fp16 [B][T][ldg], hi slots of the pair layout (the second plane is not written) */
+  uint16_t* G;              /* gate output fp16 [B][T][ldg], hi slots of ss_gemm_bf16's pair layout (the second plane is not written) */
   int64_t g_batch_stride;
   int32_t ldg;
-  int32_t mask_rows;        /* rows >= lens[b]: G = 0, Yout = 0 */
+  int32_t mask_rows;        /* rows >= lens[b]: G = 0, stream = 0 */
   const float* bias_r;      /* [256] residual half of the output-projection bias, or NULL */
-  const float* cur_bias;    /* [256] dstep_l: Yin = x + cur_bias */
+  const float* cur_bias;    /* [256] dstep_l: the stream holds x + cur_bias */
   const float* next_bias;   /* [256] dstep_{l+1}, or NULL */
   float out_scale;          /* 2^-s of the weight packs */
   float post_scale;         /* 1 / sqrt(2) */
 } ss_layer512_args;
 int ss_layer512(const ss_layer512_args* args, void* stream);
 /* 1 if the shape fits the kernel's fixed geometry and fills the chip (>= 4 rounds of 128-row tiles per CU) */
-int ss_layer512_ok(int B, int T, int C, int d_max, int ldy, int ldg);
+int ss_layer512_ok(int B, int T, int C, int d_max, int ldh, int ldg);
+/* stack entry: X fp32 [B][T][ldx] + bias (dstep_0; NULL = none) -> H and P as above; rows >= lens[b] zero */
+int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, int ldh,
+                      int64_t h_batch_stride, void* P, int B, int T, void* stream);
+int64_t ss_layer512_stream_bytes(int B, int T);
 int64_t ss_layer512_addend_floats(int B, int T);
 /* E [B][T][lde] (the layer's 512 packed addend columns start at E) -> the tiled slab the kernel reads (once per forward and layer) */
 int ss_layer512_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* out, int B, int T, void* stream);

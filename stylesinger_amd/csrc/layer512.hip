@@ -18,7 +18,11 @@
 //     epilogue reads / writes the stream's (hi, lo) fp16 pairs as 8-byte vectors straight from the accumulators (no staging pass).
 //   * Persistent workgroups (one per CU, 144 KB of LDS = two 72 KB regions): region r holds A(tile i), then G(tile i) over it; the A tile of
 //     tile i + 1 lands in the other region while tile i's epilogues run. Three barriers per tile.
-//   * The stream is double buffered in HBM (Yin -> Yout): a tile reads 8 halo rows of its neighbours, which another workgroup rewrites.
+//   * The residual stream has a layout of its own (nothing but this kernel and ss_layer512_entry touches it): H = the hi plane as plain rows
+//     [B][T][256] fp16 - what the conv's DMA fetches - and P = the (hi, lo) fp16 PAIR in accumulator order (16 bytes per lane = 4 channels of
+//     both planes; 1 KB per wave instruction) for the epilogue's read-modify-write. H is double buffered (Hin -> Hout): a tile reads 8 halo
+//     rows of its neighbours, which another workgroup rewrites; P is updated in place. (The first version read and wrote the pair layout of
+//     ss_gemm_bf16 as 8-byte vectors, 32 rows per instruction: the epilogue took 165 us per launch against the projection launch's 129.)
 // Arithmetic contract = ss_gemm_bf16 with split = 2: a * hi + a * lo of fp16 terms (weights = pairs of w * 2^s), fp32 accumulation scaled by
 // out_scale; G = fp16(g) in the hi slots of the pair layout; the stream a true fp16 pair. Results equal those of the two-launch form up to the
 // fp32 summation order (tests/test_gpu_layer512.py: both against float64 of the same terms).
@@ -48,6 +52,7 @@ constexpr int RSTEPS = 16;                 // K = 256 of the residual projection
 constexpr int WR_STEP = 2048;              // (hi, lo) x 1 KB
 constexpr int WR_WAVE = RSTEPS * WR_STEP;  // 32 768 B per wave
 constexpr int E_TILE = BM * 512 * 4;       // 262 144 B of tiled addend per tile
+constexpr int P_TILE = BM * 256 * 4;       // 131 072 B of the pair stream per tile
 constexpr int NRING = 3;                   // weight fragments of NRING - 1 k-steps in flight
 
 template <int N>
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int d = a.d;
-  const int ldy2 = a.ldy * 2;   // bytes per stream row
+  const int ldh2 = a.ldh * 2;   // bytes per row of the hi plane
 
   const __amdgpu_buffer_rsrc_t rsrc_wg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Wg + (int64_t)wave * WG_WAVE), 0, WG_WAVE, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(FUSE ? (const char*)a.Wr + (int64_t)wave * WR_WAVE : (const char*)a.Wg), 0,
@@ -95,20 +100,19 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     t0 = (tile - b * tiles_per_item) * BM;
   };
   // ---- DMA of an activation tile: 72 pieces of 2 rows; wave w issues pieces w + 8 j (j < 9). Lane i of piece p lands at (row 2 p + (i >> 5),
-  // physical slot i & 31) and fetches logical slot (i & 31) ^ (row & 15) = channels 8 s .. of the HI plane: chunk s >> 2, bytes 16 (s & 3) of
-  // its 128-byte pair line. 16 j more rows leave the swizzle unchanged. Rows outside [0, len) are out of range: the DMA writes zeros (the
-  // conv's padding).
+  // physical slot i & 31) and fetches logical slot (i & 31) ^ (row & 15) = channels 8 s .. + 7 of that row of H. 16 j more rows leave the
+  // swizzle unchanged. Rows outside [0, len) are out of range: the DMA writes zeros (the conv's padding).
   auto dma_tile = [&](int tile, char* region, int lane) {
     int b, t0;
     tile_coords(tile, b, t0);
     const int len = ss_uniform_len(a.lens, b, a.T);
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(a.Yin + (int64_t)b * a.yin_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * ldy2), 0x00020000);
+        uniform_ptr(a.Hin + (int64_t)b * a.h_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * ldh2), 0x00020000);
     const int dma_row = 2 * wave + (lane >> 5);
     const int dma_slot = (lane & 31) ^ (dma_row & 15);
-    const int voff = (t0 - HALO + dma_row) * ldy2 + (dma_slot >> 2) * 128 + (dma_slot & 3) * 16;
+    const int voff = (t0 - HALO + dma_row) * ldh2 + dma_slot * 16;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) glds16(rsrc_a, region + (wave + 8 * j) * 1024, voff + 16 * j * ldy2, 0);
+    for (int j = 0; j < 9; ++j) glds16(rsrc_a, region + (wave + 8 * j) * 1024, voff + 16 * j * ldh2, 0);
   };
 
   const float L2E = 1.44269504088896340736f;
@@ -202,9 +206,22 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
     if (tile + (int)gridDim.x < n_tiles) dma_tile(tile + gridDim.x, Rn, lane);
     const float m0 = -L2E, m1 = -2.0f * L2E;
+    // the stream's pairs of this tile (accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
+    // dead so that they fly under the rest of this epilogue, [B3] and the G pass
+    [[maybe_unused]] u32x4 pv[4][4];
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (int64_t)wave * (P_TILE / 8) : (const char*)a.Wg), 0, FUSE ? P_TILE / 8 : 0, 0x00020000);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (m + 1 < 4) load_e(ev[(m + 1) & 1], m + 1);
+      if constexpr (FUSE) {
+        if (m == 2) {
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pv[mm][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, (mm * 4 + q) * 1024, 0);
+        }
+      }
       const bool pad = t0 + 32 * m + l31 >= row_lim;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -265,13 +282,13 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 #pragma unroll
       for (int s = 0; s < NRING - 1; ++s) load_wr(wr[s], s);
       read_g(gf[0], 0);
-      // per-channel constants of this lane's 16 channels 32 w + 8 q + 4 lh + e
-      f32x4 bs[4], cb[4], nb[4];
+      // per-channel constants of this lane's 16 channels 32 w + 8 q + 4 lh + e: kb = b - cur_bias, nb = next_bias
+      f32x4 kb[4], nb[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = 32 * wave + 8 * q + 4 * lh;
-        bs[q] = a.bias_r ? *reinterpret_cast<const f32x4*>(a.bias_r + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        cb[q] = *reinterpret_cast<const f32x4*>(a.cur_bias + c0);
+        const f32x4 bsq = a.bias_r ? *reinterpret_cast<const f32x4*>(a.bias_r + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        kb[q] = bsq - *reinterpret_cast<const f32x4*>(a.cur_bias + c0);
         nb[q] = a.next_bias ? *reinterpret_cast<const f32x4*>(a.next_bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       auto rstep = [&](auto stag) {
@@ -286,44 +303,37 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       };
       unrolled_steps(rstep, std::make_integer_sequence<int, RSTEPS>{});
 
-      // ---- stream update on the (hi, lo) fp16 pairs: x = hi + lo - cur_bias ; x' = (x + acc * out_scale + b) * post_scale ; Y' = pair(x' + next_bias)
-      const __amdgpu_buffer_rsrc_t rsrc_yi = __builtin_amdgcn_make_buffer_rsrc(
-          uniform_ptr(a.Yin + (int64_t)b * a.yin_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * ldy2)), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rsrc_yo = __builtin_amdgcn_make_buffer_rsrc(
-          uniform_ptr(a.Yout + (int64_t)b * a.yout_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * ldy2)), 0x00020000);
+      // ---- stream update on the (hi, lo) fp16 pairs: x = hi + lo - cur_bias ; x' = (x + acc * out_scale + b) * post_scale ; pair(x' + next_bias).
+      // P in place (16 bytes per lane, 1 KB per instruction); the new hi plane also goes to Hout's rows (8 bytes per lane: the next layer's conv operand)
+      const __amdgpu_buffer_rsrc_t rsrc_ho = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.Hout + (int64_t)b * a.h_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * ldh2)), 0x00020000);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int grow = t0 + 32 * m + l31;
         const bool pad = grow >= row_lim;
-        const int yo = grow * ldy2 + wave * 128 + 8 * lh;   // + 16 q (+ 64 for the lo plane)
-        u32x2 hv[4], lv[4];
+        const int ho = grow * ldh2 + wave * 64 + 8 * lh;   // + 16 q
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          hv[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_yi, yo + 16 * q, 0, 0));
-          lv[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_yi, yo + 16 * q + 64, 0, 0));
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          u32x2 ho, lo;
+          u32x4 po;
 #pragma unroll
           for (int e2 = 0; e2 < 2; ++e2) {
             uint32_t hp = 0, lp = 0;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const int e = 2 * e2 + k;
-              const float hf = ss_t2f_packed<true>(hv[q][e2], k), mf = ss_t2f_packed<true>(lv[q][e2], k);
-              const float xn = (((hf + mf) - cb[q][e]) + fmaf(acc2[m][4 * q + e], a.out_scale, bs[q][e])) * a.post_scale;
+              const float hf = ss_t2f_packed<true>(pv[m][q][e2], k), mf = ss_t2f_packed<true>(pv[m][q][2 + e2], k);
+              const float xn = ((hf + mf) + fmaf(acc2[m][4 * q + e], a.out_scale, kb[q][e])) * a.post_scale;
               const float yv = pad ? 0.f : xn + nb[q][e];
               const uint16_t yh = ss_f2t<true>(yv);
               const uint16_t yl = ss_f2t<true>(yv - ss_t2f<true>(yh));
               hp |= (uint32_t)yh << (16 * k);
               lp |= (uint32_t)yl << (16 * k);
             }
-            ho[e2] = hp;
-            lo[e2] = lp;
+            po[e2] = hp;
+            po[2 + e2] = lp;
           }
-          __builtin_amdgcn_raw_buffer_store_b64(ho, rsrc_yo, yo + 16 * q, 0, 0);   // rows >= T: out of range, dropped
-          __builtin_amdgcn_raw_buffer_store_b64(lo, rsrc_yo, yo + 16 * q + 64, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(po, rsrc_p, w_voff, (m * 4 + q) * 1024, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{po[0], po[1]}, rsrc_ho, ho + 16 * q, 0, 0);   // rows >= T: out of range, dropped
         }
       }
     }
@@ -375,7 +385,52 @@ __global__ void tile_addend_kernel(const float* __restrict__ E, int lde, int64_t
   *reinterpret_cast<float4*>(out + i * 4) = v;
 }
 
+// stack entry: X fp32 [B][T][ldx] + bias -> the stream's two forms: H rows (hi plane, fp16 [B][T][ldh]) and P (pair, accumulator order:
+// [tile][wave 8][m 4][q 4][lane 64] x {hi01, hi23, lo01, lo23}); lane (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of
+// row 32 m + l31. Rows >= lens[b] are zero.
+__global__ void entry_kernel(const float* __restrict__ X, int ldx, int64_t x_batch_stride, const float* __restrict__ bias, const int32_t* __restrict__ lens,
+                             uint16_t* __restrict__ H, int ldh, int64_t h_batch_stride, uint4* __restrict__ P, int T, int tiles_per_item, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte P entry each
+  if (i >= n) return;
+  const int lane = (int)(i & 63), q = (int)(i >> 6) & 3, m = (int)(i >> 8) & 3, w = (int)(i >> 10) & 7;
+  const int64_t tile = i >> 13;
+  const int b = (int)(tile / tiles_per_item), t = (int)(tile % tiles_per_item) * BM + 32 * m + (lane & 31);
+  const int c0 = 32 * w + 8 * q + 4 * (lane >> 5);
+  const int len = lens ? min(max(lens[b], 0), T) : T;
+  uint32_t hp[2] = {0, 0}, lp[2] = {0, 0};
+  if (t < len) {
+    const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)b * x_batch_stride + (int64_t)t * ldx + c0);
+    const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float v[4] = {x.x + bb.x, x.y + bb.y, x.z + bb.z, x.w + bb.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint16_t yh = ss_f2t<true>(v[e]);
+      const uint16_t yl = ss_f2t<true>(v[e] - ss_t2f<true>(yh));
+      hp[e >> 1] |= (uint32_t)yh << (16 * (e & 1));
+      lp[e >> 1] |= (uint32_t)yl << (16 * (e & 1));
+    }
+  }
+  P[i] = make_uint4(hp[0], hp[1], lp[0], lp[1]);
+  if (t < T) *reinterpret_cast<uint2*>(H + (int64_t)b * h_batch_stride + (int64_t)t * ldh + c0) = make_uint2(hp[0], hp[1]);
+}
+
 }  // namespace
+
+extern "C" int64_t ss_layer512_stream_bytes(int B, int T) { return (int64_t)B * ss_cdiv(T, BM) * P_TILE; }
+
+extern "C" int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, int ldh,
+                                 int64_t h_batch_stride, void* P, int B, int T, void* stream) {
+  SS_CHECK_ARG(X && H && P && B > 0 && T > 0 && ldx >= 256 && (ldx % 4) == 0 && (x_batch_stride % 4) == 0 && ldh >= 256 && (ldh % 8) == 0 && (h_batch_stride % 8) == 0,
+               "ss_layer512_entry: X [B][T][ldx >= 256, %% 4], H [B][T][ldh >= 256, %% 8]");
+  SS_CHECK_ARG((((uintptr_t)X) & 15) == 0 && (((uintptr_t)H) & 15) == 0 && (((uintptr_t)P) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0),
+               "ss_layer512_entry: X / H / P / bias must be 16-byte aligned");
+  const int tpi = ss_cdiv(T, BM);
+  const int64_t n = (int64_t)B * tpi * (P_TILE / 16);
+  hipLaunchKernelGGL(entry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, x_batch_stride, bias, lens, H, ldh, h_batch_stride,
+                     (uint4*)P, T, tpi, n);
+  SS_CHECK_LAUNCH("ss_layer512_entry");
+  return SS_OK;
+}
 
 extern "C" int64_t ss_layer512_addend_floats(int B, int T) { return (int64_t)B * ss_cdiv(T, BM) * (E_TILE / 4); }
 
@@ -405,28 +460,28 @@ extern "C" int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, void
 
 // 1 if the fused layer launch can take this shape and is expected to pay: C = 256 (the kernel's fixed geometry), dilation <= 8, 32-bit offsets,
 // and at least four rounds of 128-row tiles per CU (below that the single-round kernels win)
-extern "C" int ss_layer512_ok(int B, int T, int C, int d_max, int ldy, int ldg) {
+extern "C" int ss_layer512_ok(int B, int T, int C, int d_max, int ldh, int ldg) {
   if (C != 256 || d_max < 1 || d_max > HALO || B < 1 || T < 1) return 0;
-  if (ldy < 512 || (ldy % 8) != 0 || ldg < 512 || (ldg % 8) != 0) return 0;
-  if ((int64_t)T * ldy * 2 >= (1ll << 31) || (int64_t)T * ldg * 2 >= (1ll << 31)) return 0;
+  if (ldh < 256 || (ldh % 8) != 0 || ldg < 512 || (ldg % 8) != 0) return 0;
+  if ((int64_t)T * ldh * 2 >= (1ll << 31) || (int64_t)T * ldg * 2 >= (1ll << 31)) return 0;
   return (long)ss_cdiv(T, BM) * B >= 4l * ss_n_cu() ? 1 : 0;
 }
 
 extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
   SS_CHECK_ARG(args != nullptr, "ss_layer512: null args");
   const ss_layer512_args& a = *args;
-  SS_CHECK_ARG(a.Yin && a.Wg && a.E512 && a.G, "ss_layer512: null Yin / Wg / E512 / G");
+  SS_CHECK_ARG(a.Hin && a.Wg && a.E512 && a.G, "ss_layer512: null Hin / Wg / E512 / G");
   SS_CHECK_ARG(a.B > 0 && a.T > 0 && a.d >= 1 && a.d <= HALO, "ss_layer512: B, T > 0 and 1 <= d <= 8");
-  SS_CHECK_ARG(a.ldy >= 512 && (a.ldy % 8) == 0 && a.ldg >= 512 && (a.ldg % 8) == 0 && (a.yin_batch_stride % 8) == 0 && (a.g_batch_stride % 8) == 0,
-               "ss_layer512: ldy / ldg >= 512 and multiples of 8 (pair layout of 256 channels), batch strides multiples of 8");
-  SS_CHECK_ARG((int64_t)a.T * a.ldy * 2 < (1ll << 31) && (int64_t)a.T * a.ldg * 2 < (1ll << 31), "ss_layer512: item too large for 32-bit offsets");
-  SS_CHECK_ARG((((uintptr_t)a.Yin) & 15) == 0 && (((uintptr_t)a.Wg) & 15) == 0 && (((uintptr_t)a.E512) & 15) == 0 && (((uintptr_t)a.G) & 15) == 0,
-               "ss_layer512: Yin / Wg / E512 / G must be 16-byte aligned");
+  SS_CHECK_ARG(a.ldh >= 256 && (a.ldh % 8) == 0 && a.ldg >= 512 && (a.ldg % 8) == 0 && (a.h_batch_stride % 8) == 0 && (a.g_batch_stride % 8) == 0,
+               "ss_layer512: ldh >= 256, ldg >= 512 (pair layout of 256 channels), both multiples of 8, batch strides multiples of 8");
+  SS_CHECK_ARG((int64_t)a.T * a.ldh * 2 < (1ll << 31) && (int64_t)a.T * a.ldg * 2 < (1ll << 31), "ss_layer512: item too large for 32-bit offsets");
+  SS_CHECK_ARG((((uintptr_t)a.Hin) & 15) == 0 && (((uintptr_t)a.Wg) & 15) == 0 && (((uintptr_t)a.E512) & 15) == 0 && (((uintptr_t)a.G) & 15) == 0,
+               "ss_layer512: Hin / Wg / E512 / G must be 16-byte aligned");
   SS_CHECK_ARG(a.out_scale > 0.f && a.out_scale <= 1.f, "ss_layer512: 0 < out_scale <= 1");
-  const bool fuse = a.Yout != nullptr;
+  const bool fuse = a.Hout != nullptr;
   if (fuse) {
-    SS_CHECK_ARG(a.Wr && a.cur_bias && a.Yout != a.Yin && (a.yout_batch_stride % 8) == 0 && (((uintptr_t)a.Yout) & 15) == 0 && (((uintptr_t)a.Wr) & 15) == 0,
-                 "ss_layer512: the fused form needs Wr, cur_bias and a Yout buffer different from Yin (tiles read their neighbours' halo rows)");
+    SS_CHECK_ARG(a.Wr && a.P && a.cur_bias && a.Hout != a.Hin && (((uintptr_t)a.Hout) & 15) == 0 && (((uintptr_t)a.Wr) & 15) == 0 && (((uintptr_t)a.P) & 15) == 0,
+                 "ss_layer512: the fused form needs Wr, P, cur_bias and an Hout buffer different from Hin (tiles read their neighbours' halo rows)");
     SS_CHECK_ARG((((uintptr_t)a.cur_bias) & 15) == 0 && (!a.bias_r || (((uintptr_t)a.bias_r) & 15) == 0) && (!a.next_bias || (((uintptr_t)a.next_bias) & 15) == 0),
                  "ss_layer512: bias vectors must be 16-byte aligned");
   }

@@ -40,8 +40,11 @@ def _case(B, T, lens_list, d, seed):
     y0 = x + cb
     for b in range(B):
         y0[b, lens[b]:] = 0
-    Yin = L.split_f16(y0)                                   # [B,T,2C] pair stream = x + cur_bias
+    Yin = L.split_f16(y0)                                   # [B,T,2C] pair stream = x + cur_bias in ss_gemm_bf16's layout (the two-launch form)
     yh, yl = L.split_planes(Yin)
+    H, P = L.layer512_entry(x, cb, B=B, T=T, lens=lens)     # the same stream in ss_layer512's layout: hi rows + pairs in accumulator order
+    ph, pl = L.layer512_stream_values(P, B=B, T=T)
+    assert torch.equal(H.float(), yh) and torch.equal(ph, yh) and torch.equal(pl, yl), "ss_layer512_entry = ss_split_f16 in the other layout"
     w = (torch.randn(2 * C, C, 3, generator=g) / (3 * C) ** 0.5).to(dev)
     Ws = L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=sc)     # [512][3*256*2]
     wo = (torch.randn(2 * C, C, 1, generator=g) / C ** 0.5).to(dev)           # output_projection: residual half = rows [0, C)
@@ -50,7 +53,7 @@ def _case(B, T, lens_list, d, seed):
     Lyr = 3
     Eall = torch.randn(B, T, Lyr * 2 * C, generator=g).to(dev)               # the layer's slab sits in the middle of a wider row
     Eall[..., 2 * C:4 * C] = _pack_e(E)
-    return dict(dev=dev, B=B, T=T, lens=lens, d=d, sc=sc, osc=osc, x=x, cb=cb, nb=nb, bo=bo, Yin=Yin, yh=yh, yl=yl, w=w, Ws=Ws, wo=wo, Wos=Wos, E=E,
+    return dict(dev=dev, B=B, T=T, lens=lens, d=d, sc=sc, osc=osc, x=x, cb=cb, nb=nb, bo=bo, Yin=Yin, H=H, P=P, yh=yh, yl=yl, w=w, Ws=Ws, wo=wo, Wos=Wos, E=E,
                 Eall=Eall, Lyr=Lyr)
 
 
@@ -87,8 +90,9 @@ def test_layer512_matches_float64_of_the_same_terms(B, T, lens, d):
     Wr = L.layer512_pack_res(c["Wos"])
     E512 = L.layer512_tile_addend(c["Eall"][..., 2 * C:], B=B, T=T, lde=Lyr * 2 * C)
     GA = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.float16)
-    Yout = torch.full((B, T, 2 * C), 5.0, device=dev, dtype=torch.float16)
-    L.layer512(c["Yin"], Wg, E512, GA[..., 2 * C:], B=B, T=T, d=d, lens=c["lens"], Yout=Yout, Wr=Wr, bias_r=c["bo"], cur_bias=c["cb"], next_bias=c["nb"],
+    Hout = torch.full((B, T, C), 5.0, device=dev, dtype=torch.float16)
+    P = c["P"].clone()
+    L.layer512(c["H"], Wg, E512, GA[..., 2 * C:], B=B, T=T, d=d, lens=c["lens"], Hout=Hout, P=P, Wr=Wr, bias_r=c["bo"], cur_bias=c["cb"], next_bias=c["nb"],
                out_scale=c["osc"], ldg=2 * Lyr * C, g_bs=T * 2 * Lyr * C)
     torch.cuda.synchronize()
     gah, gal = L.split_planes(GA)
@@ -99,13 +103,14 @@ def test_layer512_matches_float64_of_the_same_terms(B, T, lens, d):
     assert torch.all(gah[..., :C] == 7.0) and torch.all(gah[..., 2 * C:] == 7.0), "the neighbouring layer slots are untouched"
     assert eg <= 3e-4, eg           # one fp16 rounding of values in (-1, 1) + hardware exp / rcp
     y_ref = _stream_ref(c, got)
-    y1h, y1l = L.split_planes(Yout)
+    y1h, y1l = L.layer512_stream_values(P, B=B, T=T)
     ey = ((y1h + y1l) - y_ref).abs().max().item()
     assert ey <= 1e-5, ey
-    assert torch.equal(y1h, (y1h + y1l).to(torch.float16).float()), "hi = RNE16(value): a true fp16 pair"
+    assert torch.equal(Hout.float(), y1h), "Hout = the hi plane of the new pairs"
+    assert (y1l.abs() <= y1h.abs() * 2.0 ** -11 + 2.0 ** -24).all(), "lo = the rounding residue of hi"
     # gate-only form (the last layer): same G, no stream written
     GA2 = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.float16)
-    L.layer512(c["Yin"], Wg, E512, GA2[..., 2 * C:], B=B, T=T, d=d, lens=c["lens"], out_scale=c["osc"], ldg=2 * Lyr * C, g_bs=T * 2 * Lyr * C)
+    L.layer512(c["H"], Wg, E512, GA2[..., 2 * C:], B=B, T=T, d=d, lens=c["lens"], out_scale=c["osc"], ldg=2 * Lyr * C, g_bs=T * 2 * Lyr * C)
     assert torch.equal(GA.view(torch.int16), GA2.view(torch.int16))
     # the two-launch form it replaces: generic gate kernel + RESX on the pair-only stream (in place)
     GA3 = torch.full((B, T, 2 * Lyr * C), 7.0, device=dev, dtype=torch.float16)
@@ -131,11 +136,13 @@ def test_layer512_many_tiles_per_workgroup():
     Wg, Wr = L.layer512_pack_gate(c["Ws"]), L.layer512_pack_res(c["Wos"])
     E512 = L.layer512_tile_addend(c["Eall"][..., 2 * C:], B=B, T=T, lde=Lyr * 2 * C)
     GA = torch.zeros((B, T, 2 * C), device=dev, dtype=torch.float16)
-    Yout = torch.zeros((B, T, 2 * C), device=dev, dtype=torch.float16)
-    L.layer512(c["Yin"], Wg, E512, GA, B=B, T=T, d=2, lens=c["lens"], Yout=Yout, Wr=Wr, bias_r=c["bo"], cur_bias=c["cb"], next_bias=c["nb"], out_scale=c["osc"])
+    Hout = torch.zeros((B, T, C), device=dev, dtype=torch.float16)
+    P = c["P"].clone()
+    L.layer512(c["H"], Wg, E512, GA, B=B, T=T, d=2, lens=c["lens"], Hout=Hout, P=P, Wr=Wr, bias_r=c["bo"], cur_bias=c["cb"], next_bias=c["nb"], out_scale=c["osc"])
     got = L.split_planes(GA)[0]
     eg = (got - _reference(c)).abs().max().item()
-    y1h, y1l = L.split_planes(Yout)
+    y1h, y1l = L.layer512_stream_values(P, B=B, T=T)
     ey = ((y1h + y1l) - _stream_ref(c, got)).abs().max().item()
     print(f"layer512 {B} x {T} ({B * ((T + 127) // 128)} tiles): G {eg:.2e} stream {ey:.2e}")
     assert eg <= 3e-4 and ey <= 1e-5, (eg, ey)
+    assert torch.equal(Hout.float(), y1h)

@@ -23,7 +23,10 @@ def main():
     d = torch.device("cuda:0")
     B, T, C, NS = a.B, a.T, 256, 4
     lens = torch.full((B,), T, device=d, dtype=torch.int32)
-    Y = [L.split_f16(torch.randn(B, T, C, device=d)), torch.empty(B, T, 2 * C, device=d, dtype=torch.float16)]
+    X0 = torch.randn(B, T, C, device=d)
+    Y = [L.split_f16(X0)]
+    H0, P = L.layer512_entry(X0, None, B=B, T=T, lens=lens)
+    H = [H0, torch.empty_like(H0)]
     E = torch.randn(B, T, NS * 2 * C, device=d)
     E512 = [L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C) for s in range(NS)]
     GA = torch.empty(B, T, NS * 2 * C, device=d, dtype=torch.float16)
@@ -56,16 +59,17 @@ def main():
     def fused():
         k[0] += 1
         s = k[0] % NS
-        L.layer512(Y[k[0] & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Yout=Y[(k[0] & 1) ^ 1], Wr=Wr, bias_r=bo, cur_bias=cb, next_bias=nb,
+        L.layer512(H[k[0] & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k[0] & 1) ^ 1], P=P, Wr=Wr, bias_r=bo, cur_bias=cb, next_bias=nb,
                    ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
 
     def gate_only_new():
         k[0] += 1
         s = k[0] % NS
-        L.layer512(Y[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+        L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
 
     for name, fn, fl in (("gate128 + tile256 RESX (the launch pair)", pair, fl_gate + fl_res), ("gate128 alone", gate_only_old, fl_gate),
-                         ("layer512 fused (gate + residual projection)", fused, fl_gate + fl_res), ("layer512 gate only", gate_only_new, fl_gate)):
+                         ("layer512 fused (gate + residual projection)", fused, fl_gate + fl_res), ("layer512 gate only", gate_only_new, fl_gate),
+                         ("layer512 entry (fp32 stream -> H rows + pairs)", lambda: L.layer512_entry(X0, cb, B=B, T=T, lens=lens), 0.0)):
         if a.which != "all" and a.which not in name:
             continue
         s = timeit(fn, a.iters)
