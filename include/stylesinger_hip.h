@@ -51,8 +51,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * "mel_tail" = 0|1 small launches (<= 8 frames per CU) run the mel sampler's output projection + update + next input projection as one launch;
  * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "q4_force" = 0|1 the
  * fp16q4 kernels (ss_gemm_bf16_gate128q / _tile256q) take any launch they can compute, not only those that fill the chip (default 0; the parity
- * tests run one 30 s item through them); "layer512" = 0|1 the fp16x2 mel stack as one ss_layer512 launch per layer when the shape qualifies
- * (default 1; 0 = the gate + residual-projection launch pair). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
+ * tests run one 30 s item through them); "layer512" = 0|1|2 the fp16x2 mel stack as one ss_layer512 launch per layer when the shape qualifies
+ * (default 1; 0 = the gate + residual-projection launch pair; 2 = also for launches that do not fill the chip: the parity tests run one item through it). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
  * forwards SS_* variables once at load). */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
@@ -374,7 +374,7 @@ typedef struct ss_layer512_args {
   float post_scale;         /* 1 / sqrt(2) */
 } ss_layer512_args;
 int ss_layer512(const ss_layer512_args* args, void* stream);
-/* 1 if the shape fits the kernel's fixed geometry and fills the chip (>= 4 rounds of 128-row tiles per CU) */
+/* 1 if the shape fits the kernel's fixed geometry and fills the chip (>= 4 rounds of 128-row tiles per CU; any size with the knob layer512 = 2) */
 int ss_layer512_ok(int B, int T, int C, int d_max, int ldh, int ldg);
 /* stack entry: X fp32 [B][T][ldx] + bias (dstep_0; NULL = none) -> H and P as above; rows >= lens[b] zero */
 int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, int ldh,

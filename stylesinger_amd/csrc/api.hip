@@ -32,7 +32,7 @@ const Knob* knobs(int* n) {
       {"res_tile", &g_ss_tuning.res_tile, ok_tile},    {"skip_tile", &g_ss_tuning.skip_tile, ok_tile}, {"htile", &g_ss_tuning.htile, ok_htile},
       {"wino_tn", &g_ss_tuning.wino_tn, ok_012},       {"wino_v1", &g_ss_tuning.wino_v1, ok_01},      {"voc_wino_max_mb", &g_ss_tuning.voc_wino_max_mb, ok_mb},
       {"e16", &g_ss_tuning.e16, ok_01},                {"mel_tail", &g_ss_tuning.mel_tail, ok_01},     {"gate128", &g_ss_tuning.gate128, ok_01},
-      {"q4_force", &g_ss_tuning.q4_force, ok_01},      {"layer512", &g_ss_tuning.layer512, ok_01},
+      {"q4_force", &g_ss_tuning.q4_force, ok_01},      {"layer512", &g_ss_tuning.layer512, ok_012},
   };
   *n = (int)(sizeof(k) / sizeof(k[0]));
   return k;

@@ -62,7 +62,8 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   voc_wino_max_mb: the vocoder's grouped-Winograd convs address an item with 32-bit byte offsets; items whose stage panel (+ halo) reaches
 //     this many MiB take the direct kernel instead (default 2048 = the real limit; tests lower it to force that fallback).
 //   layer512: 1 (default) = the fp16x2 mel stack runs ONE ss_layer512 launch per layer (gate + residual projection, G kept in LDS) when the
-//     net carries the fragment-order packs and ss_layer512_ok(B, T, ...) holds; 0 = the gate + residual-projection launch pair.
+//     net carries the fragment-order packs and ss_layer512_ok(B, T, ...) holds; 0 = the gate + residual-projection launch pair; 2 = also below the
+//     chip-filling size (parity tests).
 //   q4_force: 0 (default) = the fp16q4 kernels take only launches that fill the chip (their _ok rules); 1 = any launch they can compute (parity tests run
 //     one 30 s item through them).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;

@@ -32,6 +32,12 @@ struct WsLayout {
   uint16_t* Yh;     // [B*T][C]        x + dstep of the next layer (the dilated conv's operand)
   uint16_t* GAh;    // [B*T][L*C]      gate outputs of all layers
   uint16_t* condh;  // [B*T][cond_dim] conditioner
+  // fused-layer form of the fp16x2 stack (ss_layer512, one launch per layer): the stream as hi rows (double buffered) + pairs in accumulator
+  // order, and every layer's addend slab in the kernel's accumulator order; null when the stack runs as gate + projection launches
+  uint16_t* H512[2];  // [B*T][C] fp16
+  void* P512;         // ss_layer512_stream_bytes
+  float* E512;        // [L][ss_layer512_addend_floats]
+  int64_t e512_layer; // floats per layer
   int64_t bytes;
 };
 
@@ -44,6 +50,16 @@ inline bool smode(const ss_wavenet* net) { return net->mfma_split != 0; }
 inline bool hmode(const ss_wavenet* net) { return net->mfma_bf16 && net->w_dil_h[0] && net->w_skipall_h && (net->w_cond_h || smode(net)); }
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// the fp16x2 mel stack as ONE ss_layer512 launch per layer: the net carries the fragment-order packs of every layer, one weight group, C = 256,
+// dilations <= 8, and the launch fills the chip (ss_layer512_ok); knob "layer512"
+inline bool fused512(const ss_wavenet* net, int B, int T) {
+  if (!g_ss_tuning.layer512 || net->mfma_split != 2 || !hmode(net) || net->n_groups > 1 || net->C != 256 || !net->w_skipall_h) return false;
+  for (int l = 0; l < net->L; ++l)
+    if (!net->w_dil_f[l] || (l + 1 < net->L && !net->w_out_f[l])) return false;
+  const int dmax = 1 << ((net->L < net->dil_cycle ? net->L : net->dil_cycle) - 1);
+  return ss_layer512_ok(B, T, net->C, dmax, net->C, net->L * net->C * 2) != 0;
+}
 
 WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   WsLayout w;
@@ -85,6 +101,17 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.Yh = h ? (uint16_t*)take((rows * net->C * planes + 1) / 2) : nullptr;
   w.GAh = h ? (uint16_t*)take((rows * net->L * net->C * planes + 1) / 2) : nullptr;
   w.condh = (h && !smode(net)) ? (uint16_t*)take((rows * net->cond_dim + 1) / 2) : nullptr;
+  w.H512[0] = w.H512[1] = nullptr;
+  w.P512 = nullptr;
+  w.E512 = nullptr;
+  w.e512_layer = 0;
+  if (fused512(net, B, T)) {
+    w.H512[0] = (uint16_t*)take((rows * net->C + 1) / 2);
+    w.H512[1] = (uint16_t*)take((rows * net->C + 1) / 2);
+    w.P512 = take(ss_layer512_stream_bytes(B, T) / 4);
+    w.e512_layer = ss_layer512_addend_floats(B, T);
+    w.E512 = take(w.e512_layer * net->L);
+  }
   w.bytes = off;
   return w;
 }
@@ -165,6 +192,9 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
     a.bias_group_stride = net->gs_b_cond;
   }
   SS_PROPAGATE(ss_conv_gemm(&a, stream));
+  if (w.E512)   // fused-layer form: every layer's 512 addend columns in ss_layer512's accumulator order
+    for (int l = 0; l < net->L; ++l)
+      SS_PROPAGATE(ss_layer512_tile_addend(w.E + (int64_t)l * 2 * net->C, NE, (int64_t)T * NE, w.E512 + (int64_t)l * w.e512_layer, B, T, stream));
   for (int l = 0; l < net->L; ++l)
     if (w.E16[l])
       SS_PROPAGATE(ss_gate16_tile_addend(w.E + (int64_t)l * 2 * net->C, NE, (int64_t)T * NE, w.E16[l], B, T, 2 * net->C, 1 << (l % net->dil_cycle),
@@ -183,7 +213,35 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   const int C = net->C, L = net->L;
   const int NE = L * 2 * C;
   const int sp = smode(net) ? (net->mfma_split == 2 ? 2 : 1) : 0, pl = sp ? 2 : 1;   // split form; planes per 16-bit row
-  for (int l = 0; l < L; ++l) {
+  for (int l = 0; l < L && w.E512; ++l) {   // fused-layer form: gate + residual projection of layer l in one launch, G kept in LDS
+    ss_layer512_args f;
+    memset(&f, 0, sizeof(f));
+    f.Hin = w.H512[l & 1];
+    f.h_batch_stride = (int64_t)T * C;
+    f.ldh = C;
+    f.d = 1 << (l % net->dil_cycle);
+    f.lens = lens;
+    f.B = B;
+    f.T = T;
+    f.Wg = net->w_dil_f[l];
+    f.E512 = w.E512 + (int64_t)l * w.e512_layer;
+    f.G = w.GAh + (int64_t)l * C * pl;
+    f.g_batch_stride = (int64_t)T * L * C * pl;
+    f.ldg = L * C * pl;
+    f.mask_rows = 1;
+    f.out_scale = net->mfma_out_scale;
+    f.post_scale = 0.70710678118654752440f;
+    if (l + 1 < L) {   // the residual stream of the last layer is never read (net.py:120-127)
+      f.Hout = w.H512[(l & 1) ^ 1];
+      f.P = w.P512;
+      f.Wr = net->w_out_f[l];
+      f.bias_r = net->b_out[l];
+      f.cur_bias = net->dstep + ((int64_t)step * L + l) * C;
+      f.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
+    }
+    SS_PROPAGATE(ss_layer512(&f, stream));
+  }
+  for (int l = 0; l < L && !w.E512; ++l) {
     const int d = 1 << (l % net->dil_cycle);
     ss_gemm_bf16_args g = base_args_h(net, B, T, lens);
     g.A = w.Yh;
@@ -287,6 +345,9 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
 
 // Yh = bf16(X + dstep[step][0]) : the first layer's conv operand (bf16-in-HBM mode)
 int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
+  if (w.E512)
+    return ss_layer512_entry(w.X, net->C, (int64_t)T * net->C, net->dstep + (int64_t)step * net->L * net->C, lens, w.H512[0], net->C, (int64_t)T * net->C,
+                             w.P512, B, T, stream);
   if (net->mfma_split == 2)
     return ss_split_f16(w.X, net->dstep + (int64_t)step * net->L * net->C, 1.0f, w.Yh, B, T, net->C, net->C, 2 * net->C, lens,
                         net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);

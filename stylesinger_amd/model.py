@@ -335,6 +335,10 @@ class StyleSingerHIP(torch.nn.Module):
                 t[f"w_out_h.{l}"] = to_h(out.W)
                 if self.q4 and not f0 and C == 256:   # the fp4 lo plane in the lane order of ss_gemm_bf16_gate128q
                     t[f"w_dil_q.{l}"] = L.pack_gate_q4(dil.W, shift=self.FP16_WSHIFT)[0]
+                if self.f16 and not f0 and C == 256 and tuple(t[f"w_dil_h.{l}"].shape) == (512, 3 * 256 * 2):
+                    # the same (hi, lo) terms in the fragment order ss_layer512 streams (one launch per layer at many-round sizes)
+                    t[f"w_dil_f.{l}"] = L.layer512_pack_gate(t[f"w_dil_h.{l}"])
+                    t[f"w_out_f.{l}"] = L.layer512_pack_res(t[f"w_out_h.{l}"])
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
         if self.defer_skip:  # skip halves of all output projections side by side: [C][L*C], column l*C + ci
@@ -436,6 +440,10 @@ class StyleSingerHIP(torch.nn.Module):
             if "w_skipall_q" in packs[0]:
                 net.w_skipall_q, net.gs_w_skipall_q = place("w_skipall_q")
                 net.q_scale_z = 0.25   # gate outputs in (-1, 1)
+        if len(packs) == 1 and all(f"w_dil_f.{l}" in packs[0] for l in range(Lyr)):
+            for l in range(Lyr):
+                net.w_dil_f[l], _ = place(f"w_dil_f.{l}")
+                net.w_out_f[l], _ = place(f"w_out_f.{l}")
         net.skipall_folded = 1 if self.fold_skip else 0
         # schedule tables live on the host (the loop driver passes per-step scalars by value)
         def host(name):

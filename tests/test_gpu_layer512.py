@@ -146,3 +146,53 @@ def test_layer512_many_tiles_per_workgroup():
     print(f"layer512 {B} x {T} ({B * ((T + 127) // 128)} tiles): G {eg:.2e} stream {ey:.2e}")
     assert eg <= 3e-4 and ey <= 1e-5, (eg, ey)
     assert torch.equal(Hout.float(), y1h)
+
+
+# ---- the model on the fused-layer path, against the REAL reference --------------------------------------------------------------------------
+def _force512(v):
+    L.check(L.load().ss_set_tuning(b"layer512", v), "ss_set_tuning(layer512)")
+
+
+def _fwd(model, b, **kw):
+    return model(b["txt_tokens"], mel2ph=b.get("mel2ph"), spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
+                 ref_f0=b["ref_f0"], global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"], **kw)
+
+
+@pytest.mark.parametrize("golden,bar", [("acoustic_t32_mel1000", 6e-5), ("acoustic_t5625_mel1000", 6e-5)])
+def test_fp16x2_model_on_the_fused_layer_path_vs_the_real_reference(golden, bar):
+    """BASELINE configs[3]'s denoiser through ss_layer512 (forced: one item does not fill the chip) on the reference's own noise tape against the
+    REAL reference's fp32 output: the 1000-step T = 32 golden and the item as specified (T = 5625 x 1000 steps). Same bars as the two-launch form
+    (tests/test_gpu_round5.py, test_gpu_fp16x2.py); the two forms are also compared with each other."""
+    import os
+    from oracle import harness
+    from stylesinger_amd import synth
+    from stylesinger_amd.model import StyleSingerHIP
+    if not os.path.exists(os.path.join(harness.GOLD, golden + ".pt")):
+        pytest.fail(f"{golden}.pt is missing: run oracle/gen_golden.py in the build container")
+    case = harness.load_case(golden)
+    meta, gold = case["meta"], case["out"]
+    hp, sd, batch = harness.case_setup(meta)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(meta["tape_seed"]), meta["B"], meta["T"], meta["steps_f0"], meta["steps_mel"])
+    outs = {}
+    for knob in (2, 0):
+        _force512(knob)
+        try:
+            m = StyleSingerHIP(None, hparams=dict(hp, mfma_precision="fp16x2"))
+            m.load_state_dict(sd)
+            m.eval().to("cuda:0")
+            outs[knob] = _fwd(m, {k: v.cuda() for k, v in batch.items()}, noise=noise)
+            torch.cuda.synchronize()
+        finally:
+            _force512(1)
+    got = outs[2]
+    d = (got["mel_out"].cpu() - gold["mel_out"]).abs()
+    d2 = (outs[0]["mel_out"].cpu() - gold["mel_out"]).abs()
+    dd = (got["mel_out"] - outs[0]["mel_out"]).abs()
+    uv = int(((got["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).sum())
+    print(f"{golden}, fp16x2 on ss_layer512: mel L1 {d.mean().item():.3e} max {d.max().item():.3e} vs the real reference (two-launch form {d2.mean().item():.3e}); "
+          f"the two forms differ by {dd.mean().item():.3e}; voicing flips {uv}")
+    record_measurement(f"layer512_{golden}_fp16x2_vs_fp32_reference", mel_l1=d.mean().item(), mel_max=d.max().item(), voicing_flips=uv, pinned=True,
+                       north_star=1e-4, two_launch_mel_l1=d2.mean().item(), forms_differ_by=dd.mean().item())
+    assert torch.isfinite(got["mel_out"]).all() and uv == 0
+    assert dd.mean().item() > 0, "the forced run must not be the two-launch code path"
+    assert d.mean().item() <= bar, d.mean().item()

@@ -1,0 +1,74 @@
+"""Per-phase shader-clock timing of layer512_kernel (debug build with -DSS_L512_TRACE).
+Build in the container (only layer512.hip needs the flag; the other objects are the product's):
+    mkdir -p stylesinger_amd/_abl && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSS_L512_TRACE -c stylesinger_amd/csrc/layer512.hip -o /tmp/l512t.o && \
+    hipcc --offload-arch=gfx950 -shared -fPIC -o stylesinger_amd/_abl/libss_l512trace.so /tmp/l512t.o $(ls stylesinger_amd/_obj/*.o | grep -v layer512)
+Run on the GPU box:
+    SS_LIB_PATH=stylesinger_amd/_abl/libss_l512trace.so python tools/trace_layer512.py [--B 32] [--T 5625] [--gate-only]
+Stamps per tile: 0 after [B1], 1 conv loop done, 2 after [B2], 3 gate epilogue done, 4 after [B3], 5 G pass issued, 6 projection MFMAs done, 7 tile end."""
+import argparse
+import ctypes
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stylesinger_amd import lib as L  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=5625)
+    ap.add_argument("--gate-only", action="store_true")
+    a = ap.parse_args()
+    d = torch.device("cuda:0")
+    B, T, C, NS = a.B, a.T, 256, 4
+    lens = torch.full((B,), T, device=d, dtype=torch.int32)
+    X0 = torch.randn(B, T, C, device=d)
+    H0, P = L.layer512_entry(X0, None, B=B, T=T, lens=lens)
+    H = [H0, torch.empty_like(H0)]
+    E = torch.randn(B, T, NS * 2 * C, device=d)
+    E512 = [L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C) for s in range(NS)]
+    GA = torch.empty(B, T, NS * 2 * C, device=d, dtype=torch.float16)
+    w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
+    Wg = L.layer512_pack_gate(L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=256.0))
+    wo = torch.randn(2 * C, C, 1, device=d) / math.sqrt(C)
+    Wr = L.layer512_pack_res(L.split_f16(L.pack_conv_weight(wo), scale=256.0))
+    cb, nb, bo = (torch.randn(C, device=d) for _ in range(3))
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    tr = torch.zeros(ncu * 8 * 8 * 8, device=d, dtype=torch.int64)
+
+    def run(k):
+        s = k % NS
+        if a.gate_only:
+            L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+        else:
+            L.layer512(H[k & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k & 1) ^ 1], P=P, Wr=Wr, bias_r=bo, cur_bias=cb,
+                       next_bias=nb, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+    for k in range(6):
+        run(k)
+    torch.cuda.synchronize()
+    L.check(L.load().ss_set_clock_probe(ctypes.c_void_p(tr.data_ptr())), "ss_set_clock_probe")
+    run(6)
+    torch.cuda.synchronize()
+    L.load().ss_set_clock_probe(None)
+    t = tr.view(ncu, 8, 8, 8).cpu().double()     # workgroup, wave, tile slot, stamp
+    n_tiles = B * ((T + 127) // 128)
+    full = [i for i in range(8) if (i + 1) * ncu <= n_tiles]          # tile slots every workgroup ran
+    t = t[:, :, full]
+    names = ["conv loop (48 k-steps)", "wait [B2]", "gate epilogue", "wait [B3]", "G pass", "projection MFMAs", "stream epilogue"]
+    print(f"layer512 trace, {B} x {T}, {n_tiles} tiles on {ncu} workgroups, slots {full}; shader cycles per tile, mean over workgroups and waves (min .. max of the per-wave means)")
+    for k, nm in enumerate(names):
+        dlt = t[..., k + 1] - t[..., k]
+        pw = dlt.mean(dim=(0, 2))
+        print(f"  {nm:26s} {dlt.mean().item():9.0f}   ({pw.min().item():8.0f} .. {pw.max().item():8.0f})")
+    gap = t[:, :, 1:, 0] - t[:, :, :-1, 7]
+    print(f"  {'tile end -> next [B1]':26s} {gap.mean().item():9.0f}")
+    whole = t[:, :, 1:, 0] - t[:, :, :-1, 0]
+    print(f"  {'tile period':26s} {whole.mean().item():9.0f}   matrix time of a tile at 32 cycles per MFMA and two waves per SIMD: {(768 + (0 if a.gate_only else 128)) * 2 * 32}")
+
+
+if __name__ == "__main__":
+    main()
