@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512; 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths; 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -748,9 +748,10 @@ int ss_f0track(const float* wav, int64_t wav_stride, const int32_t* n_samples, c
  * zero-padded batch wav [B][L]: out = wav * 10^(change / 20) with change = target_dbfs - 10 log10(mean over the item's lens[b] samples of wav^2)
  * when change >= 0, else out = wav. In place allowed. */
 int ss_normalize_volume(const float* wav, const int32_t* lens, float* out, int B, int L, float target_dbfs, void* stream);
-/* y[b][t] = fp32(fp16_rne(x[b][t])) for t < min(n_out[b], Lx), 0 for the rest of the ldy columns: the waveform `process_audio` returns
+/* y[b][t] = fp32(fp16_rne(x[b][t])) for t < min(n_out[b], n_in[b], Lx) (n_in: the item's own sample count, NULL = Lx), 0 for the rest of the ldy
+ * columns: the waveform `process_audio` returns
  * (inference/StyleSinger.py:86-88: padded to n_mel * hop samples, `.astype(np.float16)`), which the reference hands resemblyzer and parselmouth. */
-int ss_round_f16_rows(const float* x, int64_t ldx, int Lx, const int32_t* n_out, float* y, int64_t ldy, int B, void* stream);
+int ss_round_f16_rows(const float* x, int64_t ldx, int Lx, const int32_t* n_in, const int32_t* n_out, float* y, int64_t ldy, int B, void* stream);
 /* trim_long_silences (data_gen/tts/emotion/audio.py:58-100; called by preprocess_wav :38) AROUND the caller's voice-activity flags: the decision
  * itself is webrtcvad's (an un-vendored C library, no published text to restate); the reference's windowing, smoothing, dilation and compaction
  * run here. wav [B][wav_stride] fp32, n_samples[b] valid samples; flags [B][flags_stride] uint8, one per window of samples_per_window samples

@@ -280,8 +280,46 @@ def round5_cases():
                       keep_keys=["mel_out", "pitch_pred", "f0_denorm"])
 
 
+def run_token_encoder_case(name="token_encoder"):
+    """The REAL `TokenTextEncoder` / `build_token_encoder` (utils/text/text_encoder.py:107-147,257-259) on the phone set the checkpoint ships with
+    (ZH_checkpoint_phone_set.json) and on `example_run`'s own input (inference/StyleSinger.py:181-321; the dict literal is read with `ast`, the
+    file itself cannot be imported here: it needs resemblyzer / parselmouth / librosa). -> tests/golden/token_encoder.json (data: the phone list,
+    the example score, and the ids / strings the reference class returns) + stylesinger_amd/example_input.json (the example score alone)."""
+    import ast
+    import json
+    refimport.load()
+    from utils.text.text_encoder import TokenTextEncoder, build_token_encoder
+    phone_file = os.path.join(refimport.REF, "ZH_checkpoint_phone_set.json")
+    phones = json.load(open(phone_file))
+    enc = build_token_encoder(phone_file)
+    tree = ast.parse(open(os.path.join(refimport.REF, "inference", "StyleSinger.py")).read())
+    example = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "example_run":
+            for st in ast.walk(node):
+                if isinstance(st, ast.Assign) and getattr(st.targets[0], "id", None) == "inp":
+                    example = ast.literal_eval(st.value)
+    assert example and len(example["ph"]) == len(example["note"]) == len(example["note_dur"]) == len(example["note_type"])
+    probes = [" ".join(example["ph"]), "zh i  breathe   _NONE", "a b notaphone c <pad> <EOS> | ", "", "  uang\tvn\nve  "]
+    out = dict(phone_set=phones, example=example, vocab_size=len(enc), pad=enc.pad(), eos=enc.eos(), unk=enc.unk(), seg=enc.seg(),
+               id_to_token=[enc.id_to_token[i] for i in range(len(enc))],
+               encode=[dict(s=s_, ids=enc.encode(s_)) for s_ in probes], sil=enc.sil_phonemes())
+    ids = enc.encode(probes[0])
+    out["decode"] = [dict(ids=ids, s=enc.decode(ids)), dict(ids=ids[:5] + [0, 7, 1, 9], s=enc.decode(ids[:5] + [0, 7, 1, 9], strip_padding=True)),
+                     dict(ids=ids[:5] + [1, 7, 0, 9], s=enc.decode(ids[:5] + [1, 7, 0, 9], strip_eos=True), strip_eos=True), dict(ids=[3, 999, 4], s=enc.decode([3, 999, 4]))]
+    rev = TokenTextEncoder(None, vocab_list=phones + ["|"], replace_oov=None, reverse=True)
+    out["reverse"] = dict(vocab_size=len(rev), seg=rev.seg(), ids=rev.encode("zh i uan"), s=rev.decode(rev.encode("zh i uan")))
+    json.dump(out, open(os.path.join(GOLD, name + ".json"), "w"), indent=0)
+    pkg = os.path.join(os.path.dirname(GOLD), "..", "stylesinger_amd", "example_input.json")
+    json.dump(dict(source="inference/StyleSinger.py:186-321 (example_run's input dict)", **example), open(os.path.normpath(pkg), "w"), indent=0)
+    print("wrote", name + ".json", "and stylesinger_amd/example_input.json:", len(phones), "phones,", len(example["ph"]), "example phonemes")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--round6" in sys.argv:
+        run_token_encoder_case()
+        return
     if "--vad" in sys.argv:
         run_vad_trim_case()
         return

@@ -286,14 +286,15 @@ __global__ __launch_bounds__(256) void normalize_volume_kernel(const float* __re
   for (int i = tid; i < L; i += 256) out[(int64_t)b * L + i] = x[i] * g;
 }
 
-__global__ void round_f16_rows_kernel(const float* __restrict__ x, int64_t ldx, int Lx, const int32_t* __restrict__ n_out, float* __restrict__ y, int64_t ldy,
-                                      int B) {
+__global__ void round_f16_rows_kernel(const float* __restrict__ x, int64_t ldx, int Lx, const int32_t* __restrict__ n_in, const int32_t* __restrict__ n_out,
+                                      float* __restrict__ y, int64_t ldy, int B) {
   const int64_t total = (int64_t)B * ldy;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / ldy);
     const int64_t t = i % ldy;
     float v = 0.f;
-    if (t < n_out[b] && t < Lx) v = (float)(_Float16)x[(int64_t)b * ldx + t];   // fp32 -> fp16 conversion rounds to nearest even (v_cvt_f16_f32)
+    // samples past the item's own length are padding whatever the batch buffer holds there (MelFrontendHIP.wav2mel masks the same samples)
+    if (t < n_out[b] && t < (n_in ? min(n_in[b], Lx) : Lx)) v = (float)(_Float16)x[(int64_t)b * ldx + t];   // fp32 -> fp16 rounds to nearest even (v_cvt_f16_f32)
     y[i] = v;
   }
 }
@@ -307,11 +308,11 @@ extern "C" int ss_normalize_volume(const float* wav, const int32_t* lens, float*
   return SS_OK;
 }
 
-extern "C" int ss_round_f16_rows(const float* x, int64_t ldx, int Lx, const int32_t* n_out, float* y, int64_t ldy, int B, void* stream) {
+extern "C" int ss_round_f16_rows(const float* x, int64_t ldx, int Lx, const int32_t* n_in, const int32_t* n_out, float* y, int64_t ldy, int B, void* stream) {
   SS_CHECK_ARG(x && n_out && y && B > 0 && Lx > 0 && ldx >= Lx && ldy > 0, "ss_round_f16_rows: bad arguments");
   const int64_t total = (int64_t)B * ldy;
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(round_f16_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, Lx, n_out, y, ldy, B);
+  hipLaunchKernelGGL(round_f16_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, Lx, n_in, n_out, y, ldy, B);
   SS_CHECK_LAUNCH("round_f16_rows_kernel");
   return SS_OK;
 }

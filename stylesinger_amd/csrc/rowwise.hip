@@ -118,9 +118,10 @@ __global__ void table_add_kernel(const int32_t* __restrict__ pos, const float* _
 }
 
 // out = ((((x + v1[b]) + y1) + v2[b]) + y2) * (t < lens[b])   (every addend optional; order as in stylesinger.py:139-166)
-__global__ void add_bcast_mask_kernel(const float* __restrict__ x, const float* __restrict__ v1,
+// x and out may be the SAME buffer (the callers mask in place): neither is __restrict__
+__global__ void add_bcast_mask_kernel(const float* x, const float* __restrict__ v1,
                                       const float* __restrict__ y1, const float* __restrict__ v2,
-                                      const float* __restrict__ y2, float* __restrict__ out, int B, int T, int C,
+                                      const float* __restrict__ y2, float* out, int B, int T, int C,
                                       const int32_t* __restrict__ lens) {
   const int64_t total = (int64_t)B * T * C;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

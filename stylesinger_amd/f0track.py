@@ -79,6 +79,9 @@ def _window_tables(g, device):
     return _tables[key]
 
 
+N_TRACK_CALLS = 0   # launches of the tracker since import (tests assert that the entry point tracks each reference audio ONCE)
+
+
 @torch.no_grad()
 def track_f0_device(wavs, n_samples, n_out, sr=48000, hop_size=256, pitch_floor=80.0, pitch_ceiling=800.0, voicing_threshold=0.6):
     """wavs fp32 [B, L] on the device (zero beyond n_samples[b]; host ints) -> f0 fp32 [B, n_out] in Hz (0 = unvoiced) on the mel frame grid:
@@ -86,6 +89,8 @@ def track_f0_device(wavs, n_samples, n_out, sr=48000, hop_size=256, pitch_floor=
     inference/StyleSinger.py:112-135 hands `norm_interp_f0`."""
     if wavs.device.type != "cuda":
         raise L.StyleSingerHipError("track_f0_device needs device tensors: there is no CPU path")
+    global N_TRACK_CALLS
+    N_TRACK_CALLS += 1
     pad_size = {128: 4, 256: 2}[int(hop_size)]
     time_step = hop_size / sr * 1000 / 1000            # the reference's own expression (ms and back)
     g = geometry(sr, time_step, pitch_floor, pitch_ceiling)

@@ -7,8 +7,16 @@ form the benchmark and the data-parallel driver use.  The feature extractors of 
 (:94-137) run on the device: `preprocess_batch` computes the reference mel, the emotion embedding, the speaker
 embedding (resemblyzer's published algorithm on the emotion encoder's kernels, `speaker.py`; parity unpinned: un-vendored package),
 the f0 contour (Praat's autocorrelation method, `f0track.py`; parity unpinned: parselmouth is un-vendored) and its normalisation.
-Only `trim_long_silences` (webrtcvad, a fixed-point GMM whose tables are not in the reference tree) stays with the caller.
+`trim_long_silences` runs on the device AROUND webrtcvad's per-window decisions (a fixed-point GMM whose tables are not in the reference tree):
+they are computed on the host when the package is importable, or given by the caller; skipping the trim is an explicit opt-out
+(`vad_flags=False`), never a silent default.
+`infer_once(inp)` = the reference's entry point (inference/StyleSinger.py:175-179) with the features kept on the device between the producers and
+the model; `python -m stylesinger_amd.infer` = `example_run` (:181-331).
 """
+import json
+import os
+import warnings
+
 import numpy as np
 import torch
 
@@ -20,13 +28,28 @@ from .vocoder import get_vocoder_cls
 
 class StyleSingerInfer:
     def __init__(self, hparams=None, device=None, model_state=None, vocoder_state=None, vocoder_config=None, dictionary=None,
-                 emotion_state=None, speaker_state=None):
+                 emotion_state=None, speaker_state=None, phone_set=None):
         """`emotion_state`: state_dict of the reference's emotion encoder checkpoint (`EmotionEncoder.load_model`,
         inference/StyleSinger.py:101) - enables the emotion branch of `preprocess_batch`.
         `speaker_state`: `model_state` of resemblyzer's `pretrained.pt` (`VoiceEncoder()`, inference/StyleSinger.py:100) - enables the
         speaker branch."""
         self.hparams = make_hparams(hparams)
         self._front_hparams = hparams
+        # inference/StyleSinger.py:27-28: ph_encoder = build_token_encoder(f"{processed_data_dir}/phone_set.json"); `phone_set` overrides the path
+        # (the released checkpoint ships it as ZH_checkpoint_phone_set.json). Without one the caller passes inp['ph_token'] or sets self.ph_encoder.
+        self.ph_encoder = None
+        if phone_set is None and hparams and hparams.get("processed_data_dir"):
+            cand = os.path.join(str(hparams["processed_data_dir"]), "phone_set.json")
+            phone_set = cand if os.path.exists(cand) else None
+        if phone_set is not None:
+            from .text_encoder import build_token_encoder
+            self.ph_encoder = build_token_encoder(phone_set)
+            if dictionary is None:
+                dictionary = self.ph_encoder
+        if hparams and hparams.get("loud_norm"):
+            # process_audio passes loud_norm to librosa_wav2spec (inference/StyleSinger.py:85; utils/audios/__init__.py:55-59: pyloudnorm, un-vendored)
+            raise NotImplementedError("hparams['loud_norm'] is set: the pyloudnorm loudness normalisation of the reference mel is not implemented "
+                                      "(the released config leaves it off); refusing rather than computing a different mel")
         if device is None:
             if not torch.cuda.is_available():
                 raise L.StyleSingerHipError("StyleSingerInfer (HIP) needs a GPU: there is no CPU path")
@@ -222,18 +245,22 @@ class StyleSingerInfer:
         frames, counts = self._partials_batch(wavs, lens, lambda n: spk_slices(n, rate, min_coverage))
         return self._mean_l2norm_per_item(self.speaker_encoder.forward(frames), counts)
 
-    def process_audio_wav(self, ref_wavs, frames):
+    def process_audio_wav(self, ref_wavs, frames, valid_lens=None):
         """The waveform `process_audio` returns next to the mel (inference/StyleSinger.py:86-88): the audio zero-padded to
         n_mel * hop samples (utils/audios/__init__.py:76-78) and rounded to float16. -> ([B, max n_mel * hop] fp32 holding
-        float16-representable values, zero beyond each item's length; lengths as host ints)"""
+        float16-representable values, zero beyond each item's length; lengths as host ints). `valid_lens`: the items' own sample
+        counts - samples of the batch buffer past them are padding whatever they hold (as MelFrontendHIP.wav2mel treats them)."""
         hop = int(self.hparams["hop_size"])
         lens = [int(f) * hop for f in frames]
         x = ref_wavs.to(self.device).float().contiguous()
         out = torch.empty(x.shape[0], max(lens), device=self.device, dtype=torch.float32)
         n_out = torch.tensor(lens, dtype=torch.int32).to(self.device)
-        L.check(L.load().ss_round_f16_rows(L.ptr(x), x.shape[1], x.shape[1], L.ptr(n_out), L.ptr(out), out.shape[1], x.shape[0], L.stream_ptr()),
+        n_in = None if valid_lens is None else torch.tensor([int(v) for v in valid_lens], dtype=torch.int32).to(self.device)
+        L.check(L.load().ss_round_f16_rows(L.ptr(x), x.shape[1], x.shape[1], L.ptr(n_in), L.ptr(n_out), L.ptr(out), out.shape[1], x.shape[0], L.stream_ptr()),
                 "ss_round_f16_rows")
-        n_out.record_stream(torch.cuda.current_stream(self.device))
+        for t_ in (n_out, n_in):
+            if t_ is not None:
+                t_.record_stream(torch.cuda.current_stream(self.device))
         return out, lens
 
     @torch.no_grad()
@@ -249,7 +276,10 @@ class StyleSingerInfer:
                    default: the reference audio itself, volume-normalised on the device. `trim_long_silences` (audio.py:58-100) runs on the
                    device AROUND the caller's decisions: pass `emo_vad_flags` [B, nW] = webrtcvad's `is_speech` per 30 ms window of the
                    volume-normalised 16-bit PCM (the decision itself is an un-vendored fixed-point GMM: `vadtrim.py`); without flags the
-                   audio goes untrimmed. Pass `emo_embed` [B, 256] instead to skip this branch.
+                   audio goes untrimmed; `emo_vad_flags="webrtc"` computes them on the host with the webrtcvad package from the device-normalised
+                   audio (`vadtrim.webrtc_flags`: the reference's own call). Pass `emo_embed` [B, 256] instead to skip this branch.
+        The returned dict also carries `ref_f0_hz` [B, Tr] (the tracker's contour on the mel grid, before normalisation) for callers that mirror
+        `preprocess_input`'s `inp['f0']`.
           spk_embed [B, 256], or None -> `VoiceEncoder().embed_utterance(wav)` (:100,104) on the device (`embed_speaker_batch`;
                    needs `speaker_state`) from what the reference hands it: `process_audio`'s waveform, i.e. the reference audio
                    zero-padded to n_mel * hop samples and rounded to float16 (:87; utils/audios/__init__.py:76-78)."""
@@ -265,7 +295,7 @@ class StyleSingerInfer:
         hop = int(self.hparams["hop_size"])
         wav16 = None
         if f0_hz is None or spk_embed is None:   # the waveform the reference hands both third-party producers (:87)
-            wav16, wav16_lens = self.process_audio_wav(ref_wavs, [n // hop + 1 for n in ref_lens_h])   # frames of a centred STFT
+            wav16, wav16_lens = self.process_audio_wav(ref_wavs, [n // hop + 1 for n in ref_lens_h], ref_lens_h)   # frames of a centred STFT
         if f0_hz is None:
             from .f0track import track_f0_device
             f0_hz = track_f0_device(wav16, wav16_lens, Tr, sr=int(self.hparams["audio_sample_rate"]), hop_size=hop)
@@ -280,7 +310,12 @@ class StyleSingerInfer:
                     self._emo_frontend = EmotionMelFrontendHIP(d)
                 emo_wavs = self._emo_frontend.normalize_volume(ref_wavs, torch.tensor(ref_lens_h))
                 emo_lens = ref_lens_h
-                if emo_vad_flags is not None:   # preprocess_wav's second step (audio.py:38), around the caller's VAD flags
+                if isinstance(emo_vad_flags, str):
+                    if emo_vad_flags != "webrtc":
+                        raise ValueError(f"emo_vad_flags={emo_vad_flags!r}: expected flags, None or 'webrtc'")
+                    from .vadtrim import webrtc_flags
+                    emo_vad_flags = webrtc_flags(emo_wavs, emo_lens)
+                if emo_vad_flags is not None:   # preprocess_wav's second step (audio.py:38), around the VAD flags
                     from .vadtrim import trim_long_silences_device
                     emo_wavs, kept = trim_long_silences_device(emo_wavs, emo_lens, emo_vad_flags)
                     emo_lens = [int(v) for v in kept.cpu()]   # the partial slicing below is host arithmetic on the lengths
@@ -288,7 +323,7 @@ class StyleSingerInfer:
         if spk_embed is None:
             spk_embed = self.embed_speaker_batch(wav16, wav16_lens)
         batch = dict(txt_tokens=txt_tokens.to(d), note=note.to(d), note_dur=note_dur.to(d).float(), note_type=note_type.to(d),
-                     spk_embed=spk_embed.to(d).float(), emo_embed=emo_embed.to(d).float(), ref_mels=ref_mels, ref_f0=ref_f0)
+                     spk_embed=spk_embed.to(d).float(), emo_embed=emo_embed.to(d).float(), ref_mels=ref_mels, ref_f0=ref_f0, ref_f0_hz=f0_hz)
         if mel2ph is not None:
             batch["mel2ph"] = mel2ph.to(d)
         return batch
@@ -307,9 +342,8 @@ class StyleSingerInfer:
                     note_type=t(item["note_type"], torch.long), ref_f0=f0[None].to(d),
                     **({"mel2ph": t(item["mel2ph"], torch.long)} if "mel2ph" in item else {}))
 
-    def forward_model(self, inp, noise=None, vocoder_noise=None):
-        sample = self.input_to_batch(inp)
-        res = self.infer_batch(sample, noise=noise, vocoder_noise=None, vocode=False)
+    def _wav_from_result(self, res, vocoder_noise=None):
+        """inference/StyleSinger.py:53-63: drop all-zero frames, clip the mel, vocode with the predicted f0 (one item)."""
         mel_pred = res["mel"].cpu().numpy()
         f0_pred = res["f0"].cpu().numpy()
         mask = np.abs(mel_pred).sum(-1) > 0
@@ -317,51 +351,134 @@ class StyleSingerInfer:
         f0_pred = f0_pred[mask]
         return self.vocoder.spec2wav(mel_pred, f0=f0_pred, noise=vocoder_noise)
 
+    def forward_model(self, inp, noise=None, vocoder_noise=None):
+        sample = self.input_to_batch(inp)
+        return self._wav_from_result(self.infer_batch(sample, noise=noise, vocoder_noise=None, vocode=False), vocoder_noise)
+
     @staticmethod
     def _load_wav(path, want_sr):
         """A reference-audio FILE: 16-bit PCM WAV at the model's sample rate (the reference resamples through librosa, un-vendored: other rates
         are refused, not approximated). -> float32 mono in [-1, 1)."""
         import wave
-        with wave.open(str(path), "rb") as wf:
+        with wave.open(os.fsdecode(path), "rb") as wf:
             if wf.getsampwidth() != 2 or wf.getframerate() != want_sr:
                 raise ValueError(f"{path}: need 16-bit PCM at {want_sr} Hz (got {8 * wf.getsampwidth()} bit, {wf.getframerate()} Hz)")
             pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2").astype(np.float32).reshape(-1, wf.getnchannels())
         return pcm.mean(axis=1) / 32768.0
 
+    _warned_untrimmed = False
+
+    def _resolve_vad(self, vad_flags):
+        """`preprocess_wav` ALWAYS trims long silences (data_gen/tts/emotion/audio.py:36-38). None = do as the reference does: webrtcvad's decisions,
+        computed on the host - an ImportError where the package is missing (it is un-vendored), never a silent skip. False = explicit opt-out
+        (untrimmed audio; warns once: the emotion embedding of a recording with long pauses then differs from the reference's). Otherwise the
+        caller's flags [nW]."""
+        if vad_flags is None:
+            from .vadtrim import have_webrtcvad
+            if not have_webrtcvad():
+                raise ImportError("preprocess_input: the reference trims long silences with webrtcvad before the emotion encoder, and the package is "
+                                  "not importable here. Pass vad_flags=<webrtcvad's is_speech per 30 ms window> or vad_flags=False to skip the trim "
+                                  "explicitly (the emotion embedding then differs from the reference's for audio with long pauses).")
+            return "webrtc"
+        if vad_flags is False:
+            if not StyleSingerInfer._warned_untrimmed:
+                StyleSingerInfer._warned_untrimmed = True
+                warnings.warn("StyleSingerInfer: trim_long_silences skipped on request (vad_flags=False): emo_embed is computed from untrimmed audio")
+            return None
+        return np.asarray(vad_flags)[None]
+
     @torch.no_grad()
-    def preprocess_input(self, inp, vad_flags=None):
-        """Mirror of `StyleSingerInfer.preprocess_input` (inference/StyleSinger.py:94-137) with every producer on the device: fills `mel`,
-        `spk_embed`, `emo_embed`, `f0` (the tracker's contour in Hz on the mel grid) and `item_name` / `wav_fn` from `inp['ref_audio']` (a float
-        waveform at the model's sample rate, or the path of a 16-bit PCM WAV at that rate). `inp['ph_token']` is used when present; otherwise
-        `inp['ph']` goes through `self.ph_encoder` (any object with the reference's `encode(str)`), which the caller sets. Needs `emotion_state` and
-        `speaker_state` (the two encoders' checkpoints). `vad_flags`: webrtcvad's decisions for `trim_long_silences` (vadtrim.py); None = untrimmed."""
+    def _device_batch(self, inp, vad_flags=None):
+        """`preprocess_input` + `input_to_batch` (inference/StyleSinger.py:94-172) for ONE item with every producer on the device: the dict
+        `infer_batch` takes, device tensors only (+ `ref_f0_hz`, `n_mel`). ONE pass of the f0 tracker."""
         sr, hop = int(self.hparams["audio_sample_rate"]), int(self.hparams["hop_size"])
         audio = inp["ref_audio"]
         wav = self._load_wav(audio, sr) if isinstance(audio, (str, bytes)) or hasattr(audio, "__fspath__") else np.asarray(audio, dtype=np.float32)
         if "ph_token" not in inp:
-            enc = getattr(self, "ph_encoder", None)
-            if enc is None:
-                raise ValueError("preprocess_input: give inp['ph_token'] or set self.ph_encoder (the reference's build_token_encoder(phone_set.json))")
-            inp["ph_token"] = enc.encode(" ".join(inp["ph"]))
+            if self.ph_encoder is None:
+                raise ValueError("preprocess_input: give inp['ph_token'], construct StyleSingerInfer(..., phone_set=<phone_set.json>) or set "
+                                 "self.ph_encoder (the reference's build_token_encoder(f'{processed_data_dir}/phone_set.json'))")
+            inp["ph_token"] = self.ph_encoder.encode(" ".join(inp["ph"]))
         t = lambda x, dt: torch.as_tensor(np.asarray(x), dtype=dt)[None]
         batch = self.preprocess_batch(torch.from_numpy(wav)[None], [len(wav)], None, None, t(inp["ph_token"], torch.long), t(inp["note"], torch.long),
                                       t(inp["note_dur"], torch.float32), t(inp["note_type"], torch.long),
-                                      emo_vad_flags=None if vad_flags is None else np.asarray(vad_flags)[None])
-        n_mel = len(wav) // hop + 1
-        wav16, lens16 = self.process_audio_wav(torch.from_numpy(wav)[None], [n_mel])
-        from .f0track import track_f0_device
-        f0_hz = track_f0_device(wav16, lens16, n_mel, sr=sr, hop_size=hop)
-        inp.update(item_name=inp.get("name"), wav_fn=audio if isinstance(audio, str) else None, mel=batch["ref_mels"][0, :n_mel].cpu().numpy(),
-                   spk_embed=batch["spk_embed"][0].cpu().numpy(), emo_embed=batch["emo_embed"][0].cpu().numpy(),
-                   f0=f0_hz[0].double().cpu().numpy())
+                                      mel2ph=t(inp["mel2ph"], torch.long) if "mel2ph" in inp else None, emo_vad_flags=self._resolve_vad(vad_flags))
+        batch["n_mel"] = len(wav) // hop + 1
+        return batch
+
+    @torch.no_grad()
+    def preprocess_input(self, inp, vad_flags=None):
+        """Mirror of `StyleSingerInfer.preprocess_input` (inference/StyleSinger.py:94-137) with every producer on the device: fills `mel`,
+        `spk_embed`, `emo_embed`, `f0` (the tracker's contour in Hz on the mel grid) as numpy arrays, `ph_token`, and `item_name` / `wav_fn` from
+        `inp['ref_audio']` (a float waveform at the model's sample rate, or the path of a 16-bit PCM WAV at that rate). Needs `emotion_state` and
+        `speaker_state` (the two encoders' checkpoints). `vad_flags`: see `_resolve_vad` (None = webrtcvad on the host, False = opt out)."""
+        batch = self._device_batch(inp, vad_flags)
+        n_mel, audio = batch["n_mel"], inp["ref_audio"]
+        inp.update(item_name=inp.get("name"), wav_fn=os.fsdecode(audio) if isinstance(audio, (str, bytes)) or hasattr(audio, "__fspath__") else None,
+                   mel=batch["ref_mels"][0, :n_mel].cpu().numpy(), spk_embed=batch["spk_embed"][0].cpu().numpy(),
+                   emo_embed=batch["emo_embed"][0].cpu().numpy(), f0=batch["ref_f0_hz"][0, :n_mel].double().cpu().numpy())
         return inp
 
     def postprocess_output(self, output):
         return output
 
-    def infer_once(self, inp, vad_flags=None):
-        """inference/StyleSinger.py:175-179: preprocess_input -> forward_model -> postprocess_output. An `inp` that already carries the features
-        (`mel`, `spk_embed`, `emo_embed`, `f0`, `ph_token`) skips the preprocessing, as before."""
-        if not all(k in inp for k in ("mel", "spk_embed", "emo_embed", "f0", "ph_token")):
-            inp = self.preprocess_input(inp, vad_flags)
-        return self.postprocess_output(self.forward_model(inp))
+    def infer_once(self, inp, vad_flags=None, noise=None, vocoder_noise=None):
+        """inference/StyleSinger.py:175-179: preprocess_input -> forward_model -> postprocess_output. The features stay on the device between the
+        producers and the model (no numpy detour; `preprocess_input` is the form that returns them). An `inp` that already carries the features
+        (`mel`, `spk_embed`, `emo_embed`, `f0`, `ph_token`) skips the producers, as before."""
+        if all(k in inp for k in ("mel", "spk_embed", "emo_embed", "f0", "ph_token")):
+            return self.postprocess_output(self.forward_model(inp, noise=noise, vocoder_noise=vocoder_noise))
+        batch = self._device_batch(inp, vad_flags)
+        res = self.infer_batch({k: v for k, v in batch.items() if k not in ("n_mel", "ref_f0_hz")}, noise=noise, vocode=False)
+        return self.postprocess_output(self._wav_from_result(res, vocoder_noise))
+
+    @classmethod
+    def example_run(cls, hparams=None, ref_audio="test/test.wav", out_path="infer_out/test.wav", vad_flags=None, **ctor):
+        """inference/StyleSinger.py:181-331: the example score (stylesinger_amd/example_input.json = that method's input dict, extracted by
+        `python -m oracle.gen_golden --round6`) sung in the style of `ref_audio`, written to `out_path` as 16-bit PCM (utils/audio.py:12-17).
+        `ctor`: how to build the instance - `exp_dir` + `vocoder_dir` (the reference's checkpoints, `from_checkpoints`) or explicit
+        `model_state` / `vocoder_state` / `emotion_state` / `speaker_state` / `phone_set`."""
+        from .writer import save_wav
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "example_input.json")) as fh:
+            inp = {k: v for k, v in json.load(fh).items() if k != "source"}
+        inp["ref_audio"] = ref_audio
+        if "exp_dir" in ctor:
+            ins = cls.from_checkpoints(hparams, ctor.pop("exp_dir"), ctor.pop("vocoder_dir"), **ctor)
+        else:
+            ins = cls(hparams, **ctor)
+        out = ins.infer_once(inp, vad_flags=vad_flags)
+        os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+        save_wav(out, out_path, int(ins.hparams["audio_sample_rate"]), norm=bool(ins.hparams.get("out_wav_norm", False)))
+        print(f"Save at {out_path}.")
+        return out
+
+
+def main(argv=None):
+    """`python -m stylesinger_amd.infer --exp-dir checkpoints/<exp> --vocoder-dir <hifigan dir> --emotion-ckpt <pt> --speaker-ckpt <pt>
+    --phone-set ZH_checkpoint_phone_set.json [--ref-audio test/test.wav] [--out infer_out/test.wav] [--no-vad-trim]` = the reference's
+    `python inference/StyleSinger.py` (StyleSingerInfer.example_run)."""
+    import argparse
+    ap = argparse.ArgumentParser(description="StyleSinger example_run on the HIP path")
+    ap.add_argument("--exp-dir", required=True)
+    ap.add_argument("--vocoder-dir", required=True)
+    ap.add_argument("--emotion-ckpt", required=True, help="the reference's emotion encoder checkpoint (hparams['emotion_encoder_path'])")
+    ap.add_argument("--speaker-ckpt", required=True, help="resemblyzer's pretrained.pt")
+    ap.add_argument("--phone-set", required=True)
+    ap.add_argument("--ref-audio", default="test/test.wav")
+    ap.add_argument("--out", default="infer_out/test.wav")
+    ap.add_argument("--no-vad-trim", action="store_true", help="explicit opt-out of trim_long_silences (webrtcvad missing)")
+    a = ap.parse_args(argv)
+    emo = torch.load(a.emotion_ckpt, map_location="cpu", weights_only=False)
+    spk = torch.load(a.speaker_ckpt, map_location="cpu", weights_only=False)
+    from . import ckpt
+    state, _ = ckpt.read_state(a.exp_dir, "model")
+    if state is None:
+        raise FileNotFoundError(f"| ckpt not found in {a.exp_dir}.")
+    vstate, vcfg = ckpt.load_vocoder_ckpt(a.vocoder_dir)
+    StyleSingerInfer.example_run(None, a.ref_audio, a.out, vad_flags=False if a.no_vad_trim else None, model_state=state, vocoder_state=vstate,
+                                 vocoder_config=vcfg, emotion_state=emo.get("model_state", emo), speaker_state=spk.get("model_state", spk),
+                                 phone_set=a.phone_set)
+
+
+if __name__ == "__main__":
+    main()

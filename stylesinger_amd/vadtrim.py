@@ -34,6 +34,36 @@ def window_mask(flags, avg_width=VAD_MOVING_AVERAGE_WIDTH, max_silence=VAD_MAX_S
     return out
 
 
+def have_webrtcvad():
+    try:
+        import webrtcvad  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+def webrtc_flags(wavs, lens, sr=SAMPLING_RATE):
+    """The reference's own decision loop (data_gen/tts/emotion/audio.py:66-81) on the HOST with the webrtcvad package: per item the waveform cut
+    to whole 30 ms windows, `round(wav * 32767)` as 16-bit PCM, `Vad(mode=3).is_speech(window, sample_rate)` per window. wavs [B, L] (device or
+    host; the volume-normalised audio), lens host ints -> uint8 [B, max windows] (0 beyond an item's windows). The package is un-vendored: this
+    raises ImportError where it is missing (callers then pass flags or opt out explicitly)."""
+    import struct
+    import webrtcvad
+    spw = VAD_WINDOW_MS * sr // 1000
+    x = wavs.detach().float().cpu().numpy() if torch.is_tensor(wavs) else np.asarray(wavs, dtype=np.float32)
+    ns = [min(int(n), x.shape[1]) for n in lens]
+    max_w = max(1, max(n // spw for n in ns))
+    out = np.zeros((len(ns), max_w), dtype=np.uint8)
+    for b, n in enumerate(ns):
+        nw = n // spw
+        w = x[b, :nw * spw]
+        pcm = struct.pack("%dh" % len(w), *(np.round(w * 32767)).astype(np.int16))
+        vad = webrtcvad.Vad(mode=3)
+        for i in range(nw):
+            out[b, i] = 1 if vad.is_speech(pcm[i * spw * 2:(i + 1) * spw * 2], sample_rate=sr) else 0
+    return out
+
+
 @torch.no_grad()
 def trim_long_silences_device(wavs, lens, flags, sr=SAMPLING_RATE):
     """wavs fp32 [B, L] on the device (zero beyond lens[b]; host ints), flags [B, nW] (0/1; window w = samples [w * spw, (w + 1) * spw), spw = 30 ms)

@@ -46,6 +46,15 @@ def write_wav_pcm16(path, pcm, sr):
         f.write(hdr + b"data" + struct.pack("<I", len(data)) + data)
 
 
+def save_wav(wav, path, sr, norm=False):
+    """utils/audio.py:12-17 for ONE host waveform (the entry point's `example_run`): optional peak normalisation, `wav * 32767` truncated to int16
+    (numpy's astype, as there), mono 16-bit RIFF/WAVE. The input array is not modified."""
+    w = np.asarray(wav, dtype=np.float32)
+    if norm:
+        w = w / np.abs(w).max()
+    write_wav_pcm16(path, (w * np.float32(32767)).astype(np.int16), sr)
+
+
 class WavWriter:
     """Asynchronous per-item writer: the device->host copy of a batch happens once, the files are written off-thread."""
 

@@ -20,7 +20,7 @@ def test_library_loads_and_exports_header_symbols():
     assert len(names) >= 30
     for n in names:
         assert hasattr(l, n), n
-    assert l.ss_abi_version() == lib.ABI_VERSION == 15
+    assert l.ss_abi_version() == lib.ABI_VERSION == 16
     assert l.ss_last_error() is not None
 
 
@@ -42,7 +42,7 @@ def test_argument_errors_are_reported_not_crashed():
     assert l.ss_f0track_workspace_bytes(2, 143, 899) > 2 * 143 * 900 * 8 and l.ss_f0track_workspace_bytes(0, 1, 1) == 0
     assert l.ss_vad_trim(None, 0, None, None, 0, 1, 1, 480, 8, 6, None, 0, None, None, None) != 0 and b"ss_vad_trim" in l.ss_last_error()
     assert l.ss_normalize_volume(None, None, None, 1, 1, -30.0, None) != 0
-    assert l.ss_round_f16_rows(None, 0, 0, None, None, 0, 1, None) != 0
+    assert l.ss_round_f16_rows(None, 0, 0, None, None, None, 0, 1, None) != 0
     assert not hasattr(l, "ss_fused_gate_res")   # the dataflow-launch experiment is built from tools/experiments/, not shipped in the library
     assert l.ss_set_tuning(b"q4_force", 1) == 0 and l.ss_get_tuning(b"q4_force") == 1 and l.ss_set_tuning(b"q4_force", 0) == 0
     assert l.ss_set_tuning(b"tile128", 1) != 0 and l.ss_set_tuning(b"skip_deep", 1) != 0      # removed in round 5
@@ -450,3 +450,100 @@ def test_speaker_encoder_partial_slicing_known_answers():
     assert [(s.start, s.stop) for s in m] == [(0, 160)]
     _, m = speaker.compute_partial_slices(16000 * 2 - 2000, min_coverage=0.5)
     assert len(m) == 2
+
+
+def test_token_text_encoder_equals_the_reference_class(golden_dir, tmp_path):
+    """`build_token_encoder(phone_set.json)` / `TokenTextEncoder` (utils/text/text_encoder.py:107-147,257-259; used at inference/StyleSinger.py:28,96
+    and as the model's dictionary) - bit-exact against what the REAL class returned in the build container (tests/golden/token_encoder.json,
+    `python -m oracle.gen_golden --round6`): example_run's phoneme list with ZH_checkpoint_phone_set.json, out-of-vocabulary and reserved
+    tokens, whitespace, decode with padding / EOS stripping, the reversed form. Where /root/reference is mounted the two classes are also run
+    side by side on random token strings."""
+    import json
+    import random
+    from stylesinger_amd.text_encoder import TokenTextEncoder, build_token_encoder
+    gold = json.load(open(os.path.join(golden_dir, "token_encoder.json")))
+    pf = tmp_path / "phone_set.json"
+    pf.write_text(json.dumps(gold["phone_set"]))
+    enc = build_token_encoder(str(pf))
+    assert len(enc) == enc.vocab_size == gold["vocab_size"] == 61
+    assert (enc.pad(), enc.eos(), enc.unk(), enc.seg()) == (gold["pad"], gold["eos"], gold["unk"], gold["seg"])
+    assert [enc.id_to_token[i] for i in range(len(enc))] == gold["id_to_token"]
+    for case in gold["encode"]:
+        assert enc.encode(case["s"]) == case["ids"], case["s"]
+    assert enc.encode(" ".join(gold["example"]["ph"])) == gold["encode"][0]["ids"]       # what preprocess_input computes (inference/StyleSinger.py:96)
+    d = gold["decode"]
+    assert enc.decode(d[0]["ids"]) == d[0]["s"] and enc.decode(d[1]["ids"], strip_padding=True) == d[1]["s"]
+    assert enc.decode(d[2]["ids"], strip_eos=True) == d[2]["s"] and enc.decode(d[3]["ids"]) == d[3]["s"]
+    assert enc.sil_phonemes() == gold["sil"]
+    rev = TokenTextEncoder(None, vocab_list=gold["phone_set"] + ["|"], replace_oov=None, reverse=True)
+    r = gold["reverse"]
+    assert (len(rev), rev.seg(), rev.encode("zh i uan"), rev.decode(rev.encode("zh i uan"))) == (r["vocab_size"], r["seg"], r["ids"], r["s"])
+    with pytest.raises(KeyError):
+        rev.encode("notaphone")
+    vf = tmp_path / "vocab.txt"
+    enc.store_to_file(str(vf))
+    again = TokenTextEncoder(str(vf))
+    assert again.token_to_id == enc.token_to_id
+    from oracle import refimport
+    if refimport.available():
+        refimport.load()
+        from utils.text.text_encoder import build_token_encoder as ref_build
+        ref = ref_build(os.path.join(refimport.REF, "ZH_checkpoint_phone_set.json"))
+        rng = random.Random(7)
+        pool = gold["phone_set"] + ["<pad>", "<EOS>", "<UNK>", "|", "xx", "a1"]
+        for _ in range(200):
+            s_ = " ".join(rng.choice(pool) for _ in range(rng.randrange(0, 40)))
+            ids = ref.encode(s_)
+            assert enc.encode(s_) == ids
+            assert enc.decode(ids) == ref.decode(ids)
+
+
+def test_entry_point_host_logic_without_a_gpu(tmp_path, golden_dir):
+    """Host-side contracts of the reference-shaped entry point (inference/StyleSinger.py:94-137,175-331) that need no device: the explicit opt-out
+    of `trim_long_silences` (the reference always trims, audio.py:36-38), `loud_norm` refused instead of ignored (utils/audios/__init__.py:55-59
+    is pyloudnorm), bytes paths, the example score shipped with the package, `save_wav` = utils/audio.py:12-17."""
+    import json
+    import wave
+    import warnings
+    import numpy as np
+    from stylesinger_amd import vadtrim, writer
+    from stylesinger_amd.infer import StyleSingerInfer
+    inf = StyleSingerInfer.__new__(StyleSingerInfer)       # no device: only the host helpers are exercised
+    if not vadtrim.have_webrtcvad():
+        with pytest.raises(ImportError, match="vad_flags=False"):
+            inf._resolve_vad(None)
+    else:
+        assert inf._resolve_vad(None) == "webrtc"
+    StyleSingerInfer._warned_untrimmed = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert inf._resolve_vad(False) is None and inf._resolve_vad(False) is None
+    assert len([x for x in w if "trim_long_silences skipped" in str(x.message)]) == 1, "warns once"
+    f = inf._resolve_vad([1, 0, 1])
+    assert f.shape == (1, 3)
+    with pytest.raises(NotImplementedError, match="loud_norm"):
+        StyleSingerInfer(dict(loud_norm=True), device="cuda")      # refused before anything touches a device
+    # a bytes path reaches wave.open as a path, not as "b'...'"
+    p = tmp_path / "a.wav"
+    pcm = (np.arange(-500, 500) * 30).astype("<i2")
+    with wave.open(str(p), "wb") as wf:
+        wf.setnchannels(1)
+        wf.setsampwidth(2)
+        wf.setframerate(48000)
+        wf.writeframes(pcm.tobytes())
+    a = StyleSingerInfer._load_wav(str(p), 48000)
+    b = StyleSingerInfer._load_wav(os.fsencode(str(p)), 48000)
+    assert np.array_equal(a, b) and np.array_equal(a, pcm.astype(np.float32) / 32768.0)
+    with pytest.raises(ValueError, match="16-bit PCM at 44100"):
+        StyleSingerInfer._load_wav(str(p), 44100)
+    # the example score = the reference's example_run input (fixture generated from the reference by oracle/gen_golden.py --round6)
+    gold = json.load(open(os.path.join(golden_dir, "token_encoder.json")))
+    ex = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stylesinger_amd", "example_input.json")))
+    for k in ("name", "ph", "note", "note_dur", "note_type"):
+        assert ex[k] == gold["example"][k], k
+    # save_wav: wav * 32767 truncated toward zero, as numpy's astype(int16) does in the reference
+    x = np.array([0.0, 0.5, -0.5, 0.99999, -1.0, 1e-5], dtype=np.float32)
+    writer.save_wav(x, str(tmp_path / "o.wav"), 48000)
+    with wave.open(str(tmp_path / "o.wav"), "rb") as wf:
+        got = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2")
+    assert np.array_equal(got, (x * 32767).astype(np.int16)) and x[1] == 0.5, "input not modified"
