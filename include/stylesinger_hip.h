@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths; 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames; 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -62,6 +62,12 @@ int ss_get_tuning(const char* key);
  * (s_memrealtime): [0] / [1] / 10 = the shader clock in GHz the chip sustained under that load (it clocks to its power budget:
  * 2.4 GHz nominal, ~2.0 GHz measured in these loops). Pass NULL to switch it off. Results never change. */
 int ss_set_clock_probe(void* dev_u64x2);
+/* Range guard of the "fp16q4" precision: its kernels convert their fp16 A operand to fp4 with a FIXED power-of-two scale (q_scale), which
+ * saturates at |a| > 6 q_scale. While dev_u32x2 is non-null every ss_gemm_bf16_gate128q / ss_gemm_bf16_tile256q call first reduces
+ * max |a| / (6 q_scale) over the operand it is about to read into dev_u32x2[0] (gate) / [1] (skip GEMM) as float bits (atomicMax; the caller
+ * zeroes the words): a value > 1 means the second product of that launch is degraded - use "fp16x2". One extra HBM pass per guarded launch:
+ * the model arms it for the first (eager) forward of every plan only. Pass NULL to switch it off. Results never change. */
+int ss_set_q4_guard(void* dev_u32x2);
 
 /* ------------------------------------------------------------------------------------------
  * Generic fp32-MFMA implicit-GEMM 1-D convolution / linear layer.
@@ -344,20 +350,21 @@ int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
  * weight fragments streamed L2 -> registers in the order ss_layer512_pack_gate / _pack_res lay them out, the conditioner addend in the
  * accumulator order of ss_layer512_tile_addend. Same arithmetic contract as ss_gemm_bf16 with split = 2 (results equal up to the fp32
  * summation order).
- * The residual stream x + dstep_l lives in a layout of its own, written by ss_layer512_entry and by this launch only:
- *   H  fp16 [B][T][ldh]: the hi term as plain rows (the conv's operand). DOUBLE BUFFERED: Hout must differ from Hin (a tile reads halo rows its
- *      neighbours rewrite);
- *   P  the (hi, lo) fp16 pair in accumulator order, ss_layer512_stream_bytes(B, T) bytes, updated in place:
- *      [tile = b * ceil(T / 128) + t / 128][wave 8][m 4][q 4][lane 64] x 16 bytes {hi01, hi23, lo01, lo23}; lane (l31, lh) of (wave, m, q)
- *      holds channels 32 wave + 8 q + 4 lh .. + 3 of row 32 m + l31 of the tile.
+ * The residual stream lives in a layout of its own, written by ss_layer512_entry and by this launch only:
+ *   H  = fp16(x + dstep_l), the conv's operand, in slot-major tiles: [tile = b * ceil(T / 128) + t / 128][slot 32][row 128] x 8 channels
+ *      (slot s = channels 8 s .. 8 s + 7), ss_layer512_h_elems(B, T) elements. DOUBLE BUFFERED: Hout must differ from Hin (a tile reads halo
+ *      rows its neighbours rewrite). Rows >= lens[b] are zero (every producer masks them);
+ *   P  x itself in FP32, in accumulator order, ss_layer512_stream_bytes(B, T) bytes, updated in place:
+ *      [tile][wave 8][m 4][q 4][lane 64] x 4 floats; lane (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row
+ *      32 m + l31 of the tile. (The two-launch form keeps the stream as an fp16 pair - 22 bits; fp32 costs the same bytes and a third of the
+ *      epilogue's instructions.)
  * Hout == NULL: gate only (the last layer: its residual stream is never read); P and Wr are then unused. */
 typedef struct ss_layer512_args {
-  const uint16_t* Hin;      /* fp16 [B][T][ldh] = hi term of x + dstep_l */
-  int64_t h_batch_stride;   /* elements; the same for Hout */
-  int32_t ldh;              /* elements, >= 256, multiple of 8; also the row stride of Hout */
+  const uint16_t* Hin;      /* fp16(x + dstep_l), slot-major tiles */
   int32_t d;                /* dilation, 1..8: taps (-d, 0, d) */
-  uint16_t* Hout;           /* hi term of x' + next_bias, or NULL */
-  void* P;                  /* pair stream, read and rewritten in place */
+  int32_t reserved0_;
+  uint16_t* Hout;           /* fp16(x' + next_bias), or NULL */
+  void* P;                  /* fp32 stream x, read and rewritten in place (x') */
   const int32_t* lens;
   int32_t B, T;
   const uint16_t* Wg;       /* ss_layer512_pack_gate of the layer's ss_split_f16 dilated-conv pack (786 432 elements) */
@@ -368,20 +375,22 @@ typedef struct ss_layer512_args {
   int32_t ldg;
   int32_t mask_rows;        /* rows >= lens[b]: G = 0, stream = 0 */
   const float* bias_r;      /* [256] residual half of the output-projection bias, or NULL */
-  const float* cur_bias;    /* [256] dstep_l: the stream holds x + cur_bias */
   const float* next_bias;   /* [256] dstep_{l+1}, or NULL */
+  const void* reserved_;
   float out_scale;          /* 2^-s of the weight packs */
   float post_scale;         /* 1 / sqrt(2) */
 } ss_layer512_args;
 int ss_layer512(const ss_layer512_args* args, void* stream);
 /* 1 if the shape fits the kernel's fixed geometry and fills the chip (>= 4 rounds of 128-row tiles per CU; any size with the knob layer512 = 2) */
-int ss_layer512_ok(int B, int T, int C, int d_max, int ldh, int ldg);
-/* stack entry: X fp32 [B][T][ldx] + bias (dstep_0; NULL = none) -> H and P as above; rows >= lens[b] zero */
-int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, int ldh,
-                      int64_t h_batch_stride, void* P, int B, int T, void* stream);
+int ss_layer512_ok(int B, int T, int C, int d_max, int ldg);
+/* stack entry: X fp32 [B][T][ldx] -> P = x and H = fp16(x + bias) (bias = dstep_0; NULL = none) as above; rows >= lens[b] zero */
+int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, void* P, int B, int T,
+                      void* stream);
 int64_t ss_layer512_stream_bytes(int B, int T);
+int64_t ss_layer512_h_elems(int B, int T);
 int64_t ss_layer512_addend_floats(int B, int T);
-/* E [B][T][lde] (the layer's 512 packed addend columns start at E) -> the tiled slab the kernel reads (once per forward and layer) */
+/* E [B][T][lde] (the layer's 512 packed addend columns start at E) -> the tiled slab the kernel reads (once per forward and layer); stored as
+ * the gate's exp2 arguments: E * -log2(e) in the sigmoid blocks, E * -2 log2(e) in the tanh blocks */
 int ss_layer512_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* out, int B, int T, void* stream);
 /* ss_split_f16 pack [512][3 * 256 * 2] of the gate-interleaved dilated-conv weights -> fragment order (786 432 elements) */
 int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, void* stream);
@@ -631,9 +640,11 @@ int ss_prodiff_sample(const ss_wavenet* net, float* x, const float* cond, const 
 /* q_sample + norm_spec: x = sqrt_ac*((mel-min)/(max-min)*2-1) + sqrt_1mac*z  (shallow_diffusion_tts.py:199-204,271-272) */
 int ss_mel_qsample(const float* coarse_mel, const float* spec_min, const float* spec_max, float sqrt_ac, float sqrt_1mac,
                    const float* noise, uint64_t seed, const uint64_t* seed_dev, float* x, int B, int T, int M, void* stream);
-/* denorm_spec (+ optional row mask): mel = (x+1)/2*(max-min)+min (shallow_diffusion_tts.py:274-275) */
+/* denorm_spec (+ optional row mask): mel = (x+1)/2*(max-min)+min (shallow_diffusion_tts.py:274-275). nonfinite (optional device word, never
+ * cleared here): set to 1 when a VALID frame's value is NaN / inf - the cheap, unconditional form of the fp16 modes' range check (their residual
+ * stream overflows beyond 65504; the host reads the word wherever it synchronises anyway). */
 int ss_mel_denorm(const float* x, const float* spec_min, const float* spec_max, float* mel, int B, int T, int M,
-                  const int32_t* lens, void* stream);
+                  const int32_t* lens, int32_t* nonfinite, void* stream);
 
 /* Joint Gaussian(f0)/multinomial(uv) reverse loop (GaussianMultinomialDiffusion.sample,
  * gaussian_multinomial_diffusion.py:922-942 with gaussian_p_sample :326-333, p_sample :410-413).

@@ -66,6 +66,11 @@ extern "C" int ss_set_clock_probe(void* dev_u64x2) {
   g_ss_tuning.clock_probe = static_cast<unsigned long long*>(dev_u64x2);
   return SS_OK;
 }
+unsigned int* g_ss_q4_guard = nullptr;
+extern "C" int ss_set_q4_guard(void* dev_u32x2) {
+  g_ss_q4_guard = static_cast<unsigned int*>(dev_u32x2);
+  return SS_OK;
+}
 extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
 
 int ss_n_cu() {

@@ -69,6 +69,11 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
                   int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; int layer512; };
 extern SsTuning g_ss_tuning;
+// fp16q4 range guard (ss_set_q4_guard): while non-null, every fp16q4 launch first reduces max |a| / (6 q_scale) over the fp16 operand it is about
+// to convert to fp4 into guard[which] (which = 0 gate, 1 skip GEMM; float bits, atomicMax): > 1 means the fixed scale saturates
+extern unsigned int* g_ss_q4_guard;
+struct ss_gemm_bf16_args;
+int ss_q4_guard_launch(const ss_gemm_bf16_args* a, int which, void* stream);
 // compute units of the current device (cached per device; 256 when no device can be queried): the tiling picks model a launch as
 // workgroup layers per CU, so the count must be the device's, not MI355X's
 int ss_n_cu();

@@ -34,7 +34,7 @@ struct WsLayout {
   uint16_t* condh;  // [B*T][cond_dim] conditioner
   // fused-layer form of the fp16x2 stack (ss_layer512, one launch per layer): the stream as hi rows (double buffered) + pairs in accumulator
   // order, and every layer's addend slab in the kernel's accumulator order; null when the stack runs as gate + projection launches
-  uint16_t* H512[2];  // [B*T][C] fp16
+  uint16_t* H512[2];  // ss_layer512_h_elems: slot-major tiles
   void* P512;         // ss_layer512_stream_bytes
   float* E512;        // [L][ss_layer512_addend_floats]
   int64_t e512_layer; // floats per layer
@@ -58,7 +58,7 @@ inline bool fused512(const ss_wavenet* net, int B, int T) {
   for (int l = 0; l < net->L; ++l)
     if (!net->w_dil_f[l] || (l + 1 < net->L && !net->w_out_f[l])) return false;
   const int dmax = 1 << ((net->L < net->dil_cycle ? net->L : net->dil_cycle) - 1);
-  return ss_layer512_ok(B, T, net->C, dmax, net->C, net->L * net->C * 2) != 0;
+  return ss_layer512_ok(B, T, net->C, dmax, net->L * net->C * 2) != 0;
 }
 
 WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
@@ -106,8 +106,8 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.E512 = nullptr;
   w.e512_layer = 0;
   if (fused512(net, B, T)) {
-    w.H512[0] = (uint16_t*)take((rows * net->C + 1) / 2);
-    w.H512[1] = (uint16_t*)take((rows * net->C + 1) / 2);
+    w.H512[0] = (uint16_t*)take((ss_layer512_h_elems(B, T) + 1) / 2);
+    w.H512[1] = (uint16_t*)take((ss_layer512_h_elems(B, T) + 1) / 2);
     w.P512 = take(ss_layer512_stream_bytes(B, T) / 4);
     w.e512_layer = ss_layer512_addend_floats(B, T);
     w.E512 = take(w.e512_layer * net->L);
@@ -217,8 +217,6 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     ss_layer512_args f;
     memset(&f, 0, sizeof(f));
     f.Hin = w.H512[l & 1];
-    f.h_batch_stride = (int64_t)T * C;
-    f.ldh = C;
     f.d = 1 << (l % net->dil_cycle);
     f.lens = lens;
     f.B = B;
@@ -236,7 +234,6 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
       f.P = w.P512;
       f.Wr = net->w_out_f[l];
       f.bias_r = net->b_out[l];
-      f.cur_bias = net->dstep + ((int64_t)step * L + l) * C;
       f.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
     }
     SS_PROPAGATE(ss_layer512(&f, stream));
@@ -346,8 +343,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
 // Yh = bf16(X + dstep[step][0]) : the first layer's conv operand (bf16-in-HBM mode)
 int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
   if (w.E512)
-    return ss_layer512_entry(w.X, net->C, (int64_t)T * net->C, net->dstep + (int64_t)step * net->L * net->C, lens, w.H512[0], net->C, (int64_t)T * net->C,
-                             w.P512, B, T, stream);
+    return ss_layer512_entry(w.X, net->C, (int64_t)T * net->C, net->dstep + (int64_t)step * net->L * net->C, lens, w.H512[0], w.P512, B, T, stream);
   if (net->mfma_split == 2)
     return ss_split_f16(w.X, net->dstep + (int64_t)step * net->L * net->C, 1.0f, w.Yh, B, T, net->C, net->C, 2 * net->C, lens,
                         net->n_groups > 1 ? B / net->n_groups : 0, net->gs_dstep, stream);
@@ -732,7 +728,7 @@ __global__ void mel_qsample_kernel(const float* __restrict__ mel, const float* _
 
 __global__ void mel_denorm_kernel(const float* __restrict__ x, const float* __restrict__ smin,
                                   const float* __restrict__ smax, float* __restrict__ mel, int B, int T, int M,
-                                  const int32_t* __restrict__ lens) {
+                                  const int32_t* __restrict__ lens, int32_t* __restrict__ nonfinite) {
   const int64_t n = (int64_t)B * T * M;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % M);
@@ -740,6 +736,7 @@ __global__ void mel_denorm_kernel(const float* __restrict__ x, const float* __re
     const int b = (int)(r / T), t = (int)(r % T);
     float v = (x[i] + 1.0f) / 2.0f * (smax[c] - smin[c]) + smin[c];
     if (lens && t >= lens[b]) v = 0.f;
+    else if (nonfinite && !isfinite(v)) atomicOr(nonfinite, 1);   // a valid frame left the number range (fp16 modes: the stream overflowed)
     mel[i] = v;
   }
 }
@@ -1190,10 +1187,10 @@ extern "C" int ss_mel_qsample(const float* coarse_mel, const float* spec_min, co
 }
 
 extern "C" int ss_mel_denorm(const float* x, const float* spec_min, const float* spec_max, float* mel, int B, int T, int M,
-                             const int32_t* lens, void* stream) {
+                             const int32_t* lens, int32_t* nonfinite, void* stream) {
   SS_CHECK_ARG(x && spec_min && spec_max && mel, "ss_mel_denorm: null pointer");
   hipLaunchKernelGGL(mel_denorm_kernel, dim3(grid_for((int64_t)B * T * M)), dim3(256), 0, (hipStream_t)stream, x, spec_min,
-                     spec_max, mel, B, T, M, lens);
+                     spec_max, mel, B, T, M, lens, nonfinite);
   SS_CHECK_LAUNCH("ss_mel_denorm");
   return SS_OK;
 }

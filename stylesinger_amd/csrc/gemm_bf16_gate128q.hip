@@ -355,6 +355,42 @@ extern "C" int ss_gemm_bf16_gate128q_ok(const ss_gemm_bf16_args* a) {
   return (g_ss_tuning.q4_force || tiles >= 8l * ss_n_cu()) ? 1 : 0;   // four rounds of two workgroups per CU
 }
 
+// ---- fp16q4 range guard: max |a| / (6 q_scale) over the hi plane of the A operand (rows < lens[b]) -> atomicMax on the float's bits
+namespace {
+__global__ void q4_guard_kernel(const uint16_t* __restrict__ A, int64_t a_batch_stride, int lda, int K, int T, const int32_t* __restrict__ lens, float inv_limit,
+                                unsigned int* __restrict__ out, int64_t n) {
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // one 16-byte group of 8 channels each
+    const int g = (int)(i % (K / 8));
+    const int64_t r = i / (K / 8);
+    const int b = (int)(r / T), t = (int)(r % T);
+    if (lens && t >= lens[b]) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(A + (int64_t)b * a_batch_stride + (int64_t)t * lda + (g >> 2) * 64 + (g & 3) * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      m = fmaxf(m, fabsf(ss_t2f_packed<true>(w[k], 0)));
+      m = fmaxf(m, fabsf(ss_t2f_packed<true>(w[k], 1)));
+    }
+  }
+  m *= inv_limit;
+  if (!(m == m)) m = INFINITY;   // a NaN operand counts as out of range
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+}  // namespace
+
+int ss_q4_guard_launch(const ss_gemm_bf16_args* a, int which, void* stream) {
+  if (!g_ss_q4_guard) return SS_OK;
+  const int64_t n = (int64_t)a->B * a->T * (a->K / 8);
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(q4_guard_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->A, a->a_batch_stride, a->lda, a->K, a->T, a->lens, 1.0f / (6.0f * a->q_scale),
+                     g_ss_q4_guard + which, n);
+  SS_CHECK_LAUNCH("ss_q4_guard");
+  return SS_OK;
+}
+
 extern "C" int ss_gemm_bf16_gate128q(const ss_gemm_bf16_args* args, void* stream) {
   SS_CHECK_ARG(args != nullptr, "ss_gemm_bf16_gate128q: null args");
   const ss_gemm_bf16_args& a = *args;
@@ -383,6 +419,7 @@ extern "C" int ss_gemm_bf16_gate128q(const ss_gemm_bf16_args* args, void* stream
     ss_set_error("ss_gemm_bf16_gate128q: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
     return SS_ERR_HIP;
   }
+  SS_PROPAGATE(ss_q4_guard_launch(&a, 0, stream));
   hipLaunchKernelGGL(gate128q_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, n_tiles, a.tap_off[2], g_ss_tuning.clock_probe);
   SS_CHECK_LAUNCH("ss_gemm_bf16_gate128q");
   return SS_OK;

@@ -269,6 +269,7 @@ extern "C" int ss_gemm_bf16_tile256q(const ss_gemm_bf16_args* args, void* stream
     ss_set_error("ss_gemm_bf16_tile256q: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
     return SS_ERR_HIP;
   }
+  SS_PROPAGATE(ss_q4_guard_launch(&a, 1, stream));
   hipLaunchKernelGGL(tile256q_store_kernel, dim3(m_tiles), dim3(512), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, a.K / 32);
   SS_CHECK_LAUNCH("ss_gemm_bf16_tile256q");
   return SS_OK;

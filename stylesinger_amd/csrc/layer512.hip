@@ -18,15 +18,21 @@
 //     epilogue reads / writes the stream's (hi, lo) fp16 pairs as 8-byte vectors straight from the accumulators (no staging pass).
 //   * Persistent workgroups (one per CU, 144 KB of LDS = two 72 KB regions): region r holds A(tile i), then G(tile i) over it; the A tile of
 //     tile i + 1 lands in the other region while tile i's epilogues run. Three barriers per tile.
-//   * The residual stream has a layout of its own (nothing but this kernel and ss_layer512_entry touches it): H = the hi plane as plain rows
-//     [B][T][256] fp16 - what the conv's DMA fetches - and P = the (hi, lo) fp16 PAIR in accumulator order (16 bytes per lane = 4 channels of
-//     both planes; 1 KB per wave instruction) for the epilogue's read-modify-write. H is double buffered (Hin -> Hout): a tile reads 8 halo
-//     rows of its neighbours, which another workgroup rewrites; P is updated in place. (The first version read and wrote the pair layout of
-//     ss_gemm_bf16 as 8-byte vectors, 32 rows per instruction: the epilogue took 165 us per launch against the projection launch's 129.)
+//   * The residual stream has a layout of its own (nothing but this kernel and ss_layer512_entry touches it): H = fp16(x + dstep_l) - what the
+//     conv's DMA fetches - in SLOT-MAJOR tiles [tile][slot 32][row 128] x 16 bytes (slot = 8 channels), and P = x itself in FP32 in accumulator
+//     order (16 bytes per lane = 4 channels; 1 KB per wave instruction) for the epilogue's read-modify-write. The LDS image of a tile is
+//     slot-major too, so the DMA moves contiguous kilobytes, the fragment reads are conflict-free without a swizzle, and the epilogue's 8-byte
+//     H stores of a wave instruction tile 512 contiguous bytes. H is double buffered (Hin -> Hout): a tile reads 8 halo rows of its
+//     neighbours, which another workgroup rewrites; P is updated in place. (History: v0 read and wrote ss_gemm_bf16's pair layout as 8-byte vectors, 32 rows per
+//     instruction - the epilogue took 165 us per launch against the projection launch's 129; v1 kept the stream as an fp16 (hi, lo) pair in
+//     accumulator order - 16 VALU instructions per element to unpack / re-split, 7.5 k cycles per tile, profiles/r06_trace_layer512_v1_fused.log.
+//     The fp32 stream costs the same 4 bytes per element, 5 instructions, and is 2 bits MORE precise than the pair.)
 // Arithmetic contract = ss_gemm_bf16 with split = 2: a * hi + a * lo of fp16 terms (weights = pairs of w * 2^s), fp32 accumulation scaled by
-// out_scale; G = fp16(g) in the hi slots of the pair layout; the stream a true fp16 pair. Results equal those of the two-launch form up to the
+// out_scale; G = fp16(g) in the hi slots of the pair layout; the conv's operand fp16(x + dstep_l); the stream itself fp32 (the two-launch form
+// keeps it as an fp16 pair = 22 bits). Results equal those of the two-launch form up to the
 // fp32 summation order (tests/test_gpu_layer512.py: both against float64 of the same terms).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/stylesinger_hip.h"
 #include "pair16.h"
 #include <type_traits>
@@ -43,8 +49,10 @@ namespace {
 constexpr int BM = 128;                    // rows per tile
 constexpr int HALO = 8;                    // dilations up to 8
 constexpr int AROWS = BM + 2 * HALO;       // 144 staged rows
-constexpr int ROWB = 512;                  // bytes per LDS row: 256 channels, hi plane (fp16)
-constexpr int REGION = AROWS * ROWB;       // 73 728 B; two regions
+constexpr int SLOTB = AROWS * 16 + 16;     // bytes per LDS slot: 8 channels (16 B) of 144 rows + 16 B of padding (lanes that walk the slots of a row
+                                           // are then 4 banks apart)
+constexpr int REGION = 32 * SLOTB;         // 74 240 B; two regions
+constexpr int H_TILE = BM * 512;           // 65 536 B of H per tile: [slot 32][row 128] x 16 B
 constexpr int KSTEPS = 48;                 // 8 chunks x 3 taps x 2 k-steps of 16 channels
 constexpr int WG_STEP = 4096;              // bytes of gate weights per wave and k-step: (hi, lo) x 2 column blocks x 1 KB
 constexpr int WG_WAVE = KSTEPS * WG_STEP;  // 196 608 B per wave
@@ -54,6 +62,7 @@ constexpr int WR_WAVE = RSTEPS * WR_STEP;  // 32 768 B per wave
 constexpr int E_TILE = BM * 512 * 4;       // 262 144 B of tiled addend per tile
 constexpr int P_TILE = BM * 256 * 4;       // 131 072 B of the pair stream per tile
 constexpr int NRING = 3;                   // weight fragments of NRING - 1 k-steps in flight
+constexpr int NRING_R = 5;                 // ... of the residual projection (8 MFMAs per k-step: half the cover per step)
 
 // -DSS_L512_TRACE (debug builds, tools/trace_layer512.py): lane 0 of every wave stamps the shader clock at 8 points of every tile into the
 // buffer handed over through ss_set_clock_probe ([workgroup][wave][tile slot < 8][8]); the product build compiles none of it.
@@ -103,41 +112,52 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     probe_c0 = __builtin_readcyclecounter();
     probe_r0 = __builtin_amdgcn_s_memrealtime();
   }
-  extern __shared__ __attribute__((aligned(16))) char smem_l512[];   // 144 KB: two regions of 144 rows x 512 B
+  extern __shared__ __attribute__((aligned(16))) char smem_l512[];   // 145 KB: two regions of 32 slots x 2320 B
 
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int d = a.d;
-  const int ldh2 = a.ldh * 2;   // bytes per row of the hi plane
 
   const __amdgpu_buffer_rsrc_t rsrc_wg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Wg + (int64_t)wave * WG_WAVE), 0, WG_WAVE, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(FUSE ? (const char*)a.Wr + (int64_t)wave * WR_WAVE : (const char*)a.Wg), 0,
                                                                          FUSE ? WR_WAVE : 0, 0x00020000);
-  auto tile_coords = [&](int tile, int& b, int& t0) {
+  const __amdgpu_buffer_rsrc_t rsrc_hi = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.Hin), 0, __builtin_amdgcn_readfirstlane(n_tiles * H_TILE), 0x00020000);
+  auto tile_coords = [&](int tile, int& b, int& ti) {
     b = tile / tiles_per_item;
-    t0 = (tile - b * tiles_per_item) * BM;
+    ti = tile - b * tiles_per_item;
   };
-  // ---- DMA of an activation tile: 72 pieces of 2 rows; wave w issues pieces w + 8 j (j < 9). Lane i of piece p lands at (row 2 p + (i >> 5),
-  // physical slot i & 31) and fetches logical slot (i & 31) ^ (row & 15) = channels 8 s .. + 7 of that row of H. 16 j more rows leave the
-  // swizzle unchanged. Rows outside [0, len) are out of range: the DMA writes zeros (the conv's padding).
+  // ---- DMA of an activation tile. H and the LDS image are both SLOT-MAJOR: slot s (8 channels = 16 bytes) of all rows, row after row. LDS row
+  // L = tile row L - HALO. Wave w stages slots 4 w .. 4 w + 3, three pieces of 64 rows each: LDS rows [0, 64), [64, 128) and [80, 144) (the
+  // last one rewrites 48 rows with the same bytes: every piece is a full 1 KB, no lane masking). A piece reads H contiguously except where it
+  // crosses into the previous / next tile of the item (the halo); rows outside the item are out of range: the DMA writes zeros (the conv's
+  // padding; rows in [len, T) hold zeros already - every producer of H masks them).
   auto dma_tile = [&](int tile, char* region, int lane) {
-    int b, t0;
-    tile_coords(tile, b, t0);
-    const int len = ss_uniform_len(a.lens, b, a.T);
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(a.Hin + (int64_t)b * a.h_batch_stride), 0, __builtin_amdgcn_readfirstlane(len * ldh2), 0x00020000);
-    const int dma_row = 2 * wave + (lane >> 5);
-    const int dma_slot = (lane & 31) ^ (dma_row & 15);
-    const int voff = (t0 - HALO + dma_row) * ldh2 + dma_slot * 16;
+    int b, ti;
+    tile_coords(tile, b, ti);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) glds16(rsrc_a, region + (wave + 8 * j) * 1024, voff + 16 * j * ldh2, 0);
+    for (int j = 0; j < 3; ++j) {
+      const int L = (j == 2 ? 80 : 64 * j) + lane;   // LDS row
+      const int rho = L - HALO;                      // row relative to the tile
+      const int dt = rho < 0 ? -1 : (rho >= BM ? 1 : 0);
+      const bool ok = (unsigned)(ti + dt) < (unsigned)tiles_per_item;
+      const int base = ok ? (tile + dt) * H_TILE + (rho - dt * BM) * 16 : (int)0x80000000;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int s_ = 4 * wave + k;
+        glds16(rsrc_hi, region + s_ * SLOTB + (j == 2 ? 80 : 64 * j) * 16, base, s_ * (BM * 16));
+      }
+    }
   };
 
+  // sigmoid(v0) * tanh(v1) = (1 - b) / ((1 + a) (1 + b)) with a = e^-v0, b = e^-2 v1: two exp2, ONE rcp. The addend slab arrives pre-multiplied
+  // by -log2(e) (sigmoid columns) / -2 log2(e) (tanh columns) (tile_addend_kernel), so the exponents are one FMA from the accumulators.
+  // b is capped at 2^30 (tanh = -1 to fp32 precision there) so that (1 - b) * 0 cannot become inf * 0 when (1 + a) overflows.
   const float L2E = 1.44269504088896340736f;
-  auto sigm = [](float x, float mul) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * mul)); };
+  const float ka = -L2E * a.out_scale, kbx = -2.0f * L2E * a.out_scale;
 
   int tile = blockIdx.x;
   if (tile < n_tiles) dma_tile(tile, smem_l512, tid0 & 63);
+  if constexpr (FUSE) wait_vmcnt<0>();   // (the fused form waits for the NEXT tile's pieces before its stream epilogue, not at [B1]: see there)
   int it = 0;
   for (; tile < n_tiles; tile += gridDim.x, ++it) {
     // per-lane constants are recomputed per tile from an opaque copy of the thread id: hoisted out of this loop they would stay live across
@@ -146,23 +166,18 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int w_voff = lane * 16;
-    // ---- activation fragments (the matrix instruction's B operand): lane (l31, lh) reads channels 16 ks + 8 lh .. + 7 of LDS row
-    // HALO + (tap - 1) d + 32 m + l31; 16-byte slot s of row r sits at physical slot s ^ (r & 15): the 16 rows of a ds_read_b128 lane group
-    // touch 16 distinct 16-byte units. 32 m more rows leave the swizzle unchanged.
-    int a_off[3], a_sw[3];
+    // ---- activation fragments (the matrix instruction's B operand): lane (l31, lh) reads slot 4 cc + 2 ks + lh (channels 16 ks + 8 lh .. + 7
+    // of chunk cc) of LDS row HALO + (tap - 1) d + 32 m + l31: 32 lanes read 512 contiguous bytes - conflict-free without a swizzle
+    int a_off[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int row = HALO + (j - 1) * d + l31;
-      a_off[j] = row * ROWB;
-      a_sw[j] = (row & 15) ^ lh;
-    }
-    // G tile (rows 0 .. 127 of the region, same swizzle): fragment reads of the residual projection and the epilogue's 8-byte writes
-    const int g_off = l31 * ROWB, g_sw = (l31 & 15) ^ lh;
-    const int gw_sw = l31 & 15;
+    for (int j = 0; j < 3; ++j) a_off[j] = (HALO + (j - 1) * d + l31) * 16 + lh * SLOTB;
+    // G tile (rows 0 .. 127, same slot-major form): fragment reads of the residual projection and the gate epilogue's 8-byte writes
+    const int g_off = l31 * 16 + lh * SLOTB;
     char* const Rc = smem_l512 + (it & 1) * REGION;   // A(tile), then G(tile)
     char* const Rn = smem_l512 + ((it & 1) ^ 1) * REGION;
-    int b, t0;
-    tile_coords(tile, b, t0);
+    int b, ti;
+    tile_coords(tile, b, ti);
+    const int t0 = ti * BM;
     const int len = ss_uniform_len(a.lens, b, a.T);
     const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
 
@@ -183,13 +198,15 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     };
     auto read_act = [&](bf16x8 (&dst)[4], int S) {
       const int cc = S / 6, tap = (S / 2) % 3, ks = S & 1;
-      const int ao = a_off[tap] + (((4 * cc + 2 * ks) ^ a_sw[tap]) << 4);
+      const int ao = a_off[tap] + (4 * cc + 2 * ks) * SLOTB;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + ao + m * 32 * ROWB);
+      for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + ao + m * 512);
     };
 #pragma unroll
     for (int s = 0; s < NRING - 1; ++s) load_w(wq[s], s);
-    wait_vmcnt<4 * (NRING - 1)>();   // my DMA pieces of this tile have landed (only the ring's loads are younger)
+    // my DMA pieces of this tile have landed: only the ring's loads are younger. (Fused form: already waited for - a vmcnt wait HERE would also
+    // wait for the stream epilogue's 32 stores, a full memory round trip per tile: 5.3 k cycles in the v1 trace.)
+    if constexpr (!FUSE) wait_vmcnt<4 * (NRING - 1)>();
     __builtin_amdgcn_s_barrier();    // [B1] everyone's pieces have
     L512_STAMP(0);
     read_act(act[0], 0);
@@ -211,6 +228,9 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     L512_STAMP(1);
 
     // ---- gate epilogue. Addend slab in accumulator order: block (nb, m), quarter q -> one 16-byte load per lane, 1 KB per wave instruction.
+    // Request order = order of need (vmcnt retires in order: whatever is waited for drags everything older with it): E(m = 0) | E(1) | E(2) |
+    // E(3), the stream P | the next tile's DMA pieces last - v2 issued them right after [B2], and the first E wait then also waited for a
+    // 72 KB fetch nobody needs for another 25 k cycles (the gate epilogue took 20 k cycles per tile, profiles/r06_trace_layer512_v2.log).
     const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr((const char*)a.E512 + (int64_t)tile * E_TILE + (int64_t)wave * (E_TILE / 8)), 0, E_TILE / 8, 0x00020000);
     f32x4 ev[2][2][4];
@@ -225,11 +245,9 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
     __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
     L512_STAMP(2);
-    if (tile + (int)gridDim.x < n_tiles) dma_tile(tile + gridDim.x, Rn, lane);
-    const float m0 = -L2E, m1 = -2.0f * L2E;
-    // the stream's pairs of this tile (accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
-    // dead so that they fly under the rest of this epilogue, [B3] and the G pass
-    [[maybe_unused]] u32x4 pv[4][4];
+    // the stream of this tile (fp32, accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
+    // dead so that the loads fly under the rest of this epilogue, [B3] and the G pass
+    [[maybe_unused]] f32x4 pv[4][4];
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (int64_t)wave * (P_TILE / 8) : (const char*)a.Wg), 0, FUSE ? P_TILE / 8 : 0, 0x00020000);
 #pragma unroll
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 #pragma unroll
           for (int mm = 0; mm < 4; ++mm)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pv[mm][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, (mm * 4 + q) * 1024, 0);
+            for (int q = 0; q < 4; ++q) pv[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, (mm * 4 + q) * 1024, 0));
         }
       }
       const bool pad = t0 + 32 * m + l31 >= row_lim;
@@ -253,35 +271,35 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int e = 2 * e2 + k, r = 4 * q + e;
-            const float v0 = fmaf(acc[0][m][r], a.out_scale, ev[m & 1][0][q][e]);
-            const float v1 = fmaf(acc[1][m][r], a.out_scale, ev[m & 1][1][q][e]);
-            float g = sigm(v0, m0) * fmaf(sigm(v1, m1), 2.0f, -1.0f);   // sigmoid(v0) * tanh(v1), net.py:72-73
+            const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, ev[m & 1][0][q][e]));
+            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, ev[m & 1][1][q][e]), 30.0f));
+            float g = (1.0f - eb) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));   // sigmoid(v0) * tanh(v1), net.py:72-73
             if (pad) g = 0.f;
             v |= (uint32_t)ss_f2t<true>(g) << (16 * k);
           }
           pk[e2] = v;
         }
-        // channels 32 w + 8 q + 4 lh .. + 3 of row 32 m + l31: logical slot 4 w + q, bytes 8 lh .. of it
-        char* dst = Rc + (32 * m + l31) * ROWB + (((4 * wave + q) ^ gw_sw) << 4) + 8 * lh;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{pk[0], pk[1]};
+        // channels 32 w + 8 q + 4 lh .. + 3 of row 32 m + l31: slot 4 w + q, bytes 8 lh .. of the row's 16: a wave writes 512 contiguous bytes
+        *reinterpret_cast<u32x2*>(Rc + (4 * wave + q) * SLOTB + (32 * m + l31) * 16 + 8 * lh) = u32x2{pk[0], pk[1]};
       }
     }
+    if (tile + (int)gridDim.x < n_tiles) dma_tile(tile + gridDim.x, Rn, lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // my G writes are done
     L512_STAMP(3);
     __builtin_amdgcn_s_barrier();         // [B3] the G tile is complete
     L512_STAMP(4);
 
-    // ---- G -> HBM (the skip GEMM's operand): 128 rows x 32 slots of 16 B, eight per thread; the hi halves of the pair layout's 128-byte lines
+    // ---- G -> HBM (the skip GEMM's operand, ss_gemm_bf16's pair layout): 128 rows x 32 slots, eight per thread; lanes walk the slots of a row
+    // (LDS stride 2320 B = 4 banks x 16 B apart: conflict-free), the hi halves of the row's 128-byte pair lines in HBM
     {
       const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(
           uniform_ptr(a.G + (int64_t)b * a.g_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldg * 2)), 0x00020000);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int p = tid + 512 * j;
-        const int R = p >> 5, ps = p & 31;
-        const int s = ps ^ (R & 15);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(Rc + p * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_g, (t0 + R) * a.ldg * 2 + (s >> 2) * 128 + (s & 3) * 16, 0, 0);   // rows >= T dropped
+        const int R = p >> 5, s_ = p & 31;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Rc + s_ * SLOTB + R * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_g, (t0 + R) * a.ldg * 2 + (s_ >> 2) * 128 + (s_ & 3) * 16, 0, 0);   // rows >= T dropped
       }
     }
     L512_STAMP(5);
@@ -292,79 +310,68 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
-      bf16x8 wr[NRING][2];
+      bf16x8 wr[NRING_R][2];
       bf16x8 gf[2][4];
       auto load_wr = [&](bf16x8 (&dst)[2], int S) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) dst[p] = ldw(rsrc_wr, w_voff + p * 1024, S * WR_STEP);
       };
       auto read_g = [&](bf16x8 (&dst)[4], int S) {
-        const int go = g_off + (((2 * S) ^ g_sw) << 4);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + go + m * 32 * ROWB);
+        for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + g_off + 2 * S * SLOTB + m * 512);
       };
 #pragma unroll
-      for (int s = 0; s < NRING - 1; ++s) load_wr(wr[s], s);
+      for (int s = 0; s < NRING_R - 1; ++s) load_wr(wr[s], s);
       read_g(gf[0], 0);
-      // per-channel constants of this lane's 16 channels 32 w + 8 q + 4 lh + e: kb = b - cur_bias, nb = next_bias
-      f32x4 kb[4], nb[4];
+      // per-channel constants of this lane's 16 channels 32 w + 8 q + 4 lh + e
+      f32x4 bs[4], nb[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = 32 * wave + 8 * q + 4 * lh;
-        const f32x4 bsq = a.bias_r ? *reinterpret_cast<const f32x4*>(a.bias_r + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        kb[q] = bsq - *reinterpret_cast<const f32x4*>(a.cur_bias + c0);
+        bs[q] = a.bias_r ? *reinterpret_cast<const f32x4*>(a.bias_r + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
         nb[q] = a.next_bias ? *reinterpret_cast<const f32x4*>(a.next_bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       auto rstep = [&](auto stag) {
         constexpr int S = decltype(stag)::value;
-        if constexpr (S + NRING - 1 < RSTEPS) load_wr(wr[(S + NRING - 1) % NRING], S + NRING - 1);
+        if constexpr (S + NRING_R - 1 < RSTEPS) load_wr(wr[(S + NRING_R - 1) % NRING_R], S + NRING_R - 1);
         if constexpr (S + 1 < RSTEPS) read_g(gf[(S + 1) & 1], S + 1);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc2[m] = ss_mfma_32x32x16<true>(wr[S % NRING][p], gf[S & 1][m], acc2[m]);
+          for (int m = 0; m < 4; ++m) acc2[m] = ss_mfma_32x32x16<true>(wr[S % NRING_R][p], gf[S & 1][m], acc2[m]);
         __builtin_amdgcn_sched_barrier(0);
       };
       unrolled_steps(rstep, std::make_integer_sequence<int, RSTEPS>{});
       L512_STAMP(6);
 
-      // ---- stream update on the (hi, lo) fp16 pairs: x = hi + lo - cur_bias ; x' = (x + acc * out_scale + b) * post_scale ; pair(x' + next_bias).
-      // P in place (16 bytes per lane, 1 KB per instruction); the new hi plane also goes to Hout's rows (8 bytes per lane: the next layer's conv operand)
-      const __amdgpu_buffer_rsrc_t rsrc_ho = __builtin_amdgcn_make_buffer_rsrc(
-          uniform_ptr(a.Hout + (int64_t)b * a.h_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * ldh2)), 0x00020000);
+      // ---- stream update: x' = (x + acc * out_scale + b) * post_scale in fp32, in place in P (16 bytes per lane, 1 KB per instruction);
+      // fp16(x' + next_bias) goes to Hout's slot-major tile: 8 bytes per lane, the two lane halves fill a row's 16-byte slot, 32 rows in a row -
+      // 512 contiguous bytes per instruction. Everything of mine that is in flight has to land first anyway (the stream loads) - and with it
+      // the next tile's DMA pieces, which [B1] then needs no memory wait for.
+      wait_vmcnt<0>();
+      const __amdgpu_buffer_rsrc_t rsrc_ho = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Hout + (int64_t)tile * H_TILE), 0, H_TILE, 0x00020000);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int grow = t0 + 32 * m + l31;
-        const bool pad = grow >= row_lim;
-        const int ho = grow * ldh2 + wave * 64 + 8 * lh;   // + 16 q
+        const bool pad = t0 + 32 * m + l31 >= row_lim;
+        const int ho = (32 * m + l31) * 16 + 8 * lh;   // + slot (4 w + q) * 2048
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          u32x4 po;
+          f32x4 xo;
+          uint32_t hp[2] = {0, 0};
 #pragma unroll
-          for (int e2 = 0; e2 < 2; ++e2) {
-            uint32_t hp = 0, lp = 0;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int e = 2 * e2 + k;
-              const float hf = ss_t2f_packed<true>(pv[m][q][e2], k), mf = ss_t2f_packed<true>(pv[m][q][2 + e2], k);
-              const float xn = ((hf + mf) + fmaf(acc2[m][4 * q + e], a.out_scale, kb[q][e])) * a.post_scale;
-              const float yv = pad ? 0.f : xn + nb[q][e];
-              const uint16_t yh = ss_f2t<true>(yv);
-              const uint16_t yl = ss_f2t<true>(yv - ss_t2f<true>(yh));
-              hp |= (uint32_t)yh << (16 * k);
-              lp |= (uint32_t)yl << (16 * k);
-            }
-            po[e2] = hp;
-            po[2 + e2] = lp;
+          for (int e = 0; e < 4; ++e) {
+            const float xn = (pv[m][q][e] + fmaf(acc2[m][4 * q + e], a.out_scale, bs[q][e])) * a.post_scale;
+            xo[e] = pad ? 0.f : xn;
+            hp[e >> 1] |= (uint32_t)ss_f2t<true>(pad ? 0.f : xn + nb[q][e]) << (16 * (e & 1));
           }
-          __builtin_amdgcn_raw_buffer_store_b128(po, rsrc_p, w_voff, (m * 4 + q) * 1024, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{po[0], po[1]}, rsrc_ho, ho + 16 * q, 0, 0);   // rows >= T: out of range, dropped
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), rsrc_p, w_voff, (m * 4 + q) * 1024, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{hp[0], hp[1]}, rsrc_ho, ho, (4 * wave + q) * (BM * 16), 0);
         }
       }
     }
     L512_STAMP(7);
     // (no barrier here: the next tile's [B1] is reached by a wave only after its reads of this G tile, and this region is next written by
-    // the DMA issued after the next tile's [B2])
+    // the DMA issued before the next tile's [B3] - after its [B2], which every wave reaches only after [B1])
   }
   if (probing && tid0 == 0) {
     atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
@@ -398,7 +405,8 @@ __global__ void pack_res_kernel(const uint16_t* __restrict__ src, uint16_t* __re
   *reinterpret_cast<uint4*>(dst + (int64_t)i * 8) = *reinterpret_cast<const uint4*>(s);
 }
 // conditioner addend E [B][T][lde] (this layer's 512 packed columns) -> [tile][wave 8][nb 2][m 4][q 4][lane 64][4]: lane (l31, lh) holds packed
-// columns 64 wave + 32 nb + 8 q + 4 lh .. + 3 of row 32 m + l31 of the tile; rows >= T are zero
+// columns 64 wave + 32 nb + 8 q + 4 lh .. + 3 of row 32 m + l31 of the tile; rows >= T are zero. The values are stored as the gate's exp2
+// arguments: times -log2(e) in the sigmoid blocks (nb = 0), times -2 log2(e) in the tanh blocks (nb = 1).
 __global__ void tile_addend_kernel(const float* __restrict__ E, int lde, int64_t e_batch_stride, float* __restrict__ out, int T, int tiles_per_item, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 each
   if (i >= n) return;
@@ -408,14 +416,15 @@ __global__ void tile_addend_kernel(const float* __restrict__ E, int lde, int64_t
   const int col = 64 * w + 32 * nb + 8 * q + 4 * (lane >> 5);
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (t < T) v = *reinterpret_cast<const float4*>(E + (int64_t)b * e_batch_stride + (int64_t)t * lde + col);
-  *reinterpret_cast<float4*>(out + i * 4) = v;
+  const float k = nb ? -2.0f * 1.44269504088896340736f : -1.44269504088896340736f;
+  *reinterpret_cast<float4*>(out + i * 4) = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
 }
 
-// stack entry: X fp32 [B][T][ldx] + bias -> the stream's two forms: H rows (hi plane, fp16 [B][T][ldh]) and P (pair, accumulator order:
-// [tile][wave 8][m 4][q 4][lane 64] x {hi01, hi23, lo01, lo23}); lane (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of
-// row 32 m + l31. Rows >= lens[b] are zero.
+// stack entry: X fp32 [B][T][ldx] -> the stream's two forms: P = x in accumulator order ([tile][wave 8][m 4][q 4][lane 64] x 4 floats; lane
+// (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row 32 m + l31) and H = fp16(x + bias) in slot-major tiles
+// ([tile][slot 32][row 128] x 8 channels). Rows >= lens[b] are zero.
 __global__ void entry_kernel(const float* __restrict__ X, int ldx, int64_t x_batch_stride, const float* __restrict__ bias, const int32_t* __restrict__ lens,
-                             uint16_t* __restrict__ H, int ldh, int64_t h_batch_stride, uint4* __restrict__ P, int T, int tiles_per_item, int64_t n) {
+                             uint16_t* __restrict__ H, float4* __restrict__ P, int T, int tiles_per_item, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte P entry each
   if (i >= n) return;
   const int lane = (int)(i & 63), q = (int)(i >> 6) & 3, m = (int)(i >> 8) & 3, w = (int)(i >> 10) & 7;
@@ -423,37 +432,33 @@ __global__ void entry_kernel(const float* __restrict__ X, int ldx, int64_t x_bat
   const int b = (int)(tile / tiles_per_item), t = (int)(tile % tiles_per_item) * BM + 32 * m + (lane & 31);
   const int c0 = 32 * w + 8 * q + 4 * (lane >> 5);
   const int len = lens ? min(max(lens[b], 0), T) : T;
-  uint32_t hp[2] = {0, 0}, lp[2] = {0, 0};
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t hp[2] = {0, 0};
   if (t < len) {
-    const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)b * x_batch_stride + (int64_t)t * ldx + c0);
+    x = *reinterpret_cast<const float4*>(X + (int64_t)b * x_batch_stride + (int64_t)t * ldx + c0);
     const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float v[4] = {x.x + bb.x, x.y + bb.y, x.z + bb.z, x.w + bb.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint16_t yh = ss_f2t<true>(v[e]);
-      const uint16_t yl = ss_f2t<true>(v[e] - ss_t2f<true>(yh));
-      hp[e >> 1] |= (uint32_t)yh << (16 * (e & 1));
-      lp[e >> 1] |= (uint32_t)yl << (16 * (e & 1));
-    }
+    for (int e = 0; e < 4; ++e) hp[e >> 1] |= (uint32_t)ss_f2t<true>(v[e]) << (16 * (e & 1));
   }
-  P[i] = make_uint4(hp[0], hp[1], lp[0], lp[1]);
-  if (t < T) *reinterpret_cast<uint2*>(H + (int64_t)b * h_batch_stride + (int64_t)t * ldh + c0) = make_uint2(hp[0], hp[1]);
+  P[i] = x;
+  *reinterpret_cast<uint2*>(H + tile * (H_TILE / 2) + ((4 * w + q) * BM + 32 * m + (lane & 31)) * 8 + 4 * (lane >> 5)) = make_uint2(hp[0], hp[1]);
 }
 
 }  // namespace
 
 extern "C" int64_t ss_layer512_stream_bytes(int B, int T) { return (int64_t)B * ss_cdiv(T, BM) * P_TILE; }
 
-extern "C" int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, int ldh,
-                                 int64_t h_batch_stride, void* P, int B, int T, void* stream) {
-  SS_CHECK_ARG(X && H && P && B > 0 && T > 0 && ldx >= 256 && (ldx % 4) == 0 && (x_batch_stride % 4) == 0 && ldh >= 256 && (ldh % 8) == 0 && (h_batch_stride % 8) == 0,
-               "ss_layer512_entry: X [B][T][ldx >= 256, %% 4], H [B][T][ldh >= 256, %% 8]");
+extern "C" int64_t ss_layer512_h_elems(int B, int T) { return (int64_t)B * ss_cdiv(T, BM) * (H_TILE / 2); }
+
+extern "C" int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, void* P, int B, int T,
+                                 void* stream) {
+  SS_CHECK_ARG(X && H && P && B > 0 && T > 0 && ldx >= 256 && (ldx % 4) == 0 && (x_batch_stride % 4) == 0, "ss_layer512_entry: X [B][T][ldx >= 256, %% 4]");
   SS_CHECK_ARG((((uintptr_t)X) & 15) == 0 && (((uintptr_t)H) & 15) == 0 && (((uintptr_t)P) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0),
                "ss_layer512_entry: X / H / P / bias must be 16-byte aligned");
   const int tpi = ss_cdiv(T, BM);
   const int64_t n = (int64_t)B * tpi * (P_TILE / 16);
-  hipLaunchKernelGGL(entry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, x_batch_stride, bias, lens, H, ldh, h_batch_stride,
-                     (uint4*)P, T, tpi, n);
+  hipLaunchKernelGGL(entry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, x_batch_stride, bias, lens, H, (float4*)P, T, tpi, n);
   SS_CHECK_LAUNCH("ss_layer512_entry");
   return SS_OK;
 }
@@ -486,10 +491,10 @@ extern "C" int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, void
 
 // 1 if the fused layer launch can take this shape and is expected to pay: C = 256 (the kernel's fixed geometry), dilation <= 8, 32-bit offsets,
 // and at least four rounds of 128-row tiles per CU (below that the single-round kernels win)
-extern "C" int ss_layer512_ok(int B, int T, int C, int d_max, int ldh, int ldg) {
+extern "C" int ss_layer512_ok(int B, int T, int C, int d_max, int ldg) {
   if (C != 256 || d_max < 1 || d_max > HALO || B < 1 || T < 1) return 0;
-  if (ldh < 256 || (ldh % 8) != 0 || ldg < 512 || (ldg % 8) != 0) return 0;
-  if ((int64_t)T * ldh * 2 >= (1ll << 31) || (int64_t)T * ldg * 2 >= (1ll << 31)) return 0;
+  if (ldg < 512 || (ldg % 8) != 0) return 0;
+  if ((int64_t)T * ldg * 2 >= (1ll << 31) || (int64_t)B * ss_cdiv(T, BM) * H_TILE >= (1ll << 31)) return 0;
   return (g_ss_tuning.layer512 == 2 || (long)ss_cdiv(T, BM) * B >= 4l * ss_n_cu()) ? 1 : 0;   // knob = 2: any shape (parity tests run one item)
 }
 
@@ -498,22 +503,25 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
   const ss_layer512_args& a = *args;
   SS_CHECK_ARG(a.Hin && a.Wg && a.E512 && a.G, "ss_layer512: null Hin / Wg / E512 / G");
   SS_CHECK_ARG(a.B > 0 && a.T > 0 && a.d >= 1 && a.d <= HALO, "ss_layer512: B, T > 0 and 1 <= d <= 8");
-  SS_CHECK_ARG(a.ldh >= 256 && (a.ldh % 8) == 0 && a.ldg >= 512 && (a.ldg % 8) == 0 && (a.h_batch_stride % 8) == 0 && (a.g_batch_stride % 8) == 0,
-               "ss_layer512: ldh >= 256, ldg >= 512 (pair layout of 256 channels), both multiples of 8, batch strides multiples of 8");
-  SS_CHECK_ARG((int64_t)a.T * a.ldh * 2 < (1ll << 31) && (int64_t)a.T * a.ldg * 2 < (1ll << 31), "ss_layer512: item too large for 32-bit offsets");
+  SS_CHECK_ARG(a.ldg >= 512 && (a.ldg % 8) == 0 && (a.g_batch_stride % 8) == 0, "ss_layer512: ldg >= 512 (pair layout of 256 channels), a multiple of 8, as the batch stride");
+  SS_CHECK_ARG((int64_t)a.T * a.ldg * 2 < (1ll << 31) && (int64_t)a.B * ss_cdiv(a.T, BM) * H_TILE < (1ll << 31), "ss_layer512: too large for 32-bit offsets");
   SS_CHECK_ARG((((uintptr_t)a.Hin) & 15) == 0 && (((uintptr_t)a.Wg) & 15) == 0 && (((uintptr_t)a.E512) & 15) == 0 && (((uintptr_t)a.G) & 15) == 0,
                "ss_layer512: Hin / Wg / E512 / G must be 16-byte aligned");
   SS_CHECK_ARG(a.out_scale > 0.f && a.out_scale <= 1.f, "ss_layer512: 0 < out_scale <= 1");
   const bool fuse = a.Hout != nullptr;
   if (fuse) {
-    SS_CHECK_ARG(a.Wr && a.P && a.cur_bias && a.Hout != a.Hin && (((uintptr_t)a.Hout) & 15) == 0 && (((uintptr_t)a.Wr) & 15) == 0 && (((uintptr_t)a.P) & 15) == 0,
-                 "ss_layer512: the fused form needs Wr, P, cur_bias and an Hout buffer different from Hin (tiles read their neighbours' halo rows)");
-    SS_CHECK_ARG((((uintptr_t)a.cur_bias) & 15) == 0 && (!a.bias_r || (((uintptr_t)a.bias_r) & 15) == 0) && (!a.next_bias || (((uintptr_t)a.next_bias) & 15) == 0),
+    SS_CHECK_ARG(a.Wr && a.P && a.Hout != a.Hin && (((uintptr_t)a.Hout) & 15) == 0 && (((uintptr_t)a.Wr) & 15) == 0 && (((uintptr_t)a.P) & 15) == 0,
+                 "ss_layer512: the fused form needs Wr, P and an Hout buffer different from Hin (tiles read their neighbours' halo rows)");
+    SS_CHECK_ARG((!a.bias_r || (((uintptr_t)a.bias_r) & 15) == 0) && (!a.next_bias || (((uintptr_t)a.next_bias) & 15) == 0),
                  "ss_layer512: bias vectors must be 16-byte aligned");
   }
   const int tpi = ss_cdiv(a.T, BM);
   const int n_tiles = tpi * a.B;
-  const int grid = n_tiles < ss_n_cu() ? n_tiles : ss_n_cu();
+  int grid = n_tiles < ss_n_cu() ? n_tiles : ss_n_cu();
+#ifdef SS_L512_TRACE
+  if (const char* e = getenv("SS_L512_GRID")) grid = atoi(e) > 0 && atoi(e) < grid ? atoi(e) : grid;   // trace builds: fewer CUs (is a phase memory-starved? it is not:
+                                                                                                       // profiles/r06_trace_layer512_v2_experiments.log)
+#endif
   const size_t lds = (size_t)2 * REGION;
   auto go = [&](auto kern) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

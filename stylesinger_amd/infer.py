@@ -122,6 +122,9 @@ class StyleSingerInfer:
         def finish(entry):
             res, strm = entry
             main.wait_stream(strm)
+            if self.model.f16:   # the fp16 modes' range check, where this path waits for the batch anyway
+                strm.synchronize()
+                self.model.check_finite(res["model_out"])
             # the results were allocated from the side stream's pool and are handed to the caller's stream: tell the allocator, or
             # the next batch on that side stream could reuse the memory while `main` still reads it
             for v in list(res.values()) + list(res.get("model_out", {}).values()):
@@ -165,6 +168,7 @@ class StyleSingerInfer:
         frame count and queue the files on `writer` (a writer.WavWriter)."""
         from .writer import wav_to_pcm16
         res = self.infer_batch(batch, seed=seed)
+        self.model.check_finite(res["model_out"])
         hop = self.vocoder.model.hop
         pcm = wav_to_pcm16(res["wav"], res["lens"], hop, norm=bool(self.hparams.get("out_wav_norm", False)))
         writer.submit_batch(names, pcm, res["lens"], hop)
@@ -345,6 +349,7 @@ class StyleSingerInfer:
     def _wav_from_result(self, res, vocoder_noise=None):
         """inference/StyleSinger.py:53-63: drop all-zero frames, clip the mel, vocode with the predicted f0 (one item)."""
         mel_pred = res["mel"].cpu().numpy()
+        self.model.check_finite(res["model_out"])   # (the copy above synchronised)
         f0_pred = res["f0"].cpu().numpy()
         mask = np.abs(mel_pred).sum(-1) > 0
         mel_pred = np.clip(mel_pred[mask], self.hparams["mel_vmin"], self.hparams["mel_vmax"])

@@ -91,9 +91,9 @@ HEPI_STORE, HEPI_GATE, HEPI_RESX = 0, 1, 2
 
 class Layer512Args(C.Structure):
     _fields_ = [
-        ("Hin", _vp), ("h_batch_stride", C.c_int64), ("ldh", C.c_int32), ("d", C.c_int32), ("Hout", _vp), ("P", _vp),
+        ("Hin", _vp), ("d", C.c_int32), ("reserved0_", C.c_int32), ("Hout", _vp), ("P", _vp),
         ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("Wg", _vp), ("Wr", _vp), ("E512", _vp), ("G", _vp), ("g_batch_stride", C.c_int64),
-        ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("cur_bias", _vp), ("next_bias", _vp), ("out_scale", C.c_float),
+        ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("next_bias", _vp), ("reserved_", _vp), ("out_scale", C.c_float),
         ("post_scale", C.c_float),
     ]
 
@@ -670,30 +670,35 @@ def layer512_tile_addend(E, *, B, T, lde=None, e_bs=None, out=None):
 
 
 def layer512_entry(X, bias=None, *, B, T, lens=None):
-    """ss_layer512_entry: X fp32 [B][T][256] (+ bias) -> (H fp16 [B][T][256] hi rows, P uint8 pair stream in accumulator order)"""
-    H = torch.empty(B, T, 256, device=X.device, dtype=torch.float16)
+    """ss_layer512_entry: X fp32 [B][T][256] -> (H = fp16(X + bias) in slot-major tiles (fp16 [elems]), P = X in accumulator order (uint8 buffer of fp32))"""
+    H = torch.empty(load().ss_layer512_h_elems(B, T), device=X.device, dtype=torch.float16)
     P = torch.empty(load().ss_layer512_stream_bytes(B, T), device=X.device, dtype=torch.uint8)
-    check(load().ss_layer512_entry(ptr(X), X.shape[-1], T * X.shape[-1], ptr(bias), ptr(lens), ptr(H), 256, T * 256, ptr(P), B, T, stream_ptr()), "ss_layer512_entry")
+    check(load().ss_layer512_entry(ptr(X), X.shape[-1], T * X.shape[-1], ptr(bias), ptr(lens), ptr(H), ptr(P), B, T, stream_ptr()), "ss_layer512_entry")
     return H, P
 
 
-def layer512_stream_values(P, *, B, T):
-    """the pair stream P -> (hi, lo) fp32 [B][T][256] (test helper: the index map of include/stylesinger_hip.h)"""
+def layer512_h_values(H, *, B, T):
+    """H (slot-major tiles [tile][slot 32][row 128][8]) -> fp16 [B][T][256] (test helper)"""
     nt = (T + 127) // 128
-    v = P.view(torch.float16).view(B * nt, 8, 4, 4, 2, 32, 2, 4)          # tile, wave, m, q, lh, l31, plane, e
-    v = v.permute(0, 2, 5, 1, 3, 4, 7, 6).reshape(B, nt * 128, 256, 2)     # tile, (m, l31) = row, (wave, q, lh, e) = channel, plane
-    return v[:, :T, :, 0].float(), v[:, :T, :, 1].float()
+    return H.view(B * nt, 32, 128, 8).permute(0, 2, 1, 3).reshape(B, nt * 128, 256)[:, :T]
 
 
-def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None, bias_r=None, cur_bias=None, next_bias=None, out_scale=1.0 / 256.0,
+def layer512_stream_values(P, *, B, T):
+    """the fp32 stream P (accumulator order) -> [B][T][256] (test helper: the index map of include/stylesinger_hip.h)"""
+    nt = (T + 127) // 128
+    v = P.view(torch.float32).view(B * nt, 8, 4, 4, 2, 32, 4)          # tile, wave, m, q, lh, l31, e
+    return v.permute(0, 2, 5, 1, 3, 4, 6).reshape(B, nt * 128, 256)[:, :T]   # tile, (m, l31) = row, (wave, q, lh, e) = channel
+
+
+def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None, bias_r=None, next_bias=None, out_scale=1.0 / 256.0,
              post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True):
     """ss_layer512: one launch per residual layer (gate + residual projection) of the fp16x2 mel denoiser; see include/stylesinger_hip.h."""
     a = Layer512Args()
-    a.Hin = ptr(Hin); a.ldh = Hin.shape[-1]; a.h_batch_stride = T * a.ldh; a.d = d
+    a.Hin = ptr(Hin); a.d = d
     a.Hout = ptr(Hout); a.P = ptr(P)
     a.lens = ptr(lens); a.B = B; a.T = T; a.Wg = ptr(Wg); a.Wr = ptr(Wr); a.E512 = ptr(E512)
     a.G = ptr(G); a.ldg = ldg if ldg is not None else G.shape[-1]; a.g_batch_stride = g_bs if g_bs is not None else T * a.ldg
-    a.mask_rows = int(mask_rows); a.bias_r = ptr(bias_r); a.cur_bias = ptr(cur_bias); a.next_bias = ptr(next_bias)
+    a.mask_rows = int(mask_rows); a.bias_r = ptr(bias_r); a.next_bias = ptr(next_bias)
     a.out_scale = out_scale; a.post_scale = post_scale
     check(load().ss_layer512(C.byref(a), stream_ptr()), "ss_layer512")
 

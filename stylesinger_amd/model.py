@@ -64,6 +64,7 @@ class _DiffPlan:
         f32 = dict(device=dev, dtype=torch.float32)
         self.B, self.T = B, T
         self.seed = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.nonfinite = torch.zeros(1, device=dev, dtype=torch.int32)   # set by ss_mel_denorm when a valid frame is NaN / inf
         # f0 pair: items [0,B) = agnostic net, [B,2B) = specific net (grouped launches)
         self.lens2 = torch.zeros(2 * B, device=dev, dtype=torch.int32)
         self.lens = self.lens2[:B]
@@ -746,7 +747,7 @@ class StyleSingerHIP(torch.nn.Module):
         self._run_mel(pl, (zq_n, zs_n), ddim_ts=self.ddim_timesteps(ddim_steps) if sampler == "ddim" else None,
                       plms_interval=plms_interval if sampler == "plms" else None, eta=eta)
         mel_out = torch.empty(B, T, M, device=dev, dtype=torch.float32)
-        L.check(lib.ss_mel_denorm(L.ptr(pl.xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(pl.lens),
+        L.check(lib.ss_mel_denorm(L.ptr(pl.xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(pl.lens), None,
                                   L.stream_ptr()), "denorm")
         return mel_out
 
@@ -1056,29 +1057,58 @@ class StyleSingerHIP(torch.nn.Module):
                 pl.g_ddim[key].replay()
             else:
                 self._run_mel(pl, ddim_ts=ddim_ts, eta=eta)
-        elif noise is not None:
-            nz = noise["mel"]
-            self._run_mel(pl, (mel_tape(nz["z_q"], ()), mel_tape(nz["z_steps"], (K,))))
-        elif graphs:
+        elif noise is not None or not graphs:
+            # "fp16q4": the kernels behind the mode convert their fp16 operand to fp4 on a FIXED scale (q_scale_gate / q_scale_z): on the first
+            # (eager) forward of every plan the library reduces max |a| / (6 q_scale) over every operand those launches read (ss_set_q4_guard);
+            # a checkpoint whose stream leaves the scale's range is refused instead of silently degrading the second product
+            guard = torch.zeros(2, device=dev, dtype=torch.int32) if (self.q4 and pl.uses <= 1) else None
+            if guard is not None:
+                L.check(lib.ss_set_q4_guard(L.ptr(guard)), "ss_set_q4_guard")
+            try:
+                if noise is not None:
+                    nz = noise["mel"]
+                    self._run_mel(pl, (mel_tape(nz["z_q"], ()), mel_tape(nz["z_steps"], (K,))))
+                else:
+                    self._run_mel(pl)
+            finally:
+                if guard is not None:
+                    L.check(lib.ss_set_q4_guard(None), "ss_set_q4_guard")
+            if guard is not None:
+                worst = guard.view(torch.float32).cpu()
+                if float(worst.max()) > 1.0:
+                    raise L.StyleSingerHipError(
+                        f"mfma_precision=fp16q4: an operand of the fp4 second product leaves its fixed scale (max |a| / (6 q_scale): gate "
+                        f"{float(worst[0]):.3g}, skip GEMM {float(worst[1]):.3g}; the stream x + dstep must stay within +-{6 * 2.0:g}) - this checkpoint "
+                        f"needs mfma_precision='fp16x2' (no fixed activation scale)")
+        else:
             if pl.g_mel is None:
                 pl.g_mel = self._capture(lambda: self._run_mel(pl))
             pl.g_mel.replay()
-        else:
-            self._run_mel(pl)
         xm = pl.xm
-        if self.f16 and pl.uses <= 1 and not torch.isfinite(xm).all():
-            # fp16 terms carry the residual stream x + dstep and the gate outputs inside the stack: unlike the bf16 modes they overflow beyond
-            # 65504. Checked on the first forward of every plan (one host sync); a checkpoint that trips it needs mfma_precision="bf16x2".
-            raise L.StyleSingerHipError("mfma_precision=fp16x2: non-finite mel after the diffusion loop - the residual stream of this checkpoint "
-                                        "leaves the fp16 range (|x + dstep| > 65504); use mfma_precision='bf16x2' (fp32 exponent range)")
         mel_out = torch.empty(B, T, M, **f32)
         # the reference does not mask padded frames here (shallow_diffusion_tts.py:305-306); with per-item
         # lengths the frames past lens[b] are not part of the utterance, so they are written as 0.
-        L.check(lib.ss_mel_denorm(L.ptr(xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(lens_t), st()), "denorm")
+        pl.nonfinite.zero_()
+        L.check(lib.ss_mel_denorm(L.ptr(xm), L.ptr(pk["spec_min"]), L.ptr(pk["spec_max"]), L.ptr(mel_out), B, T, M, L.ptr(lens_t), L.ptr(pl.nonfinite), st()), "denorm")
+        # fp16 terms carry the residual stream x + dstep and the gate outputs inside the stack: unlike the bf16 modes they overflow beyond 65504.
+        # The denorm kernel flags a non-finite valid frame on EVERY forward (ret["nonfinite"], a device word: `check_finite(ret)` wherever the
+        # caller synchronises anyway - infer.py does); the first forward of every plan checks it here (one host sync).
+        ret["nonfinite"] = pl.nonfinite.clone()
+        if self.f16 and pl.uses <= 1:
+            self.check_finite(ret)
         ret["mel_out"] = mel_out
         ret["diff"] = 0.0
         ret["lens"] = lens_t
         return self._crop_frames(ret, T, T_out)
+
+    def check_finite(self, ret):
+        """Raise if the forward that produced `ret` wrote a non-finite valid mel frame (reads one device word: a host sync)."""
+        flag = ret.get("nonfinite")
+        if flag is not None and int(flag.item()) != 0:
+            if self.f16:
+                raise L.StyleSingerHipError("mfma_precision=fp16x2: non-finite mel after the diffusion loop - the residual stream of this checkpoint "
+                                            "leaves the fp16 range (|x + dstep| > 65504); use mfma_precision='bf16x2' (fp32 exponent range)")
+            raise L.StyleSingerHipError("non-finite mel after the diffusion loop")
 
     _FRAME_KEYS = ("mel2ph", "style", "pitch_pred", "f0_denorm", "f0_denorm_pred", "pitch_coarse", "f0_a", "uv_a", "f0_b", "uv_b",
                    "decoder_inp", "decoder_out", "fs2_mel", "x_mask", "diff_cond", "mel_out")
