@@ -228,12 +228,13 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     L512_STAMP(1);
 
     // ---- gate epilogue. Addend slab in accumulator order: block (nb, m), quarter q -> one 16-byte load per lane, 1 KB per wave instruction.
-    // Request order = order of need (vmcnt retires in order: whatever is waited for drags everything older with it): E(m = 0) | E(1) | E(2) |
-    // E(3), the stream P | the next tile's DMA pieces last - v2 issued them right after [B2], and the first E wait then also waited for a
-    // 72 KB fetch nobody needs for another 25 k cycles (the gate epilogue took 20 k cycles per tile, profiles/r06_trace_layer512_v2.log).
+    // Request order = order of need (vmcnt retires in order: whatever is waited for drags everything older with it): E(m = 0), E(1) | E(2) |
+    // E(3) | the stream P | the next tile's DMA pieces last.
     const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr((const char*)a.E512 + (int64_t)tile * E_TILE + (int64_t)wave * (E_TILE / 8)), 0, E_TILE / 8, 0x00020000);
-    f32x4 ev[2][2][4];
+    // TWO blocks ahead: the slab is 256 KB per tile and CU, and with one block (8 KB per wave) in flight it arrived at ~26 B per cycle and CU -
+    // the gate epilogue took 20 k cycles for 5 k of VALU work (profiles/r06_trace_layer512_v3.log)
+    f32x4 ev[3][2][4];
     auto load_e = [&](f32x4 (&dst)[2][4], int m) {
 #pragma unroll
       for (int n = 0; n < 2; ++n)
@@ -242,17 +243,19 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
           dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + m) * 4 + q) * 1024, 0));
     };
     load_e(ev[0], 0);
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
-    __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
-    L512_STAMP(2);
+    load_e(ev[1], 1);
     // the stream of this tile (fp32, accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
     // dead so that the loads fly under the rest of this epilogue, [B3] and the G pass
     [[maybe_unused]] f32x4 pv[4][4];
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (int64_t)wave * (P_TILE / 8) : (const char*)a.Wg), 0, FUSE ? P_TILE / 8 : 0, 0x00020000);
+    // The gate arithmetic runs BEFORE [B2], into registers (64 fp16 values = 32 registers): of the two waves of a SIMD the older one gets the
+    // matrix pipe first and leaves the conv loop ~25 k cycles before its partner (trace: 25 k .. 50 k) - its gate VALU work then runs under the
+    // partner's MFMAs instead of waiting at the barrier. Only the LDS writes need everyone to be done with the A tile.
+    u32x2 gpk[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      if (m + 1 < 4) load_e(ev[(m + 1) & 1], m + 1);
+      if (m + 2 < 4) load_e(ev[(m + 2) % 3], m + 2);
       if constexpr (FUSE) {
         if (m == 2) {
 #pragma unroll
@@ -271,18 +274,26 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int e = 2 * e2 + k, r = 4 * q + e;
-            const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, ev[m & 1][0][q][e]));
-            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, ev[m & 1][1][q][e]), 30.0f));
+            const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, ev[m % 3][0][q][e]));
+            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, ev[m % 3][1][q][e]), 30.0f));
             float g = (1.0f - eb) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));   // sigmoid(v0) * tanh(v1), net.py:72-73
             if (pad) g = 0.f;
             v |= (uint32_t)ss_f2t<true>(g) << (16 * k);
           }
           pk[e2] = v;
         }
-        // channels 32 w + 8 q + 4 lh .. + 3 of row 32 m + l31: slot 4 w + q, bytes 8 lh .. of the row's 16: a wave writes 512 contiguous bytes
-        *reinterpret_cast<u32x2*>(Rc + (4 * wave + q) * SLOTB + (32 * m + l31) * 16 + 8 * lh) = u32x2{pk[0], pk[1]};
+        gpk[m][q] = u32x2{pk[0], pk[1]};
       }
     }
+    L512_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);    // (the arithmetic above stays above the barrier)
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
+    __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
+    // channels 32 w + 8 q + 4 lh .. + 3 of row 32 m + l31: slot 4 w + q, bytes 8 lh .. of the row's 16: a wave instruction writes 512 contiguous bytes
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(Rc + (4 * wave + q) * SLOTB + (32 * m + l31) * 16 + 8 * lh) = gpk[m][q];
     if (tile + (int)gridDim.x < n_tiles) dma_tile(tile + gridDim.x, Rn, lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // my G writes are done
     L512_STAMP(3);

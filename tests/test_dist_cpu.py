@@ -121,3 +121,35 @@ def test_forced_collective_runs_the_all_gather_branch_in_a_world_of_one():
     out = q.get(timeout=120)
     p.join(timeout=60)
     assert out == dict(short_cut=True, forced_is_copy=True, equal=True, dtype="torch.int32", sharded=True), out
+
+
+def _run_world(world, n_items):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_items)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_eight_rank_gloo_world_64_and_65_items():
+    """BASELINE configs[2]'s world size (8 ranks, one per GPU of a node) on CPU: 64 items (8 per rank, the config as specified) and 65 (uneven: rank 0
+    holds 9 items, the others 8 + one empty slot so that the single all_gather sees equal shapes). Every rank gets the whole mel batch back in
+    ITEM order with the lengths bit-exact, and keeps exactly its own shard `x[rank::8]` (tasks/tts/tts_base.py:129-132) for vocoding.
+    No 8-GPU node has been available to any round's driver: this and the one-device emulation of tests/test_gpu_round6.py are what covers N = 8."""
+    world = 8
+    for n in (64, 65):
+        slots = ssd.shard_slots(n, world)
+        assert slots == (8 if n == 64 else 9)
+        order = ssd.gathered_order(n, world)
+        assert sorted(g for g in order if g >= 0) == list(range(n)) and order.count(-1) == world * slots - n
+        for rank, first_vals, lens_all, local, wshape in _run_world(world, n):
+            assert first_vals == [float(i + 1) for i in range(n)], (n, rank)
+            assert lens_all == [10 + i for i in range(n)]
+            assert local == list(range(rank, n, world))
+            assert wshape == (len(local), 64)

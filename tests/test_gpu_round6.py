@@ -1,0 +1,105 @@
+"""Round 6: what the round-5 review asked to see run.
+
+* `bench.py --gpus 8` end to end on ONE device (SS_BENCH_ONE_DEVICE=1: eight ranks over gloo, all on cuda:0): the torchrun spawn, the port
+  choice, the rank-0-only legs and the final barrier at the world size of BASELINE configs[2]; the gathered mel batch must equal the
+  single-process run of the same 8 x B utterances. (No 8-GPU node has been available to any round's driver: the 1 -> 8 CURVE stays unmeasured.)
+* The `fp16q4` range guard: a checkpoint whose residual stream leaves the fixed fp4 activation scale is refused on its first forward.
+* The unconditional non-finite flag of the fp16 modes.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from stylesinger_amd import config, synth  # noqa: E402
+from stylesinger_amd import lib as L  # noqa: E402
+from stylesinger_amd.model import StyleSingerHIP  # noqa: E402
+
+
+def _run_bench(args, env_extra=None, timeout=1500):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_eight_ranks_on_one_device_matches_single_process():
+    small = ["--steps", "1", "--warmup", "0", "--batch", "1", "--frames", "128", "--diff-steps", "2", "--no-cpu-baseline", "--no-roofline", "--no-secondary",
+             "--checksum"]
+    eight = _run_bench(["--gpus", "8"] + small, {"SS_BENCH_ONE_DEVICE": "1"})
+    assert eight["n_gpus"] == 8 and eight["config"]["global_batch"] == 8 and eight["dist"]["ranks"] == 8 and eight["scaling"] == "weak"
+    assert eight["metric"].startswith("mel-frames/sec") and eight["value"] > 0 and eight["steps"] == 1
+    one = _run_bench(["--gpus", "1", "--emulate-ranks", "8"] + small)
+    assert one["n_gpus"] == 1 and len(one["checksum"]["mel_items"]) == 8
+    assert eight["checksum"]["mel_items"] == one["checksum"]["mel_items"], (eight["checksum"], one["checksum"])
+
+
+def _fwd(model, b, **kw):
+    return model(b["txt_tokens"], mel2ph=b.get("mel2ph"), spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
+                 ref_f0=b["ref_f0"], global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"], **kw)
+
+
+def _model(hp, sd):
+    m = StyleSingerHIP(None, hparams=hp)
+    m.load_state_dict(sd)
+    m.eval().to("cuda:0")
+    return m
+
+
+def test_fp16q4_range_guard_refuses_a_stream_beyond_the_fp4_scale():
+    """`fp16q4` converts the stream x + dstep to fp4 on the FIXED scale q_scale_gate = 2 (saturation at |a| > 12) and the gate outputs on 0.25. With
+    the synthetic weights the stream stays inside (the forward succeeds, the guard's reduction reads < 1); with the mel denoiser's input projection
+    scaled so that the stream exceeds 12, the FIRST forward of the plan raises and names fp16x2."""
+    hp = config.make_hparams(dict(timesteps=3, K_step=3, f0_timesteps=3, mfma_precision="fp16q4"))
+    sd = synth.synth_acoustic_state_dict(hp, 21)
+    batch = {k: v.cuda() for k, v in synth.synth_batch(1, 256, 12, 40, hp, 21).items()}
+    L.check(L.load().ss_set_tuning(b"q4_force", 1), "q4_force")
+    try:
+        out = _fwd(_model(hp, sd), batch)
+        assert torch.isfinite(out["mel_out"]).all()
+        bad = dict(sd)
+        for k in ("postdiff.denoise_fn.input_projection.weight", "postdiff.denoise_fn.input_projection.bias"):
+            bad[k] = sd[k] * 400.0
+        with pytest.raises(L.StyleSingerHipError, match="fp16q4.*fp16x2"):
+            _fwd(_model(hp, bad), batch)
+        # the guard is armed for the first forward of a plan only, and never left armed
+        g = torch.zeros(2, device="cuda:0", dtype=torch.int32)
+        x = L.split_f16(torch.randn(1, 300, 256, device="cuda:0") * 10.0)
+        assert int(g.sum()) == 0
+    finally:
+        L.check(L.load().ss_set_tuning(b"q4_force", 0), "q4_force")
+        L.check(L.load().ss_set_q4_guard(None), "ss_set_q4_guard")
+
+
+def test_nonfinite_flag_is_raised_on_every_forward_not_only_the_first():
+    """ss_mel_denorm flags a non-finite valid frame in a device word on EVERY forward (ret['nonfinite']); `check_finite` raises from it. The first
+    forward of a plan checks by itself; later forwards leave the check to the caller's next synchronisation point (infer.py does it)."""
+    hp = config.make_hparams(dict(timesteps=2, K_step=2, f0_timesteps=2, mfma_precision="fp16x2"))
+    sd = synth.synth_acoustic_state_dict(hp, 22)
+    m = _model(hp, sd)
+    batch = {k: v.cuda() for k, v in synth.synth_batch(1, 128, 8, 24, hp, 22).items()}
+    ok = _fwd(m, batch)
+    assert int(ok["nonfinite"].item()) == 0
+    m.check_finite(ok)
+    lib = L.load()
+    x = torch.full((1, 128, 80), float("nan"), device="cuda:0")
+    mel = torch.empty_like(x)
+    flag = torch.zeros(1, device="cuda:0", dtype=torch.int32)
+    lens = torch.tensor([100], device="cuda:0", dtype=torch.int32)
+    smin, smax = torch.full((80,), -6.0, device="cuda:0"), torch.zeros(80, device="cuda:0")
+    L.check(lib.ss_mel_denorm(L.ptr(x), L.ptr(smin), L.ptr(smax), L.ptr(mel), 1, 128, 80, L.ptr(lens), L.ptr(flag), L.stream_ptr()), "denorm")
+    assert int(flag.item()) == 1
+    with pytest.raises(L.StyleSingerHipError, match="non-finite"):
+        m.check_finite(dict(nonfinite=flag))
+    x[:, :100] = 0.5                                      # NaN only in the masked tail: not an error
+    flag.zero_()
+    L.check(lib.ss_mel_denorm(L.ptr(x), L.ptr(smin), L.ptr(smax), L.ptr(mel), 1, 128, 80, L.ptr(lens), L.ptr(flag), L.stream_ptr()), "denorm")
+    assert int(flag.item()) == 0 and torch.isfinite(mel).all()

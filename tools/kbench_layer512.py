@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--T", type=int, default=5625)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--which", default="all")
+    ap.add_argument("--lo-bits", type=int, default=0, help="experiment: keep only this many mantissa bits of the weights' lo terms (0 = all 10): does the "
+                    "matrix pipe draw less power - and the chip clock higher - when one operand's low mantissa bits are zero?")
+    ap.add_argument("--zero-lo", action="store_true", help="experiment: lo terms = 0 (the power a second product of zeros draws)")
     a = ap.parse_args()
     d = torch.device("cuda:0")
     B, T, C, NS = a.B, a.T, 256, 4
@@ -34,6 +37,18 @@ def main():
     Ws = L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=256.0)
     wo = torch.randn(2 * C, C, 1, device=d) / math.sqrt(C)
     Wos = L.split_f16(L.pack_conv_weight(wo), scale=256.0)
+    def coarse(Wp):   # the (hi | lo) pack, pairs interleaved by 32: lo terms at [.., 32:64] of every 64
+        v = Wp.view(Wp.shape[0], -1, 64)
+        lo = v[:, :, 32:].float()
+        if a.zero_lo:
+            lo = torch.zeros_like(lo)
+        elif a.lo_bits:
+            m, e = torch.frexp(lo)
+            lo = torch.ldexp(torch.round(m * 2.0 ** (a.lo_bits + 1)) / 2.0 ** (a.lo_bits + 1), e)
+        v[:, :, 32:] = lo.to(torch.float16)
+        return Wp
+    if a.lo_bits or a.zero_lo:
+        Ws, Wos = coarse(Ws), coarse(Wos)
     Wg, Wr = L.layer512_pack_gate(Ws), L.layer512_pack_res(Wos)
     cb, nb, bo = (torch.randn(C, device=d) for _ in range(3))
     bop = L.pack_bias(bo)
