@@ -149,8 +149,25 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         Xh = L.split_f16(X) if f16 else L.split_bf16(X) if split else L.to_bf16(X)
         Gh = torch.empty(B, T, C * (2 if split else 1), device=dev, dtype=torch.float16 if f16 else torch.bfloat16)
 
+    # fp16x2 at many-round sizes: the loop runs ONE ss_layer512 launch per layer (gate + residual projection, G kept in LDS) - that kernel is
+    # then the dominant one (knob "layer512"; ss_layer512_ok is the library's own dispatch rule)
+    fused = bool(hbm and f16 and not q4 and L.load().ss_get_tuning(b"layer512") >= 1 and all(f"w_dil_f.{l}" in packs for l in range(Lyr)) and
+                 L.load().ss_layer512_ok(B, T, C, 8, Lyr * C * 2))
+    if fused:
+        H0, Pst = L.layer512_entry(X, None, B=B, T=T, lens=lens)
+        Hb = [H0, torch.empty_like(H0)]
+        NS = 4   # addend slabs to cycle through (each 369 MB at the C4 shape: more than the L2 / Infinity Cache keep)
+        E512 = [L.layer512_tile_addend(E[:, :, s_ * 2 * C:], B=B, T=T, lde=Lyr * 2 * C) for s_ in range(NS)]
+        GAf = torch.empty(B, T, NS * 2 * C, device=dev, dtype=torch.float16)
+        nbv = torch.randn(C, device=dev)
+
     def launch(l):
         d = 1 << (l % 4)
+        if fused:
+            L.layer512(Hb[l & 1], packs[f"w_dil_f.{l}"], E512[l % NS], GAf[..., (l % NS) * 2 * C:], B=B, T=T, d=d, lens=lens, Hout=Hb[(l & 1) ^ 1], P=Pst,
+                       Wr=packs[f"w_out_f.{l}"], bias_r=packs[f"b_out.{l}"], next_bias=nbv, out_scale=2.0 ** -infer.model.FP16_WSHIFT, ldg=NS * 2 * C,
+                       g_bs=T * NS * 2 * C)
+            return
         if hbm and q4:   # what run_residual_stack launches in fp16q4 mode when the launch fills the chip (ss_gemm_bf16_gate128q)
             L.gemm_bf16(Xh, packs[f"w_dil_q.{l}"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
                         E=E[:, :, l * 2 * C:], lde=Lyr * 2 * C, e_bs=T * Lyr * 2 * C, out=Gh, split=3, out_scale=2.0 ** -infer.model.FP16_WSHIFT, q_scale=2.0, gate256=128)
@@ -189,7 +206,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                      lda=Lyr * C, a_bs=T * Lyr * C, lens=lens, bias=packs[f"b_out.{l}"], ldr=C, ldc=C, post_scale=0.70710678)
     # the chip clocks to its power budget: have the kernel report the shader clock it really ran at (ss_set_clock_probe; the
     # probe pointer is a launch parameter, so it is set before the capture below)
-    probing = wino or (hbm and f16)   # the Winograd gates and gate128_kernel / gate128q_kernel carry the probe
+    probing = wino or (hbm and f16)   # the Winograd gates, gate128_kernel / gate128q_kernel and layer512_kernel carry the probe
     probe = torch.zeros(2, device=dev, dtype=torch.int64) if probing else None
     if probing:
         L.check(L.load().ss_set_clock_probe(probe.data_ptr()), "ss_set_clock_probe")
@@ -252,15 +269,17 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         dense = {"us_per_launch": dense_sec * 1e6, "clock_ghz": dense_clock, "note": "20 identical gate launches back to back (throttled regime)"}
     if probing:
         L.check(L.load().ss_set_clock_probe(None), "ss_set_clock_probe")
-    flops = 2.0 * B * T * (3 * C) * (2 * C)
+    flops = 2.0 * B * T * (3 * C) * (2 * C) + (2.0 * B * T * C * C if fused else 0.0)   # fused: + the residual half of output_projection
     # x3: six bf16 products each; bf16x2: three; fp16x2: two; fp16q4: one fp16 product + one fp4 product of the same shape (counted as two products:
     # the fp4 instruction does 4x the work per issue, so its pipe time is a quarter - `frac` is flops over the FP16 peak and overstates pipe time)
     executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 2.0 if f16 else 3.0 if split else 1.0)
     peak = PEAK_BF16_MFMA if (bf16 or x3) else PEAK_FP32_MFMA
     # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
-    g256 = hbm and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
-    g128 = hbm and f16 and L.load().ss_get_tuning(b"gate128") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 128) >= 2048   # ss_gemm_bf16_gate128_ok's shape rule
-    hbm_name = ("gate128q_kernel (fp16 operands in HBM, weights = fp16 hi terms + block-scaled fp4 lo terms: 16 fp16 MFMAs + 4 fp4 ones per step, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if (g128 and q4) else
+    g256 = hbm and not fused and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
+    g128 = hbm and not fused and f16 and L.load().ss_get_tuning(b"gate128") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 128) >= 2048   # ss_gemm_bf16_gate128_ok's shape rule
+    hbm_name = ("layer512_kernel<true> (ONE launch per residual layer: dilated conv + addend + gate + residual projection + stream update; fp16 operands, weights as "
+                "(hi, lo) fp16 pairs streamed L2 -> registers in fragment order, 2 products, 128 rows x all 512 columns per persistent workgroup, G kept in LDS, direct" if fused else
+                "gate128q_kernel (fp16 operands in HBM, weights = fp16 hi terms + block-scaled fp4 lo terms: 16 fp16 MFMAs + 4 fp4 ones per step, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if (g128 and q4) else
                 "gate128_kernel (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if g128 else
                 "gate256_kernel<8, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x256 tiles by LDS-DMA, direct" if g256 and f16 else
                 "gemm_bf16_kernel<GATE, 2> (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, direct" if f16 else
@@ -276,8 +295,8 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
     traffic = None
     pmc_src = None
-    form = (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16q4" if q4 else "fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
-    for fn in ("r05_pmc_gate128.json", "r05_pmc_gate.json", "r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
+    form = "layer512" if fused else (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16q4" if q4 else "fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
+    for fn in ("r06_pmc_layer512.json", "r05_pmc_gate128.json", "r05_pmc_gate.json", "r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj):
             continue
@@ -301,6 +320,18 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                     us = float(row["AverageNs"]) * 1e-3
                     in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak,
                                "source": "profiles/r05_bench_c2_1stream_kernel_stats.csv"}
+                    break
+        except (KeyError, ValueError, OSError):
+            in_loop = None
+    csv_l512 = os.path.join(ROOT, "profiles", "r06_bench_c4_layer512_20steps_kernel_stats.csv")
+    if fused and B * T == 180000 and os.path.exists(csv_l512):   # this round's dominant C4 kernel inside the graph-replayed loop
+        try:
+            import csv
+            for row in csv.DictReader(open(csv_l512)):
+                if "layer512_kernel" in row["Name"] and "ELb1E" in row["Name"] or "layer512_kernel<true>" in row["Name"]:
+                    us = float(row["AverageNs"]) * 1e-3
+                    in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak,
+                               "source": "profiles/r06_bench_c4_layer512_20steps_kernel_stats.csv"}
                     break
         except (KeyError, ValueError, OSError):
             in_loop = None
@@ -332,8 +363,49 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                 # kernel: s_memtime cycles / s_memrealtime), so the matrix pipes can deliver peak * clock_ghz / 2.4 at most
                 clock_ghz=clock_ghz, executed_mfma_frac_at_clock=(executed / sec / (peak * clock_ghz / 2.4)) if clock_ghz else None,
                 traffic=traffic, traffic_source=pmc_src, us_per_launch=sec * 1e6, flops_per_launch=flops,
-                launches_per_step=None, algorithmic_bytes_per_launch=((2 if split else 1) * (B * T * (2.0 * C + 2.0 * C) + 2.0 * 3 * C * 2 * C) + B * T * 4.0 * 2 * C) if hbm else
-                (4.0 * B * T * (C + 2 * C + C) + 4.0 * (6 if wino_m == 4 else 4 if wino else 3) * C * 2 * C))
+                launches_per_step=None, algorithmic_bytes_per_launch=_algorithmic_bytes(B * T, C, hbm, split, f16, fused, wino, wino_m))
+
+
+def _algorithmic_bytes(rows, C, hbm, split, f16, fused, wino, wino_m):
+    """HBM bytes one launch of the dominant kernel has to move, per precision mode:
+    fused fp16x2 layer: conv operand H (fp16, + 16 halo rows per 128) + addend (fp32 x 2C) + stream x (fp32, read + rewritten) + G out (fp16) + H out (fp16);
+    fp16x2 / fp16q4 gate: ONE plane of the operand pair is fetched and one written (the second term is never read by the matrix cores);
+    bf16x2 gate: both planes in and out; plain bf16: one 2-byte plane; fp32: X, addend, G."""
+    if fused:
+        return rows * (2.0 * C * 144 / 128 + 4.0 * 2 * C + 2 * 4.0 * C + 2.0 * C + 2.0 * C) + 2 * 2.0 * (3 * C * 2 * C + C * C)
+    if hbm:
+        pin = 1 if (f16 or not split) else 2          # operand planes fetched
+        pout = 1 if (f16 or not split) else 2         # output planes written
+        pw = 2 if split else 1                        # weight planes
+        return rows * (2.0 * C * pin + 2.0 * C * pout + 4.0 * 2 * C) + pw * 2.0 * 3 * C * 2 * C
+    return 4.0 * rows * (C + 2 * C + C) + 4.0 * (6 if wino_m == 4 else 4 if wino else 3) * C * 2 * C
+
+
+def top_kernels(csv_name, flops_by_kernel=None, n=8):
+    """The time budget of a committed rocprofv3 --kernel-trace --stats summary (profiles/<csv_name>): the n kernels with the largest share - name,
+    share of GPU time, calls, average us - and, where the executed matrix flops per launch are known (`flops_by_kernel`: substring -> (flop, peak)),
+    the fraction of the data-sheet peak recomputed from that average. Read from the file at run time: never constants in this script."""
+    import csv
+    path = os.path.join(ROOT, "profiles", csv_name)
+    if not os.path.exists(path):
+        return None
+    rows = []
+    try:
+        for row in csv.DictReader(open(path)):
+            rows.append((float(row["TotalDurationNs"]), row))
+    except (KeyError, ValueError, OSError):
+        return None
+    total = sum(t for t, _ in rows) or 1.0
+    out = []
+    for t, row in sorted(rows, key=lambda r: -r[0])[:n]:
+        name = row["Name"]
+        ent = {"kernel": name if len(name) <= 96 else name[:93] + "...", "share": round(t / total, 4), "calls": int(row["Calls"]), "avg_us": round(float(row["AverageNs"]) * 1e-3, 2)}
+        for key, (fl, pk) in (flops_by_kernel or {}).items():
+            if key in name:
+                ent["executed_mfma_frac"] = round(fl / (float(row["AverageNs"]) * 1e-9) / pk, 4)
+                break
+        out.append(ent)
+    return {"source": "profiles/" + csv_name, "kernels": out}
 
 
 def mel_loop_in_run(infer, B, T, S_mel, executed_flop_per_frame_step, peak):

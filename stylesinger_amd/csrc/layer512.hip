@@ -244,15 +244,18 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     };
     load_e(ev[0], 0);
     load_e(ev[1], 1);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
+    __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
+    L512_STAMP(2);
+    // (Measured and dropped: the gate arithmetic AHEAD of [B2], into registers, so that the wave that leaves the conv loop first - the older wave of
+    // a SIMD gets the matrix pipe, 25 k against 50 k cycles - works under its partner's MFMAs instead of waiting at the barrier. Its VALU stream
+    // then competes with the partner's MFMA issue: conv loop 50 -> 62 k cycles, gate arithmetic 30 k; 403.6 against 397.7 us per launch -
+    // profiles/r06_trace_layer512_v5_gate_math_before_b2.log. Work moved between the two waves of a SIMD is zero-sum, as the guide says.)
     // the stream of this tile (fp32, accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
     // dead so that the loads fly under the rest of this epilogue, [B3] and the G pass
     [[maybe_unused]] f32x4 pv[4][4];
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (int64_t)wave * (P_TILE / 8) : (const char*)a.Wg), 0, FUSE ? P_TILE / 8 : 0, 0x00020000);
-    // The gate arithmetic runs BEFORE [B2], into registers (64 fp16 values = 32 registers): of the two waves of a SIMD the older one gets the
-    // matrix pipe first and leaves the conv loop ~25 k cycles before its partner (trace: 25 k .. 50 k) - its gate VALU work then runs under the
-    // partner's MFMAs instead of waiting at the barrier. Only the LDS writes need everyone to be done with the A tile.
-    u32x2 gpk[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (m + 2 < 4) load_e(ev[(m + 2) % 3], m + 2);
@@ -282,18 +285,10 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
           }
           pk[e2] = v;
         }
-        gpk[m][q] = u32x2{pk[0], pk[1]};
+        // channels 32 w + 8 q + 4 lh .. + 3 of row 32 m + l31: slot 4 w + q, bytes 8 lh .. of the row's 16: a wave writes 512 contiguous bytes
+        *reinterpret_cast<u32x2*>(Rc + (4 * wave + q) * SLOTB + (32 * m + l31) * 16 + 8 * lh) = u32x2{pk[0], pk[1]};
       }
     }
-    L512_STAMP(2);
-    __builtin_amdgcn_sched_barrier(0);    // (the arithmetic above stays above the barrier)
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
-    __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
-    // channels 32 w + 8 q + 4 lh .. + 3 of row 32 m + l31: slot 4 w + q, bytes 8 lh .. of the row's 16: a wave instruction writes 512 contiguous bytes
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(Rc + (4 * wave + q) * SLOTB + (32 * m + l31) * 16 + 8 * lh) = gpk[m][q];
     if (tile + (int)gridDim.x < n_tiles) dma_tile(tile + gridDim.x, Rn, lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // my G writes are done
     L512_STAMP(3);

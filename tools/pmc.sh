@@ -19,7 +19,7 @@ for fn in f:
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
         cnt[(k, r["Counter_Name"])] += 1
 for k, d in agg.items():
-    if "conv_gemm" in k or "attention" in k or "wino" in k or "gemm16" in k or "gate256" in k or "gemm_bf16" in k:
+    if any(t in k for t in ("conv_gemm", "attention", "wino", "gemm16", "gate256", "gate128", "tile256", "gemm_bf16", "layer512")):
         print(k)
         for c, v in d.items(): print(f"    {c:32s} avg/dispatch = {v / cnt[(k, c)]:.4g}   (n={cnt[(k,c)]})")
 PY

@@ -4,8 +4,7 @@ Build in the container (only layer512.hip needs the flag; the other objects are 
     hipcc --offload-arch=gfx950 -shared -fPIC -o stylesinger_amd/_abl/libss_l512trace.so /tmp/l512t.o $(ls stylesinger_amd/_obj/*.o | grep -v layer512)
 Run on the GPU box:
     SS_LIB_PATH=stylesinger_amd/_abl/libss_l512trace.so python tools/trace_layer512.py [--B 32] [--T 5625] [--gate-only]
-Stamps per tile: 0 after [B1], 1 conv loop done, 2 gate arithmetic done (before [B2]), 3 G written to LDS (after [B2]), 4 after [B3], 5 G pass issued,
-6 projection MFMAs done, 7 tile end."""
+Stamps per tile: 0 after [B1], 1 conv loop done, 2 after [B2], 3 gate epilogue done, 4 after [B3], 5 G pass issued, 6 projection MFMAs done, 7 tile end."""
 import argparse
 import ctypes
 import math
@@ -68,7 +67,7 @@ def main():
     n_tiles = B * ((T + 127) // 128)
     full = [i for i in range(8) if (i + 1) * ncu <= n_tiles]          # tile slots every workgroup ran
     t = t[:, :, full]
-    names = ["conv loop (48 k-steps)", "gate arithmetic", "wait [B2] + G to LDS", "wait [B3]", "G pass", "projection MFMAs", "stream epilogue"]
+    names = ["conv loop (48 k-steps)", "wait [B2]", "gate epilogue", "wait [B3]", "G pass", "projection MFMAs", "stream epilogue"]
     print(f"layer512 trace, {B} x {T}, {n_tiles} tiles on {ncu} workgroups, slots {full}; shader cycles per tile, mean over workgroups and waves (min .. max of the per-wave means)")
     for k, nm in enumerate(names):
         dlt = t[..., k + 1] - t[..., k]
