@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=None, help="mel frames per utterance (1500 = 8 s)")
     ap.add_argument("--diff-steps", type=int, default=None, help="override mel AND f0 diffusion steps")
     ap.add_argument("--targets", type=int, default=None, help="c5: target scores per step")
+    ap.add_argument("--refs", type=int, default=None, help="c5: reference voices on this GPU (the full per-GPU share of BASELINE configs[4] = --refs 32 --targets 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--checksum", action="store_true", help="add per-utterance mel checksums of the LAST step to the JSON line (tests)")
@@ -686,6 +687,8 @@ def main():
             cfg["ddim_steps"] = min(cfg["ddim_steps"], args.diff_steps)
     if args.targets:
         cfg["targets"] = args.targets
+    if args.refs and "refs" in cfg:
+        cfg["refs"] = args.refs
     precision = os.environ.get("SS_PRECISION", cfg["precision"])
     hp_over = dict(timesteps=cfg["mel_steps"], K_step=cfg["mel_steps"], f0_timesteps=cfg["f0_steps"], mfma_precision=precision)
     hp = config.make_hparams(hp_over)
@@ -889,6 +892,11 @@ def main():
         if sweep_mode and last.get("sweep_stats"):
             out["style_cache"] = dict(last["sweep_stats"], note="per step: every reference is encoded once (style_encodes) and served from the "
                                                                 "cache for each further target (style_cache_hits)")
+            m_ = infer.model
+            out["plan_cache"] = {"lookups": getattr(m_, "plan_lookups", 0), "misses": getattr(m_, "plan_misses", 0), "evictions": getattr(m_, "plan_evictions", 0),
+                                 "plans_resident": len(m_._plans), "hipgraph_captures": m_.n_captures,
+                                 "note": "whole run (warm-up + timed steps): one diffusion plan (workspace + captured hipGraphs) per (batch, frame bucket); "
+                                         "every target of the sweep has the same frame count here, so one plan serves all forwards"}
             # the sampler of this config is pinned to the reference through eta = 1 / stride 1 == p_sample (tests/test_gpu_round4.py,
             # tests/test_oracle_golden.py); the deterministic eta = 0 form used here shares every line of it but sigma
             out["parity"] = {"pinned": True, "sampler": "ss_meldiff_sample_ddim eta=0, 50 of 100 network times",

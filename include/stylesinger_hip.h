@@ -52,7 +52,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "q4_force" = 0|1 the
  * fp16q4 kernels (ss_gemm_bf16_gate128q / _tile256q) take any launch they can compute, not only those that fill the chip (default 0; the parity
  * tests run one 30 s item through them); "layer512" = 0|1|2 the fp16x2 mel stack as one ss_layer512 launch per layer when the shape qualifies
- * (default 1; 0 = the gate + residual-projection launch pair; 2 = also for launches that do not fill the chip: the parity tests run one item through it). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
+ * (default 1; 0 = the gate + residual-projection launch pair; 2 = also for launches that do not fill the chip: the parity tests run one item through it); "layer512_tail" = 0|1 ss_layer512 runs the tiles of
+ * an under-filled last round as half tiles (default 1; identical results). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
  * forwards SS_* variables once at load). */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
@@ -68,6 +69,9 @@ int ss_set_clock_probe(void* dev_u64x2);
  * zeroes the words): a value > 1 means the second product of that launch is degraded - use "fp16x2". One extra HBM pass per guarded launch:
  * the model arms it for the first (eager) forward of every plan only. Pass NULL to switch it off. Results never change. */
 int ss_set_q4_guard(void* dev_u32x2);
+/* Measurement aid (tools/launch_floor.py): an EMPTY kernel launched with the given geometry - a captured chain of these with the launch count and
+ * grid sizes of a diffusion loop is the floor the loop's dependent launch edges cost, whatever the kernels do. */
+int ss_debug_null_launch(int grid, int block, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generic fp32-MFMA implicit-GEMM 1-D convolution / linear layer.

@@ -14,7 +14,7 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 1, 0, 1};
+SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 1, 0, 1, 1};
 
 namespace {
 struct Knob { const char* key; int* slot; bool (*ok)(int); };
@@ -33,6 +33,7 @@ const Knob* knobs(int* n) {
       {"wino_tn", &g_ss_tuning.wino_tn, ok_012},       {"wino_v1", &g_ss_tuning.wino_v1, ok_01},      {"voc_wino_max_mb", &g_ss_tuning.voc_wino_max_mb, ok_mb},
       {"e16", &g_ss_tuning.e16, ok_01},                {"mel_tail", &g_ss_tuning.mel_tail, ok_01},     {"gate128", &g_ss_tuning.gate128, ok_01},
       {"q4_force", &g_ss_tuning.q4_force, ok_01},      {"layer512", &g_ss_tuning.layer512, ok_012},
+      {"layer512_tail", &g_ss_tuning.layer512_tail, ok_01},
   };
   *n = (int)(sizeof(k) / sizeof(k[0]));
   return k;
@@ -66,6 +67,19 @@ extern "C" int ss_set_clock_probe(void* dev_u64x2) {
   g_ss_tuning.clock_probe = static_cast<unsigned long long*>(dev_u64x2);
   return SS_OK;
 }
+// measurement aid: an empty kernel with the launch geometry of a real one - the floor of a dependent launch edge (tools/launch_floor.py)
+namespace {
+__global__ void null_kernel(int* sink) {
+  if (sink && blockIdx.x == 0x7fffffff) *sink = 0;   // never true: keeps the kernel from being optimised to nothing at all
+}
+}  // namespace
+extern "C" int ss_debug_null_launch(int grid, int block, void* stream) {
+  SS_CHECK_ARG(grid > 0 && block > 0 && block <= 1024, "ss_debug_null_launch: grid > 0, 0 < block <= 1024");
+  hipLaunchKernelGGL(null_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, (int*)nullptr);
+  SS_CHECK_LAUNCH("ss_debug_null_launch");
+  return SS_OK;
+}
+
 unsigned int* g_ss_q4_guard = nullptr;
 extern "C" int ss_set_q4_guard(void* dev_u32x2) {
   g_ss_q4_guard = static_cast<unsigned int*>(dev_u32x2);

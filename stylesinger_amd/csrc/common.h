@@ -64,10 +64,12 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   layer512: 1 (default) = the fp16x2 mel stack runs ONE ss_layer512 launch per layer (gate + residual projection, G kept in LDS) when the
 //     net carries the fragment-order packs and ss_layer512_ok(B, T, ...) holds; 0 = the gate + residual-projection launch pair; 2 = also below the
 //     chip-filling size (parity tests).
+//   layer512_tail: 1 (default) = ss_layer512 cuts the tiles of its last round into half tiles when that round would keep at most half of the
+//     workgroups busy (1408 tiles on 256 CUs: makespan 5.6 instead of 6 tile periods); 0 = whole tiles only (A/B; results are identical).
 //   q4_force: 0 (default) = the fp16q4 kernels take only launches that fill the chip (their _ok rules); 1 = any launch they can compute (parity tests run
 //     one 30 s item through them).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
-                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; int layer512; };
+                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; int layer512; int layer512_tail; };
 extern SsTuning g_ss_tuning;
 // fp16q4 range guard (ss_set_q4_guard): while non-null, every fp16q4 launch first reduces max |a| / (6 q_scale) over the fp16 operand it is about
 // to convert to fp4 into guard[which] (which = 0 gate, 1 skip GEMM; float bits, atomicMax): > 1 means the fixed scale saturates

@@ -100,8 +100,14 @@ __device__ __forceinline__ bf16x8 ldw(__amdgpu_buffer_rsrc_t rsrc, int voff, int
 }
 __device__ __forceinline__ int acc_rr(int r) { return (r & 3) + 8 * (r >> 2); }
 
+// One work item of a persistent workgroup: a whole 128-row tile (nm = 4 row blocks of 32) or, in the last round, half of one (nm = 2, rows r0 ..
+// r0 + 63 of the tile) - see the schedule in layer512_kernel.
+struct L512Item {
+  int tile, r0, nm;
+};
+
 template <bool FUSE>
-__global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args a, int tiles_per_item, int n_tiles, unsigned long long* clock_probe) {
+__global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args a, int tiles_per_item, int n_tiles, int split_tail, unsigned long long* clock_probe) {
 #ifdef SS_L512_TRACE
   const bool probing = false;
 #else
@@ -122,29 +128,52 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
   const __amdgpu_buffer_rsrc_t rsrc_wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(FUSE ? (const char*)a.Wr + (int64_t)wave * WR_WAVE : (const char*)a.Wg), 0,
                                                                          FUSE ? WR_WAVE : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_hi = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.Hin), 0, __builtin_amdgcn_readfirstlane(n_tiles * H_TILE), 0x00020000);
+
+  // ---- schedule. Workgroup g of W takes tiles g, g + W, ... With n_tiles = k W + R the last round would keep R workgroups busy for a whole tile
+  // period while the others idle (BASELINE configs[3]: 1408 tiles on 256 CUs = 5.5 rounds, makespan 6). When 0 < R <= W / 2 (split_tail, decided by
+  // the launcher) the R tiles of that round are cut into 2 R HALF tiles of 64 rows - same code with two row blocks instead of four - so that the
+  // round costs about 0.6 of a tile period.
+  const int W = gridDim.x, g = blockIdx.x;
+  const int full_rounds = split_tail ? n_tiles / W : 0;
+  const int n_items = split_tail ? full_rounds + ((g >> 1) < n_tiles - full_rounds * W ? 1 : 0) : (n_tiles - g + W - 1) / W;
+  auto item = [&](int i) {
+    L512Item r;
+    if (split_tail && i >= full_rounds) {
+      r.tile = full_rounds * W + (g >> 1);
+      r.r0 = 64 * (g & 1);
+      r.nm = 2;
+    } else {
+      r.tile = g + i * W;
+      r.r0 = 0;
+      r.nm = 4;
+    }
+    return r;
+  };
   auto tile_coords = [&](int tile, int& b, int& ti) {
     b = tile / tiles_per_item;
     ti = tile - b * tiles_per_item;
   };
   // ---- DMA of an activation tile. H and the LDS image are both SLOT-MAJOR: slot s (8 channels = 16 bytes) of all rows, row after row. LDS row
-  // L = tile row L - HALO. Wave w stages slots 4 w .. 4 w + 3, three pieces of 64 rows each: LDS rows [0, 64), [64, 128) and [80, 144) (the
-  // last one rewrites 48 rows with the same bytes: every piece is a full 1 KB, no lane masking). A piece reads H contiguously except where it
-  // crosses into the previous / next tile of the item (the halo); rows outside the item are out of range: the DMA writes zeros (the conv's
-  // padding; rows in [len, T) hold zeros already - every producer of H masks them).
-  auto dma_tile = [&](int tile, char* region, int lane) {
+  // L = tile row r0 + L - HALO. Wave w stages slots 4 w .. 4 w + 3 in pieces of 64 rows: LDS rows [0, 64), [64, 128) and [80, 144) of a whole
+  // tile (the last one rewrites 48 rows with the same bytes: every piece is a full 1 KB, no lane masking), [0, 64) and [16, 80) of a half tile.
+  // A piece reads H contiguously except where it crosses into the previous / next tile of the item (the halo); rows outside the item are out of
+  // range: the DMA writes zeros (the conv's padding; rows in [len, T) hold zeros already - every producer of H masks them).
+  auto dma_item = [&](const L512Item& it_, char* region, int lane) {
     int b, ti;
-    tile_coords(tile, b, ti);
+    tile_coords(it_.tile, b, ti);
+    const int npiece = it_.nm == 4 ? 3 : 2;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int L = (j == 2 ? 80 : 64 * j) + lane;   // LDS row
-      const int rho = L - HALO;                      // row relative to the tile
+      if (j >= npiece) break;
+      const int L0 = it_.nm == 4 ? (j == 2 ? 80 : 64 * j) : 16 * j;
+      const int rho = it_.r0 + L0 + lane - HALO;     // row relative to the tile
       const int dt = rho < 0 ? -1 : (rho >= BM ? 1 : 0);
       const bool ok = (unsigned)(ti + dt) < (unsigned)tiles_per_item;
-      const int base = ok ? (tile + dt) * H_TILE + (rho - dt * BM) * 16 : (int)0x80000000;
+      const int base = ok ? (it_.tile + dt) * H_TILE + (rho - dt * BM) * 16 : (int)0x80000000;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int s_ = 4 * wave + k;
-        glds16(rsrc_hi, region + s_ * SLOTB + (j == 2 ? 80 : 64 * j) * 16, base, s_ * (BM * 16));
+        glds16(rsrc_hi, region + s_ * SLOTB + L0 * 16, base, s_ * (BM * 16));
       }
     }
   };
@@ -155,56 +184,55 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
   const float L2E = 1.44269504088896340736f;
   const float ka = -L2E * a.out_scale, kbx = -2.0f * L2E * a.out_scale;
 
-  int tile = blockIdx.x;
-  if (tile < n_tiles) dma_tile(tile, smem_l512, tid0 & 63);
-  if constexpr (FUSE) wait_vmcnt<0>();   // (the fused form waits for the NEXT tile's pieces before its stream epilogue, not at [B1]: see there)
-  int it = 0;
-  for (; tile < n_tiles; tile += gridDim.x, ++it) {
-    // per-lane constants are recomputed per tile from an opaque copy of the thread id: hoisted out of this loop they would stay live across
+  // ---- one work item; NM = row blocks of 32 (4: a tile, 2: half of one)
+  auto run_item = [&](auto nm_tag, const L512Item cur, const bool has_next, const L512Item nxt, const int it) {
+    constexpr int NM = decltype(nm_tag)::value;
+    // per-lane constants are recomputed per item from an opaque copy of the thread id: hoisted out of the item loop they would stay live across
     // the 128-accumulator conv loop and spill
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int w_voff = lane * 16;
+    const int tile = cur.tile, r0 = cur.r0, mb0 = cur.r0 >> 5;   // mb0: the item's first row block inside its tile (addend / stream / H layouts)
     // ---- activation fragments (the matrix instruction's B operand): lane (l31, lh) reads slot 4 cc + 2 ks + lh (channels 16 ks + 8 lh .. + 7
     // of chunk cc) of LDS row HALO + (tap - 1) d + 32 m + l31: 32 lanes read 512 contiguous bytes - conflict-free without a swizzle
     int a_off[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) a_off[j] = (HALO + (j - 1) * d + l31) * 16 + lh * SLOTB;
-    // G tile (rows 0 .. 127, same slot-major form): fragment reads of the residual projection and the gate epilogue's 8-byte writes
+    // G tile (rows 0 .. 32 NM - 1, same slot-major form): fragment reads of the residual projection and the gate epilogue's 8-byte writes
     const int g_off = l31 * 16 + lh * SLOTB;
-    char* const Rc = smem_l512 + (it & 1) * REGION;   // A(tile), then G(tile)
+    char* const Rc = smem_l512 + (it & 1) * REGION;   // A(item), then G(item)
     char* const Rn = smem_l512 + ((it & 1) ^ 1) * REGION;
     int b, ti;
     tile_coords(tile, b, ti);
-    const int t0 = ti * BM;
+    const int t0 = ti * BM + r0;                      // first row of the item inside its utterance
     const int len = ss_uniform_len(a.lens, b, a.T);
     const int row_lim = a.mask_rows ? (len < a.T ? len : a.T) : a.T;
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NM];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
     // ---- the dilated conv: 48 k-steps, no barrier. Weight ring: fragments of k-step S + NRING - 1 are requested before the MFMAs of step S.
     bf16x8 wq[NRING][4];   // [plane * 2 + nb]
-    bf16x8 act[2][4];
+    bf16x8 act[2][NM];
     auto load_w = [&](bf16x8 (&dst)[4], int S) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) dst[p] = ldw(rsrc_wg, w_voff + p * 1024, S * WG_STEP);
     };
-    auto read_act = [&](bf16x8 (&dst)[4], int S) {
+    auto read_act = [&](bf16x8 (&dst)[NM], int S) {
       const int cc = S / 6, tap = (S / 2) % 3, ks = S & 1;
       const int ao = a_off[tap] + (4 * cc + 2 * ks) * SLOTB;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + ao + m * 512);
+      for (int m = 0; m < NM; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + ao + m * 512);
     };
 #pragma unroll
     for (int s = 0; s < NRING - 1; ++s) load_w(wq[s], s);
-    // my DMA pieces of this tile have landed: only the ring's loads are younger. (Fused form: already waited for - a vmcnt wait HERE would also
+    // my DMA pieces of this item have landed: only the ring's loads are younger. (Fused form: already waited for - a vmcnt wait HERE would also
     // wait for the stream epilogue's 32 stores, a full memory round trip per tile: 5.3 k cycles in the v1 trace.)
     if constexpr (!FUSE) wait_vmcnt<4 * (NRING - 1)>();
     __builtin_amdgcn_s_barrier();    // [B1] everyone's pieces have
@@ -215,13 +243,13 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       if constexpr (S + NRING - 1 < KSTEPS) load_w(wq[(S + NRING - 1) % NRING], S + NRING - 1);
       if constexpr (S + 1 < KSTEPS) read_act(act[(S + 1) & 1], S + 1);
       const bf16x8 (&w)[4] = wq[S % NRING];
-      const bf16x8 (&x)[4] = act[S & 1];
+      const bf16x8 (&x)[NM] = act[S & 1];
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc[n][m] = ss_mfma_32x32x16<true>(w[p * 2 + n], x[m], acc[n][m]);
+          for (int m = 0; m < NM; ++m) acc[n][m] = ss_mfma_32x32x16<true>(w[p * 2 + n], x[m], acc[n][m]);
       __builtin_amdgcn_sched_barrier(0);
     };
     unrolled_steps(kstep, std::make_integer_sequence<int, KSTEPS>{});
@@ -229,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 
     // ---- gate epilogue. Addend slab in accumulator order: block (nb, m), quarter q -> one 16-byte load per lane, 1 KB per wave instruction.
     // Request order = order of need (vmcnt retires in order: whatever is waited for drags everything older with it): E(m = 0), E(1) | E(2) |
-    // E(3) | the stream P | the next tile's DMA pieces last.
+    // E(3) | the stream P | the next item's DMA pieces last.
     const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr((const char*)a.E512 + (int64_t)tile * E_TILE + (int64_t)wave * (E_TILE / 8)), 0, E_TILE / 8, 0x00020000);
     // TWO blocks ahead: the slab is 256 KB per tile and CU, and with one block (8 KB per wave) in flight it arrived at ~26 B per cycle and CU -
@@ -240,31 +268,32 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + m) * 4 + q) * 1024, 0));
+          dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + mb0 + m) * 4 + q) * 1024, 0));
     };
     load_e(ev[0], 0);
     load_e(ev[1], 1);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
-    __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last tile ended
+    __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last item ended
     L512_STAMP(2);
     // (Measured and dropped: the gate arithmetic AHEAD of [B2], into registers, so that the wave that leaves the conv loop first - the older wave of
     // a SIMD gets the matrix pipe, 25 k against 50 k cycles - works under its partner's MFMAs instead of waiting at the barrier. Its VALU stream
     // then competes with the partner's MFMA issue: conv loop 50 -> 62 k cycles, gate arithmetic 30 k; 403.6 against 397.7 us per launch -
     // profiles/r06_trace_layer512_v5_gate_math_before_b2.log. Work moved between the two waves of a SIMD is zero-sum, as the guide says.)
-    // the stream of this tile (fp32, accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
+    // the stream of this item (fp32, accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
     // dead so that the loads fly under the rest of this epilogue, [B3] and the G pass
-    [[maybe_unused]] f32x4 pv[4][4];
+    [[maybe_unused]] f32x4 pv[NM][4];
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (int64_t)wave * (P_TILE / 8) : (const char*)a.Wg), 0, FUSE ? P_TILE / 8 : 0, 0x00020000);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      if (m + 2 < 4) load_e(ev[(m + 2) % 3], m + 2);
+    for (int m = 0; m < NM; ++m) {
+      if (m + 2 < NM) load_e(ev[(m + 2) % 3], m + 2);
       if constexpr (FUSE) {
-        if (m == 2) {
+        if (m == NM - 2) {
 #pragma unroll
-          for (int mm = 0; mm < 4; ++mm)
+          for (int mm = 0; mm < NM; ++mm)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pv[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, (mm * 4 + q) * 1024, 0));
+            for (int q = 0; q < 4; ++q)
+              pv[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, ((mb0 + mm) * 4 + q) * 1024, 0));
         }
       }
       const bool pad = t0 + 32 * m + l31 >= row_lim;
@@ -279,9 +308,9 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
             const int e = 2 * e2 + k, r = 4 * q + e;
             const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, ev[m % 3][0][q][e]));
             const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, ev[m % 3][1][q][e]), 30.0f));
-            float g = (1.0f - eb) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));   // sigmoid(v0) * tanh(v1), net.py:72-73
-            if (pad) g = 0.f;
-            v |= (uint32_t)ss_f2t<true>(g) << (16 * k);
+            float g_ = (1.0f - eb) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));   // sigmoid(v0) * tanh(v1), net.py:72-73
+            if (pad) g_ = 0.f;
+            v |= (uint32_t)ss_f2t<true>(g_) << (16 * k);
           }
           pk[e2] = v;
         }
@@ -289,19 +318,19 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
         *reinterpret_cast<u32x2*>(Rc + (4 * wave + q) * SLOTB + (32 * m + l31) * 16 + 8 * lh) = u32x2{pk[0], pk[1]};
       }
     }
-    if (tile + (int)gridDim.x < n_tiles) dma_tile(tile + gridDim.x, Rn, lane);
+    if (has_next) dma_item(nxt, Rn, lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // my G writes are done
     L512_STAMP(3);
     __builtin_amdgcn_s_barrier();         // [B3] the G tile is complete
     L512_STAMP(4);
 
-    // ---- G -> HBM (the skip GEMM's operand, ss_gemm_bf16's pair layout): 128 rows x 32 slots, eight per thread; lanes walk the slots of a row
+    // ---- G -> HBM (the skip GEMM's operand, ss_gemm_bf16's pair layout): 32 NM rows x 32 slots, 2 NM per thread; lanes walk the slots of a row
     // (LDS stride 2320 B = 4 banks x 16 B apart: conflict-free), the hi halves of the row's 128-byte pair lines in HBM
     {
       const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(
           uniform_ptr(a.G + (int64_t)b * a.g_batch_stride), 0, __builtin_amdgcn_readfirstlane((int)((int64_t)a.T * a.ldg * 2)), 0x00020000);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 2 * NM; ++j) {
         const int p = tid + 512 * j;
         const int R = p >> 5, s_ = p & 31;
         const u32x4 v = *reinterpret_cast<const u32x4*>(Rc + s_ * SLOTB + R * 16);
@@ -310,21 +339,21 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     }
     L512_STAMP(5);
     if constexpr (FUSE) {
-      // ---- residual projection from the G tile: out^T[channel][row], wave w owns channels 32 w .. + 31; 16 k-steps of 8 MFMAs
-      f32x16 acc2[4];
+      // ---- residual projection from the G tile: out^T[channel][row], wave w owns channels 32 w .. + 31; 16 k-steps of 2 NM MFMAs
+      f32x16 acc2[NM];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
       bf16x8 wr[NRING_R][2];
-      bf16x8 gf[2][4];
+      bf16x8 gf[2][NM];
       auto load_wr = [&](bf16x8 (&dst)[2], int S) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) dst[p] = ldw(rsrc_wr, w_voff + p * 1024, S * WR_STEP);
       };
-      auto read_g = [&](bf16x8 (&dst)[4], int S) {
+      auto read_g = [&](bf16x8 (&dst)[NM], int S) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + g_off + 2 * S * SLOTB + m * 512);
+        for (int m = 0; m < NM; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(Rc + g_off + 2 * S * SLOTB + m * 512);
       };
 #pragma unroll
       for (int s = 0; s < NRING_R - 1; ++s) load_wr(wr[s], s);
@@ -344,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc2[m] = ss_mfma_32x32x16<true>(wr[S % NRING_R][p], gf[S & 1][m], acc2[m]);
+          for (int m = 0; m < NM; ++m) acc2[m] = ss_mfma_32x32x16<true>(wr[S % NRING_R][p], gf[S & 1][m], acc2[m]);
         __builtin_amdgcn_sched_barrier(0);
       };
       unrolled_steps(rstep, std::make_integer_sequence<int, RSTEPS>{});
@@ -353,31 +382,44 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       // ---- stream update: x' = (x + acc * out_scale + b) * post_scale in fp32, in place in P (16 bytes per lane, 1 KB per instruction);
       // fp16(x' + next_bias) goes to Hout's slot-major tile: 8 bytes per lane, the two lane halves fill a row's 16-byte slot, 32 rows in a row -
       // 512 contiguous bytes per instruction. Everything of mine that is in flight has to land first anyway (the stream loads) - and with it
-      // the next tile's DMA pieces, which [B1] then needs no memory wait for.
+      // the next item's DMA pieces, which [B1] then needs no memory wait for.
       wait_vmcnt<0>();
       const __amdgpu_buffer_rsrc_t rsrc_ho = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Hout + (int64_t)tile * H_TILE), 0, H_TILE, 0x00020000);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < NM; ++m) {
         const bool pad = t0 + 32 * m + l31 >= row_lim;
-        const int ho = (32 * m + l31) * 16 + 8 * lh;   // + slot (4 w + q) * 2048
+        const int ho = (r0 + 32 * m + l31) * 16 + 8 * lh;   // + slot (4 w + q) * 2048
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 xo;
           uint32_t hp[2] = {0, 0};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            // no contraction here: H must be fp16 of the STORED x' plus the bias - a multiply-add fused across the two would round differently
+            // from the value the next layer's epilogue reads back from P, and differently between the whole- and the half-tile instantiation
+#pragma clang fp contract(off)
             const float xn = (pv[m][q][e] + fmaf(acc2[m][4 * q + e], a.out_scale, bs[q][e])) * a.post_scale;
             xo[e] = pad ? 0.f : xn;
             hp[e >> 1] |= (uint32_t)ss_f2t<true>(pad ? 0.f : xn + nb[q][e]) << (16 * (e & 1));
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), rsrc_p, w_voff, (m * 4 + q) * 1024, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), rsrc_p, w_voff, ((mb0 + m) * 4 + q) * 1024, 0);
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{hp[0], hp[1]}, rsrc_ho, ho, (4 * wave + q) * (BM * 16), 0);
         }
       }
     }
     L512_STAMP(7);
-    // (no barrier here: the next tile's [B1] is reached by a wave only after its reads of this G tile, and this region is next written by
-    // the DMA issued before the next tile's [B3] - after its [B2], which every wave reaches only after [B1])
+    // (no barrier here: the next item's [B1] is reached by a wave only after its reads of this G tile, and this region is next written by
+    // the DMA issued before the next item's [B3] - after its [B2], which every wave reaches only after [B1])
+  };
+
+  if (n_items > 0) dma_item(item(0), smem_l512, tid0 & 63);
+  if constexpr (FUSE) wait_vmcnt<0>();   // (the fused form waits for the NEXT item's pieces before its stream epilogue, not at [B1]: see there)
+  for (int it = 0; it < n_items; ++it) {
+    const L512Item cur = item(it);
+    const bool has_next = it + 1 < n_items;
+    const L512Item nxt = item(has_next ? it + 1 : it);
+    if (cur.nm == 4) run_item(std::integral_constant<int, 4>{}, cur, has_next, nxt, it);
+    else run_item(std::integral_constant<int, 2>{}, cur, has_next, nxt, it);
   }
   if (probing && tid0 == 0) {
     atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
@@ -528,6 +570,9 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
   if (const char* e = getenv("SS_L512_GRID")) grid = atoi(e) > 0 && atoi(e) < grid ? atoi(e) : grid;   // trace builds: fewer CUs (is a phase memory-starved? it is not:
                                                                                                        // profiles/r06_trace_layer512_v2_experiments.log)
 #endif
+  // the last round as half tiles when it would keep at most half of the workgroups busy (see the schedule in the kernel); knob "layer512_tail"
+  const int rem = n_tiles % grid;
+  const int split_tail = (g_ss_tuning.layer512_tail != 0 && n_tiles >= grid && rem > 0 && 2 * rem <= grid) ? 1 : 0;
   const size_t lds = (size_t)2 * REGION;
   auto go = [&](auto kern) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -535,7 +580,7 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
       ss_set_error("ss_layer512: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
       return SS_ERR_HIP;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, tpi, n_tiles, g_ss_tuning.clock_probe);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, tpi, n_tiles, split_tail, g_ss_tuning.clock_probe);
     return SS_OK;
   };
   SS_PROPAGATE(fuse ? go(&layer512_kernel<true>) : go(&layer512_kernel<false>));

@@ -628,7 +628,9 @@ class StyleSingerHIP(torch.nn.Module):
         the workspaces of forwards that run CONCURRENTLY on different HIP streams (forward(plan_slot=...))."""
         key = (B, T, dev.index) if slot == 0 else (B, T, dev.index, slot)
         pl = self._plans.get(key)
+        self.plan_lookups = getattr(self, "plan_lookups", 0) + 1
         if pl is None:
+            self.plan_misses = getattr(self, "plan_misses", 0) + 1
             pl = _DiffPlan(self, B, T, dev)
             self._plans[key] = pl
             total = sum(p.bytes for p in self._plans.values())
@@ -640,6 +642,7 @@ class StyleSingerHIP(torch.nn.Module):
                     synced = True
                 _, old = self._plans.popitem(last=False)   # least recently used
                 total -= old.bytes
+                self.plan_evictions = getattr(self, "plan_evictions", 0) + 1
         else:
             self._plans.move_to_end(key)
         return pl
