@@ -525,7 +525,7 @@ def secondary_configs():
                      "e2e_fraction_of_mfma_peak": d["config"].get("e2e_fraction_of_mfma_peak"),
                      "roofline": {k: rl.get(k) for k in ("bound", "kernel", "measured", "achieved", "peak", "unit", "frac", "algorithmic_frac", "executed_mfma_frac", "traffic",
                                                          "traffic_source", "us_per_launch", "hbm_frac", "algorithmic_bytes_per_launch", "clock_ghz",
-                                                         "executed_mfma_frac_at_clock", "from_committed_profile")},
+                                                         "executed_mfma_frac_at_clock", "from_committed_profile", "top_kernels")},
                      "wall_s_incl_setup": round(time.perf_counter() - t0, 1)}
         name = "c1_gpu" if name == "c1" else name
         if "parity" in d:
@@ -914,6 +914,24 @@ def main():
         if not args.no_roofline:
             rl = kernel_roofline(infer, B, T, bf16)
             rl["launches_per_step"] = 20 * S_mel
+            # the whole time budget from this round's committed rocprofv3 summaries (read at run time; shares are of GPU time of THAT profiled
+            # command, named in `source`): every kernel above a percent with its recomputed executed-MFMA fraction where the flops are known
+            if args.config == "c2" and B * T == 12000:
+                F32 = PEAK_FP32_MFMA
+                rl["top_kernels"] = top_kernels("r06_bench_c2_1stream_kernel_stats.csv", {
+                    "wino43_gate16_kernel<2": (2.0 * 12000 * 768 * 512 * 0.5, F32), "wino43_gate16_kernel<3": (2.0 * 24000 * 576 * 384 * 0.5, F32),
+                    "gemm16_res_kernel<6, 8": (2.0 * 12000 * 256 * 256, F32), "gemm16_res_kernel<6, 6": (2.0 * 24000 * 192 * 192, F32),
+                    "gemm16_store_kernel<4>": (2.0 * 12000 * 5120 * 256, F32), "gemm16_store_kernel<6>": (2.0 * 24000 * 1920 * 192, F32)}) or \
+                    top_kernels("r05_bench_c2_1stream_kernel_stats.csv")
+            elif args.config in ("c4", "c4f16") and B * T == 180000:
+                H16 = PEAK_BF16_MFMA
+                tk = top_kernels("r06_bench_c4_layer512_20steps_kernel_stats.csv", {
+                    "layer512_kernel<true>": (2 * (2.0 * 180000 * 768 * 512 + 2.0 * 180000 * 256 * 256), H16), "layer512_kernel<false>": (2 * 2.0 * 180000 * 768 * 512, H16),
+                    "tile256s_kernel<0, true>": (2 * 2.0 * 180000 * 5120 * 256, H16)}, n=10)
+                if tk:
+                    tk["note"] = ("profiled command: bench.py --config c4 --diff-steps 20 (20 mel steps AND 20 f0 steps: the f0 loops' and the vocoder's shares are ~10x "
+                                  "what they are in the 1000-step config; the per-launch averages are what carries over)")
+                rl["top_kernels"] = tk
             if not sweep_mode and not bf16 and wino and world == 1:
                 mel_exec = MEL_FLOP_PER_FRAME_STEP - MEL_COND_FLOP - MEL_GATE_FLOP * wino_saved
                 rl["mel_loop_in_run"] = mel_loop_in_run(infer, B, T, S_mel, mel_exec, peak)
