@@ -55,6 +55,7 @@ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 // dilations <= 8, and the launch fills the chip (ss_layer512_ok); knob "layer512"
 inline bool fused512(const ss_wavenet* net, int B, int T) {
   if (!g_ss_tuning.layer512 || net->mfma_split != 2 || !hmode(net) || net->n_groups > 1 || net->C != 256 || !net->w_skipall_h) return false;
+  if (net->w_dil_q[0] && net->q_scale_gate > 0.f) return false;   // "fp16q4": its gate runs the second product on the fp4 instruction (gate128q), two launches per layer
   for (int l = 0; l < net->L; ++l)
     if (!net->w_dil_f[l] || (l + 1 < net->L && !net->w_out_f[l])) return false;
   const int dmax = 1 << ((net->L < net->dil_cycle ? net->L : net->dil_cycle) - 1);
