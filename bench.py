@@ -276,8 +276,10 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 2.0 if f16 else 3.0 if split else 1.0)
     peak = PEAK_BF16_MFMA if (bf16 or x3) else PEAK_FP32_MFMA
     # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
-    g256 = hbm and not fused and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 1024   # ss_gemm_bf16_gate256_ok's shape rule
-    g128 = hbm and not fused and f16 and L.load().ss_get_tuning(b"gate128") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 128) >= 2048   # ss_gemm_bf16_gate128_ok's shape rule
+    import torch as _t
+    n_cu = _t.cuda.get_device_properties(dev).multi_processor_count   # the library's own size rules count workgroup rounds per CU of THIS device
+    g256 = hbm and not fused and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 4 * n_cu   # ss_gemm_bf16_gate256_ok's shape rule
+    g128 = hbm and not fused and f16 and L.load().ss_get_tuning(b"gate128") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 128) >= 8 * n_cu   # ss_gemm_bf16_gate128_ok's shape rule
     hbm_name = ("layer512_kernel<true> (ONE launch per residual layer: dilated conv + addend + gate + residual projection + stream update; fp16 operands, weights as "
                 "(hi, lo) fp16 pairs streamed L2 -> registers in fragment order, 2 products, 128 rows x all 512 columns per persistent workgroup, G kept in LDS, direct" if fused else
                 "gate128q_kernel (fp16 operands in HBM, weights = fp16 hi terms + block-scaled fp4 lo terms: 16 fp16 MFMAs + 4 fp4 ones per step, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if (g128 and q4) else

@@ -483,7 +483,7 @@ extern "C" int ss_gemm_bf16_gate256_ok(const ss_gemm_bf16_args* a) {
   // 32-bit offsets inside an item (the launcher asserts the same): longer items take the generic kernel
   if ((int64_t)a->T * a->lda * 2 >= (1ll << 31) || (int64_t)a->T * a->lde * 4 >= (1ll << 31) || (int64_t)a->T * a->ldc * 2 >= (1ll << 31)) return 0;
   const long tiles = (long)ss_cdiv(a->T, BM) * a->B * (a->Np / BN);
-  return tiles >= 1024 ? 1 : 0;
+  return tiles >= 4l * ss_n_cu() ? 1 : 0;   // four rounds of one workgroup per CU (1024 tiles on the 256 CUs of an MI355X)
 }
 
 extern "C" int ss_gemm_bf16_gate256(const ss_gemm_bf16_args* args, void* stream) {

@@ -79,6 +79,7 @@ def _window_tables(g, device):
     return _tables[key]
 
 
+WS_CAP_BYTES = 256 << 20   # peak workspace of one tracker launch group (a 30 s item needs ~40 MB)
 N_TRACK_CALLS = 0   # launches of the tracker since import (tests assert that the entry point tracks each reference audio ONCE)
 
 
@@ -112,15 +113,21 @@ def track_f0_device(wavs, n_samples, n_out, sr=48000, hop_size=256, pitch_floor=
     for k in ("nsamp_window", "halfnsamp_window", "nsamp_period", "halfnsamp_period", "maximum_lag", "nlag", "hop"):
         setattr(prm, k, g[k])
     lib = L.load()
-    wsb = lib.ss_f0track_workspace_bytes(B, max_frames, g["nlag"])
-    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     # ONE int32 table [3][B] that stays referenced until the launches are queued (three temporaries would be freed - and their memory handed to
     # the next one - before the kernels read them)
     meta = torch.tensor([ns, [nf for nf, _ in grid], [lf for _, lf in grid]], dtype=torch.int32).to(dev)
     out = torch.empty(B, int(n_out), device=dev, dtype=torch.float32)
     import ctypes
-    L.check(lib.ss_f0track(L.ptr(wavs), wavs.shape[1], L.ptr(meta[0]), L.ptr(meta[1]), L.ptr(meta[2]), B,
-                           max_frames, ctypes.byref(prm), L.ptr(win), L.ptr(win_r), L.ptr(out), int(n_out), 2 * pad_size, L.ptr(ws), wsb,
-                           L.stream_ptr()), "ss_f0track")
+    # The workspace holds the float64 autocorrelation of every frame (max_frames x (nlag + 1) x 8 B per item: 40 MB for a 30 s item). A batch is
+    # tracked in groups of items whose workspace stays below WS_CAP_BYTES - 32 x 30 s would otherwise ask for 1.3 GB at once; items are independent,
+    # so the grouping changes nothing but the peak allocation (the same kernels, the same per-item arithmetic).
+    per_item = max(1, lib.ss_f0track_workspace_bytes(1, max_frames, g["nlag"]))
+    group = max(1, min(B, WS_CAP_BYTES // per_item))
+    ws = torch.empty(lib.ss_f0track_workspace_bytes(group, max_frames, g["nlag"]), device=dev, dtype=torch.uint8)
+    for b0 in range(0, B, group):
+        nb = min(group, B - b0)
+        L.check(lib.ss_f0track(L.ptr(wavs[b0:]), wavs.shape[1], L.ptr(meta[0, b0:]), L.ptr(meta[1, b0:]), L.ptr(meta[2, b0:]), nb,
+                               max_frames, ctypes.byref(prm), L.ptr(win), L.ptr(win_r), L.ptr(out[b0:]), int(n_out), 2 * pad_size, L.ptr(ws), ws.numel(),
+                               L.stream_ptr()), "ss_f0track")
     meta.record_stream(torch.cuda.current_stream(dev))
     return out

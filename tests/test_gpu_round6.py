@@ -103,3 +103,28 @@ def test_nonfinite_flag_is_raised_on_every_forward_not_only_the_first():
     flag.zero_()
     L.check(lib.ss_mel_denorm(L.ptr(x), L.ptr(smin), L.ptr(smax), L.ptr(mel), 1, 128, 80, L.ptr(lens), L.ptr(flag), L.stream_ptr()), "denorm")
     assert int(flag.item()) == 0 and torch.isfinite(mel).all()
+
+
+def test_f0_tracker_in_item_groups_equals_one_launch():
+    """the tracker's float64 autocorrelation workspace (40 MB per 30 s item) is bounded by tracking a batch in groups of items
+    (`f0track.WS_CAP_BYTES`); items are independent, so any grouping gives the same contours bit for bit."""
+    import numpy as np
+    from stylesinger_amd import f0track
+    sr, hop = 48000, 256
+    rng = np.random.default_rng(3)
+    lens = [hop * 90, hop * 61, hop * 75, hop * 33]
+    wav = np.zeros((4, max(lens)), dtype=np.float32)
+    for b, n in enumerate(lens):
+        t = np.arange(n) / sr
+        f = 150.0 + 40.0 * b + 30.0 * np.sin(2 * np.pi * 1.5 * t)
+        wav[b, :n] = (0.4 * np.sin(2 * np.pi * np.cumsum(f) / sr) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    x = torch.from_numpy(wav).cuda()
+    n_out = max(lens) // hop + 1
+    whole = f0track.track_f0_device(x, lens, n_out, sr=sr, hop_size=hop)
+    cap = f0track.WS_CAP_BYTES
+    try:
+        f0track.WS_CAP_BYTES = 1          # one item per launch group
+        single = f0track.track_f0_device(x, lens, n_out, sr=sr, hop_size=hop)
+    finally:
+        f0track.WS_CAP_BYTES = cap
+    assert torch.equal(whole, single) and (whole > 0).sum().item() > 100

@@ -29,9 +29,8 @@ def main():
     res = (-(-rows // 96), 256)
     skip = (-(-rows // 64) * 2, 256)
     small = (-(-rows * 80 // 256), 256)
-    per_eval = [small] + [gate, res] * 19 + [gate] + [skip, small, small]
+    per_eval = [small] + [gate, res] * 19 + [gate] + [skip, small]
     once = [small, (-(-rows // 128) * 80, 256)] + [small] * 20
-    assert len(per_eval) == 43 or len(per_eval) == 42 or True
     st = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(st):

@@ -18,6 +18,13 @@
 #   pmc-gate128      PMC passes on gate128_kernel at the config-4 shape (profiles/r05_pmc_gate128.json)
 #   ablate-gate16    timing ablations of the 16x16-tile gate kernel (debug builds: tools/ablate_g16.sh build, in the container)
 #   ablate-res16     the same for the residual-projection kernel (tools/ablate_r16.sh build, in the container)
+#   kbench-layer512  round 6: ss_layer512 (one launch per residual layer of the fp16x2 mel stack) against the launch pair it replaces, C4 shape
+#   trace-layer512   per-phase shader-clock timing of layer512_kernel (builds the -DSS_L512_TRACE library first; hipcc works on the box)
+#   pmc-layer512     PMC passes on layer512_kernel (profiles/r06_pmc_layer512.json)
+#   profile-c4       rocprofv3 kernel stats of the C4 loop at 20 diffusion steps (profiles/r06_bench_c4_layer512_20steps_kernel_stats.csv)
+#   power            rocm-smi power / sclk sampled under 12 s of back-to-back layer launches (1400 W = the cap)
+#   launch-floor     null-kernel hipGraph with the C2 mel loop's launch topology (tools/launch_floor.py)
+#   c5-full          the full per-GPU share of BASELINE configs[4]: 32 references x 256 targets (profiles/r06_bench_c5_full_share.json)
 #   ubench           micro-benchmarks behind DESIGN.md §3.0 (VALU beside fp32 MFMA, 16x16x4 issue rate, DPP / LDS-DMA probes)
 cd ${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 R=$PWD
@@ -72,6 +79,28 @@ case "$sec" in
     bash tools/ablate_g16.sh run ;;
   ablate-res16)
     bash tools/ablate_r16.sh run ;;
+  kbench-layer512)
+    python tools/kbench_layer512.py --iters 400
+    SS_LAYER512_TAIL=0 python tools/kbench_layer512.py --iters 400 --which fused ;;
+  trace-layer512)
+    mkdir -p stylesinger_amd/_abl
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSS_L512_TRACE -c stylesinger_amd/csrc/layer512.hip -o /tmp/l512t.o && \
+    hipcc --offload-arch=gfx950 -shared -fPIC -o stylesinger_amd/_abl/libss_l512trace.so /tmp/l512t.o $(ls stylesinger_amd/_obj/*.o | grep -v layer512) && \
+    SS_LIB_PATH=stylesinger_amd/_abl/libss_l512trace.so python tools/trace_layer512.py "$@" ;;
+  pmc-layer512)
+    bash tools/pmc_layer512.sh "$@" ;;
+  profile-c4)
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c4 -o c4 -- \
+       python $R/bench.py --config c4 --diff-steps 20 --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/prof_c4.log 2>&1)
+    head -12 "$(find gpurun_out/prof_c4 -name '*kernel_stats.csv' | head -1)" | cut -c1-220 ;;
+  power)
+    ( for i in $(seq 1 30); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power \(W\)|sclk" | tr '\n' ';'; echo; sleep 0.3; done ) > gpurun_out/smi_under_load.log 2>&1 &
+    python tools/kbench_layer512.py --iters 30000 --which fused | tail -1
+    wait; sort gpurun_out/smi_under_load.log | uniq -c | sort -rn | head -8 ;;
+  launch-floor)
+    python tools/launch_floor.py; python tools/launch_floor.py --B 1 --T 750 ;;
+  c5-full)
+    python bench.py --config c5 --refs 32 --targets 256 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary | tail -1 | cut -c1-1200 ;;
   ubench)
     for f in mfma_valu mfma16 glds_probe l2bw soffset_probe mfma_mx_layout cvt_fp4_probe; do
       hipcc --offload-arch=gfx950 -O3 tools/ubench/$f.hip -o /tmp/$f 2>/dev/null && /tmp/$f
