@@ -314,15 +314,16 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # above runs the kernel back to back, where the chip clocks down; in the loop it alternates with the projections): average duration of
     # the C2 launches and the executed-MFMA fraction that follows from it. null when no such profile exists for this kernel / shape.
     in_loop = None
-    csv_path = os.path.join(ROOT, "profiles", "r05_bench_c2_1stream_kernel_stats.csv")
-    if wino_m == 4 and mt and not x3 and B * T == 12000 and os.path.exists(csv_path):
+    csv_name = next((n for n in ("r06_bench_c2_1stream_kernel_stats.csv", "r05_bench_c2_1stream_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", n))), "")
+    csv_path = os.path.join(ROOT, "profiles", csv_name)
+    if wino_m == 4 and mt and not x3 and B * T == 12000 and csv_name:
         try:
             import csv
             for row in csv.DictReader(open(csv_path)):
                 if f"wino43_gate16_kernel<{mt}" in row["Name"]:
                     us = float(row["AverageNs"]) * 1e-3
                     in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak,
-                               "source": "profiles/r05_bench_c2_1stream_kernel_stats.csv"}
+                               "source": "profiles/" + csv_name}
                     break
         except (KeyError, ValueError, OSError):
             in_loop = None

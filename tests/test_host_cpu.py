@@ -46,6 +46,14 @@ def test_argument_errors_are_reported_not_crashed():
     assert not hasattr(l, "ss_fused_gate_res")   # the dataflow-launch experiment is built from tools/experiments/, not shipped in the library
     assert l.ss_set_tuning(b"q4_force", 1) == 0 and l.ss_get_tuning(b"q4_force") == 1 and l.ss_set_tuning(b"q4_force", 0) == 0
     assert l.ss_set_tuning(b"tile128", 1) != 0 and l.ss_set_tuning(b"skip_deep", 1) != 0      # removed in round 5
+    # round-6 entry points
+    import ctypes
+    assert l.ss_layer512(None, None) != 0 and b"ss_layer512" in l.ss_last_error()
+    a = lib.Layer512Args()
+    assert l.ss_layer512(ctypes.byref(a), None) != 0 and b"null Hin" in l.ss_last_error()
+    assert l.ss_layer512_entry(None, 256, 0, None, None, None, None, 1, 1, None) != 0 and l.ss_layer512_tile_addend(None, 512, 0, None, 1, 1, None) != 0
+    assert l.ss_layer512_pack_gate(None, None, None) != 0 and l.ss_layer512_pack_res(None, None, None) != 0
+    assert l.ss_debug_null_launch(0, 64, None) != 0 and l.ss_set_q4_guard(None) == 0
 
 
 def test_param_spec_matches_reference_dump(golden_dir):
@@ -375,6 +383,16 @@ def test_launch_planning_functions_of_the_library_run_without_a_gpu():
         assert l.ss_set_tuning(key, before) == 0
     assert l.ss_set_tuning(b"htile", 96) != 0 and b"htile" in l.ss_last_error()
     assert l.ss_get_tuning(b"nope") < 0
+    # round 6: the fused residual layer of the fp16x2 mel stack. Size rule = four rounds of 128-row tiles per CU (256 CUs without a device): the
+    # BASELINE configs[3] shape qualifies (32 x 44 = 1408 tiles), C2's does not; the knob value 2 lifts the size rule (parity tests), never the shape rules
+    assert l.ss_get_tuning(b"layer512") == 1 and l.ss_get_tuning(b"layer512_tail") == 1
+    assert l.ss_layer512_ok(32, 5625, 256, 8, 20 * 256 * 2) == 1 and l.ss_layer512_ok(8, 1500, 256, 8, 20 * 256 * 2) == 0
+    assert l.ss_layer512_ok(32, 5625, 192, 8, 20 * 192 * 2) == 0 and l.ss_layer512_ok(32, 5625, 256, 16, 20 * 256 * 2) == 0
+    assert l.ss_set_tuning(b"layer512", 2) == 0 and l.ss_layer512_ok(1, 100, 256, 8, 512) == 1 and l.ss_layer512_ok(1, 100, 192, 8, 512) == 0
+    assert l.ss_set_tuning(b"layer512", 1) == 0 and l.ss_set_tuning(b"layer512", 3) != 0
+    # buffer sizes: 44 tiles per 30 s item; addend 128 x 512 floats, stream 128 x 256 fp32, H 128 x 256 fp16 per tile
+    assert l.ss_layer512_addend_floats(32, 5625) == 1408 * 128 * 512 and l.ss_layer512_stream_bytes(32, 5625) == 1408 * 128 * 256 * 4
+    assert l.ss_layer512_h_elems(32, 5625) == 1408 * 128 * 256 and l.ss_layer512_h_elems(1, 1) == 128 * 256
 
 
 def test_gate128_index_math_against_a_tagged_lds_image(tmp_path):
