@@ -933,7 +933,8 @@ def main():
                     "tile256s_kernel<0, true>": (2 * 2.0 * 180000 * 5120 * 256, H16)}, n=10)
                 if tk:
                     tk["note"] = ("profiled command: bench.py --config c4 --diff-steps 20 (20 mel steps AND 20 f0 steps: the f0 loops' and the vocoder's shares are ~10x "
-                                  "what they are in the 1000-step config; the per-launch averages are what carries over)")
+                                  "what they are in the 1000-step config; the per-launch averages are what carries over; the 19 000-20 000 launches of 11-15 us are the in-run parity "
+                                  "measurement - one T = 32 item x 1000 steps on the generic kernels - not the C4 loop)")
                 rl["top_kernels"] = tk
             if not sweep_mode and not bf16 and wino and world == 1:
                 mel_exec = MEL_FLOP_PER_FRAME_STEP - MEL_COND_FLOP - MEL_GATE_FLOP * wino_saved
