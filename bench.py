@@ -53,6 +53,9 @@ CONFIGS = {
     # fp16x2 with the second product of the mel gate and of the skip GEMM on gfx950's block-scaled fp4 matrix instruction (validated on hardware in
     # round 5: tests/test_gpu_fp16q4.py, tests/test_gpu_round5.py)
     "c4q": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16q4", sampler="ddpm"),
+    # round 6: ONE fp16 product per hidden GEMM, the weight rounding noise-shaped over the evaluations by cycling 32 weight sets ("fp16sd"):
+    # half the matrix work and weight bytes of fp16x2 at its parity (2.2e-5 on the reference's 1000-step golden in the CPU restatement)
+    "c4sd": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16sd", sampler="ddpm"),
     # (the name the round-4 records of the fp16x2 mode were taken under: same as c4)
     "c4f16": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16x2", sampler="ddpm"),
     # one GPU's share of configs[4] (256 refs x 256 targets over 8 GPUs = 32 refs x 256 targets per GPU), at a representative size: 64 references x
@@ -152,6 +155,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
 
     # fp16x2 at many-round sizes: the loop runs ONE ss_layer512 launch per layer (gate + residual projection, G kept in LDS) - that kernel is
     # then the dominant one (knob "layer512"; ss_layer512_ok is the library's own dispatch rule)
+    sd = bool(getattr(infer.model, "sd", False))   # "fp16sd": one weight term (one product); the packs are [N sets][...], the launch below uses set l % N
     fused = bool(hbm and f16 and not q4 and L.load().ss_get_tuning(b"layer512") >= 1 and all(f"w_dil_f.{l}" in packs for l in range(Lyr)) and
                  L.load().ss_layer512_ok(B, T, C, 8, Lyr * C * 2))
     if fused:
@@ -165,9 +169,12 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     def launch(l):
         d = 1 << (l % 4)
         if fused:
-            L.layer512(Hb[l & 1], packs[f"w_dil_f.{l}"], E512[l % NS], GAf[..., (l % NS) * 2 * C:], B=B, T=T, d=d, lens=lens, Hout=Hb[(l & 1) ^ 1], P=Pst,
-                       Wr=packs[f"w_out_f.{l}"], bias_r=packs[f"b_out.{l}"], next_bias=nbv, out_scale=2.0 ** -infer.model.FP16_WSHIFT, ldg=NS * 2 * C,
-                       g_bs=T * NS * 2 * C)
+            wg_, wr_ = packs[f"w_dil_f.{l}"], packs[f"w_out_f.{l}"]
+            if sd:
+                wg_, wr_ = wg_[l % wg_.shape[0]], wr_[l % wr_.shape[0]]
+            L.layer512(Hb[l & 1], wg_, E512[l % NS], GAf[..., (l % NS) * 2 * C:], B=B, T=T, d=d, lens=lens, Hout=Hb[(l & 1) ^ 1], P=Pst,
+                       Wr=wr_, bias_r=packs[f"b_out.{l}"], next_bias=nbv, out_scale=2.0 ** -infer.model.FP16_WSHIFT, ldg=NS * 2 * C,
+                       g_bs=T * NS * 2 * C, n_products=1 if sd else 2)
             return
         if hbm and q4:   # what run_residual_stack launches in fp16q4 mode when the launch fills the chip (ss_gemm_bf16_gate128q)
             L.gemm_bf16(Xh, packs[f"w_dil_q.{l}"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
@@ -273,14 +280,17 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     flops = 2.0 * B * T * (3 * C) * (2 * C) + (2.0 * B * T * C * C if fused else 0.0)   # fused: + the residual half of output_projection
     # x3: six bf16 products each; bf16x2: three; fp16x2: two; fp16q4: one fp16 product + one fp4 product of the same shape (counted as two products:
     # the fp4 instruction does 4x the work per issue, so its pipe time is a quarter - `frac` is flops over the FP16 peak and overstates pipe time)
-    executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 2.0 if f16 else 3.0 if split else 1.0)
+    executed = flops * ((6.0 / 12.0 if wino_m == 4 else 4.0 / 6.0) if wino else 1.0) * (6.0 if x3 else 1.0 if sd else 2.0 if f16 else 3.0 if split else 1.0)
     peak = PEAK_BF16_MFMA if (bf16 or x3) else PEAK_FP32_MFMA
     # the bf16 GATE case goes to the 256x256-tile LDS-DMA kernel when the shape qualifies (ss_gemm_bf16_gate256_ok) and the knob is on
     import torch as _t
     n_cu = _t.cuda.get_device_properties(dev).multi_processor_count   # the library's own size rules count workgroup rounds per CU of THIS device
     g256 = hbm and not fused and L.load().ss_get_tuning(b"gate256") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 256) >= 4 * n_cu   # ss_gemm_bf16_gate256_ok's shape rule
     g128 = hbm and not fused and f16 and L.load().ss_get_tuning(b"gate128") == 1 and C == 256 and -(-T // 256) * B * (2 * C // 128) >= 8 * n_cu   # ss_gemm_bf16_gate128_ok's shape rule
-    hbm_name = ("layer512_kernel<true> (ONE launch per residual layer: dilated conv + addend + gate + residual projection + stream update; fp16 operands, weights as "
+    hbm_name = ("layer512_kernel<true, 1> (ONE launch per residual layer: dilated conv + addend + gate + residual projection + stream update; fp16 operands, ONE fp16 weight "
+                "term streamed L2 -> registers in fragment order - the weight rounding is noise-shaped over the evaluations by cycling weight sets -, 1 product, 128 rows x all 512 "
+                "columns per persistent workgroup, G kept in LDS, direct" if (fused and sd) else
+                "layer512_kernel<true> (ONE launch per residual layer: dilated conv + addend + gate + residual projection + stream update; fp16 operands, weights as "
                 "(hi, lo) fp16 pairs streamed L2 -> registers in fragment order, 2 products, 128 rows x all 512 columns per persistent workgroup, G kept in LDS, direct" if fused else
                 "gate128q_kernel (fp16 operands in HBM, weights = fp16 hi terms + block-scaled fp4 lo terms: 16 fp16 MFMAs + 4 fp4 ones per step, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if (g128 and q4) else
                 "gate128_kernel (fp16 operands in HBM, weights as (hi, lo) fp16 pairs, 2 products, 256x128 tiles by LDS-DMA, 2 workgroups per CU, direct" if g128 else
@@ -298,7 +308,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     # tools/pmc.sh; profiles/r02_pmc_gate.json): never a constant in the code. null when no profile of this round/shape exists.
     traffic = None
     pmc_src = None
-    form = "layer512" if fused else (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16q4" if q4 else "fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
+    form = "layer512sd" if (fused and sd) else "layer512" if fused else (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16q4" if q4 else "fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
     for fn in ("r06_pmc_layer512.json", "r05_pmc_gate128.json", "r05_pmc_gate.json", "r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj):
@@ -328,7 +338,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         except (KeyError, ValueError, OSError):
             in_loop = None
     csv_l512 = os.path.join(ROOT, "profiles", "r06_bench_c4_layer512_20steps_kernel_stats.csv")
-    if fused and B * T == 180000 and os.path.exists(csv_l512):   # this round's dominant C4 kernel inside the graph-replayed loop
+    if fused and not sd and B * T == 180000 and os.path.exists(csv_l512):   # this round's dominant C4 kernel inside the graph-replayed loop
         try:
             import csv
             for row in csv.DictReader(open(csv_l512)):
@@ -505,7 +515,7 @@ def secondary_configs():
     reports value, ms_per_step, dtype and its own live roofline block; c4 (fp16x2: meets north_star) and c4bf16 (plain bf16 operands: does not) carry
     their parity status, c5 its style-cache accounting, c1 is the B = 1 latency shape (`c1_gpu`)."""
     out = {}
-    for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4q", 1, 1), ("c4bf16x2", 1, 1), ("c2x3", 6, 3)):
+    for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4sd", 1, 1), ("c4q", 1, 1), ("c4bf16x2", 1, 1), ("c2x3", 6, 3)):
         # (c4bf16 - plain bf16 operands, 2.5e-3 from the reference: does not meet north_star - left the default line in round 5 to keep the run
         # within minutes; `python bench.py --config c4bf16` still measures it)
         # (c5: a step is a whole 2048-pair sweep, ~45 s: no untimed warm-up sweep - the first timed step carries the one-off graph captures, ~2 s)
@@ -855,11 +865,13 @@ def main():
                       f"sampler + 2x{cfg['f0_steps']}-step f0 loops + HiFi-GAN-NSF, per-reference style cache"}
         desc["c2x3"] = desc["c2"]
         desc["c1"] = desc["c2"].replace("utterances per GPU", "utterance (latency shape of inference/StyleSinger.py:175-186), one at a time")
-        desc["c4bf16"] = desc["c4f16"] = desc["c4bf16x2"] = desc["c4q"] = desc["c4"]
+        desc["c4bf16"] = desc["c4f16"] = desc["c4bf16x2"] = desc["c4q"] = desc["c4sd"] = desc["c4"]
         desc = desc[args.config]
         x3 = getattr(infer.model, "x3", False)
         split = bool(getattr(infer.model, "split", False))
-        prec = ("fp16 MFMA, weights as (hi, lo) fp16 pairs (2 products per hidden GEMM, fp32 accumulate), residual stream an fp16 pair, conditioner projection / sampler / state / vocoder fp32" if getattr(infer.model, "f16", False) else
+        prec = ("fp16 MFMA, ONE fp16 weight term per element (1 product per hidden GEMM of the mel denoiser, fp32 accumulate), its rounding noise-shaped over the network evaluations "
+                f"by cycling {getattr(infer.model, 'sd_sets', 0)} sigma-delta weight sets; conditioner projection / sampler / state / vocoder fp32, f0 denoisers bf16x2" if getattr(infer.model, "sd", False) else
+                "fp16 MFMA, weights as (hi, lo) fp16 pairs (2 products per hidden GEMM, fp32 accumulate), residual stream an fp16 pair, conditioner projection / sampler / state / vocoder fp32" if getattr(infer.model, "f16", False) else
                 "bf16 MFMA on (hi, mid) operand pairs (3 products per hidden GEMM, fp32 accumulate), conditioner projection / sampler / state / vocoder fp32" if split else
                 "bf16-operand MFMA, fp32 accumulate/sampler/state" if bf16 else
                 "fp32 products of the F(4,3) gates from 3 bf16 terms per operand (6 bf16 MFMA products, fp32 accumulate), rest exact fp32 MFMA" if x3 else
@@ -867,7 +879,7 @@ def main():
         out = {
             "metric": "mel-frames/sec (end-to-end infer incl. vocoder)", "value": value, "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("fp16q4 (fp16 MFMA + block-scaled fp4 MFMA for the weights' lo terms)" if getattr(infer.model, "q4", False) else "fp16x2 (fp16 MFMA, weights as hi+lo fp16 pairs)" if getattr(infer.model, "f16", False) else "bf16x2 (bf16 MFMA, operands as hi+mid bf16 pairs)" if getattr(infer.model, "split", False) else "bf16") if bf16 else ("f32 via 3xbf16 split operands (gates)" if x3 else "f32"),
+            "scaling": "weak", "vs_baseline": None, "dtype": ("fp16sd (fp16 MFMA, ONE fp16 weight term; rounding noise-shaped over the evaluations)" if getattr(infer.model, "sd", False) else "fp16q4 (fp16 MFMA + block-scaled fp4 MFMA for the weights' lo terms)" if getattr(infer.model, "q4", False) else "fp16x2 (fp16 MFMA, weights as hi+lo fp16 pairs)" if getattr(infer.model, "f16", False) else "bf16x2 (bf16 MFMA, operands as hi+mid bf16 pairs)" if getattr(infer.model, "split", False) else "bf16") if bf16 else ("f32 via 3xbf16 split operands (gates)" if x3 else "f32"),
             "data": "synthetic (seeded random weights + inputs; no checkpoint ships)",
             "clock_ghz_timed_region": clock_timed,
             "config": {"workload": f"{args.config}: {desc}, {prec}", "name": args.config,
@@ -875,7 +887,7 @@ def main():
                        "diffusion_loops": {"on": "hipGraph replay", "auto": "hipGraph replay (captured on the 2nd use of a shape)",
                                            "off": "eager launches"}.get(str(infer.model.use_graphs), str(infer.model.use_graphs)),
                        "hipgraph_captures": infer.model.n_captures, "frame_bucket": infer.model.t_bucket,
-                       "mfma_precision": ("fp16q4" if getattr(infer.model, "q4", False) else "fp16x2" if getattr(infer.model, "f16", False) else "bf16x2" if split else "bf16") if bf16 else ("bf16x3" if x3 else "fp32"),
+                       "mfma_precision": ("fp16sd" if getattr(infer.model, "sd", False) else "fp16q4" if getattr(infer.model, "q4", False) else "fp16x2" if getattr(infer.model, "f16", False) else "bf16x2" if split else "bf16") if bf16 else ("bf16x3" if x3 else "fp32"),
                        "step_overlap": (f"{args.streams} HIP streams: consecutive batches run concurrently" if step_streams else
                                         "vocoder(i) on a 2nd stream under acoustic(i+1)" if args.pipeline else "none (one stream)"),
                        "gflop_per_frame": {"algorithmic": flop_alg / 1e9, "cond_proj_hoisted": flop_hoisted / 1e9,
@@ -947,7 +959,7 @@ def main():
                              "meets_north_star": True, "measured_on": "tests/test_gpu_round3.py::test_bf16x3_mode_matches_the_reference_golden_chain, "
                                                                        "profiles/r03_parity.json"}
         if split:
-            out["parity"] = parity_block("fp16q4" if getattr(infer.model, "q4", False) else "fp16x2" if getattr(infer.model, "f16", False) else "bf16x2", dev)
+            out["parity"] = parity_block("fp16sd" if getattr(infer.model, "sd", False) else "fp16q4" if getattr(infer.model, "q4", False) else "fp16x2" if getattr(infer.model, "f16", False) else "bf16x2", dev)
         elif bf16:   # no reference arithmetic exists for bf16 operands: the distance to the fp32 reference is a measured fact, not parity
             live = measure_parity_on_1000_step_golden("bf16", dev)
             out["parity"] = {"pinned": False, "measured_in_this_run": live, "mel_l1_vs_fp32_reference": live["mel_l1"], "north_star_mel_l1": 1e-4,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames; 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames, "fp16sd" (ss_wavenet.n_wsets / mfma_products / ws_*, ss_layer512_args.n_products); 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -307,7 +307,9 @@ typedef struct ss_gemm_bf16_args {
    * the fp4 terms of lo in the kernel's lane order + their E8M0 block scales (stylesinger_amd.lib.pack_gate_q4, layout: csrc/gate128_layout.h
    * g128q); the kernel converts its own fp16 A fragments to fp4 with the fixed power-of-two scale q_scale: q = fp4(a / q_scale). */
   float q_scale;
-  int32_t reserved_;
+  /* split = 2 with ONE weight term ("fp16sd": W is an ss_split_f16 pack whose lo terms are zero): kernels that know the flag skip the second product
+   * and do not fetch the lo plane (ss_gemm_bf16_tile256, SS_HEPI_STORE); the others compute the same result with a product of zeros */
+  int32_t one_product;
   /* RESX with split operands and X == NULL ("pair-only residual stream"): the stream lives ONLY as the (hi, mid) pair Y = x + cur_bias (16
    * significand bits - measured harmless on the reference's 1000-step golden: 2.4e-6 either way, oracle/bf16x2_numerics.py). The epilogue reads
    * its element of Y, recovers x = hi + mid - cur_bias, and writes Y = pair(x_new + next_bias) in place: 3 instead of 4 KB per row of traffic. */
@@ -366,7 +368,8 @@ int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
 typedef struct ss_layer512_args {
   const uint16_t* Hin;      /* fp16(x + dstep_l), slot-major tiles */
   int32_t d;                /* dilation, 1..8: taps (-d, 0, d) */
-  int32_t reserved0_;
+  int32_t n_products;       /* weight terms per element = matrix products per GEMM: 2 (or 0) = "fp16x2" (hi, lo); 1 = "fp16sd": Wg / Wr hold ONE fp16 term
+                             * (packs made with n_products = 1; the caller cycles noise-shaped weight sets over the evaluations, ss_wavenet.n_wsets) */
   uint16_t* Hout;           /* fp16(x' + next_bias), or NULL */
   void* P;                  /* fp32 stream x, read and rewritten in place (x') */
   const int32_t* lens;
@@ -396,10 +399,11 @@ int64_t ss_layer512_addend_floats(int B, int T);
 /* E [B][T][lde] (the layer's 512 packed addend columns start at E) -> the tiled slab the kernel reads (once per forward and layer); stored as
  * the gate's exp2 arguments: E * -log2(e) in the sigmoid blocks, E * -2 log2(e) in the tanh blocks */
 int ss_layer512_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* out, int B, int T, void* stream);
-/* ss_split_f16 pack [512][3 * 256 * 2] of the gate-interleaved dilated-conv weights -> fragment order (786 432 elements) */
-int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, void* stream);
-/* ss_split_f16 pack [>= 256][256 * 2] of the output projection (first 256 rows = residual half) -> fragment order (131 072 elements) */
-int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, void* stream);
+/* ss_split_f16 pack [512][3 * 256 * 2] of the gate-interleaved dilated-conv weights -> fragment order (786 432 elements; n_products = 1: the hi
+ * terms only, 393 216 elements) */
+int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, int n_products, void* stream);
+/* ss_split_f16 pack [>= 256][256 * 2] of the output projection (first 256 rows = residual half) -> fragment order (131 072 elements; n_products = 1: 65 536) */
+int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, int n_products, void* stream);
 /* y = bf16(x + bias) (RNE; bias per column, optional, per weight group), rows >= lens[b] -> 0. Also converts packed weights
  * (B = 1, T = rows): the bf16 weight copies of the checkpoint packer. */
 int ss_to_bf16(const float* x, const float* bias, uint16_t* y, int B, int T, int C, int ldx, int ldy, const int32_t* lens,
@@ -601,6 +605,16 @@ typedef struct ss_wavenet {
    * layer (w_out_f of the last layer is unused). */
   const uint16_t* w_dil_f[SS_MAX_LAYERS];
   const uint16_t* w_out_f[SS_MAX_LAYERS];
+  /* "fp16sd" precision (round 6; mfma_split = 2 data path with ONE fp16 weight term and a noise-shaped rounding): n_wsets > 1 -> every w_*_h / w_*_f
+   * pointer above addresses set 0 of n_wsets weight sets laid out ws_* elements apart; network evaluation j of a sampling loop (j = 0 for its first
+   * evaluation) uses set j % n_wsets. The sets are a first-order sigma-delta sequence of fp16 roundings of the same scaled fp32 weight
+   * (r_0 = 0, W_k = RNE16(w 2^s + r_k), r_(k+1) = r_k + (w 2^s - W_k)): their sum is n_wsets * w 2^s up to one fp16 rounding, so the weight rounding
+   * averages out over the steps instead of adding up (oracle/dither_numerics.py: 2.2e-5 on the reference's 1000-step golden with 32 sets; plain
+   * one-product fp16: 1.94e-4; fp16x2: 1.9e-5). The pair-layout packs (w_*_h) carry zero lo terms - the generic two-product kernels then compute the
+   * one-product result exactly - and the fragment-order packs (w_*_f) one term only (ss_layer512 with n_products = 1). mfma_products = 1 says so. */
+  int32_t n_wsets;
+  int32_t mfma_products;   /* 0 | 2: two weight terms (fp16x2); 1: one (fp16sd) */
+  int64_t ws_w_dil_h, ws_w_out_h, ws_w_skipall_h, ws_w_dil_f, ws_w_out_f;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

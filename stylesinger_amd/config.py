@@ -46,6 +46,8 @@ DEFAULT_HPARAMS = dict(
     # not a reference key: "fp32" (exact fp32 MFMA, the parity default) or "bf16" (BASELINE config 4: bf16 operands on
     # the matrix cores for the denoisers' hidden GEMMs and the vocoder convs, fp32 accumulate / sampler / state)
     mfma_precision="fp32",
+    # not a reference key: number of noise-shaped weight sets of mfma_precision "fp16sd" (one fp16 product per GEMM)
+    fp16sd_sets=32,
     # ProDiff decoder (hparams['decoder'] == 'prodiff', egs/stylesinger.yaml:145-155): timesteps = 8 teacher steps there
     timescale=1, pndm_speedup=None,
     # not a reference key: frame bucket of the hipGraph / plan cache (StyleSingerHIP.t_bucket)

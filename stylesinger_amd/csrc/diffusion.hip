@@ -51,6 +51,12 @@ inline bool hmode(const ss_wavenet* net) { return net->mfma_bf16 && net->w_dil_h
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// "fp16sd": which of the net's noise-shaped weight sets the CURRENT network evaluation uses. The samplers set the evaluation index before every
+// evaluation (0 for the first one of a loop, in an order that does not depend on how a loop is cut into calls); the stack adds set * stride to
+// every 16-bit weight pointer. Launch parameters only: a captured hipGraph replays the same sequence.
+thread_local int g_wset_eval = 0;
+inline int64_t wset_off(const ss_wavenet* net, int64_t stride) { return net->n_wsets > 1 ? (int64_t)(g_wset_eval % net->n_wsets) * stride : 0; }
+
 // the fp16x2 mel stack as ONE ss_layer512 launch per layer: the net carries the fragment-order packs of every layer, one weight group, C = 256,
 // dilations <= 8, and the launch fills the chip (ss_layer512_ok); knob "layer512"
 inline bool fused512(const ss_wavenet* net, int B, int T) {
@@ -222,7 +228,8 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     f.lens = lens;
     f.B = B;
     f.T = T;
-    f.Wg = net->w_dil_f[l];
+    f.Wg = net->w_dil_f[l] + wset_off(net, net->ws_w_dil_f);
+    f.n_products = net->mfma_products == 1 ? 1 : 2;
     f.E512 = w.E512 + (int64_t)l * w.e512_layer;
     f.G = w.GAh + (int64_t)l * C * pl;
     f.g_batch_stride = (int64_t)T * L * C * pl;
@@ -233,7 +240,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     if (l + 1 < L) {   // the residual stream of the last layer is never read (net.py:120-127)
       f.Hout = w.H512[(l & 1) ^ 1];
       f.P = w.P512;
-      f.Wr = net->w_out_f[l];
+      f.Wr = net->w_out_f[l] + wset_off(net, net->ws_w_out_f);
       f.bias_r = net->b_out[l];
       f.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
     }
@@ -252,7 +259,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     g.tap_off[0] = -d;
     g.tap_off[1] = 0;
     g.tap_off[2] = d;
-    g.W = net->w_dil_h[l];
+    g.W = net->w_dil_h[l] + wset_off(net, net->ws_w_dil_h);
     g.w_group_stride = net->gs_w_dil_h;
     g.N = C;
     g.Np = 2 * C;
@@ -286,7 +293,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     o.split = sp;
     o.out_scale = net->mfma_out_scale;
     o.K = C;
-    o.W = net->w_out_h[l];
+    o.W = net->w_out_h[l] + wset_off(net, net->ws_w_out_h);
     o.w_group_stride = net->gs_w_out_h;
     o.N = C;
     o.Np = C;  // the residual half = the first C packed rows
@@ -316,7 +323,8 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   k.split = sp;
   k.out_scale = net->mfma_out_scale;
   k.K = L * C;
-  k.W = net->w_skipall_h;
+  k.W = net->w_skipall_h + wset_off(net, net->ws_w_skipall_h);
+  k.one_product = net->mfma_products == 1 ? 1 : 0;
   k.w_group_stride = net->gs_w_skipall_h;
   k.N = C;
   k.Np = round_up32(C);
@@ -995,6 +1003,7 @@ extern "C" int ss_meldiff_sample(const ss_wavenet* net, float* x, const float* c
   const bool tail = g_ss_tuning.mel_tail != 0 && !net->mfma_bf16 && (int64_t)B * T <= 8L * ss_n_cu() && (C % 4) == 0 && (M % 4) == 0 &&
                     (size_t)(MTR * C + MTR * Kp_in) * 4 <= 48 * 1024;
   for (int t = step_hi - 1; t >= step_lo; --t) {
+    g_wset_eval = net->steps - 1 - t;   // evaluation index of the whole loop, whatever [step_lo, step_hi) this call covers
     const float sigma = t > 0 ? expf(0.5f * net->post_logvar[t]) : 0.0f;
     const float* noise_t = noise ? noise + (int64_t)t * B * T * M : nullptr;
     if (!tail) {
@@ -1026,9 +1035,11 @@ extern "C" int ss_prodiff_sample(const ss_wavenet* net, float* x, const float* c
   SS_CHECK_ARG(ws_bytes >= w.bytes, "ss_prodiff_sample: workspace too small");
   const int M = net->in_dim;
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
-  for (int t = n_steps - 1; t >= 0; --t)
+  for (int t = n_steps - 1; t >= 0; --t) {
+    g_wset_eval = n_steps - 1 - t;
     SS_PROPAGATE(mel_step(net, x, lens, B, T, w, t, 0.0f, 0.0f, c1[t], c2[t], t > 0 ? sigma[t] : 0.0f,
                           noise ? noise + (int64_t)t * B * T * M : nullptr, seed, seed_dev, (uint32_t)t, stream, 1));
+  }
   return SS_OK;
 }
 
@@ -1056,6 +1067,7 @@ extern "C" int ss_meldiff_sample_ddim(const ss_wavenet* net, float* x, const flo
   const int M = net->in_dim;
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
   for (int i = 0; i < n_ts; ++i) {
+    g_wset_eval = i;
     const int t = ts[i];
     const double ac_t = alphas_cumprod[t];
     const double ac_p = (i + 1 < n_ts) ? alphas_cumprod[ts[i + 1]] : 1.0;
@@ -1111,6 +1123,7 @@ extern "C" int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const flo
   if (do_precompute) SS_PROPAGATE(precompute_cond(net, cond, lens, B, T, w, stream));
   const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   int n_hist = 0, cur = 0;
+  g_wset_eval = 0;   // PLMS: evaluations counted as they come (the first step evaluates twice)
   const int t_first = (step_hi - 1) / interval * interval;  // reversed(range(0, K_step, interval)), shallow_diffusion_tts.py:254-260
   for (int t = t_first; t >= 0; t -= interval) {
     const int tp = t - interval > 0 ? t - interval : 0;
@@ -1121,11 +1134,13 @@ extern "C" int ss_meldiff_sample_plms(const ss_wavenet* net, float* x, const flo
     const float ke = 1.0f / (a_t_sq * (sqrtf((1.0f - a_p) * a_t) + sqrtf((1.0f - a_t) * a_p)));
     float* e0 = slot[cur];
     SS_PROPAGATE(mel_eps(net, x, e0, lens, B, T, w, t, stream));
+    ++g_wset_eval;
     auto h = [&](int back) { return slot[(cur + 5 - back) % 5]; };
     if (n_hist == 0) {
       hipLaunchKernelGGL(plms_update_kernel, dim3(blocks), dim3(256), 0, stream, x, x_pred, e0, e0, e0, e0, 0, d, kx, ke, n);
       float* e_prev = slot[(cur + 1) % 5];  // scratch: overwritten by the next step's eps
       SS_PROPAGATE(mel_eps(net, x_pred, e_prev, lens, B, T, w, tp, stream));
+      ++g_wset_eval;
       hipLaunchKernelGGL(plms_update_kernel, dim3(blocks), dim3(256), 0, stream, x, x, e0, e_prev, e0, e0, 1, d, kx, ke, n);
     } else {
       const int order = n_hist == 1 ? 2 : n_hist == 2 ? 3 : 4;

@@ -39,7 +39,9 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ds
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
 
-template <int EPI, bool W2>
+// ONE (with W2; "fp16sd", ss_gemm_bf16_args.one_product): a single fp16 weight term - the lo plane of the weights is neither fetched (dead DMA lanes, as the
+// A operand's second plane) nor read, 16 MFMAs per step instead of 32 (the 8 of the second k-step deferred past the barrier with the DMA pieces between them)
+template <int EPI, bool W2, bool ONE = false>
 __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int kchunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_t256[];   // 128 KB: [A0 32 K][B0 32 K][A1 32 K][B1 32 K]; epilogue: 2 x 64 KB staging
   char* const A0 = smem_t256;
@@ -76,10 +78,11 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   const int a_voff = ((t0 + r0) * a.lda + slot0 * 8) * 2;   // rows >= len are out of range: the DMA writes zeros
   const int b_voff = (r0 * ldw + slot0 * 8) * 2;            // packed weight rows >= Np read zeros
   const int a_lo_dead = (W2 && slot0 >= 4) ? (int)0x80000000 : 0;   // W2: the A operand's second plane is never read - its lanes fetch nothing (zeros)
+  const int b_lo_dead = (ONE && slot0 >= 4) ? (int)0x80000000 : 0;  // ONE: nor is the weights'
   auto piece = [&](char* Ab, char* Bb, int c, int i) {     // i = 0..3: A pieces, 4..7: B pieces of chunk c
     const int j = i & 3;
     if (i < 4) glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | a_lo_dead, c * ROWB);
-    else glds16(rsrc_w, Bb + (wave + 8 * j) * 8 * ROWB, b_voff, c * ROWB + 64 * j * ldw * 2);
+    else glds16(rsrc_w, Bb + (wave + 8 * j) * 8 * ROWB, b_voff | b_lo_dead, c * ROWB + 64 * j * ldw * 2);
   };
 
   // fragment addresses (see gate256_kernel): row = 128 wm + 32 m + l31 for A, 64 wn + 32 n + l31 for B; slot (2 ks) ^ swz = hi, (4 + 2 ks) ^ swz = mid
@@ -132,6 +135,22 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
     else rd_a(4, am0);
     rd_b(0, bh0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ONE) {              // one weight term: the 8 MFMAs of the second k-step deferred by the previous step, a DMA piece after each
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = (i >> 1) & 3, n = i & 1;
+        acc[m][n] = ss_mfma_32x32x16<true>(p_ah[m], p_bh[n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) piece(An, Bn, c + 1, i);   // wave-uniform branch
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma8(ah0, bh0);                // k-step 0 now; the second k-step's group (p_ah x p_bh) after the next barrier
+      __builtin_amdgcn_sched_barrier(0);
+      rd_a(2, p_ah);
+      rd_b(2, p_bh);
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {    // the 16 MFMAs deferred by the previous step, one DMA piece of the next chunk after each of the first 8
       const int m = (i >> 1) & 3, n = i & 1;
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
     step(A0, B0, A1, B1, c, true);
     step(A1, B1, A0, B0, c + 1, c + 2 < kchunks);
   }
-  mfma8(p_ah, p_bm);
+  if constexpr (!ONE) mfma8(p_ah, p_bm);
   mfma8(p_ah, p_bh);
 
   // ---- epilogue: four passes of 64 rows (accumulator block m = q of every wave: tile rows 128 wm + 32 q + (0..31) -> staging row 32 wm + ..),
@@ -348,7 +367,8 @@ extern "C" int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream)
   if (a.epi == SS_HEPI_STORE) {
     SS_CHECK_ARG(a.C && (a.N % 4) == 0 && (a.ldc % 4) == 0 && (int64_t)a.T * a.ldc * 4 < (1ll << 31) && (a.act == SS_ACT_NONE_ || a.act == SS_ACT_RELU_),
                  "ss_gemm_bf16_tile256: STORE needs C, N %% 4 == 0, ldc %% 4 == 0, act none | relu");
-    SS_PROPAGATE(a.split == 2 ? go(&tile256s_kernel<SS_HEPI_STORE, true>) : go(&tile256s_kernel<SS_HEPI_STORE, false>));
+    SS_PROPAGATE(a.split == 2 ? (a.one_product ? go(&tile256s_kernel<SS_HEPI_STORE, true, true>) : go(&tile256s_kernel<SS_HEPI_STORE, true>))
+                              : go(&tile256s_kernel<SS_HEPI_STORE, false>));
   } else {
     SS_CHECK_ARG(a.epi == SS_HEPI_RESX && a.X == nullptr && a.Y && a.cur_bias && (a.N % 32) == 0 && a.ldy >= 2 * a.N && (a.ldy % 8) == 0 &&
                      (int64_t)a.T * a.ldy * 2 < (1ll << 31), "ss_gemm_bf16_tile256: RESX on the pair-only stream (X = NULL, Y, cur_bias), N %% 32 == 0");

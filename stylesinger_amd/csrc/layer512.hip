@@ -54,15 +54,17 @@ constexpr int SLOTB = AROWS * 16 + 16;     // bytes per LDS slot: 8 channels (16
 constexpr int REGION = 32 * SLOTB;         // 74 240 B; two regions
 constexpr int H_TILE = BM * 512;           // 65 536 B of H per tile: [slot 32][row 128] x 16 B
 constexpr int KSTEPS = 48;                 // 8 chunks x 3 taps x 2 k-steps of 16 channels
-constexpr int WG_STEP = 4096;              // bytes of gate weights per wave and k-step: (hi, lo) x 2 column blocks x 1 KB
-constexpr int WG_WAVE = KSTEPS * WG_STEP;  // 196 608 B per wave
 constexpr int RSTEPS = 16;                 // K = 256 of the residual projection
-constexpr int WR_STEP = 2048;              // (hi, lo) x 1 KB
-constexpr int WR_WAVE = RSTEPS * WR_STEP;  // 32 768 B per wave
+// NP = weight terms per element = matrix products per GEMM: 2 = "fp16x2" (hi, lo), 1 = "fp16sd" (one term; the rounding is noise-shaped over the
+// loop's evaluations by cycling weight SETS, see ss_wavenet.n_wsets)
+constexpr int wg_step(int NP) { return NP * 2048; }             // bytes of gate weights per wave and k-step: NP planes x 2 column blocks x 1 KB
+constexpr int wg_wave(int NP) { return KSTEPS * wg_step(NP); }  // 196 608 B per wave (NP = 2)
+constexpr int wr_step(int NP) { return NP * 1024; }
+constexpr int wr_wave(int NP) { return RSTEPS * wr_step(NP); }  // 32 768 B per wave (NP = 2)
 constexpr int E_TILE = BM * 512 * 4;       // 262 144 B of tiled addend per tile
 constexpr int P_TILE = BM * 256 * 4;       // 131 072 B of the pair stream per tile
-constexpr int NRING = 3;                   // weight fragments of NRING - 1 k-steps in flight
-constexpr int NRING_R = 5;                 // ... of the residual projection (8 MFMAs per k-step: half the cover per step)
+constexpr int nring(int NP) { return NP == 2 ? 3 : 5; }     // weight fragments of nring - 1 k-steps in flight (one product: 8 MFMAs per k-step, half the cover per step)
+constexpr int nring_r(int NP) { return NP == 2 ? 5 : 8; }   // ... of the residual projection (4 NP MFMAs per k-step)
 
 // -DSS_L512_TRACE (debug builds, tools/trace_layer512.py): lane 0 of every wave stamps the shader clock at 8 points of every tile into the
 // buffer handed over through ss_set_clock_probe ([workgroup][wave][tile slot < 8][8]); the product build compiles none of it.
@@ -106,7 +108,7 @@ struct L512Item {
   int tile, r0, nm;
 };
 
-template <bool FUSE>
+template <bool FUSE, int NP>
 __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args a, int tiles_per_item, int n_tiles, int split_tail, unsigned long long* clock_probe) {
 #ifdef SS_L512_TRACE
   const bool probing = false;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int d = a.d;
 
+  constexpr int WG_STEP = wg_step(NP), WG_WAVE = wg_wave(NP), WR_STEP = wr_step(NP), WR_WAVE = wr_wave(NP), NRING = nring(NP), NRING_R = nring_r(NP);
   const __amdgpu_buffer_rsrc_t rsrc_wg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Wg + (int64_t)wave * WG_WAVE), 0, WG_WAVE, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(FUSE ? (const char*)a.Wr + (int64_t)wave * WR_WAVE : (const char*)a.Wg), 0,
                                                                          FUSE ? WR_WAVE : 0, 0x00020000);
@@ -218,11 +221,11 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
         for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
     // ---- the dilated conv: 48 k-steps, no barrier. Weight ring: fragments of k-step S + NRING - 1 are requested before the MFMAs of step S.
-    bf16x8 wq[NRING][4];   // [plane * 2 + nb]
+    bf16x8 wq[NRING][2 * NP];   // [plane * 2 + nb]
     bf16x8 act[2][NM];
-    auto load_w = [&](bf16x8 (&dst)[4], int S) {
+    auto load_w = [&](bf16x8 (&dst)[2 * NP], int S) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) dst[p] = ldw(rsrc_wg, w_voff + p * 1024, S * WG_STEP);
+      for (int p = 0; p < 2 * NP; ++p) dst[p] = ldw(rsrc_wg, w_voff + p * 1024, S * WG_STEP);
     };
     auto read_act = [&](bf16x8 (&dst)[NM], int S) {
       const int cc = S / 6, tap = (S / 2) % 3, ks = S & 1;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     for (int s = 0; s < NRING - 1; ++s) load_w(wq[s], s);
     // my DMA pieces of this item have landed: only the ring's loads are younger. (Fused form: already waited for - a vmcnt wait HERE would also
     // wait for the stream epilogue's 32 stores, a full memory round trip per tile: 5.3 k cycles in the v1 trace.)
-    if constexpr (!FUSE) wait_vmcnt<4 * (NRING - 1)>();
+    if constexpr (!FUSE) wait_vmcnt<2 * NP * (NRING - 1)>();
     __builtin_amdgcn_s_barrier();    // [B1] everyone's pieces have
     L512_STAMP(0);
     read_act(act[0], 0);
@@ -242,10 +245,10 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       constexpr int S = decltype(stag)::value;
       if constexpr (S + NRING - 1 < KSTEPS) load_w(wq[(S + NRING - 1) % NRING], S + NRING - 1);
       if constexpr (S + 1 < KSTEPS) read_act(act[(S + 1) & 1], S + 1);
-      const bf16x8 (&w)[4] = wq[S % NRING];
+      const bf16x8 (&w)[2 * NP] = wq[S % NRING];
       const bf16x8 (&x)[NM] = act[S & 1];
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -345,11 +348,11 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
-      bf16x8 wr[NRING_R][2];
+      bf16x8 wr[NRING_R][NP];
       bf16x8 gf[2][NM];
-      auto load_wr = [&](bf16x8 (&dst)[2], int S) {
+      auto load_wr = [&](bf16x8 (&dst)[NP], int S) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) dst[p] = ldw(rsrc_wr, w_voff + p * 1024, S * WR_STEP);
+        for (int p = 0; p < NP; ++p) dst[p] = ldw(rsrc_wr, w_voff + p * 1024, S * WR_STEP);
       };
       auto read_g = [&](bf16x8 (&dst)[NM], int S) {
 #pragma unroll
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
         if constexpr (S + NRING_R - 1 < RSTEPS) load_wr(wr[(S + NRING_R - 1) % NRING_R], S + NRING_R - 1);
         if constexpr (S + 1 < RSTEPS) read_g(gf[(S + 1) & 1], S + 1);
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
           for (int m = 0; m < NM; ++m) acc2[m] = ss_mfma_32x32x16<true>(wr[S % NRING_R][p], gf[S & 1][m], acc2[m]);
         __builtin_amdgcn_sched_barrier(0);
@@ -431,10 +434,10 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 // gate weights: the ss_split_f16 pack of the interleaved dilated-conv weights, [512 packed columns][3 taps x 256 channels x (hi | lo)] with pairs
 // interleaved by 32 (line (tap * 8 + cc) of a row = 32 hi + 32 lo terms) -> fragment order [wave 8][k-step 48][plane 2][nb 2][lane 64][8]:
 // k-step S = (cc * 3 + tap) * 2 + ks; lane (l31, lh) holds channels 32 cc + 16 ks + 8 lh .. + 7 of packed column 64 wave + 32 nb + l31
-__global__ void pack_gate_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte fragment each: 8 * 48 * 4 * 64 = 98 304
-  if (i >= 8 * KSTEPS * 4 * 64) return;
-  const int lane = i & 63, pn = (i >> 6) & 3, S = (i >> 8) % KSTEPS, w = i / (256 * KSTEPS);
+__global__ void pack_gate_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int np) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte fragment each: 8 * 48 * 2 np * 64 (np = 2: 98 304)
+  if (i >= 8 * KSTEPS * 2 * np * 64) return;
+  const int lane = i & 63, pn = (i >> 6) % (2 * np), S = (i / (64 * 2 * np)) % KSTEPS, w = i / (64 * 2 * np * KSTEPS);
   const int plane = pn >> 1, nb = pn & 1, l31 = lane & 31, lh = lane >> 5;
   const int cc = S / 6, tap = (S / 2) % 3, ks = S & 1;
   const int col = 64 * w + 32 * nb + l31;
@@ -443,10 +446,10 @@ __global__ void pack_gate_kernel(const uint16_t* __restrict__ src, uint16_t* __r
 }
 // residual weights: [>= 256 rows][256 channels x (hi | lo)] pairs interleaved by 32 -> [wave 8][k-step 16][plane 2][lane 64][8]: lane (l31, lh)
 // holds channels 16 S + 8 lh .. + 7 of output channel 32 wave + l31
-__global__ void pack_res_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 8 * 16 * 2 * 64 = 16 384 fragments
-  if (i >= 8 * RSTEPS * 2 * 64) return;
-  const int lane = i & 63, plane = (i >> 6) & 1, S = (i >> 7) % RSTEPS, w = i / (128 * RSTEPS);
+__global__ void pack_res_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int np) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 8 * 16 * np * 64 fragments (np = 2: 16 384)
+  if (i >= 8 * RSTEPS * np * 64) return;
+  const int lane = i & 63, plane = (i >> 6) % np, S = (i / (64 * np)) % RSTEPS, w = i / (64 * np * RSTEPS);
   const int l31 = lane & 31, lh = lane >> 5;
   const int row = 32 * w + l31, k = 16 * S + 8 * lh;
   const uint16_t* s = src + (int64_t)row * (256 * 2) + (k >> 5) * 64 + plane * 32 + (k & 31);
@@ -523,16 +526,18 @@ extern "C" int ss_layer512_tile_addend(const float* E, int lde, int64_t e_batch_
   return SS_OK;
 }
 
-extern "C" int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, void* stream) {
+extern "C" int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, int n_products, void* stream) {
   SS_CHECK_ARG(w_pairs && out && (((uintptr_t)w_pairs) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "ss_layer512_pack_gate: 16-byte aligned pointers");
-  hipLaunchKernelGGL(pack_gate_kernel, dim3(8 * KSTEPS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w_pairs, out);
+  SS_CHECK_ARG(n_products == 1 || n_products == 2, "ss_layer512_pack_gate: n_products = 1 (hi terms only) | 2");
+  hipLaunchKernelGGL(pack_gate_kernel, dim3(8 * KSTEPS * 2 * n_products * 64 / 256), dim3(256), 0, (hipStream_t)stream, w_pairs, out, n_products);
   SS_CHECK_LAUNCH("ss_layer512_pack_gate");
   return SS_OK;
 }
 
-extern "C" int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, void* stream) {
+extern "C" int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, int n_products, void* stream) {
   SS_CHECK_ARG(w_pairs && out && (((uintptr_t)w_pairs) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "ss_layer512_pack_res: 16-byte aligned pointers");
-  hipLaunchKernelGGL(pack_res_kernel, dim3(8 * RSTEPS * 2 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w_pairs, out);
+  SS_CHECK_ARG(n_products == 1 || n_products == 2, "ss_layer512_pack_res: n_products = 1 (hi terms only) | 2");
+  hipLaunchKernelGGL(pack_res_kernel, dim3(8 * RSTEPS * n_products * 64 / 256), dim3(256), 0, (hipStream_t)stream, w_pairs, out, n_products);
   SS_CHECK_LAUNCH("ss_layer512_pack_res");
   return SS_OK;
 }
@@ -583,7 +588,9 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, tpi, n_tiles, split_tail, g_ss_tuning.clock_probe);
     return SS_OK;
   };
-  SS_PROPAGATE(fuse ? go(&layer512_kernel<true>) : go(&layer512_kernel<false>));
+  SS_CHECK_ARG(a.n_products == 0 || a.n_products == 1 || a.n_products == 2, "ss_layer512: n_products = 1 | 2 (0 = 2)");
+  if (a.n_products == 1) SS_PROPAGATE(fuse ? go(&layer512_kernel<true, 1>) : go(&layer512_kernel<false, 1>));
+  else SS_PROPAGATE(fuse ? go(&layer512_kernel<true, 2>) : go(&layer512_kernel<false, 2>));
   SS_CHECK_LAUNCH("ss_layer512");
   return SS_OK;
 }

@@ -71,7 +71,8 @@ class WaveNet(C.Structure):
            ("mfma_split", C.c_int32), ("mfma_out_scale", C.c_float),
            ("w_dil_q", _vp * SS_MAX_LAYERS), ("gs_w_dil_q", C.c_int64), ("q_scale_gate", C.c_float), ("q_scale_z", C.c_float),
            ("w_skipall_q", _vp), ("gs_w_skipall_q", C.c_int64),
-           ("w_dil_f", _vp * SS_MAX_LAYERS), ("w_out_f", _vp * SS_MAX_LAYERS)]
+           ("w_dil_f", _vp * SS_MAX_LAYERS), ("w_out_f", _vp * SS_MAX_LAYERS),
+           ("n_wsets", C.c_int32), ("mfma_products", C.c_int32)] + [(n, C.c_int64) for n in ("ws_w_dil_h", "ws_w_out_h", "ws_w_skipall_h", "ws_w_dil_f", "ws_w_out_f")]
 
 
 class GemmBf16Args(C.Structure):
@@ -82,7 +83,7 @@ class GemmBf16Args(C.Structure):
         ("gate_mode", C.c_int32), ("e_batch_stride", C.c_int64), ("X", _vp), ("x_batch_stride", C.c_int64), ("ldx", C.c_int32),
         ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
         ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
-        ("split", C.c_int32), ("out_scale", C.c_float), ("q_scale", C.c_float), ("reserved_", C.c_int32), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
+        ("split", C.c_int32), ("out_scale", C.c_float), ("q_scale", C.c_float), ("one_product", C.c_int32), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
     ]
 
 
@@ -91,7 +92,7 @@ HEPI_STORE, HEPI_GATE, HEPI_RESX = 0, 1, 2
 
 class Layer512Args(C.Structure):
     _fields_ = [
-        ("Hin", _vp), ("d", C.c_int32), ("reserved0_", C.c_int32), ("Hout", _vp), ("P", _vp),
+        ("Hin", _vp), ("d", C.c_int32), ("n_products", C.c_int32), ("Hout", _vp), ("P", _vp),
         ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("Wg", _vp), ("Wr", _vp), ("E512", _vp), ("G", _vp), ("g_batch_stride", C.c_int64),
         ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("next_bias", _vp), ("reserved_", _vp), ("out_scale", C.c_float),
         ("post_scale", C.c_float),
@@ -603,7 +604,7 @@ def split_planes(y):
 
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
               next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False,
-              split=0, cur_bias=None, out_scale=1.0, q_scale=0.0):
+              split=0, cur_bias=None, out_scale=1.0, q_scale=0.0, one_product=False):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -625,6 +626,7 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.split = split
     a.out_scale = out_scale
     a.q_scale = q_scale
+    a.one_product = int(one_product)
     a.cur_bias = ptr(cur_bias)
     if gate256 and epi == HEPI_STORE and split == 3:   # the fp16q4 skip GEMM
         check(load().ss_gemm_bf16_tile256q(C.byref(a), stream_ptr()), "ss_gemm_bf16_tile256q")
@@ -644,19 +646,20 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     check(load().ss_gemm_bf16(C.byref(a), stream_ptr()), "ss_gemm_bf16")
 
 
-def layer512_pack_gate(w_pairs):
-    """ss_split_f16 pack [512][3*256*2] of the gate-interleaved dilated-conv weights -> the fragment order ss_layer512 streams (fp16 [786432])."""
+def layer512_pack_gate(w_pairs, n_products=2):
+    """ss_split_f16 pack [512][3*256*2] of the gate-interleaved dilated-conv weights -> the fragment order ss_layer512 streams (fp16 [786432];
+    n_products = 1: the hi terms only, [393216])."""
     assert w_pairs.dtype == torch.float16 and tuple(w_pairs.shape) == (512, 3 * 256 * 2) and w_pairs.is_contiguous(), tuple(w_pairs.shape)
-    out = torch.empty(8 * 48 * 4 * 64 * 8, device=w_pairs.device, dtype=torch.float16)
-    check(load().ss_layer512_pack_gate(ptr(w_pairs), ptr(out), stream_ptr()), "ss_layer512_pack_gate")
+    out = torch.empty(8 * 48 * 2 * n_products * 64 * 8, device=w_pairs.device, dtype=torch.float16)
+    check(load().ss_layer512_pack_gate(ptr(w_pairs), ptr(out), n_products, stream_ptr()), "ss_layer512_pack_gate")
     return out
 
 
-def layer512_pack_res(w_pairs):
-    """ss_split_f16 pack [>= 256][256*2] of the output projection (first 256 rows = residual half) -> fragment order (fp16 [131072])."""
+def layer512_pack_res(w_pairs, n_products=2):
+    """ss_split_f16 pack [>= 256][256*2] of the output projection (first 256 rows = residual half) -> fragment order (fp16 [131072]; n_products = 1: [65536])."""
     assert w_pairs.dtype == torch.float16 and w_pairs.shape[0] >= 256 and w_pairs.shape[1] == 512 and w_pairs.is_contiguous(), tuple(w_pairs.shape)
-    out = torch.empty(8 * 16 * 2 * 64 * 8, device=w_pairs.device, dtype=torch.float16)
-    check(load().ss_layer512_pack_res(ptr(w_pairs), ptr(out), stream_ptr()), "ss_layer512_pack_res")
+    out = torch.empty(8 * 16 * n_products * 64 * 8, device=w_pairs.device, dtype=torch.float16)
+    check(load().ss_layer512_pack_res(ptr(w_pairs), ptr(out), n_products, stream_ptr()), "ss_layer512_pack_res")
     return out
 
 
@@ -691,10 +694,10 @@ def layer512_stream_values(P, *, B, T):
 
 
 def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None, bias_r=None, next_bias=None, out_scale=1.0 / 256.0,
-             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True):
+             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True, n_products=2):
     """ss_layer512: one launch per residual layer (gate + residual projection) of the fp16x2 mel denoiser; see include/stylesinger_hip.h."""
     a = Layer512Args()
-    a.Hin = ptr(Hin); a.d = d
+    a.Hin = ptr(Hin); a.d = d; a.n_products = n_products
     a.Hout = ptr(Hout); a.P = ptr(P)
     a.lens = ptr(lens); a.B = B; a.T = T; a.Wg = ptr(Wg); a.Wr = ptr(Wr); a.E512 = ptr(E512)
     a.G = ptr(G); a.ldg = ldg if ldg is not None else G.shape[-1]; a.g_batch_stride = g_bs if g_bs is not None else T * a.ldg

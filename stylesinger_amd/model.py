@@ -177,8 +177,8 @@ class StyleSingerHIP(torch.nn.Module):
         # per-layer output projection = residual half only; skip sum of all layers as one K = L*C GEMM per step
         self.defer_skip = os.environ.get("SS_DEFER_SKIP", "1") not in ("0", "off", "false")
         prec = os.environ.get("SS_PRECISION", hp.get("mfma_precision", "fp32"))
-        if prec not in ("fp32", "bf16", "bf16x2", "fp16x2", "fp16q4", "bf16x3"):
-            raise ValueError(f"mfma_precision={prec!r}: expected fp32 | bf16 | bf16x2 | fp16x2 | fp16q4 | bf16x3")
+        if prec not in ("fp32", "bf16", "bf16x2", "fp16x2", "fp16q4", "fp16sd", "bf16x3"):
+            raise ValueError(f"mfma_precision={prec!r}: expected fp32 | bf16 | bf16x2 | fp16x2 | fp16q4 | fp16sd | bf16x3")
         # "bf16x2" (BASELINE config 4 at fp32-grade parity): the bf16 mode's data path (hidden GEMMs on the bf16 matrix cores, operands bf16
         # in HBM) with every operand a (hi, mid) PAIR of bf16 terms and three products hi*hi + hi*mid + mid*hi per GEMM; the step-invariant
         # conditioner projection in exact fp32, skip_projection folded into the K = L*C skip GEMM as in fp32 mode. Measured on the reference's
@@ -190,10 +190,17 @@ class StyleSingerHIP(torch.nn.Module):
         # "fp16q4": fp16x2 with the second product of the mel gate and of the skip GEMM on the block-scaled fp4 matrix instruction where the launch
         # fills the chip (ss_gemm_bf16_gate128q / _tile256q; validated on hardware in round 5: 2.6e-5 vs the real reference at T = 5625 x 1000 steps);
         # oracle contract set_matmul_rounding("fp16q4")
+        # "fp16sd" (round 6): fp16x2's data path with ONE fp16 weight term per element - half the matrix work and half the weight bytes - and the weight
+        # rounding NOISE-SHAPED over the loop's network evaluations: evaluation j uses weight set j % N, the N sets being a first-order sigma-delta
+        # sequence of fp16 roundings of the same weight (their sum is N w up to one rounding), so the rounding averages out over the steps instead
+        # of adding up coherently: 2.2e-5 on the reference's 1000-step golden with N = 32 (plain one-product fp16: 1.94e-4; fp16x2: 1.9e-5;
+        # oracle/dither_numerics.py, oracle contract set_matmul_rounding("fp16sd")). The f0 denoisers keep bf16x2 as in the other fp16 modes.
+        self.sd = prec == "fp16sd"
+        self.sd_sets = max(1, int(os.environ.get("SS_SD_SETS", hp.get("fp16sd_sets", 32)))) if self.sd else 0
         self.q4 = prec == "fp16q4"
-        self.f16 = prec in ("fp16x2", "fp16q4")
-        self.split = prec in ("bf16x2", "fp16x2", "fp16q4")
-        self.bf16 = prec in ("bf16", "bf16x2", "fp16x2", "fp16q4")
+        self.f16 = prec in ("fp16x2", "fp16q4", "fp16sd")
+        self.split = prec in ("bf16x2", "fp16x2", "fp16q4", "fp16sd")
+        self.bf16 = prec in ("bf16", "bf16x2", "fp16x2", "fp16q4", "fp16sd")
         # opt-in "bf16x3": fp32 products of the F(4,3) gate from operands split into three bf16 terms on the bf16 matrix cores
         # (ss_wino43_gate16x; fp32-grade results, oracle/bf16x3_numerics.py); everything else as the fp32 mode
         self.x3 = prec == "bf16x3"
@@ -264,6 +271,21 @@ class StyleSingerHIP(torch.nn.Module):
             raise ValueError("mfma_precision=fp16x2: a hidden-layer weight exceeds 128 in magnitude (fp16 range after the 2^8 shift)")
         return L.split_f16(w, scale=2.0 ** self.FP16_WSHIFT)
 
+    def _sd_sets(self, w):
+        """"fp16sd": packed fp32 weight [rows][K] -> fp16 [N][rows][2 K], the N noise-shaped one-term weight sets in the pair layout with ZERO lo terms
+        (the two-product kernels then compute the one-product result exactly). Sigma-delta in the scaled domain: r_0 = 0, W_k = RNE16(w 2^s + r_k),
+        r_(k+1) = r_k + (w 2^s - W_k): sum_k W_k = N w 2^s - r_N, |r_N| <= half an fp16 ulp."""
+        if float(w.abs().max()) * 2.0 ** self.FP16_WSHIFT >= 32768.0:
+            raise ValueError("mfma_precision=fp16sd: a hidden-layer weight exceeds 128 in magnitude (fp16 range after the 2^8 shift)")
+        ws = w.float() * 2.0 ** self.FP16_WSHIFT
+        r = torch.zeros_like(ws)
+        sets = []
+        for _ in range(self.sd_sets):
+            wk = (ws + r).to(torch.float16).float()
+            r = r + (ws - wk)
+            sets.append(L.split_f16(wk, scale=1.0))    # hi = W_k exactly (it is an fp16 number), lo = 0
+        return torch.stack(sets).contiguous()
+
     def _pack_conv(self, wname, bname=None, *, half=0, scale0=None, row_scale=1.0, bias2=None):
         w = self.p(wname)
         if w.dim() == 2:
@@ -332,14 +354,20 @@ class StyleSingerHIP(torch.nn.Module):
                     t[f"w_dil_x3.{l}"] = L.split3_weights(t[f"w_dil_wino.{l}"], dil.Kp)
             if self.bf16_hbm:  # bf16 weight copies (rounded once, RNE): the operands of ss_gemm_bf16
                 to_h = (lambda w_: self._split_w(w_, f0)) if self.split else L.to_bf16   # split: pairs interleaved by 32 along every row
+                if self.sd and not f0:   # N one-term weight sets per tensor ([N][rows][2 K]; set 0 first)
+                    to_h = self._sd_sets
                 t[f"w_dil_h.{l}"] = to_h(dil.W)
                 t[f"w_out_h.{l}"] = to_h(out.W)
                 if self.q4 and not f0 and C == 256:   # the fp4 lo plane in the lane order of ss_gemm_bf16_gate128q
                     t[f"w_dil_q.{l}"] = L.pack_gate_q4(dil.W, shift=self.FP16_WSHIFT)[0]
-                if self.f16 and not f0 and C == 256 and tuple(t[f"w_dil_h.{l}"].shape) == (512, 3 * 256 * 2):
-                    # the same (hi, lo) terms in the fragment order ss_layer512 streams (one launch per layer at many-round sizes)
-                    t[f"w_dil_f.{l}"] = L.layer512_pack_gate(t[f"w_dil_h.{l}"])
-                    t[f"w_out_f.{l}"] = L.layer512_pack_res(t[f"w_out_h.{l}"])
+                if self.f16 and not f0 and C == 256 and tuple(t[f"w_dil_h.{l}"].shape[-2:]) == (512, 3 * 256 * 2):
+                    # the same terms in the fragment order ss_layer512 streams (one launch per layer at many-round sizes); fp16sd: one term, N sets
+                    if self.sd:
+                        t[f"w_dil_f.{l}"] = torch.stack([L.layer512_pack_gate(w_, 1) for w_ in t[f"w_dil_h.{l}"]]).contiguous()
+                        t[f"w_out_f.{l}"] = torch.stack([L.layer512_pack_res(w_, 1) for w_ in t[f"w_out_h.{l}"]]).contiguous()
+                    else:
+                        t[f"w_dil_f.{l}"] = L.layer512_pack_gate(t[f"w_dil_h.{l}"])
+                        t[f"w_out_f.{l}"] = L.layer512_pack_res(t[f"w_out_h.{l}"])
             wc_rows.append(cnd.W)
             bc_rows.append(cnd.bias)
         if self.defer_skip:  # skip halves of all output projections side by side: [C][L*C], column l*C + ci
@@ -364,7 +392,7 @@ class StyleSingerHIP(torch.nn.Module):
         t["b_cond"] = torch.cat(bc_rows, 0).contiguous()
         if self.bf16_hbm:
             t["w_cond_h"] = L.to_bf16(t["w_cond"])     # (unused in split mode: the hoisted projection runs in fp32 there)
-            t["w_skipall_h"] = self._split_w(t["w_skipall"], f0) if self.split else L.to_bf16(t["w_skipall"])
+            t["w_skipall_h"] = (self._sd_sets(t["w_skipall"]) if (self.sd and not f0) else self._split_w(t["w_skipall"], f0)) if self.split else L.to_bf16(t["w_skipall"])
             if self.q4 and not f0 and t["w_skipall"].shape[1] % 64 == 0:   # the fp4 lo plane in the lane order of ss_gemm_bf16_tile256q
                 t["w_skipall_q"] = L.pack_skip_q4(t["w_skipall"], shift=self.FP16_WSHIFT)[0]
         skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
@@ -433,6 +461,13 @@ class StyleSingerHIP(torch.nn.Module):
         net.mfma_bf16 = 1 if self.bf16 else 0
         net.mfma_split = (2 if (self.f16 and not f0) else 1) if self.split else 0
         net.mfma_out_scale = 2.0 ** -self.FP16_WSHIFT if (self.f16 and not f0) else 1.0
+        if self.sd and not f0:   # every w_*_h / w_*_f tensor is [N][...]: pointer = set 0, ws_* = elements between sets
+            assert len(packs) == 1
+            net.n_wsets, net.mfma_products = self.sd_sets, 1
+            net.ws_w_dil_h, net.ws_w_out_h = packs[0]["w_dil_h.0"][0].numel(), packs[0]["w_out_h.0"][0].numel()
+            net.ws_w_skipall_h = packs[0]["w_skipall_h"][0].numel()
+            if "w_dil_f.0" in packs[0]:
+                net.ws_w_dil_f, net.ws_w_out_f = packs[0]["w_dil_f.0"][0].numel(), packs[0]["w_out_f.0"][0].numel()
         if self.q4 and not f0:
             for l in range(Lyr):
                 if f"w_dil_q.{l}" in packs[0]:

@@ -59,10 +59,12 @@ def _case(B, T, lens_list, d, seed):
                 Eall=Eall, Lyr=Lyr)
 
 
-def _reference(c):
-    """float64 math on the terms the matrix cores see"""
+def _reference(c, one=False):
+    """float64 math on the terms the matrix cores see (one: the hi terms of the weights only - n_products = 1)"""
     d, osc, sc, lens, B = c["d"], c["osc"], c["sc"], c["lens"], c["B"]
     wh, wl = _split_ref(c["w"], sc)
+    if one:
+        wl = torch.zeros_like(wl)
     conv = lambda a, ww: torch.nn.functional.conv1d(a.double().transpose(1, 2), ww.double(), padding=d, dilation=d).transpose(1, 2)
     z = (conv(c["yh"], wl) + conv(c["yh"], wh)) * osc + c["E"].double()
     g_ref = (torch.sigmoid(z[..., :C]) * torch.tanh(z[..., C:])).float()
@@ -71,11 +73,13 @@ def _reference(c):
     return g_ref
 
 
-def _stream_ref(c, g16, pair=False):
+def _stream_ref(c, g16, pair=False, one=False):
     """x' (fp32 stream form) or x' + next_bias from the pair stream (two-launch form), from the fp16 gate outputs the kernel itself produced (so that
     the projection is checked on its own operands)"""
     osc, sc, lens, B = c["osc"], c["sc"], c["lens"], c["B"]
     woh, wol = (t.double() for t in _split_ref(c["wo"][:C, :, 0], sc))
+    if one:
+        wol = torch.zeros_like(wol)
     gh = g16.double()
     proj = (gh @ wol.t() + gh @ woh.t()) * osc
     x_in = ((c["yh"] + c["yl"]) - c["cb"]) if pair else c["x"]
@@ -161,6 +165,35 @@ def test_layer512_many_tiles_per_workgroup():
     assert torch.equal(L.layer512_h_values(Hout, B=B, T=T), h_ref.to(torch.float16))
 
 
+def test_layer512_one_product_matches_float64_of_the_hi_terms():
+    """n_products = 1 ("fp16sd": one fp16 weight term, packs made with n_products = 1 from the hi terms): the launch against float64 of exactly that
+    one product - and bit for bit against the two-product launch fed with ZERO lo terms (a * 0 adds nothing to an fp32 accumulator)."""
+    B, T, d = 3, 900, 2
+    c = _case(B, T, [900, 777, 130], d, seed=41)
+    Lyr = c["Lyr"]
+    E512 = L.layer512_tile_addend(c["Eall"][..., 2 * C:], B=B, T=T, lde=Lyr * 2 * C)
+    def zero_lo(Wp):   # the (hi | lo) pack, pairs interleaved by 32: lo terms at [32, 64) of every 64
+        W0 = Wp.clone()
+        W0.view(W0.shape[0], -1, 64)[:, :, 32:] = 0
+        return W0
+    Ws0, Wos0 = zero_lo(c["Ws"]), zero_lo(c["Wos"])
+    outs = []
+    for np_, Wg, Wr in ((1, L.layer512_pack_gate(c["Ws"], 1), L.layer512_pack_res(c["Wos"], 1)), (2, L.layer512_pack_gate(Ws0), L.layer512_pack_res(Wos0))):
+        GA = torch.zeros((B, T, 2 * C), device=c["dev"], dtype=torch.float16)
+        Hout = torch.zeros_like(c["H"])
+        P = c["P"].clone()
+        L.layer512(c["H"], Wg, E512, GA, B=B, T=T, d=d, lens=c["lens"], Hout=Hout, P=P, Wr=Wr, bias_r=c["bo"], next_bias=c["nb"], out_scale=c["osc"], n_products=np_)
+        outs.append((GA, Hout, P))
+    got = L.split_planes(outs[0][0])[0]
+    eg = (got - _reference(c, one=True)).abs().max().item()
+    ey = (L.layer512_stream_values(outs[0][2], B=B, T=T) - _stream_ref(c, got, one=True)).abs().max().item()
+    e2 = (got - _reference(c)).abs().max().item()
+    print(f"layer512 one product: G vs float64 of the hi terms {eg:.2e}, stream {ey:.2e}; vs the two-term weights {e2:.2e} (what the second product is worth per launch)")
+    assert eg <= 3e-4 and ey <= 4e-6, (eg, ey)
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), "one product = two products with zero lo terms, bit for bit"
+
+
 def test_layer512_half_tile_tail_is_bit_identical_to_whole_tiles():
     """300 tiles on 256 workgroups: the 44 tiles of the second round run as 88 HALF tiles (knob layer512_tail, default on) - same arithmetic per
     row, so G, the stream and H must equal the whole-tile schedule bit for bit; and both match float64 of the same terms."""
@@ -214,6 +247,42 @@ def _force512(v):
 def _fwd(model, b, **kw):
     return model(b["txt_tokens"], mel2ph=b.get("mel2ph"), spk_embed=b["spk_embed"], emo_embed=b["emo_embed"], ref_mels=b["ref_mels"],
                  ref_f0=b["ref_f0"], global_steps=320000, infer=True, note=b["note"], note_dur=b["note_dur"], note_type=b["note_type"], **kw)
+
+
+@pytest.mark.parametrize("golden,knob", [("acoustic_t32_mel1000", 0), ("acoustic_t32_mel1000", 2), ("acoustic_t5625_mel1000", 2)])
+def test_fp16sd_model_vs_the_real_reference(golden, knob):
+    """"fp16sd" (ONE fp16 product per hidden GEMM of the mel denoiser, the weight rounding noise-shaped over the 1000 evaluations by cycling 32
+    sigma-delta weight sets) against the REAL reference's fp32 output on the reference's own noise tape: the 1000-step T = 32 golden on the generic
+    two-product kernels fed with zero lo terms (knob 0) and on ss_layer512 with n_products = 1 (knob 2: forced, one item does not fill the chip), and
+    BASELINE configs[3] as specified (T = 5625 x 1000 steps). Bar 6e-5 = fp16x2's (north_star 1e-4); CPU restatement: 2.2e-5 / plain one-product fp16: 1.9e-4."""
+    import os
+    from oracle import harness
+    from stylesinger_amd import synth
+    from stylesinger_amd.model import StyleSingerHIP
+    if not os.path.exists(os.path.join(harness.GOLD, golden + ".pt")):
+        pytest.fail(f"{golden}.pt is missing: run oracle/gen_golden.py in the build container")
+    case = harness.load_case(golden)
+    meta, gold = case["meta"], case["out"]
+    hp, sd, batch = harness.case_setup(meta)
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(meta["tape_seed"]), meta["B"], meta["T"], meta["steps_f0"], meta["steps_mel"])
+    _force512(knob)
+    try:
+        m = StyleSingerHIP(None, hparams=dict(hp, mfma_precision="fp16sd"))
+        m.load_state_dict(sd)
+        m.eval().to("cuda:0")
+        assert m.sd and m.sd_sets == 32
+        got = _fwd(m, {k: v.cuda() for k, v in batch.items()}, noise=noise)
+        torch.cuda.synchronize()
+    finally:
+        _force512(1)
+    d = (got["mel_out"].cpu() - gold["mel_out"]).abs()
+    uv = int(((got["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).sum())
+    path = "ss_layer512, one product" if knob == 2 else "generic kernels, zero lo terms"
+    print(f"{golden}, fp16sd ({path}): mel L1 {d.mean().item():.3e} max {d.max().item():.3e} vs the real reference; voicing flips {uv}")
+    name = "c4_as_specified_t5625_1000steps_fp16sd_vs_fp32_reference" if "5625" in golden else f"fp16sd_t32_1000steps_knob{knob}_vs_fp32_reference"
+    record_measurement(name, mel_l1=d.mean().item(), mel_max=d.max().item(), voicing_flips=uv, pinned=True, north_star=1e-4, golden=golden, path=path)
+    assert torch.isfinite(got["mel_out"]).all() and uv == 0
+    assert d.mean().item() <= 6e-5, d.mean().item()
 
 
 @pytest.mark.parametrize("golden,bar", [("acoustic_t32_mel1000", 6e-5), ("acoustic_t5625_mel1000", 6e-5)])

@@ -128,3 +128,38 @@ def test_f0_tracker_in_item_groups_equals_one_launch():
     finally:
         f0track.WS_CAP_BYTES = cap
     assert torch.equal(whole, single) and (whole > 0).sum().item() > 100
+
+
+def test_skip_gemm_with_one_weight_term_equals_two_products_with_zero_lo_terms():
+    """"fp16sd": the K = L C skip GEMM on `tile256s_kernel<STORE, true, ONE>` - one fp16 weight term, the lo plane of the weights neither fetched nor
+    multiplied - against the two-product kernel on the same pack (whose lo terms are zero): the non-zero products enter every accumulator in the same
+    order, so the outputs are equal bit for bit; and both match float64 of the one product."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(77)
+    B, T, C, Lyr = 2, 1500, 256, 4
+    K = Lyr * C
+    lens = torch.tensor([T, T - 211], dtype=torch.int32, device=dev)
+    x = torch.randn(B, T, K, generator=g).to(dev) * 0.5
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    A = L.split_f16(x)
+    w = (torch.randn(C, K, 1, generator=g) / K ** 0.5).to(dev)
+    Wp = L.pack_conv_weight(w)
+    wk = (Wp * 256.0).to(torch.float16).float()
+    W1 = L.split_f16(wk, scale=1.0)                 # hi = the fp16 term, lo = 0
+    assert float(L.split_planes(W1)[1].abs().max()) == 0.0
+    bias = torch.randn(C, generator=g).to(dev)
+    outs = []
+    for one in (True, False):
+        S = torch.empty(B, T, C, device=dev)
+        L.gemm_bf16(A, W1, B=B, T=T, K=K, taps=(0,), N=C, Np=W1.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=L.pack_bias(bias), split=2,
+                    out_scale=1.0 / 256.0, gate256=True, one_product=one)
+        outs.append(S)
+    assert torch.equal(outs[0], outs[1])
+    xh = x.to(torch.float16).double()
+    ref = torch.relu(xh @ (wk[:C, :K].double().t() / 256.0) + bias.double()).float()
+    for b in range(B):
+        ref[b, lens[b]:] = 0
+    err = (outs[0] - ref).abs().max().item()
+    print(f"skip GEMM, one weight term: vs float64 {err:.2e}; bit-identical to the two-product kernel with zero lo terms")
+    assert err <= 2e-5

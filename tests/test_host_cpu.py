@@ -52,7 +52,7 @@ def test_argument_errors_are_reported_not_crashed():
     a = lib.Layer512Args()
     assert l.ss_layer512(ctypes.byref(a), None) != 0 and b"null Hin" in l.ss_last_error()
     assert l.ss_layer512_entry(None, 256, 0, None, None, None, None, 1, 1, None) != 0 and l.ss_layer512_tile_addend(None, 512, 0, None, 1, 1, None) != 0
-    assert l.ss_layer512_pack_gate(None, None, None) != 0 and l.ss_layer512_pack_res(None, None, None) != 0
+    assert l.ss_layer512_pack_gate(None, None, 2, None) != 0 and l.ss_layer512_pack_res(None, None, 2, None) != 0
     assert l.ss_debug_null_launch(0, 64, None) != 0 and l.ss_set_q4_guard(None) == 0
 
 

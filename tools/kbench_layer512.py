@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--lo-bits", type=int, default=0, help="experiment: keep only this many mantissa bits of the weights' lo terms (0 = all 10): does the "
                     "matrix pipe draw less power - and the chip clock higher - when one operand's low mantissa bits are zero?")
     ap.add_argument("--zero-lo", action="store_true", help="experiment: lo terms = 0 (the power a second product of zeros draws)")
+    ap.add_argument("--one", action="store_true", help="n_products = 1: ONE fp16 weight term (the fp16sd mode's launch; the pair column still shows fp16x2's two launches)")
     a = ap.parse_args()
     d = torch.device("cuda:0")
     B, T, C, NS = a.B, a.T, 256, 4
@@ -49,13 +50,15 @@ def main():
         return Wp
     if a.lo_bits or a.zero_lo:
         Ws, Wos = coarse(Ws), coarse(Wos)
-    Wg, Wr = L.layer512_pack_gate(Ws), L.layer512_pack_res(Wos)
+    NP = 1 if a.one else 2
+    Wg, Wr = L.layer512_pack_gate(Ws, NP), L.layer512_pack_res(Wos, NP)
     cb, nb, bo = (torch.randn(C, device=d) for _ in range(3))
     bop = L.pack_bias(bo)
     k = [0]
     res = []
     fl_gate = 2.0 * 2.0 * B * T * 3 * C * 2 * C
     fl_res = 2.0 * 2.0 * B * T * C * C
+    fl1 = 0.5 if a.one else 1.0   # executed flops of the layer512 rows with one product
 
     def pair():
         k[0] += 1
@@ -75,15 +78,16 @@ def main():
         k[0] += 1
         s = k[0] % NS
         L.layer512(H[k[0] & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k[0] & 1) ^ 1], P=P, Wr=Wr, bias_r=bo, next_bias=nb,
-                   ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+                   ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
 
     def gate_only_new():
         k[0] += 1
         s = k[0] % NS
-        L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+        L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
 
     for name, fn, fl in (("gate128 + tile256 RESX (the launch pair)", pair, fl_gate + fl_res), ("gate128 alone", gate_only_old, fl_gate),
-                         ("layer512 fused (gate + residual projection)", fused, fl_gate + fl_res), ("layer512 gate only", gate_only_new, fl_gate),
+                         ("layer512 fused (gate + residual projection)" + (", ONE product" if a.one else ""), fused, (fl_gate + fl_res) * fl1),
+                         ("layer512 gate only" + (", ONE product" if a.one else ""), gate_only_new, fl_gate * fl1),
                          ("layer512 entry (fp32 stream -> H rows + pairs)", lambda: L.layer512_entry(X0, cb, B=B, T=T, lens=lens), 0.0)):
         if a.which != "all" and a.which not in name:
             continue
