@@ -315,6 +315,12 @@ typedef struct ss_gemm_bf16_args {
    * its element of Y, recovers x = hi + mid - cur_bias, and writes Y = pair(x_new + next_bias) in place: 3 instead of 4 KB per row of traffic. */
   const float* cur_bias;
   int64_t cur_bias_group_stride;
+  /* split = 2, SS_HEPI_STORE through ss_gemm_bf16_tile256 only (round 6): the A operand is COMPACT - a row holds its K fp16 hi terms contiguously
+   * (lda >= K elements), no interleaved second plane. The fp16x2 / fp16sd matrix cores never read that plane, but in the pair layout it shares every
+   * 128-byte line with the hi terms, so the K = L C skip GEMM pulled twice the bytes it used from HBM (ss_layer512 writes G in this form with
+   * g_compact = 1). ss_gemm_bf16 refuses the flag for launches its other kernels would take. */
+  int32_t a_compact;
+  int32_t reserved2_;
 } ss_gemm_bf16_args;
 int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream);
 /* The SS_HEPI_GATE form of ss_gemm_bf16 for many-round launches (BASELINE config 4): three taps (-d, 0, d) with d <= 8, K = 256,
@@ -377,13 +383,15 @@ typedef struct ss_layer512_args {
   const uint16_t* Wg;       /* ss_layer512_pack_gate of the layer's ss_split_f16 dilated-conv pack (786 432 elements) */
   const uint16_t* Wr;       /* ss_layer512_pack_res of the residual half of the ss_split_f16 output-projection pack (131 072 elements) */
   const float* E512;        /* ss_layer512_tile_addend of this layer's 512 addend columns: ss_layer512_addend_floats(B, T) floats */
-  uint16_t* G;              /* gate output fp16 [B][T][ldg], hi slots of ss_gemm_bf16's pair layout (the second plane is not written) */
+  uint16_t* G;              /* gate output fp16 [B][T][ldg]: hi slots of ss_gemm_bf16's pair layout (the second plane is not written; ldg >= 512), or with
+                             * g_compact the 256 channels contiguously (ldg >= 256) - the skip GEMM's a_compact operand */
   int64_t g_batch_stride;
   int32_t ldg;
   int32_t mask_rows;        /* rows >= lens[b]: G = 0, stream = 0 */
   const float* bias_r;      /* [256] residual half of the output-projection bias, or NULL */
   const float* next_bias;   /* [256] dstep_{l+1}, or NULL */
-  const void* reserved_;
+  int32_t g_compact;        /* 1: G rows are compact (see G) */
+  int32_t reserved_;
   float out_scale;          /* 2^-s of the weight packs */
   float post_scale;         /* 1 / sqrt(2) */
 } ss_layer512_args;

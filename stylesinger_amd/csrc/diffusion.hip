@@ -38,6 +38,7 @@ struct WsLayout {
   void* P512;         // ss_layer512_stream_bytes
   float* E512;        // [L][ss_layer512_addend_floats]
   int64_t e512_layer; // floats per layer
+  bool g_compact;     // fused form whose skip GEMM runs on the many-round kernel: GAh rows hold the L*C hi terms only (no dead second plane)
   int64_t bytes;
 };
 
@@ -106,7 +107,9 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.KP = w.ksplit > 1 ? take((int64_t)w.ksplit * rows * net->C) : nullptr;
   const int planes = smode(net) ? 2 : 1;
   w.Yh = h ? (uint16_t*)take((rows * net->C * planes + 1) / 2) : nullptr;
-  w.GAh = h ? (uint16_t*)take((rows * net->L * net->C * planes + 1) / 2) : nullptr;
+  // the skip GEMM's many-round kernel reads a compact operand (ss_gemm_bf16_args.a_compact; its size rule: >= 2 rounds of 256-row tiles)
+  w.g_compact = fused512(net, B, T) && g_ss_tuning.gate256 != 0 && (long)ss_cdiv(T, 256) * B >= 2L * ss_n_cu() && ((net->L * net->C) % 64) == 0 && net->C <= 256;
+  w.GAh = h ? (uint16_t*)take((rows * net->L * net->C * (w.g_compact ? 1 : planes) + 1) / 2) : nullptr;
   w.condh = (h && !smode(net)) ? (uint16_t*)take((rows * net->cond_dim + 1) / 2) : nullptr;
   w.H512[0] = w.H512[1] = nullptr;
   w.P512 = nullptr;
@@ -231,9 +234,11 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     f.Wg = net->w_dil_f[l] + wset_off(net, net->ws_w_dil_f);
     f.n_products = net->mfma_products == 1 ? 1 : 2;
     f.E512 = w.E512 + (int64_t)l * w.e512_layer;
-    f.G = w.GAh + (int64_t)l * C * pl;
-    f.g_batch_stride = (int64_t)T * L * C * pl;
-    f.ldg = L * C * pl;
+    const int gpl = w.g_compact ? 1 : pl;   // planes per G row
+    f.G = w.GAh + (int64_t)l * C * gpl;
+    f.g_batch_stride = (int64_t)T * L * C * gpl;
+    f.ldg = L * C * gpl;
+    f.g_compact = w.g_compact ? 1 : 0;
     f.mask_rows = 1;
     f.out_scale = net->mfma_out_scale;
     f.post_scale = 0.70710678118654752440f;
@@ -318,8 +323,9 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   }
   ss_gemm_bf16_args k = base_args_h(net, B, T, lens);
   k.A = w.GAh;
-  k.lda = L * C * pl;
-  k.a_batch_stride = (int64_t)T * L * C * pl;
+  k.lda = L * C * (w.g_compact ? 1 : pl);
+  k.a_batch_stride = (int64_t)T * L * C * (w.g_compact ? 1 : pl);
+  k.a_compact = w.g_compact ? 1 : 0;
   k.split = sp;
   k.out_scale = net->mfma_out_scale;
   k.K = L * C;

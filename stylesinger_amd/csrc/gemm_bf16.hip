@@ -554,6 +554,10 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
                "ss_gemm_bf16: item too large for 32-bit offsets");
   SS_CHECK_ARG(a.split >= 0 && a.split <= 2, "ss_gemm_bf16: split=%d", a.split);
   SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16: split = 2 needs 0 < out_scale <= 1 (got %g)", (double)a.out_scale);
+  if (a.a_compact) {   // the compact A operand exists in the many-round STORE kernel only
+    SS_CHECK_ARG(a.epi == SS_HEPI_STORE && a.C && ss_gemm_bf16_tile256_ok(&a), "ss_gemm_bf16: a_compact needs a launch ss_gemm_bf16_tile256 takes (split = 2, STORE, >= 2 rounds of 256-row tiles)");
+    return ss_gemm_bf16_tile256(&a, stream_);
+  }
   if (a.split) {   // pairs interleaved by 32: physical rows hold 2 x the logical channels
     SS_CHECK_ARG((a.K % 32) == 0 && a.lda >= 2 * a.K, "ss_gemm_bf16: split operands need K %% 32 == 0 and lda >= 2 K (K=%d lda=%d)", a.K, a.lda);
     SS_CHECK_ARG(a.epi != SS_HEPI_GATE || (a.ldc >= 2 * a.N && (a.N % 32) == 0), "ss_gemm_bf16: split GATE writes 2 N bf16 per row (ldc=%d N=%d)", a.ldc, a.N);

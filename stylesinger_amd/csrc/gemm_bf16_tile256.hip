@@ -79,9 +79,12 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   const int b_voff = (r0 * ldw + slot0 * 8) * 2;            // packed weight rows >= Np read zeros
   const int a_lo_dead = (W2 && slot0 >= 4) ? (int)0x80000000 : 0;   // W2: the A operand's second plane is never read - its lanes fetch nothing (zeros)
   const int b_lo_dead = (ONE && slot0 >= 4) ? (int)0x80000000 : 0;  // ONE: nor is the weights'
+  // a_compact (W2, STORE): a row of A holds its hi terms only - chunk c at 64 c bytes of the row instead of 128 c (the LDS image keeps its 128-byte
+  // rows, the dead lanes of the second plane write zeros as before): half the bytes the launch pulls from HBM
+  const int a_chunk = (W2 && a.a_compact) ? ROWB / 2 : ROWB;
   auto piece = [&](char* Ab, char* Bb, int c, int i) {     // i = 0..3: A pieces, 4..7: B pieces of chunk c
     const int j = i & 3;
-    if (i < 4) glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | a_lo_dead, c * ROWB);
+    if (i < 4) glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | a_lo_dead, c * a_chunk);
     else glds16(rsrc_w, Bb + (wave + 8 * j) * 8 * ROWB, b_voff | b_lo_dead, c * ROWB + 64 * j * ldw * 2);
   };
 
@@ -338,7 +341,8 @@ extern "C" int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* a) {
   if (!a || (a->split != 1 && a->split != 2) || a->ntaps != 1 || a->tap_off[0] != 0) return 0;
   if (a->epi == SS_HEPI_RESX ? !(a->X == nullptr && a->Y && a->cur_bias && (a->N % 32) == 0 && a->ldy >= 2 * a->N) : a->epi != SS_HEPI_STORE) return 0;
   if (a->epi == SS_HEPI_STORE && ((a->N % 4) != 0 || (a->ldc % 4) != 0 || (a->act != SS_ACT_NONE_ && a->act != SS_ACT_RELU_))) return 0;
-  if (a->N > BN || (a->K % 64) != 0 || a->lda < 2 * a->K || (a->lda % 8) != 0) return 0;
+  if (a->a_compact && !(a->split == 2 && a->epi == SS_HEPI_STORE)) return 0;
+  if (a->N > BN || (a->K % 64) != 0 || a->lda < (a->a_compact ? 1 : 2) * a->K || (a->lda % 8) != 0) return 0;
   if ((int64_t)a->T * a->lda * 2 >= (1ll << 31) || (int64_t)a->T * a->ldc * 4 >= (1ll << 31) || (int64_t)a->T * a->ldy * 2 >= (1ll << 31) ||
       (int64_t)a->Np * a->K * 4 >= (1ll << 31)) return 0;
   return (long)ss_cdiv(a->T, BM) * a->B >= 2L * ss_n_cu() ? 1 : 0;
@@ -349,7 +353,9 @@ extern "C" int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream)
   const ss_gemm_bf16_args& a = *args;
   SS_CHECK_ARG(a.A && a.W && (a.split == 1 || a.split == 2) && a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm_bf16_tile256: split operands, one tap at offset 0");
   SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16_tile256: split = 2 needs 0 < out_scale <= 1");
-  SS_CHECK_ARG(a.N > 0 && a.N <= BN && a.Np >= a.N && (a.K % 64) == 0 && a.lda >= 2 * a.K && (a.lda % 8) == 0, "ss_gemm_bf16_tile256: N <= 256, K %% 64 == 0, lda >= 2 K");
+  SS_CHECK_ARG(!a.a_compact || (a.split == 2 && a.epi == SS_HEPI_STORE), "ss_gemm_bf16_tile256: a_compact is the fp16 (split = 2) STORE form only");
+  SS_CHECK_ARG(a.N > 0 && a.N <= BN && a.Np >= a.N && (a.K % 64) == 0 && a.lda >= (a.a_compact ? 1 : 2) * a.K && (a.lda % 8) == 0,
+               "ss_gemm_bf16_tile256: N <= 256, K %% 64 == 0, lda >= 2 K (K with a_compact)");
   SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16_tile256: A/W must be 16-byte aligned");
   SS_CHECK_ARG((int64_t)a.T * a.lda * 2 < (1ll << 31) && (int64_t)a.Np * a.K * 4 < (1ll << 31), "ss_gemm_bf16_tile256: item too large for 32-bit offsets");
   const int m_tiles_per_item = ss_cdiv(a.T, BM);

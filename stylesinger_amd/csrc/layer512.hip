@@ -337,7 +337,8 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
         const int p = tid + 512 * j;
         const int R = p >> 5, s_ = p & 31;
         const u32x4 v = *reinterpret_cast<const u32x4*>(Rc + s_ * SLOTB + R * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_g, (t0 + R) * a.ldg * 2 + (s_ >> 2) * 128 + (s_ & 3) * 16, 0, 0);   // rows >= T dropped
+        // pair layout: the hi half of chunk s_ >> 2's 128-byte line; compact: the row's 32 slots side by side (512 contiguous bytes per 32 lanes)
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_g, (t0 + R) * a.ldg * 2 + (a.g_compact ? s_ * 16 : (s_ >> 2) * 128 + (s_ & 3) * 16), 0, 0);   // rows >= T dropped
       }
     }
     L512_STAMP(5);
@@ -556,7 +557,8 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
   const ss_layer512_args& a = *args;
   SS_CHECK_ARG(a.Hin && a.Wg && a.E512 && a.G, "ss_layer512: null Hin / Wg / E512 / G");
   SS_CHECK_ARG(a.B > 0 && a.T > 0 && a.d >= 1 && a.d <= HALO, "ss_layer512: B, T > 0 and 1 <= d <= 8");
-  SS_CHECK_ARG(a.ldg >= 512 && (a.ldg % 8) == 0 && (a.g_batch_stride % 8) == 0, "ss_layer512: ldg >= 512 (pair layout of 256 channels), a multiple of 8, as the batch stride");
+  SS_CHECK_ARG(a.ldg >= (a.g_compact ? 256 : 512) && (a.ldg % 8) == 0 && (a.g_batch_stride % 8) == 0,
+               "ss_layer512: ldg >= 512 (pair layout of 256 channels; 256 with g_compact), a multiple of 8, as the batch stride");
   SS_CHECK_ARG((int64_t)a.T * a.ldg * 2 < (1ll << 31) && (int64_t)a.B * ss_cdiv(a.T, BM) * H_TILE < (1ll << 31), "ss_layer512: too large for 32-bit offsets");
   SS_CHECK_ARG((((uintptr_t)a.Hin) & 15) == 0 && (((uintptr_t)a.Wg) & 15) == 0 && (((uintptr_t)a.E512) & 15) == 0 && (((uintptr_t)a.G) & 15) == 0,
                "ss_layer512: Hin / Wg / E512 / G must be 16-byte aligned");

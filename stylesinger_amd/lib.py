@@ -84,6 +84,7 @@ class GemmBf16Args(C.Structure):
         ("post_scale", C.c_float), ("next_bias", _vp), ("next_bias_group_stride", C.c_int64), ("Y", _vp), ("y_batch_stride", C.c_int64),
         ("ldy", C.c_int32), ("ldc", C.c_int32), ("C", _vp), ("c_batch_stride", C.c_int64), ("mask_rows", C.c_int32), ("group_size", C.c_int32),
         ("split", C.c_int32), ("out_scale", C.c_float), ("q_scale", C.c_float), ("one_product", C.c_int32), ("cur_bias", _vp), ("cur_bias_group_stride", C.c_int64),
+        ("a_compact", C.c_int32), ("reserved2_", C.c_int32),
     ]
 
 
@@ -94,7 +95,7 @@ class Layer512Args(C.Structure):
     _fields_ = [
         ("Hin", _vp), ("d", C.c_int32), ("n_products", C.c_int32), ("Hout", _vp), ("P", _vp),
         ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("Wg", _vp), ("Wr", _vp), ("E512", _vp), ("G", _vp), ("g_batch_stride", C.c_int64),
-        ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("next_bias", _vp), ("reserved_", _vp), ("out_scale", C.c_float),
+        ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("next_bias", _vp), ("g_compact", C.c_int32), ("reserved_", C.c_int32), ("out_scale", C.c_float),
         ("post_scale", C.c_float),
     ]
 
@@ -604,7 +605,7 @@ def split_planes(y):
 
 def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT_NONE, E=None, lde=0, e_bs=None, X=None, post_scale=1.0,
               next_bias=None, Y=None, out=None, ldc=None, c_bs=None, lda=None, a_bs=None, mask_rows=True, gate_mode=0, gate256=False,
-              split=0, cur_bias=None, out_scale=1.0, q_scale=0.0, one_product=False):
+              split=0, cur_bias=None, out_scale=1.0, q_scale=0.0, one_product=False, a_compact=False):
     """ss_gemm_bf16: A, Wh = bf16 device tensors (A [B,T,lda], Wh packed [Np][len(taps)*K]); see include/stylesinger_hip.h."""
     a = GemmBf16Args()
     a.A = ptr(A); a.lda = lda if lda is not None else A.shape[-1]
@@ -627,6 +628,7 @@ def gemm_bf16(A, Wh, *, B, T, K, taps, N, Np, epi, lens=None, bias=None, act=ACT
     a.out_scale = out_scale
     a.q_scale = q_scale
     a.one_product = int(one_product)
+    a.a_compact = int(a_compact)
     a.cur_bias = ptr(cur_bias)
     if gate256 and epi == HEPI_STORE and split == 3:   # the fp16q4 skip GEMM
         check(load().ss_gemm_bf16_tile256q(C.byref(a), stream_ptr()), "ss_gemm_bf16_tile256q")
@@ -694,10 +696,10 @@ def layer512_stream_values(P, *, B, T):
 
 
 def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None, bias_r=None, next_bias=None, out_scale=1.0 / 256.0,
-             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True, n_products=2):
+             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True, n_products=2, g_compact=False):
     """ss_layer512: one launch per residual layer (gate + residual projection) of the fp16x2 mel denoiser; see include/stylesinger_hip.h."""
     a = Layer512Args()
-    a.Hin = ptr(Hin); a.d = d; a.n_products = n_products
+    a.Hin = ptr(Hin); a.d = d; a.n_products = n_products; a.g_compact = int(g_compact)
     a.Hout = ptr(Hout); a.P = ptr(P)
     a.lens = ptr(lens); a.B = B; a.T = T; a.Wg = ptr(Wg); a.Wr = ptr(Wr); a.E512 = ptr(E512)
     a.G = ptr(G); a.ldg = ldg if ldg is not None else G.shape[-1]; a.g_batch_stride = g_bs if g_bs is not None else T * a.ldg

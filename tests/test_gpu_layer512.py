@@ -142,6 +142,29 @@ def test_layer512_matches_float64_of_the_same_terms(B, T, lens, d):
     record_measurement("layer512_unit", B=B, T=T, d=d, G_vs_f64=eg, stream_vs_f64=ey, G_vs_two_launch=dg, stream_vs_two_launch=dy)
 
 
+def test_layer512_compact_gate_rows_equal_the_hi_plane_of_the_pair_layout():
+    """g_compact: G rows as [L C] fp16 without the (never written) second plane - the skip GEMM's a_compact operand; same values, bit for bit."""
+    B, T, d = 3, 700, 4
+    c = _case(B, T, [700, 512, 9], d, seed=5)
+    dev, Lyr = c["dev"], c["Lyr"]
+    Wg, Wr = L.layer512_pack_gate(c["Ws"]), L.layer512_pack_res(c["Wos"])
+    E512 = L.layer512_tile_addend(c["Eall"][..., 2 * C:], B=B, T=T, lde=Lyr * 2 * C)
+    res = []
+    for compact in (False, True):
+        pl = 1 if compact else 2
+        GA = torch.full((B, T, pl * Lyr * C), 7.0, device=dev, dtype=torch.float16)
+        Hout = torch.zeros_like(c["H"])
+        P = c["P"].clone()
+        L.layer512(c["H"], Wg, E512, GA[..., pl * C:], B=B, T=T, d=d, lens=c["lens"], Hout=Hout, P=P, Wr=Wr, bias_r=c["bo"], next_bias=c["nb"], out_scale=c["osc"],
+                   ldg=pl * Lyr * C, g_bs=T * pl * Lyr * C, g_compact=compact)
+        res.append((GA if compact else L.split_planes(GA)[0].to(torch.float16), Hout, P))
+    assert torch.all(res[1][0][..., :C] == 7.0) and torch.all(res[1][0][..., 2 * C:] == 7.0), "the neighbouring layer slots are untouched"
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    with pytest.raises(L.StyleSingerHipError):   # a compact row still holds all 256 channels
+        L.layer512(c["H"], Wg, E512, res[1][0], B=B, T=T, d=d, lens=c["lens"], out_scale=c["osc"], ldg=128, g_compact=True)
+
+
 def test_layer512_many_tiles_per_workgroup():
     """more tiles than CUs: the persistent loop's region alternation, the next-tile DMA and the three barriers per tile"""
     B, T = 6, 128 * 70 + 37

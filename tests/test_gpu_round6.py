@@ -163,3 +163,43 @@ def test_skip_gemm_with_one_weight_term_equals_two_products_with_zero_lo_terms()
     err = (outs[0] - ref).abs().max().item()
     print(f"skip GEMM, one weight term: vs float64 {err:.2e}; bit-identical to the two-product kernel with zero lo terms")
     assert err <= 2e-5
+
+
+@pytest.mark.parametrize("one", [True, False])
+def test_skip_gemm_compact_operand_equals_the_pair_layout(one):
+    """`a_compact`: the skip GEMM's A operand as [B, T, K] fp16 hi terms only (what ss_layer512 writes with g_compact) against the pair layout whose
+    second plane the fp16 kernels never read: the same fragments reach the matrix cores, so the outputs are equal bit for bit. Rows past an item's
+    length and the last partial tile go through the buffer bounds of the narrower rows."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(78)
+    B, T, C, Lyr = 3, 1337, 256, 5
+    K = Lyr * C
+    lens = torch.tensor([T, T - 211, 3], dtype=torch.int32, device=dev)
+    x = torch.randn(B, T, K, generator=g).to(dev) * 0.5
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    A = L.split_f16(x)
+    Ah = L.split_planes(A)[0].to(torch.float16).contiguous()       # the compact operand
+    A.view(B, T, -1, 64)[..., 32:] = 77.0                          # poison the second plane: nobody reads it
+    w = (torch.randn(C, K, 1, generator=g) / K ** 0.5).to(dev)
+    Wp = L.pack_conv_weight(w)
+    Ws = L.split_f16(L.split_planes(L.split_f16(Wp, scale=256.0))[0], scale=1.0) if one else L.split_f16(Wp, scale=256.0)
+    bias = torch.randn(C, generator=g).to(dev)
+    outs = []
+    for compact in (False, True):
+        S = torch.full((B, T, C), 3.0, device=dev)
+        L.gemm_bf16(Ah if compact else A, Ws, B=B, T=T, K=K, taps=(0,), N=C, Np=Ws.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=L.pack_bias(bias),
+                    split=2, out_scale=1.0 / 256.0, gate256=True, one_product=one, a_compact=compact)
+        outs.append(S)
+    assert torch.equal(outs[0], outs[1])
+    wh, wl = (t[:C, :K].double() for t in L.split_planes(Ws))
+    ref = torch.relu(Ah.double() @ ((wh + wl).t() / 256.0) + bias.double()).float()
+    for b in range(B):
+        ref[b, lens[b]:] = 0
+    err = (outs[1] - ref).abs().max().item()
+    print(f"skip GEMM, compact A operand (one={one}): vs float64 {err:.2e}; bit-identical to the pair layout")
+    assert err <= 2e-5
+    # the generic entry refuses the flag for a launch its other kernels would take (too few tiles for the many-round kernel)
+    with pytest.raises(L.StyleSingerHipError):
+        L.gemm_bf16(Ah[:1, :300].contiguous(), Ws, B=1, T=300, K=K, taps=(0,), N=C, Np=Ws.shape[0], epi=L.HEPI_STORE, out=torch.empty(1, 300, C, device=dev),
+                    bias=L.pack_bias(bias), split=2, out_scale=1.0 / 256.0, a_compact=True)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=5625)
     ap.add_argument("--gate-only", action="store_true")
+    ap.add_argument("--one", action="store_true", help="n_products = 1 (the fp16sd launch)")
     a = ap.parse_args()
     d = torch.device("cuda:0")
     B, T, C, NS = a.B, a.T, 256, 4
@@ -33,9 +34,10 @@ def main():
     E512 = [L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C) for s in range(NS)]
     GA = torch.empty(B, T, NS * 2 * C, device=d, dtype=torch.float16)
     w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
-    Wg = L.layer512_pack_gate(L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=256.0))
+    NP = 1 if a.one else 2
+    Wg = L.layer512_pack_gate(L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=256.0), NP)
     wo = torch.randn(2 * C, C, 1, device=d) / math.sqrt(C)
-    Wr = L.layer512_pack_res(L.split_f16(L.pack_conv_weight(wo), scale=256.0))
+    Wr = L.layer512_pack_res(L.split_f16(L.pack_conv_weight(wo), scale=256.0), NP)
     cb, nb, bo = (torch.randn(C, device=d) for _ in range(3))
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     if os.environ.get("SS_L512_GRID"):
@@ -45,10 +47,10 @@ def main():
     def run(k):
         s = k % NS
         if a.gate_only:
-            L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+            L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
         else:
             L.layer512(H[k & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k & 1) ^ 1], P=P, Wr=Wr, bias_r=bo,
-                       next_bias=nb, ldg=NS * 2 * C, g_bs=T * NS * 2 * C)
+                       next_bias=nb, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
     for k in range(6):
         run(k)
     torch.cuda.synchronize()
@@ -76,7 +78,7 @@ def main():
     gap = t[:, :, 1:, 0] - t[:, :, :-1, 7]
     print(f"  {'tile end -> next [B1]':26s} {gap.mean().item():9.0f}")
     whole = t[:, :, 1:, 0] - t[:, :, :-1, 0]
-    print(f"  {'tile period':26s} {whole.mean().item():9.0f}   matrix time of a tile at 32 cycles per MFMA and two waves per SIMD: {(768 + (0 if a.gate_only else 128)) * 2 * 32}")
+    print(f"  {'tile period':26s} {whole.mean().item():9.0f}   matrix time of a tile at 32 cycles per MFMA and two waves per SIMD: {(768 + (0 if a.gate_only else 128)) * 2 * 32 // (2 if a.one else 1)}")
 
 
 if __name__ == "__main__":
