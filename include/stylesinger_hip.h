@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 16 /* 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames, "fp16sd" (ss_wavenet.n_wsets / mfma_products / ws_*, ss_layer512_args.n_products); 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 17 /* 17: compact gate rows (ss_layer512_args.g_compact, ss_gemm_bf16_args.a_compact), compact one-term skip weights (ss_gemm_bf16_args.one_product = 2, ss_wavenet.w_skipall_c); 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames, "fp16sd" (ss_wavenet.n_wsets / mfma_products / ws_*, ss_layer512_args.n_products); 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -308,7 +308,9 @@ typedef struct ss_gemm_bf16_args {
    * g128q); the kernel converts its own fp16 A fragments to fp4 with the fixed power-of-two scale q_scale: q = fp4(a / q_scale). */
   float q_scale;
   /* split = 2 with ONE weight term ("fp16sd": W is an ss_split_f16 pack whose lo terms are zero): kernels that know the flag skip the second product
-   * and do not fetch the lo plane (ss_gemm_bf16_tile256, SS_HEPI_STORE); the others compute the same result with a product of zeros */
+   * and do not fetch the lo plane (ss_gemm_bf16_tile256, SS_HEPI_STORE); the others compute the same result with a product of zeros.
+   * one_product = 2 (ss_gemm_bf16_tile256 STORE only; ss_gemm_bf16 refuses it elsewhere): W is the COMPACT one-term pack, fp16 [Np][K] - the rows of
+   * the hi plane alone, half the bytes per tile pass and small enough to stay in an XCD's L2. */
   int32_t one_product;
   /* RESX with split operands and X == NULL ("pair-only residual stream"): the stream lives ONLY as the (hi, mid) pair Y = x + cur_bias (16
    * significand bits - measured harmless on the reference's 1000-step golden: 2.4e-6 either way, oracle/bf16x2_numerics.py). The epilogue reads
@@ -623,6 +625,11 @@ typedef struct ss_wavenet {
   int32_t n_wsets;
   int32_t mfma_products;   /* 0 | 2: two weight terms (fp16x2); 1: one (fp16sd) */
   int64_t ws_w_dil_h, ws_w_out_h, ws_w_skipall_h, ws_w_dil_f, ws_w_out_f;
+  /* mfma_products = 1, optional: the skip GEMM's weight sets WITHOUT the zero second plane - fp16 [n_wsets][Np][L C], ws_w_skipall_c elements apart.
+   * Used (with ss_gemm_bf16_args.one_product = 2) whenever the stack runs in the compact-G form; 2.6 MB per set at C = 256, L = 20 stays in one
+   * XCD's 4 MB L2 across the row tiles of a launch, which the 5.2 MB pair-layout pack does not. NULL: the pair-layout pack is used. */
+  const uint16_t* w_skipall_c;
+  int64_t ws_w_skipall_c;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

@@ -331,6 +331,10 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   k.K = L * C;
   k.W = net->w_skipall_h + wset_off(net, net->ws_w_skipall_h);
   k.one_product = net->mfma_products == 1 ? 1 : 0;
+  if (w.g_compact && net->mfma_products == 1 && net->w_skipall_c && net->n_groups <= 1) {   // the one-term sets without their zero plane (L2-resident)
+    k.W = net->w_skipall_c + wset_off(net, net->ws_w_skipall_c);
+    k.one_product = 2;
+  }
   k.w_group_stride = net->gs_w_skipall_h;
   k.N = C;
   k.Np = round_up32(C);

@@ -554,8 +554,9 @@ extern "C" int ss_gemm_bf16(const ss_gemm_bf16_args* args, void* stream_) {
                "ss_gemm_bf16: item too large for 32-bit offsets");
   SS_CHECK_ARG(a.split >= 0 && a.split <= 2, "ss_gemm_bf16: split=%d", a.split);
   SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16: split = 2 needs 0 < out_scale <= 1 (got %g)", (double)a.out_scale);
-  if (a.a_compact) {   // the compact A operand exists in the many-round STORE kernel only
-    SS_CHECK_ARG(a.epi == SS_HEPI_STORE && a.C && ss_gemm_bf16_tile256_ok(&a), "ss_gemm_bf16: a_compact needs a launch ss_gemm_bf16_tile256 takes (split = 2, STORE, >= 2 rounds of 256-row tiles)");
+  if (a.a_compact || a.one_product == 2) {   // the compact operands exist in the many-round STORE kernel only
+    SS_CHECK_ARG(a.epi == SS_HEPI_STORE && a.C && ss_gemm_bf16_tile256_ok(&a),
+                 "ss_gemm_bf16: a_compact / one_product = 2 need a launch ss_gemm_bf16_tile256 takes (split = 2, STORE, >= 2 rounds of 256-row tiles)");
     return ss_gemm_bf16_tile256(&a, stream_);
   }
   if (a.split) {   // pairs interleaved by 32: physical rows hold 2 x the logical channels

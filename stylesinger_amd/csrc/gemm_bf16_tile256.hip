@@ -58,7 +58,9 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   const int l31 = lane & 31, lh = lane >> 5;
   const int len = ss_uniform_len(a.lens, b, a.T);
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
-  const int ldw = 2 * a.K;            // bf16 per packed weight row (both planes, one tap)
+  const bool w_compact = ONE && a.one_product == 2;       // the one-term pack without its zero second plane: rows of K fp16
+  const int ldw = w_compact ? a.K : 2 * a.K;              // 16-bit elements per packed weight row (both planes, one tap)
+  const int b_chunk = w_compact ? ROWB / 2 : ROWB;
 
   auto uniform_ptr = [](const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   auto piece = [&](char* Ab, char* Bb, int c, int i) {     // i = 0..3: A pieces, 4..7: B pieces of chunk c
     const int j = i & 3;
     if (i < 4) glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | a_lo_dead, c * a_chunk);
-    else glds16(rsrc_w, Bb + (wave + 8 * j) * 8 * ROWB, b_voff | b_lo_dead, c * ROWB + 64 * j * ldw * 2);
+    else glds16(rsrc_w, Bb + (wave + 8 * j) * 8 * ROWB, b_voff | b_lo_dead, c * b_chunk + 64 * j * ldw * 2);
   };
 
   // fragment addresses (see gate256_kernel): row = 128 wm + 32 m + l31 for A, 64 wn + 32 n + l31 for B; slot (2 ks) ^ swz = hi, (4 + 2 ks) ^ swz = mid
@@ -341,7 +343,7 @@ extern "C" int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* a) {
   if (!a || (a->split != 1 && a->split != 2) || a->ntaps != 1 || a->tap_off[0] != 0) return 0;
   if (a->epi == SS_HEPI_RESX ? !(a->X == nullptr && a->Y && a->cur_bias && (a->N % 32) == 0 && a->ldy >= 2 * a->N) : a->epi != SS_HEPI_STORE) return 0;
   if (a->epi == SS_HEPI_STORE && ((a->N % 4) != 0 || (a->ldc % 4) != 0 || (a->act != SS_ACT_NONE_ && a->act != SS_ACT_RELU_))) return 0;
-  if (a->a_compact && !(a->split == 2 && a->epi == SS_HEPI_STORE)) return 0;
+  if ((a->a_compact || a->one_product == 2) && !(a->split == 2 && a->epi == SS_HEPI_STORE)) return 0;
   if (a->N > BN || (a->K % 64) != 0 || a->lda < (a->a_compact ? 1 : 2) * a->K || (a->lda % 8) != 0) return 0;
   if ((int64_t)a->T * a->lda * 2 >= (1ll << 31) || (int64_t)a->T * a->ldc * 4 >= (1ll << 31) || (int64_t)a->T * a->ldy * 2 >= (1ll << 31) ||
       (int64_t)a->Np * a->K * 4 >= (1ll << 31)) return 0;
@@ -353,7 +355,9 @@ extern "C" int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream)
   const ss_gemm_bf16_args& a = *args;
   SS_CHECK_ARG(a.A && a.W && (a.split == 1 || a.split == 2) && a.ntaps == 1 && a.tap_off[0] == 0, "ss_gemm_bf16_tile256: split operands, one tap at offset 0");
   SS_CHECK_ARG(a.split != 2 || (a.out_scale > 0.f && a.out_scale <= 1.f), "ss_gemm_bf16_tile256: split = 2 needs 0 < out_scale <= 1");
-  SS_CHECK_ARG(!a.a_compact || (a.split == 2 && a.epi == SS_HEPI_STORE), "ss_gemm_bf16_tile256: a_compact is the fp16 (split = 2) STORE form only");
+  SS_CHECK_ARG(!(a.a_compact || a.one_product == 2) || (a.split == 2 && a.epi == SS_HEPI_STORE),
+               "ss_gemm_bf16_tile256: a_compact / one_product = 2 are the fp16 (split = 2) STORE form only");
+  SS_CHECK_ARG(a.one_product >= 0 && a.one_product <= 2, "ss_gemm_bf16_tile256: one_product = 0 | 1 | 2");
   SS_CHECK_ARG(a.N > 0 && a.N <= BN && a.Np >= a.N && (a.K % 64) == 0 && a.lda >= (a.a_compact ? 1 : 2) * a.K && (a.lda % 8) == 0,
                "ss_gemm_bf16_tile256: N <= 256, K %% 64 == 0, lda >= 2 K (K with a_compact)");
   SS_CHECK_ARG((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0 && (a.a_batch_stride & 7) == 0, "ss_gemm_bf16_tile256: A/W must be 16-byte aligned");

@@ -112,6 +112,12 @@ template <bool FUSE, int NP>
 __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args a, int tiles_per_item, int n_tiles, int split_tail, unsigned long long* clock_probe) {
 #ifdef SS_L512_TRACE
   const bool probing = false;
+  // the workgroup's own life on the constant 100 MHz counter (one time axis for all XCDs; the shader-cycle counters are per XCD): start and end at
+  // [gridDim.x * 512 + 4 * blockIdx.x] of the trace buffer, with the shader cycle counter beside them
+  if (clock_probe && threadIdx.x == 0) {
+    clock_probe[(int64_t)gridDim.x * 512 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    clock_probe[(int64_t)gridDim.x * 512 + 4 * blockIdx.x + 1] = __builtin_readcyclecounter();
+  }
 #else
   const bool probing = clock_probe != nullptr && blockIdx.x == 0;
 #endif
@@ -425,6 +431,12 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     if (cur.nm == 4) run_item(std::integral_constant<int, 4>{}, cur, has_next, nxt, it);
     else run_item(std::integral_constant<int, 2>{}, cur, has_next, nxt, it);
   }
+#ifdef SS_L512_TRACE
+  if (clock_probe && threadIdx.x == 0) {
+    clock_probe[(int64_t)gridDim.x * 512 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    clock_probe[(int64_t)gridDim.x * 512 + 4 * blockIdx.x + 3] = __builtin_readcyclecounter();
+  }
+#endif
   if (probing && tid0 == 0) {
     atomicAdd(clock_probe, (unsigned long long)__builtin_readcyclecounter() - probe_c0);
     atomicAdd(clock_probe + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - probe_r0);

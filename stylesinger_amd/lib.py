@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 16  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 17  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -72,7 +72,8 @@ class WaveNet(C.Structure):
            ("w_dil_q", _vp * SS_MAX_LAYERS), ("gs_w_dil_q", C.c_int64), ("q_scale_gate", C.c_float), ("q_scale_z", C.c_float),
            ("w_skipall_q", _vp), ("gs_w_skipall_q", C.c_int64),
            ("w_dil_f", _vp * SS_MAX_LAYERS), ("w_out_f", _vp * SS_MAX_LAYERS),
-           ("n_wsets", C.c_int32), ("mfma_products", C.c_int32)] + [(n, C.c_int64) for n in ("ws_w_dil_h", "ws_w_out_h", "ws_w_skipall_h", "ws_w_dil_f", "ws_w_out_f")]
+           ("n_wsets", C.c_int32), ("mfma_products", C.c_int32)] + [(n, C.c_int64) for n in ("ws_w_dil_h", "ws_w_out_h", "ws_w_skipall_h", "ws_w_dil_f", "ws_w_out_f")] \
+        + [("w_skipall_c", _vp), ("ws_w_skipall_c", C.c_int64)]
 
 
 class GemmBf16Args(C.Structure):

@@ -393,6 +393,8 @@ class StyleSingerHIP(torch.nn.Module):
         if self.bf16_hbm:
             t["w_cond_h"] = L.to_bf16(t["w_cond"])     # (unused in split mode: the hoisted projection runs in fp32 there)
             t["w_skipall_h"] = (self._sd_sets(t["w_skipall"]) if (self.sd and not f0) else self._split_w(t["w_skipall"], f0)) if self.split else L.to_bf16(t["w_skipall"])
+            if self.sd and not f0 and t["w_skipall"].shape[1] % 64 == 0:   # the same sets without the zero plane: [N][Np][L C] (ss_wavenet.w_skipall_c)
+                t["w_skipall_c"] = L.split_planes(t["w_skipall_h"])[0].to(torch.float16).contiguous()
             if self.q4 and not f0 and t["w_skipall"].shape[1] % 64 == 0:   # the fp4 lo plane in the lane order of ss_gemm_bf16_tile256q
                 t["w_skipall_q"] = L.pack_skip_q4(t["w_skipall"], shift=self.FP16_WSHIFT)[0]
         skip = self._pack_conv(prefix + ".skip_projection.weight", prefix + ".skip_projection.bias")
@@ -466,6 +468,9 @@ class StyleSingerHIP(torch.nn.Module):
             net.n_wsets, net.mfma_products = self.sd_sets, 1
             net.ws_w_dil_h, net.ws_w_out_h = packs[0]["w_dil_h.0"][0].numel(), packs[0]["w_out_h.0"][0].numel()
             net.ws_w_skipall_h = packs[0]["w_skipall_h"][0].numel()
+            if "w_skipall_c" in packs[0]:
+                net.w_skipall_c, _ = place("w_skipall_c")
+                net.ws_w_skipall_c = packs[0]["w_skipall_c"][0].numel()
             if "w_dil_f.0" in packs[0]:
                 net.ws_w_dil_f, net.ws_w_out_f = packs[0]["w_dil_f.0"][0].numel(), packs[0]["w_out_f.0"][0].numel()
         if self.q4 and not f0:

@@ -192,6 +192,16 @@ def test_skip_gemm_compact_operand_equals_the_pair_layout(one):
                     split=2, out_scale=1.0 / 256.0, gate256=True, one_product=one, a_compact=compact)
         outs.append(S)
     assert torch.equal(outs[0], outs[1])
+    if one:   # one_product = 2: the weights without their zero plane too (fp16 [Np][K]) - again the same fragments
+        Wc = L.split_planes(Ws)[0].to(torch.float16).contiguous()
+        S = torch.full((B, T, C), 3.0, device=dev)
+        L.gemm_bf16(Ah, Wc, B=B, T=T, K=K, taps=(0,), N=C, Np=Wc.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=L.pack_bias(bias),
+                    split=2, out_scale=1.0 / 256.0, gate256=True, one_product=2, a_compact=True)
+        assert torch.equal(S, outs[0]), "compact one-term weights"
+        S2 = torch.full((B, T, C), 3.0, device=dev)
+        L.gemm_bf16(A, Wc, B=B, T=T, K=K, taps=(0,), N=C, Np=Wc.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S2, bias=L.pack_bias(bias),
+                    split=2, out_scale=1.0 / 256.0, gate256=True, one_product=2)
+        assert torch.equal(S2, outs[0]), "compact one-term weights with the pair-layout A operand"
     wh, wl = (t[:C, :K].double() for t in L.split_planes(Ws))
     ref = torch.relu(Ah.double() @ ((wh + wl).t() / 256.0) + bias.double()).float()
     for b in range(B):

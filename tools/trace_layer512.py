@@ -42,7 +42,7 @@ def main():
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     if os.environ.get("SS_L512_GRID"):
         ncu = min(ncu, int(os.environ["SS_L512_GRID"]))
-    tr = torch.zeros(ncu * 8 * 8 * 8, device=d, dtype=torch.int64)
+    tr = torch.zeros(ncu * 8 * 8 * 8 + 4 * ncu, device=d, dtype=torch.int64)
 
     def run(k):
         s = k % NS
@@ -62,10 +62,33 @@ def main():
     torch.cuda.synchronize()
     print(f"launch time (trace build, no stamps written): {e0.elapsed_time(e1) / 6 * 1e3:.1f} us")
     L.check(L.load().ss_set_clock_probe(ctypes.c_void_p(tr.data_ptr())), "ss_set_clock_probe")
+    e0.record()
     run(6)
+    e1.record()
     torch.cuda.synchronize()
+    print(f"the stamped launch: {e0.elapsed_time(e1) * 1e3:.1f} us between its events")
     L.load().ss_set_clock_probe(None)
+    life = tr[ncu * 512:].view(ncu, 4).cpu().double()   # per workgroup: start (100 MHz ticks), start (shader cycles), end, end
+    tr = tr[:ncu * 512]
     t = tr.view(ncu, 8, 8, 8).cpu().double()     # workgroup, wave, tile slot, stamp
+    # ---- the launch as a whole. The shader-cycle counters differ between XCDs, so: (1) every workgroup's start / end on the constant 100 MHz
+    # counter, relative to the earliest start; (2) a workgroup's items on its OWN cycle axis, from its own start
+    s0 = life[:, 0].min()
+    st_us, en_us = (life[:, 0] - s0) / 100.0, (life[:, 2] - s0) / 100.0
+    ghz = ((life[:, 3] - life[:, 1]) / (life[:, 2] - life[:, 0]) / 10.0)
+    print(f"workgroup life on the 100 MHz counter: start {st_us.mean().item():.1f} us after the first one (max {st_us.max().item():.1f}), end {en_us.mean().item():.1f} us "
+          f"(min {en_us.min().item():.1f}, max {en_us.max().item():.1f}); shader clock over a workgroup's life {ghz.mean().item():.3f} GHz ({ghz.min().item():.3f} .. {ghz.max().item():.3f})")
+    ran = t[..., 0] > 0
+    print("a workgroup's items on its own cycle axis (from its first instruction): [B1] and tile end, mean (min .. max) over workgroups")
+    for i in range(8):
+        sel = ran[:, 0, i]
+        if not sel.any():
+            continue
+        b1 = t[sel][:, :, i, 0].mean(dim=1) - life[sel][:, 1]
+        en = t[sel][:, :, i, 7].amax(dim=1) - life[sel][:, 1]
+        print(f"  slot {i}: {int(sel.sum()):4d} workgroups   [B1] {b1.mean().item():9.0f} ({b1.min().item():9.0f} .. {b1.max().item():9.0f})   end {en.mean().item():9.0f} ({en.min().item():9.0f} .. {en.max().item():9.0f})")
+    tot = life[:, 3] - life[:, 1]
+    print(f"  workgroup life {tot.mean().item():9.0f} cycles ({tot.min().item():9.0f} .. {tot.max().item():9.0f})")
     n_tiles = B * ((T + 127) // 128)
     full = [i for i in range(8) if (i + 1) * ncu <= n_tiles]          # tile slots every workgroup ran
     t = t[:, :, full]
