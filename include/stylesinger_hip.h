@@ -52,8 +52,9 @@ int ss_struct_sizes(int64_t* out, int n);
  * "gate128" = 0|1 fp16x2 GATE launches of very many tiles on ss_gemm_bf16_gate128 (two workgroups per CU; default 1); "q4_force" = 0|1 the
  * fp16q4 kernels (ss_gemm_bf16_gate128q / _tile256q) take any launch they can compute, not only those that fill the chip (default 0; the parity
  * tests run one 30 s item through them); "layer512" = 0|1|2 the fp16x2 mel stack as one ss_layer512 launch per layer when the shape qualifies
- * (default 1; 0 = the gate + residual-projection launch pair; 2 = also for launches that do not fill the chip: the parity tests run one item through it); "layer512_tail" = 0|1 ss_layer512 runs the tiles of
- * an under-filled last round as half tiles (default 1; identical results). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
+ * (default 1; 0 = the gate + residual-projection launch pair; 2 = also for launches that do not fill the chip: the parity tests run one item through it); "layer512_tail" = 0|1|2 ss_layer512 runs the tiles of
+ * an under-filled last round as half tiles (default 1: the even workgroups take their half tile FIRST, which puts the two halves of the chip half a tile period out of phase - one
+ * streams through HBM while the other multiplies; 2: every half tile last; 0: whole tiles only; identical results). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
  * forwards SS_* variables once at load). */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */
@@ -369,8 +370,8 @@ int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
  *      (slot s = channels 8 s .. 8 s + 7), ss_layer512_h_elems(B, T) elements. DOUBLE BUFFERED: Hout must differ from Hin (a tile reads halo
  *      rows its neighbours rewrite). Rows >= lens[b] are zero (every producer masks them);
  *   P  x itself in FP32, in accumulator order, ss_layer512_stream_bytes(B, T) bytes, updated in place:
- *      [tile][wave 8][m 4][q 4][lane 64] x 4 floats; lane (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row
- *      32 m + l31 of the tile. (The two-launch form keeps the stream as an fp16 pair - 22 bits; fp32 costs the same bytes and a third of the
+ *      [tile][m 4][q 4][wave 8][lane 64] x 4 floats; lane (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row
+ *      32 m + l31 of the tile (the eight waves' blocks of a step lie side by side: the workgroup moves 8 KB contiguous per step). (The two-launch form keeps the stream as an fp16 pair - 22 bits; fp32 costs the same bytes and a third of the
  *      epilogue's instructions.)
  * Hout == NULL: gate only (the last layer: its residual stream is never read); P and Wr are then unused. */
 typedef struct ss_layer512_args {

@@ -65,7 +65,9 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     net carries the fragment-order packs and ss_layer512_ok(B, T, ...) holds; 0 = the gate + residual-projection launch pair; 2 = also below the
 //     chip-filling size (parity tests).
 //   layer512_tail: 1 (default) = ss_layer512 cuts the tiles of its last round into half tiles when that round would keep at most half of the
-//     workgroups busy (1408 tiles on 256 CUs: makespan 5.6 instead of 6 tile periods); 0 = whole tiles only (A/B; results are identical).
+//     workgroups busy (1408 tiles on 256 CUs: makespan 5.6 instead of 6 tile periods), and the EVEN workgroups run their half tile first - the two
+//     halves of the chip are then half a tile period out of phase, one streams through HBM while the other multiplies; 2 = every half tile last (the
+//     round-6 schedule before the phase shift); 0 = whole tiles only (A/B; results are identical in all three).
 //   q4_force: 0 (default) = the fp16q4 kernels take only launches that fill the chip (their _ok rules); 1 = any launch they can compute (parity tests run
 //     one 30 s item through them).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;

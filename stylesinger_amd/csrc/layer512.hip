@@ -63,6 +63,10 @@ constexpr int wr_step(int NP) { return NP * 1024; }
 constexpr int wr_wave(int NP) { return RSTEPS * wr_step(NP); }  // 32 768 B per wave (NP = 2)
 constexpr int E_TILE = BM * 512 * 4;       // 262 144 B of tiled addend per tile
 constexpr int P_TILE = BM * 256 * 4;       // 131 072 B of the pair stream per tile
+// E and P tiles: the eight waves' blocks of one (nb, m, q) step side by side ([..][q][wave 8][lane 64]: the workgroup reads 8 KB contiguous per step).
+// (One 32 KB / 16 KB stream per wave, the first layout of round 6, measures the same: 255.5 / 351.6 against 256.4 / 350.7 us per launch,
+// profiles/r06_kbench_layer512_phase_shift.log - the HBM channel hash copes with either.)
+constexpr bool WAVE_MAJOR = false;
 constexpr int nring(int NP) { return NP == 2 ? 3 : 5; }     // weight fragments of nring - 1 k-steps in flight (one product: 8 MFMAs per k-step, half the cover per step)
 constexpr int nring_r(int NP) { return NP == 2 ? 5 : 8; }   // ... of the residual projection (4 NP MFMAs per k-step)
 
@@ -143,16 +147,26 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
   // the launcher) the R tiles of that round are cut into 2 R HALF tiles of 64 rows - same code with two row blocks instead of four - so that the
   // round costs about 0.6 of a tile period.
   const int W = gridDim.x, g = blockIdx.x;
+  // PHASES. The epilogues of a tile pull 0.46 MB per CU through HBM (addend slab, stream, next activation tile), its conv loop nothing. Workgroups
+  // that start together stay in step for the 5.5 tiles of a launch, so the whole chip asks for its 117 MB at once - 17 us at HBM's pace for 3 us of
+  // arithmetic, 38 k cycles against 17 k on a quarter of the CUs (profiles/r06_trace_layer512_warm.log) - and then leaves the memory idle during
+  // the conv loops. With a split tail the EVEN workgroups therefore run their half tile FIRST and the odd ones last: the two halves of the chip
+  // are half a tile period apart for the whole launch, one streams while the other multiplies; same items per workgroup, same end. 278 -> 255 us
+  // (one product), 375 -> 351 us (two) per launch. Which bit of the index picks the class matters (0 and 4..7: 253-257 us, 1..3: 265-274):
+  // profiles/r06_kbench_layer512_phase_shift.log; a start delay on top of it (four phases, paid for at the end) gains 3 % at best.
+  // Knob layer512_tail = 2 keeps every half tile last (A/B).
   const int full_rounds = split_tail ? n_tiles / W : 0;
-  const int n_items = split_tail ? full_rounds + ((g >> 1) < n_tiles - full_rounds * W ? 1 : 0) : (n_tiles - g + W - 1) / W;
+  const bool has_half = split_tail && (g >> 1) < n_tiles - full_rounds * W;
+  const bool half_first = has_half && full_rounds > 0 && split_tail == 1 && (g & 1) == 0;
+  const int n_items = split_tail ? full_rounds + (has_half ? 1 : 0) : (n_tiles - g + W - 1) / W;
   auto item = [&](int i) {
     L512Item r;
-    if (split_tail && i >= full_rounds) {
+    if (has_half && i == (half_first ? 0 : full_rounds)) {
       r.tile = full_rounds * W + (g >> 1);
       r.r0 = 64 * (g & 1);
       r.nm = 2;
     } else {
-      r.tile = g + i * W;
+      r.tile = g + (half_first ? i - 1 : i) * W;
       r.r0 = 0;
       r.nm = 4;
     }
@@ -268,7 +282,9 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     // Request order = order of need (vmcnt retires in order: whatever is waited for drags everything older with it): E(m = 0), E(1) | E(2) |
     // E(3) | the stream P | the next item's DMA pieces last.
     const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr((const char*)a.E512 + (int64_t)tile * E_TILE + (int64_t)wave * (E_TILE / 8)), 0, E_TILE / 8, 0x00020000);
+        uniform_ptr((const char*)a.E512 + (int64_t)tile * E_TILE + (WAVE_MAJOR ? (int64_t)wave * (E_TILE / 8) : 0)), 0, WAVE_MAJOR ? E_TILE / 8 : E_TILE, 0x00020000);
+    constexpr int BLK = WAVE_MAJOR ? 1024 : 8192;            // bytes between consecutive (nb, m, q) blocks of a wave
+    const int wave_off = WAVE_MAJOR ? 0 : wave * 1024;
     // TWO blocks ahead: the slab is 256 KB per tile and CU, and with one block (8 KB per wave) in flight it arrived at ~26 B per cycle and CU -
     // the gate epilogue took 20 k cycles for 5 k of VALU work (profiles/r06_trace_layer512_v3.log)
     f32x4 ev[3][2][4];
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + mb0 + m) * 4 + q) * 1024, 0));
+          dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + mb0 + m) * 4 + q) * BLK + wave_off, 0));
     };
     load_e(ev[0], 0);
     load_e(ev[1], 1);
@@ -292,18 +308,20 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     // dead so that the loads fly under the rest of this epilogue, [B3] and the G pass
     [[maybe_unused]] f32x4 pv[NM][4];
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (int64_t)wave * (P_TILE / 8) : (const char*)a.Wg), 0, FUSE ? P_TILE / 8 : 0, 0x00020000);
+        uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (WAVE_MAJOR ? (int64_t)wave * (P_TILE / 8) : 0) : (const char*)a.Wg), 0,
+        FUSE ? (WAVE_MAJOR ? P_TILE / 8 : P_TILE) : 0, 0x00020000);
+    auto load_p = [&]() {
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          pv[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, ((mb0 + mm) * 4 + q) * BLK + wave_off, 0));
+    };
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       if (m + 2 < NM) load_e(ev[(m + 2) % 3], m + 2);
       if constexpr (FUSE) {
-        if (m == NM - 2) {
-#pragma unroll
-          for (int mm = 0; mm < NM; ++mm)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              pv[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, ((mb0 + mm) * 4 + q) * 1024, 0));
-        }
+        if (m == NM - 2) load_p();
       }
       const bool pad = t0 + 32 * m + l31 >= row_lim;
 #pragma unroll
@@ -327,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
         *reinterpret_cast<u32x2*>(Rc + (4 * wave + q) * SLOTB + (32 * m + l31) * 16 + 8 * lh) = u32x2{pk[0], pk[1]};
       }
     }
+    // (Measured, no gain: the stream loads and this DMA after [B3] instead - 264.4 / 355.1 against 266.8 / 349.2 us, profiles/r06_kbench_layer512_phase_shift.log)
     if (has_next) dma_item(nxt, Rn, lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // my G writes are done
     L512_STAMP(3);
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
             xo[e] = pad ? 0.f : xn;
             hp[e >> 1] |= (uint32_t)ss_f2t<true>(pad ? 0.f : xn + nb[q][e]) << (16 * (e & 1));
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), rsrc_p, w_voff, ((mb0 + m) * 4 + q) * 1024, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), rsrc_p, w_voff, ((mb0 + m) * 4 + q) * BLK + wave_off, 0);
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{hp[0], hp[1]}, rsrc_ho, ho, (4 * wave + q) * (BM * 16), 0);
         }
       }
@@ -468,13 +487,14 @@ __global__ void pack_res_kernel(const uint16_t* __restrict__ src, uint16_t* __re
   const uint16_t* s = src + (int64_t)row * (256 * 2) + (k >> 5) * 64 + plane * 32 + (k & 31);
   *reinterpret_cast<uint4*>(dst + (int64_t)i * 8) = *reinterpret_cast<const uint4*>(s);
 }
-// conditioner addend E [B][T][lde] (this layer's 512 packed columns) -> [tile][wave 8][nb 2][m 4][q 4][lane 64][4]: lane (l31, lh) holds packed
+// conditioner addend E [B][T][lde] (this layer's 512 packed columns) -> [tile][nb 2][m 4][q 4][wave 8][lane 64][4]: lane (l31, lh) holds packed
 // columns 64 wave + 32 nb + 8 q + 4 lh .. + 3 of row 32 m + l31 of the tile; rows >= T are zero. The values are stored as the gate's exp2
 // arguments: times -log2(e) in the sigmoid blocks (nb = 0), times -2 log2(e) in the tanh blocks (nb = 1).
 __global__ void tile_addend_kernel(const float* __restrict__ E, int lde, int64_t e_batch_stride, float* __restrict__ out, int T, int tiles_per_item, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 each
   if (i >= n) return;
-  const int lane = (int)(i & 63), q = (int)(i >> 6) & 3, m = (int)(i >> 8) & 3, nb = (int)(i >> 10) & 1, w = (int)(i >> 11) & 7;
+  const int lane = (int)(i & 63);
+  const int q = (int)(i >> (WAVE_MAJOR ? 6 : 9)) & 3, m = (int)(i >> (WAVE_MAJOR ? 8 : 11)) & 3, nb = (int)(i >> (WAVE_MAJOR ? 10 : 13)) & 1, w = (int)(i >> (WAVE_MAJOR ? 11 : 6)) & 7;
   const int64_t tile = i >> 14;
   const int b = (int)(tile / tiles_per_item), t = (int)(tile % tiles_per_item) * BM + 32 * m + (lane & 31);
   const int col = 64 * w + 32 * nb + 8 * q + 4 * (lane >> 5);
@@ -484,14 +504,14 @@ __global__ void tile_addend_kernel(const float* __restrict__ E, int lde, int64_t
   *reinterpret_cast<float4*>(out + i * 4) = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
 }
 
-// stack entry: X fp32 [B][T][ldx] -> the stream's two forms: P = x in accumulator order ([tile][wave 8][m 4][q 4][lane 64] x 4 floats; lane
+// stack entry: X fp32 [B][T][ldx] -> the stream's two forms: P = x in accumulator order ([tile][m 4][q 4][wave 8][lane 64] x 4 floats; lane
 // (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row 32 m + l31) and H = fp16(x + bias) in slot-major tiles
 // ([tile][slot 32][row 128] x 8 channels). Rows >= lens[b] are zero.
 __global__ void entry_kernel(const float* __restrict__ X, int ldx, int64_t x_batch_stride, const float* __restrict__ bias, const int32_t* __restrict__ lens,
                              uint16_t* __restrict__ H, float4* __restrict__ P, int T, int tiles_per_item, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte P entry each
   if (i >= n) return;
-  const int lane = (int)(i & 63), q = (int)(i >> 6) & 3, m = (int)(i >> 8) & 3, w = (int)(i >> 10) & 7;
+  const int lane = (int)(i & 63), q = (int)(i >> (WAVE_MAJOR ? 6 : 9)) & 3, m = (int)(i >> (WAVE_MAJOR ? 8 : 11)) & 3, w = (int)(i >> (WAVE_MAJOR ? 10 : 6)) & 7;
   const int64_t tile = i >> 13;
   const int b = (int)(tile / tiles_per_item), t = (int)(tile % tiles_per_item) * BM + 32 * m + (lane & 31);
   const int c0 = 32 * w + 8 * q + 4 * (lane >> 5);
@@ -591,7 +611,7 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
 #endif
   // the last round as half tiles when it would keep at most half of the workgroups busy (see the schedule in the kernel); knob "layer512_tail"
   const int rem = n_tiles % grid;
-  const int split_tail = (g_ss_tuning.layer512_tail != 0 && n_tiles >= grid && rem > 0 && 2 * rem <= grid) ? 1 : 0;
+  const int split_tail = (g_ss_tuning.layer512_tail != 0 && n_tiles >= grid && rem > 0 && 2 * rem <= grid) ? g_ss_tuning.layer512_tail : 0;
   const size_t lds = (size_t)2 * REGION;
   auto go = [&](auto kern) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

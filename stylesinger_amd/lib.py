@@ -692,8 +692,8 @@ def layer512_h_values(H, *, B, T):
 def layer512_stream_values(P, *, B, T):
     """the fp32 stream P (accumulator order) -> [B][T][256] (test helper: the index map of include/stylesinger_hip.h)"""
     nt = (T + 127) // 128
-    v = P.view(torch.float32).view(B * nt, 8, 4, 4, 2, 32, 4)          # tile, wave, m, q, lh, l31, e
-    return v.permute(0, 2, 5, 1, 3, 4, 6).reshape(B, nt * 128, 256)[:, :T]   # tile, (m, l31) = row, (wave, q, lh, e) = channel
+    v = P.view(torch.float32).view(B * nt, 4, 4, 8, 2, 32, 4)          # tile, m, q, wave, lh, l31, e
+    return v.permute(0, 1, 5, 3, 2, 4, 6).reshape(B, nt * 128, 256)[:, :T]   # tile, (m, l31) = row, (wave, q, lh, e) = channel
 
 
 def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None, bias_r=None, next_bias=None, out_scale=1.0 / 256.0,

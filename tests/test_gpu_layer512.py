@@ -219,7 +219,8 @@ def test_layer512_one_product_matches_float64_of_the_hi_terms():
 
 def test_layer512_half_tile_tail_is_bit_identical_to_whole_tiles():
     """300 tiles on 256 workgroups: the 44 tiles of the second round run as 88 HALF tiles (knob layer512_tail, default on) - same arithmetic per
-    row, so G, the stream and H must equal the whole-tile schedule bit for bit; and both match float64 of the same terms."""
+    row, so G, the stream and H must equal the whole-tile schedule bit for bit; and both match float64 of the same terms. Knob 1 (default) lets the even
+    workgroups run their half tile FIRST (the phase shift between the two halves of the chip), 2 keeps every half tile last: all three schedules agree."""
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     tiles = ncu + ncu // 6 + 1
     B = 5
@@ -232,7 +233,7 @@ def test_layer512_half_tile_tail_is_bit_identical_to_whole_tiles():
     n_tiles = B * tpi
     assert n_tiles >= ncu and 0 < n_tiles % ncu <= ncu // 2, "the shape must trigger the split on this device"
     outs = []
-    for knob in (1, 0):
+    for knob in (1, 0, 2):
         L.check(L.load().ss_set_tuning(b"layer512_tail", knob), "layer512_tail")
         try:
             GA = torch.zeros((B, T, 2 * C), device=c["dev"], dtype=torch.float16)
@@ -243,7 +244,7 @@ def test_layer512_half_tile_tail_is_bit_identical_to_whole_tiles():
             outs.append((GA, Hout, P))
         finally:
             L.check(L.load().ss_set_tuning(b"layer512_tail", 1), "layer512_tail")
-    for k, name in ((1, "whole tiles"), (0, "half-tile tail")):
+    for k, name in ((1, "whole tiles"), (0, "half tiles, even workgroups first"), (2, "half tiles last")):
         got_k = L.split_planes(outs[k][0])[0]
         eg_k = (got_k - _reference(c)).abs().max().item()
         ey_k = (L.layer512_stream_values(outs[k][2], B=B, T=T) - _stream_ref(c, got_k)).abs().max().item()
@@ -253,8 +254,9 @@ def test_layer512_half_tile_tail_is_bit_identical_to_whole_tiles():
             xf, yf = (x.float(), y.float()) if x.dtype != torch.uint8 else (x.view(torch.float32), y.view(torch.float32))
             bad = (xf != yf).nonzero()
             print(f"  {nm_}: {bad.shape[0]} of {xf.numel()} elements differ, max |diff| {(xf - yf).abs().max().item():.3e}; first {bad[:4].tolist()} last {bad[-2:].tolist()}")
-    for x, y in zip(outs[0], outs[1]):
-        assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), "half tiles = whole tiles, bit for bit"
+    for other in (1, 2):
+        for x, y in zip(outs[0], outs[other]):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), "half tiles = whole tiles, bit for bit, in either order"
     got = L.split_planes(outs[0][0])[0]
     eg = (got - _reference(c)).abs().max().item()
     ey = (L.layer512_stream_values(outs[0][2], B=B, T=T) - _stream_ref(c, got)).abs().max().item()
