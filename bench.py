@@ -40,12 +40,16 @@ MEL_GATE_FLOP = 20 * 2 * 256 * 512 * 3 / 1e0   # per frame per step, direct form
 F0_GATE_FLOP = 10 * 2 * 192 * 384 * 3 / 1e0
 PEAK_FP32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA = 2500e12            # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (spec figures with sparsity are 2x)
+PEAK_HBM = 8.0e12                   # MI355X_MICROARCH.md: HBM3E, bytes / s
 
 CONFIGS = {
     "c2": dict(batch=8, frames=1500, mel_steps=100, f0_steps=100, precision="fp32", sampler="ddpm"),
-    # configs[3] on the 16-bit matrix cores AT north_star parity. "fp16x2": fp16 operands, only the weights split into (hi, lo) pairs - two
-    # products per hidden GEMM of the mel denoiser (the f0 denoisers keep bf16x2); 1.5e-5 on the reference's 1000-step golden, 2.6e-5 at T = 5625
-    "c4": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16x2", sampler="ddpm"),
+    # configs[3] on the 16-bit matrix cores AT north_star parity. Since round 6 "fp16sd": ONE fp16 product per hidden GEMM of the mel denoiser, the weight
+    # rounding noise-shaped over the evaluations by cycling 32 sigma-delta weight sets: half the matrix work and weight bytes of fp16x2 at
+    # its parity - 1.75e-5 on the reference's 1000-step golden, 1.68e-5 on the item as specified (T = 5625 x 1000 steps), bar 1e-4. The f0 denoisers keep bf16x2.
+    "c4": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16sd", sampler="ddpm"),
+    # "fp16x2" (configs[3]'s mode of rounds 4-5): fp16 operands, only the weights split into (hi, lo) pairs - two products per hidden GEMM; 1.5e-5 / 1.45e-5
+    "c4x2": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16x2", sampler="ddpm"),
     # "bf16x2": every operand a (hi, mid) bf16 pair, three products per hidden GEMM: 2.2e-6 on the same golden, 15 % slower
     "c4bf16x2": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="bf16x2", sampler="ddpm"),
     # the same workload with plain bf16 operands (one product; 2.5e-3 from the fp32 reference after 1000 steps: does NOT meet north_star)
@@ -53,10 +57,9 @@ CONFIGS = {
     # fp16x2 with the second product of the mel gate and of the skip GEMM on gfx950's block-scaled fp4 matrix instruction (validated on hardware in
     # round 5: tests/test_gpu_fp16q4.py, tests/test_gpu_round5.py)
     "c4q": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16q4", sampler="ddpm"),
-    # round 6: ONE fp16 product per hidden GEMM, the weight rounding noise-shaped over the evaluations by cycling 32 weight sets ("fp16sd"):
-    # half the matrix work and weight bytes of fp16x2 at its parity (2.2e-5 on the reference's 1000-step golden in the CPU restatement)
+    # (the name fp16sd was first measured under in round 6: same as c4)
     "c4sd": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16sd", sampler="ddpm"),
-    # (the name the round-4 records of the fp16x2 mode were taken under: same as c4)
+    # (the name the round-4 records of the fp16x2 mode were taken under: same as c4x2)
     "c4f16": dict(batch=32, frames=5625, mel_steps=1000, f0_steps=100, precision="fp16x2", sampler="ddpm"),
     # one GPU's share of configs[4] (256 refs x 256 targets over 8 GPUs = 32 refs x 256 targets per GPU), at a representative size: 64 references x
     # 32 targets = 2048 pairs per step, batches of 32 references per target (the per-GPU reference count of the full sweep)
@@ -337,15 +340,15 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
                     break
         except (KeyError, ValueError, OSError):
             in_loop = None
-    csv_l512 = os.path.join(ROOT, "profiles", "r06_bench_c4_layer512_20steps_kernel_stats.csv")
-    if fused and not sd and B * T == 180000 and os.path.exists(csv_l512):   # this round's dominant C4 kernel inside the graph-replayed loop
+    l512_name = "r06_bench_c4_fp16sd_20steps_kernel_stats.csv" if sd else "r06_bench_c4x2_20steps_kernel_stats.csv"
+    csv_l512 = os.path.join(ROOT, "profiles", l512_name)
+    if fused and B * T == 180000 and os.path.exists(csv_l512):   # this round's dominant C4 kernel inside the graph-replayed loop
         try:
             import csv
             for row in csv.DictReader(open(csv_l512)):
-                if "layer512_kernel" in row["Name"] and "ELb1E" in row["Name"] or "layer512_kernel<true>" in row["Name"]:
+                if f"layer512_kernel<true, {1 if sd else 2}>" in row["Name"]:
                     us = float(row["AverageNs"]) * 1e-3
-                    in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak,
-                               "source": "profiles/r06_bench_c4_layer512_20steps_kernel_stats.csv"}
+                    in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak, "source": "profiles/" + l512_name}
                     break
         except (KeyError, ValueError, OSError):
             in_loop = None
@@ -367,17 +370,24 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     dense_block = None
     if dense is not None:
         dense_block = dict(dense, frac=executed / (dense["us_per_launch"] * 1e-6) / peak)
-    return dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)", from_committed_profile=in_loop,
-                measured=("loop context: replay of 20 x (gate, residual projection) minus replay of the 20 projections, per gate launch" if dense is not None
-                          else "20 launches of the kernel back to back in a hipGraph"), dense_replay=dense_block,
-                achieved=executed / sec / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=executed / sec / peak,
-                algorithmic_tflops=flops / sec / 1e12, algorithmic_frac=flops / sec / peak,
-                executed_mfma_frac=executed / sec / peak, executed_flops_per_launch=executed,
-                # `peak` is the data-sheet figure at 2.4 GHz; under this load the chip sustains `clock_ghz` (measured inside the
-                # kernel: s_memtime cycles / s_memrealtime), so the matrix pipes can deliver peak * clock_ghz / 2.4 at most
-                clock_ghz=clock_ghz, executed_mfma_frac_at_clock=(executed / sec / (peak * clock_ghz / 2.4)) if clock_ghz else None,
-                traffic=traffic, traffic_source=pmc_src, us_per_launch=sec * 1e6, flops_per_launch=flops,
-                launches_per_step=None, algorithmic_bytes_per_launch=_algorithmic_bytes(B * T, C, hbm, split, f16, fused, wino, wino_m))
+    abytes = _algorithmic_bytes(B * T, C, hbm, split, f16, fused, wino, wino_m)
+    out = dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)", from_committed_profile=in_loop,
+               measured=("loop context: replay of 20 x (gate, residual projection) minus replay of the 20 projections, per gate launch" if dense is not None
+                         else "20 launches of the kernel back to back in a hipGraph"), dense_replay=dense_block,
+               achieved=executed / sec / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=executed / sec / peak,
+               algorithmic_tflops=flops / sec / 1e12, algorithmic_frac=flops / sec / peak,
+               executed_mfma_frac=executed / sec / peak, executed_flops_per_launch=executed,
+               # `peak` is the data-sheet figure at 2.4 GHz; under this load the chip sustains `clock_ghz` (measured inside the
+               # kernel: s_memtime cycles / s_memrealtime), so the matrix pipes can deliver peak * clock_ghz / 2.4 at most
+               clock_ghz=clock_ghz, executed_mfma_frac_at_clock=(executed / sec / (peak * clock_ghz / 2.4)) if clock_ghz else None,
+               traffic=traffic, traffic_source=pmc_src, us_per_launch=sec * 1e6, flops_per_launch=flops,
+               launches_per_step=None, algorithmic_bytes_per_launch=abytes, hbm_frac=abytes / sec / PEAK_HBM)
+    if fused and out["hbm_frac"] > out["frac"]:
+        # the fused layer launch is closer to its HBM roof than to its matrix roof (one product: 1.03 GB in ~255 us = 0.50 of 8 TB/s against 0.26 of the
+        # fp16 matrix peak; its epilogues stream the addend slab and the residual stream in bursts - DESIGN.md 3.1l): the bound is named accordingly,
+        # the matrix figures stay beside it
+        out.update(bound="hbm", achieved=abytes / sec / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=out["hbm_frac"])
+    return out
 
 
 def _algorithmic_bytes(rows, C, hbm, split, f16, fused, wino, wino_m):
@@ -446,7 +456,7 @@ def mel_loop_in_run(infer, B, T, S_mel, executed_flop_per_frame_step, peak):
             "executed_mfma_frac": executed_flop_per_frame_step * S_mel * B * T / (ms * 1e-3) / peak, "frames": B * T}
 
 
-PARITY_FILES = ("r04_parity.json", "r05_parity.json")   # written by the GPU tests through tests/conftest.py::record_measurement; later wins
+PARITY_FILES = ("r04_parity.json", "r05_parity.json", "r06_parity.json")   # written by the GPU tests through tests/conftest.py::record_measurement; later wins
 
 
 def _parity_record(name):
@@ -504,7 +514,7 @@ def parity_block(mode, dev):
             "mel_l1_vs_fp32_reference_1000_step_golden": live["mel_l1"],
             "from_committed_gpu_tests": {"c4_as_specified_t5625_x_1000_steps_vs_the_real_reference": spec or None,
                                          "t5625_x_100_steps_vs_fp32_oracle": shape or None,
-                                         "files": ["profiles/" + f for f in PARITY_FILES], "tests": "tests/test_gpu_round5.py, tests/test_gpu_fp16x2.py, tests/test_gpu_round4.py"},
+                                         "files": ["profiles/" + f for f in PARITY_FILES], "tests": "tests/test_gpu_layer512.py, tests/test_gpu_round5.py, tests/test_gpu_fp16x2.py, tests/test_gpu_round4.py"},
             "meets_north_star": bool(vals) and max(vals) <= 1e-4}
 
 
@@ -512,10 +522,10 @@ def secondary_configs():
     """The other single-GPU BASELINE configs, one step each, so that the driver's default run observes them too (round-2 verdict):
     c5 = one GPU's share of the style-transfer sweep (50-step DDIM), c4 = 32 x 30 s, 1000-step mel diffusion, bf16-operand MFMA.
     Each runs in its own process AFTER the c2 line's timed region (own plans / graphs / precision mode, memory returned on exit) and
-    reports value, ms_per_step, dtype and its own live roofline block; c4 (fp16x2: meets north_star) and c4bf16 (plain bf16 operands: does not) carry
+    reports value, ms_per_step, dtype and its own live roofline block; c4 (fp16sd), c4x2 (fp16x2), c4q, c4bf16x2 (all meet north_star) carry
     their parity status, c5 its style-cache accounting, c1 is the B = 1 latency shape (`c1_gpu`)."""
     out = {}
-    for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4sd", 1, 1), ("c4q", 1, 1), ("c4bf16x2", 1, 1), ("c2x3", 6, 3)):
+    for name, steps, streams in (("c1", 10, 1), ("c5", 2, 1), ("c4", 1, 1), ("c4x2", 1, 1), ("c4q", 1, 1), ("c4bf16x2", 1, 1), ("c2x3", 6, 3)):
         # (c4bf16 - plain bf16 operands, 2.5e-3 from the reference: does not meet north_star - left the default line in round 5 to keep the run
         # within minutes; `python bench.py --config c4bf16` still measures it)
         # (c5: a step is a whole 2048-pair sweep, ~45 s: no untimed warm-up sweep - the first timed step carries the one-off graph captures, ~2 s)
@@ -865,7 +875,7 @@ def main():
                       f"sampler + 2x{cfg['f0_steps']}-step f0 loops + HiFi-GAN-NSF, per-reference style cache"}
         desc["c2x3"] = desc["c2"]
         desc["c1"] = desc["c2"].replace("utterances per GPU", "utterance (latency shape of inference/StyleSinger.py:175-186), one at a time")
-        desc["c4bf16"] = desc["c4f16"] = desc["c4bf16x2"] = desc["c4q"] = desc["c4sd"] = desc["c4"]
+        desc["c4bf16"] = desc["c4f16"] = desc["c4x2"] = desc["c4bf16x2"] = desc["c4q"] = desc["c4sd"] = desc["c4"]
         desc = desc[args.config]
         x3 = getattr(infer.model, "x3", False)
         split = bool(getattr(infer.model, "split", False))
@@ -938,15 +948,18 @@ def main():
                     "gemm16_res_kernel<6, 8": (2.0 * 12000 * 256 * 256, F32), "gemm16_res_kernel<6, 6": (2.0 * 24000 * 192 * 192, F32),
                     "gemm16_store_kernel<4>": (2.0 * 12000 * 5120 * 256, F32), "gemm16_store_kernel<6>": (2.0 * 24000 * 1920 * 192, F32)}) or \
                     top_kernels("r05_bench_c2_1stream_kernel_stats.csv")
-            elif args.config in ("c4", "c4f16") and B * T == 180000:
+            elif args.config in ("c4", "c4sd", "c4x2", "c4f16") and B * T == 180000:
                 H16 = PEAK_BF16_MFMA
-                tk = top_kernels("r06_bench_c4_layer512_20steps_kernel_stats.csv", {
-                    "layer512_kernel<true>": (2 * (2.0 * 180000 * 768 * 512 + 2.0 * 180000 * 256 * 256), H16), "layer512_kernel<false>": (2 * 2.0 * 180000 * 768 * 512, H16),
-                    "tile256s_kernel<0, true>": (2 * 2.0 * 180000 * 5120 * 256, H16)}, n=10)
+                one = args.config in ("c4", "c4sd")
+                npr = 1 if one else 2
+                tk = top_kernels("r06_bench_c4_fp16sd_20steps_kernel_stats.csv" if one else "r06_bench_c4x2_20steps_kernel_stats.csv", {
+                    f"layer512_kernel<true, {npr}>": (npr * (2.0 * 180000 * 768 * 512 + 2.0 * 180000 * 256 * 256), H16),
+                    f"layer512_kernel<false, {npr}>": (npr * 2.0 * 180000 * 768 * 512, H16),
+                    "tile256s_kernel<0, true, true>" if one else "tile256s_kernel<0, true, false>": (npr * 2.0 * 180000 * 5120 * 256, H16)}, n=10)
                 if tk:
-                    tk["note"] = ("profiled command: bench.py --config c4 --diff-steps 20 (20 mel steps AND 20 f0 steps: the f0 loops' and the vocoder's shares are ~10x "
-                                  "what they are in the 1000-step config; the per-launch averages are what carries over; the 19 000-20 000 launches of 11-15 us are the in-run parity "
-                                  "measurement - one T = 32 item x 1000 steps on the generic kernels - not the C4 loop)")
+                    tk["note"] = (f"profiled command: bench.py --config {'c4' if one else 'c4x2'} --diff-steps 20 (20 mel steps AND 20 f0 steps: the f0 loops' and the vocoder's "
+                                  "shares are ~10x what they are in the 1000-step config; the per-launch averages are what carries over; the 19 000-20 000 launches of 11-16 us are "
+                                  "the per-step projections of the diffusion embedding, once per process)")
                 rl["top_kernels"] = tk
             if not sweep_mode and not bf16 and wino and world == 1:
                 mel_exec = MEL_FLOP_PER_FRAME_STEP - MEL_COND_FLOP - MEL_GATE_FLOP * wino_saved

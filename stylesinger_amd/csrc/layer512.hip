@@ -137,6 +137,8 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
   const int d = a.d;
 
   constexpr int WG_STEP = wg_step(NP), WG_WAVE = wg_wave(NP), WR_STEP = wr_step(NP), WR_WAVE = wr_wave(NP), NRING = nring(NP), NRING_R = nring_r(NP);
+  // (Measured, no effect: a deeper weight ring - 6 / 7 / 8 k-steps instead of 5, 4 instead of 3 with two products - and separate copies of the gate
+  // weights per group of CUs (is the one 98 KB stream per wave an L2 hot spot? no: 2 / 4 copies cost 1-3 %): profiles/r06_kbench_layer512_phase_shift.log)
   const __amdgpu_buffer_rsrc_t rsrc_wg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Wg + (int64_t)wave * WG_WAVE), 0, WG_WAVE, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(FUSE ? (const char*)a.Wr + (int64_t)wave * WR_WAVE : (const char*)a.Wg), 0,
                                                                          FUSE ? WR_WAVE : 0, 0x00020000);

@@ -110,8 +110,11 @@ def test_fp16q4_mode_on_the_1000_step_golden_of_the_real_reference():
     assert uv == 0 and d.mean().item() <= 8e-5, d.mean().item()
 
 
-def test_c4_batch_items_match_their_single_runs():
-    """B = 32 x T = 5625 in `fp16x2` (20 + 2 x 20 steps keep it to seconds): the only size at which `ss_gemm_bf16` dispatches the mel gate to
+@pytest.mark.parametrize("mode", ["fp16x2", "fp16sd"])
+def test_c4_batch_items_match_their_single_runs(mode):
+    """(round 6: also in `fp16sd` - the batch then runs ss_layer512 with one product, compact gate rows and the compact one-term skip weights, the B = 1
+    runs the generic kernels on the pair layout with zero lo terms.)
+    B = 32 x T = 5625 in `fp16x2` (20 + 2 x 20 steps keep it to seconds): the only size at which `ss_gemm_bf16` dispatches the mel gate to
     `gate128_kernel` (>= 2048 tiles of 256 x 128) and runs `tile256s_kernel` over many rounds - reached here through `StyleSingerHIP.forward`, not
     through a forced unit test. Size-independent property (the reference only ever runs B = 1): items 0, 13, 31 against their own B = 1 runs on the
     same noise tape - integers exactly; mel: a B = 1 launch takes the generic tiles (other summation orders inside the fp32 accumulators), and a
@@ -120,13 +123,13 @@ def test_c4_batch_items_match_their_single_runs():
     anchor is therefore the item's B = 1 run in FP32 mode: both fp16x2 results must lie within the mode's bar (6e-5) of it."""
     S = 20
     over = dict(timesteps=S, K_step=S, f0_timesteps=S)
-    hp16 = config.make_hparams(dict(over, mfma_precision="fp16x2"))
+    hp16 = config.make_hparams(dict(over, mfma_precision=mode))
     sd = synth.synth_acoustic_state_dict(hp16, 91)
     B, T, Tp, Tr = 32, 5625, 105, 1500
     batch = synth.synth_batch(B, T, Tp, Tr, hp16, 91)
     noise = synth.draw_acoustic_noise(synth.NoiseTape(92), B, T, S, S)
     model = _model(hp16, sd)
-    assert model.f16 and model.split
+    assert model.f16 and model.split and model.sd == (mode == "fp16sd")
     full = _fwd(model, {k: v.cuda() for k, v in batch.items()}, noise=noise)
     assert torch.isfinite(full["mel_out"]).all()
     exact = _model(config.make_hparams(dict(over, mfma_precision="fp32")), sd)
@@ -144,12 +147,12 @@ def test_c4_batch_items_match_their_single_runs():
         e = (one["mel_out"][0] - full["mel_out"][i]).abs()
         eb = (full["mel_out"][i] - ref["mel_out"][0]).abs().mean().item()
         es = (one["mel_out"][0] - ref["mel_out"][0]).abs().mean().item()
-        print(f"item {i} of the B=32 x T=5625 fp16x2 batch: vs its fp32 B=1 run {eb:.3e}; the fp16x2 B=1 run vs fp32 {es:.3e}; batch item vs fp16x2 B=1 run "
+        print(f"item {i} of the B=32 x T=5625 {mode} batch: vs its fp32 B=1 run {eb:.3e}; the {mode} B=1 run vs fp32 {es:.3e}; batch item vs {mode} B=1 run "
               f"{e.mean().item():.3e} (max {e.max().item():.3e}); coarse-pitch flips {cf}")
         worst = dict(batch_vs_fp32=max(worst["batch_vs_fp32"], eb), single_vs_fp32=max(worst["single_vs_fp32"], es),
                      batch_vs_single=max(worst["batch_vs_single"], e.mean().item()), batch_vs_single_max=max(worst["batch_vs_single_max"], e.max().item()))
         assert cf == 0
-    record_measurement("c4_b32_t5625_20steps_fp16x2_items_vs_b1_runs", items=[0, 13, 31], **worst)
+    record_measurement(f"c4_b32_t5625_20steps_{mode}_items_vs_b1_runs", items=[0, 13, 31], **worst)
     assert worst["batch_vs_fp32"] <= 6e-5 and worst["single_vs_fp32"] <= 6e-5 and worst["batch_vs_single"] <= 6e-5, worst
 
 
