@@ -21,7 +21,9 @@
 #   kbench-layer512  round 6: ss_layer512 (one launch per residual layer of the fp16x2 mel stack) against the launch pair it replaces, C4 shape
 #   trace-layer512   per-phase shader-clock timing of layer512_kernel (builds the -DSS_L512_TRACE library first; hipcc works on the box)
 #   pmc-layer512     PMC passes on layer512_kernel (profiles/r06_pmc_layer512.json)
-#   profile-c4       rocprofv3 kernel stats of the C4 loop at 20 diffusion steps (profiles/r06_bench_c4_layer512_20steps_kernel_stats.csv)
+#   profile-c4 [cfg] rocprofv3 kernel stats of the C4 loop at 20 diffusion steps (cfg = c4 (fp16sd, default) | c4x2: profiles/r06_bench_c4_fp16sd_20steps_kernel_stats.csv,
+#                    r06_bench_c4x2_20steps_kernel_stats.csv)
+#   phases-layer512  the layer launch with its half tiles first / last and as whole tiles (knob layer512_tail; profiles/r06_kbench_layer512_phase_shift.log)
 #   power            rocm-smi power / sclk sampled under 12 s of back-to-back layer launches (1400 W = the cap)
 #   launch-floor     null-kernel hipGraph with the C2 mel loop's launch topology (tools/launch_floor.py)
 #   c5-full          the full per-GPU share of BASELINE configs[4]: 32 references x 256 targets (profiles/r06_bench_c5_full_share.json)
@@ -81,6 +83,7 @@ case "$sec" in
     bash tools/ablate_r16.sh run ;;
   kbench-layer512)
     python tools/kbench_layer512.py --iters 400
+    python tools/kbench_layer512.py --iters 400 --one --which layer512
     SS_LAYER512_TAIL=0 python tools/kbench_layer512.py --iters 400 --which fused ;;
   trace-layer512)
     mkdir -p stylesinger_amd/_abl
@@ -89,9 +92,11 @@ case "$sec" in
     SS_LIB_PATH=stylesinger_amd/_abl/libss_l512trace.so python tools/trace_layer512.py "$@" ;;
   pmc-layer512)
     bash tools/pmc_layer512.sh "$@" ;;
+  phases-layer512)
+    for k in 1 2 0; do echo "--- layer512_tail = $k"; SS_LAYER512_TAIL=$k python tools/kbench_layer512.py --one --iters 400 --which fused; SS_LAYER512_TAIL=$k python tools/kbench_layer512.py --iters 400 --which fused; done ;;
   profile-c4)
     (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c4 -o c4 -- \
-       python $R/bench.py --config c4 --diff-steps 20 --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/prof_c4.log 2>&1)
+       python $R/bench.py --config ${1:-c4} --diff-steps 20 --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/prof_c4.log 2>&1)
     head -12 "$(find gpurun_out/prof_c4 -name '*kernel_stats.csv' | head -1)" | cut -c1-220 ;;
   power)
     ( for i in $(seq 1 30); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power \(W\)|sclk" | tr '\n' ';'; echo; sleep 0.3; done ) > gpurun_out/smi_under_load.log 2>&1 &
