@@ -54,7 +54,8 @@ int ss_struct_sizes(int64_t* out, int n);
  * tests run one 30 s item through them); "layer512" = 0|1|2 the fp16x2 mel stack as one ss_layer512 launch per layer when the shape qualifies
  * (default 1; 0 = the gate + residual-projection launch pair; 2 = also for launches that do not fill the chip: the parity tests run one item through it); "layer512_tail" = 0|1|2 ss_layer512 runs the tiles of
  * an under-filled last round as half tiles (default 1: the even workgroups take their half tile FIRST, which puts the two halves of the chip half a tile period out of phase - one
- * streams through HBM while the other multiplies; 2: every half tile last; 0: whole tiles only; identical results). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
+ * streams through HBM while the other multiplies; 2: every half tile last; 0: whole tiles only; identical results); "skip_dense" = 0|1 (default 1) the skip GEMM with both operands compact (a_compact and one_product = 2) runs 64 channels per
+ * step with every DMA lane live; 0 keeps the 32-channel steps (identical results). The library reads NO environment variable: a direct C caller sets knobs here (the Python binding
  * forwards SS_* variables once at load). */
 int ss_set_tuning(const char* key, int value);
 /* current value of a tuning knob (>= 0), or < 0 for an unknown key */

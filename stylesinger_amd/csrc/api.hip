@@ -14,7 +14,7 @@ void ss_set_error(const char* fmt, ...) {
 
 extern "C" const char* ss_last_error(void) { return g_err; }
 
-SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 1, 0, 1, 1};
+SsTuning g_ss_tuning = {0, nullptr, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 2048, 1, 1, 1, 0, 1, 1, 1};
 
 namespace {
 struct Knob { const char* key; int* slot; bool (*ok)(int); };
@@ -33,7 +33,7 @@ const Knob* knobs(int* n) {
       {"wino_tn", &g_ss_tuning.wino_tn, ok_012},       {"wino_v1", &g_ss_tuning.wino_v1, ok_01},      {"voc_wino_max_mb", &g_ss_tuning.voc_wino_max_mb, ok_mb},
       {"e16", &g_ss_tuning.e16, ok_01},                {"mel_tail", &g_ss_tuning.mel_tail, ok_01},     {"gate128", &g_ss_tuning.gate128, ok_01},
       {"q4_force", &g_ss_tuning.q4_force, ok_01},      {"layer512", &g_ss_tuning.layer512, ok_012},
-      {"layer512_tail", &g_ss_tuning.layer512_tail, ok_012},
+      {"layer512_tail", &g_ss_tuning.layer512_tail, ok_012},       {"skip_dense", &g_ss_tuning.skip_dense, ok_01},
   };
   *n = (int)(sizeof(k) / sizeof(k[0]));
   return k;

@@ -68,10 +68,12 @@ static inline int ss_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //     workgroups busy (1408 tiles on 256 CUs: makespan 5.6 instead of 6 tile periods), and the EVEN workgroups run their half tile first - the two
 //     halves of the chip are then half a tile period out of phase, one streams through HBM while the other multiplies; 2 = every half tile last (the
 //     round-6 schedule before the phase shift); 0 = whole tiles only (A/B; results are identical in all three).
+//   skip_dense: 1 (default) = the fp16sd skip GEMM with both operands compact runs 64 channels per step (tile256s_kernel<.., DENSE>); 0 = 32-channel steps
+//     with dead DMA lanes (A/B; results are identical: the same products enter every accumulator in the same order).
 //   q4_force: 0 (default) = the fp16q4 kernels take only launches that fill the chip (their _ok rules); 1 = any launch they can compute (parity tests run
 //     one 30 s item through them).
 struct SsTuning { int wave_prio; unsigned long long* clock_probe; int gate16; int res_tile; int skip_tile; int res16; int skip16; int gate256; int gate16_ks;
-                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; int layer512; int layer512_tail; };
+                  int htile; int wino_tn; int wino_v1; int voc_wino_max_mb; int e16; int mel_tail; int gate128; int q4_force; int layer512; int layer512_tail; int skip_dense; };
 extern SsTuning g_ss_tuning;
 // fp16q4 range guard (ss_set_q4_guard): while non-null, every fp16q4 launch first reduces max |a| / (6 q_scale) over the fp16 operand it is about
 // to convert to fp4 into guard[which] (which = 0 gate, 1 skip GEMM; float bits, atomicMax): > 1 means the fixed scale saturates

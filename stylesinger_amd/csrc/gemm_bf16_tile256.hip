@@ -41,7 +41,10 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ds
 
 // ONE (with W2; "fp16sd", ss_gemm_bf16_args.one_product): a single fp16 weight term - the lo plane of the weights is neither fetched (dead DMA lanes, as the
 // A operand's second plane) nor read, 16 MFMAs per step instead of 32 (the 8 of the second k-step deferred past the barrier with the DMA pieces between them)
-template <int EPI, bool W2, bool ONE = false>
+// DENSE (with ONE; both operands compact: a_compact and one_product = 2, K %% 128 == 0): nothing but single fp16 terms on either side, so a 128-byte LDS
+// row holds 64 CHANNELS (two chunks side by side) instead of 32 channels and a dead plane: every DMA lane fetches, a step is four k-steps of one product
+// (32 MFMAs, the 16 of its second half deferred past the barrier), and the K loop has half the steps, barriers and DMA instructions.
+template <int EPI, bool W2, bool ONE = false, bool DENSE = false>
 __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_args a, int m_tiles_per_item, int m_tiles, int kchunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_t256[];   // 128 KB: [A0 32 K][B0 32 K][A1 32 K][B1 32 K]; epilogue: 2 x 64 KB staging
   char* const A0 = smem_t256;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   const int grp_w = a.group_size > 0 ? b / a.group_size : 0;
   const bool w_compact = ONE && a.one_product == 2;       // the one-term pack without its zero second plane: rows of K fp16
   const int ldw = w_compact ? a.K : 2 * a.K;              // 16-bit elements per packed weight row (both planes, one tap)
-  const int b_chunk = w_compact ? ROWB / 2 : ROWB;
+  const int b_chunk = (w_compact && !DENSE) ? ROWB / 2 : ROWB;
 
   auto uniform_ptr = [](const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -79,11 +82,11 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   const int slot0 = (lane & 7) ^ ((r0 >> 1) & 7);
   const int a_voff = ((t0 + r0) * a.lda + slot0 * 8) * 2;   // rows >= len are out of range: the DMA writes zeros
   const int b_voff = (r0 * ldw + slot0 * 8) * 2;            // packed weight rows >= Np read zeros
-  const int a_lo_dead = (W2 && slot0 >= 4) ? (int)0x80000000 : 0;   // W2: the A operand's second plane is never read - its lanes fetch nothing (zeros)
-  const int b_lo_dead = (ONE && slot0 >= 4) ? (int)0x80000000 : 0;  // ONE: nor is the weights'
+  const int a_lo_dead = (W2 && !DENSE && slot0 >= 4) ? (int)0x80000000 : 0;   // W2: the A operand's second plane is never read - its lanes fetch nothing (zeros)
+  const int b_lo_dead = (ONE && !DENSE && slot0 >= 4) ? (int)0x80000000 : 0;  // ONE: nor is the weights'
   // a_compact (W2, STORE): a row of A holds its hi terms only - chunk c at 64 c bytes of the row instead of 128 c (the LDS image keeps its 128-byte
   // rows, the dead lanes of the second plane write zeros as before): half the bytes the launch pulls from HBM
-  const int a_chunk = (W2 && a.a_compact) ? ROWB / 2 : ROWB;
+  const int a_chunk = (W2 && a.a_compact && !DENSE) ? ROWB / 2 : ROWB;   // (DENSE: a step takes 128 contiguous bytes = 64 channels of a compact row)
   auto piece = [&](char* Ab, char* Bb, int c, int i) {     // i = 0..3: A pieces, 4..7: B pieces of chunk c
     const int j = i & 3;
     if (i < 4) glds16(rsrc_a, Ab + (wave + 8 * j) * 8 * ROWB, (a_voff + 64 * j * a.lda * 2) | a_lo_dead, c * a_chunk);
@@ -104,10 +107,14 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
 
   // the two product groups (hi x mid, hi x hi of the second k-step) a step defers past the next barrier; zero fragments before the first step
   bf16x8 p_ah[4], p_bh[2], p_bm[2];
+  [[maybe_unused]] bf16x8 p_a6[4];   // DENSE: the A fragments of channels 48..63 (p_ah: 32..47, p_bh / p_bm: the weights' of the same two k-steps)
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) p_ah[m][e] = (__bf16)0.f;
+    for (int e = 0; e < 8; ++e) {
+      p_ah[m][e] = (__bf16)0.f;
+      if constexpr (DENSE) p_a6[m][e] = (__bf16)0.f;
+    }
 #pragma unroll
   for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -140,6 +147,34 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
     else rd_a(4, am0);
     rd_b(0, bh0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DENSE) {            // 64 channels per step: the previous step's channels 32..63 (two deferred groups) first, a DMA piece after each of the first 8
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i >> 1) & 3, n = i & 1;
+        acc[m][n] = ss_mfma_32x32x16<true>(i < 8 ? p_ah[m] : p_a6[m], i < 8 ? p_bh[n] : p_bm[n], acc[m][n]);
+        if (i < 8) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) piece(An, Bn, c + 1, i);   // wave-uniform branch
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 a2[4], b2[2];
+      rd_a(2, a2);
+      rd_b(2, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(ah0, bh0);                // channels 0..15
+      __builtin_amdgcn_sched_barrier(0);
+      rd_a(4, p_ah);
+      rd_b(4, p_bh);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(a2, b2);                  // channels 16..31; 32..47 (p_ah x p_bh) and 48..63 (p_a6 x p_bm) after the next barrier
+      __builtin_amdgcn_sched_barrier(0);
+      rd_a(6, p_a6);
+      rd_b(6, p_bm);
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
     if constexpr (ONE) {              // one weight term: the 8 MFMAs of the second k-step deferred by the previous step, a DMA piece after each
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -212,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void tile256s_kernel(const ss_gemm_bf16_arg
   }
   if constexpr (!ONE) mfma8(p_ah, p_bm);
   mfma8(p_ah, p_bh);
+  if constexpr (DENSE) mfma8(p_a6, p_bm);   // channels 48..63 of the last step, after its 32..47: every accumulator takes its products in channel order
 
   // ---- epilogue: four passes of 64 rows (accumulator block m = q of every wave: tile rows 128 wm + 32 q + (0..31) -> staging row 32 wm + ..),
   // staged as fp32 [64][256] in alternating 64-KB halves of the operand memory, then processed row-contiguously
@@ -365,19 +401,21 @@ extern "C" int ss_gemm_bf16_tile256(const ss_gemm_bf16_args* args, void* stream)
   const int m_tiles_per_item = ss_cdiv(a.T, BM);
   const int m_tiles = m_tiles_per_item * a.B;
   const size_t lds = (size_t)128 * 1024;
+  // both operands compact and K a multiple of 128: 64 channels per step (tile256s_kernel<.., DENSE>); knob "skip_dense" = 0 keeps 32-channel steps (A/B)
+  const bool dense = a.epi == SS_HEPI_STORE && a.split == 2 && a.a_compact && a.one_product == 2 && (a.K % 128) == 0 && g_ss_tuning.skip_dense != 0;
   auto go = [&](auto kern) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       ss_set_error("ss_gemm_bf16_tile256: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(e));
       return SS_ERR_HIP;
     }
-    hipLaunchKernelGGL(kern, dim3(m_tiles), dim3(512), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, a.K / 32);
+    hipLaunchKernelGGL(kern, dim3(m_tiles), dim3(512), lds, (hipStream_t)stream, a, m_tiles_per_item, m_tiles, a.K / (dense ? 64 : 32));
     return SS_OK;
   };
   if (a.epi == SS_HEPI_STORE) {
     SS_CHECK_ARG(a.C && (a.N % 4) == 0 && (a.ldc % 4) == 0 && (int64_t)a.T * a.ldc * 4 < (1ll << 31) && (a.act == SS_ACT_NONE_ || a.act == SS_ACT_RELU_),
                  "ss_gemm_bf16_tile256: STORE needs C, N %% 4 == 0, ldc %% 4 == 0, act none | relu");
-    SS_PROPAGATE(a.split == 2 ? (a.one_product ? go(&tile256s_kernel<SS_HEPI_STORE, true, true>) : go(&tile256s_kernel<SS_HEPI_STORE, true>))
+    SS_PROPAGATE(a.split == 2 ? (dense ? go(&tile256s_kernel<SS_HEPI_STORE, true, true, true>) : a.one_product ? go(&tile256s_kernel<SS_HEPI_STORE, true, true>) : go(&tile256s_kernel<SS_HEPI_STORE, true>))
                               : go(&tile256s_kernel<SS_HEPI_STORE, false>));
   } else {
     SS_CHECK_ARG(a.epi == SS_HEPI_RESX && a.X == nullptr && a.Y && a.cur_bias && (a.N % 32) == 0 && a.ldy >= 2 * a.N && (a.ldy % 8) == 0 &&

@@ -183,7 +183,7 @@ def load():
         raise StyleSingerHipError(f"ctypes mirror out of sync with include/stylesinger_hip.h: C={tuple(sizes)} py={mine}")
     _lib = lib
     for env, key in (("SS_WAVE_PRIO", b"wave_prio"), ("SS_GATE16", b"gate16"), ("SS_GATE16_KS", b"gate16_ks"), ("SS_GATE256", b"gate256"), ("SS_RES16", b"res16"), ("SS_SKIP16", b"skip16"), ("SS_RES_TILE", b"res_tile"), ("SS_SKIP_TILE", b"skip_tile"), ("SS_E16", b"e16"), ("SS_MEL_TAIL", b"mel_tail"), ("SS_HTILE", b"htile"),
-                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_Q4_FORCE", b"q4_force"), ("SS_LAYER512", b"layer512"), ("SS_LAYER512_TAIL", b"layer512_tail")):
+                     ("SS_WINO_TN", b"wino_tn"), ("SS_WINO_V1", b"wino_v1"), ("SS_GATE128", b"gate128"), ("SS_Q4_FORCE", b"q4_force"), ("SS_SKIP_DENSE", b"skip_dense"), ("SS_LAYER512", b"layer512"), ("SS_LAYER512_TAIL", b"layer512_tail")):
         val = os.environ.get(env)
         if val is not None:   # validated by the library; an out-of-range value is an error, not a silent different tile
             check(lib.ss_set_tuning(key, int(val)), f"ss_set_tuning({env}={val})")

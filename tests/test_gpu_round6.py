@@ -197,7 +197,15 @@ def test_skip_gemm_compact_operand_equals_the_pair_layout(one):
         S = torch.full((B, T, C), 3.0, device=dev)
         L.gemm_bf16(Ah, Wc, B=B, T=T, K=K, taps=(0,), N=C, Np=Wc.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=L.pack_bias(bias),
                     split=2, out_scale=1.0 / 256.0, gate256=True, one_product=2, a_compact=True)
-        assert torch.equal(S, outs[0]), "compact one-term weights"
+        assert torch.equal(S, outs[0]), f"compact one-term weights (64 channels per step: tile256s_kernel<.., DENSE>): max diff {(S - outs[0]).abs().max().item():.3e}"
+        L.check(L.load().ss_set_tuning(b"skip_dense", 0), "skip_dense")
+        try:
+            S0 = torch.full((B, T, C), 3.0, device=dev)
+            L.gemm_bf16(Ah, Wc, B=B, T=T, K=K, taps=(0,), N=C, Np=Wc.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S0, bias=L.pack_bias(bias),
+                        split=2, out_scale=1.0 / 256.0, gate256=True, one_product=2, a_compact=True)
+        finally:
+            L.check(L.load().ss_set_tuning(b"skip_dense", 1), "skip_dense")
+        assert torch.equal(S0, outs[0]), "compact one-term weights, 32-channel steps"
         S2 = torch.full((B, T, C), 3.0, device=dev)
         L.gemm_bf16(A, Wc, B=B, T=T, K=K, taps=(0,), N=C, Np=Wc.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S2, bias=L.pack_bias(bias),
                     split=2, out_scale=1.0 / 256.0, gate256=True, one_product=2)

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--gate128", action="store_true", help="with --f16: the gate on ss_gemm_bf16_gate128 (256 x 128 tiles, two workgroups per CU)")
     ap.add_argument("--pair-only", action="store_true", help="res with --split: the pair-only residual stream (X = NULL, Y read + rewritten in place)")
     ap.add_argument("--no-e", action="store_true", help="gate without the conditioner addend (what-if: how much of the launch is the addend?)")
+    ap.add_argument("--compact", type=int, default=0, help="with --f16 --which skip: 1 = compact A (hi terms only), 2 = + compact one-term weights (one_product = 2: the fp16sd "
+                    "skip GEMM; knob SS_SKIP_DENSE=0 keeps its 32-channel steps)")
     ap.add_argument("--e-layout", default="row", help="'row' = [B][T][L*2C], 'layer' = [L][B][T][2C]")
     a = ap.parse_args()
     a.split = a.split or a.f16
@@ -89,6 +91,14 @@ def main():
             def fs():
                 L.gemm_bf16(GA, Wq, B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=L.round_up(C, 32), epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S,
                             bias=bsk, split=3, out_scale=1.0 / 256.0, q_scale=0.25, gate256=True)
+        elif a.compact:
+            GAc = L.split_planes(GA)[0].to(torch.float16).contiguous()
+            Wc = L.split_planes(Wsk)[0].to(torch.float16).contiguous() if a.compact == 2 else Wsk
+            nprod = 1.0 if a.compact == 2 else nprod
+
+            def fs():
+                L.gemm_bf16(GAc, Wc, B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=Wc.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=bsk, a_compact=True,
+                            one_product=2 if a.compact == 2 else 0, **skw)
         else:
             def fs():
                 L.gemm_bf16(GA, Wsk, B=B, T=T, K=Lyr * C, taps=(0,), N=C, Np=Wsk.shape[0], epi=L.HEPI_STORE, lens=lens, act=L.ACT_RELU, out=S, bias=bsk, **skw)
