@@ -165,8 +165,10 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         H0, Pst = L.layer512_entry(X, None, B=B, T=T, lens=lens)
         Hb = [H0, torch.empty_like(H0)]
         NS = 4   # addend slabs to cycle through (each 369 MB at the C4 shape: more than the L2 / Infinity Cache keep)
-        E512 = [L.layer512_tile_addend(E[:, :, s_ * 2 * C:], B=B, T=T, lde=Lyr * 2 * C) for s_ in range(NS)]
-        GAf = torch.empty(B, T, NS * 2 * C, device=dev, dtype=torch.float16)
+        e16 = sd and int(getattr(infer.model, "sd_e_sets", 0)) > 0   # fp16sd: the addend as fp16 sigma-delta sets (one set per launch), as the product's loop
+        E512 = [(L.layer512_tile_addend_f16(E[:, :, s_ * 2 * C:], 1, B=B, T=T, lde=Lyr * 2 * C)[0] if e16 else
+                 L.layer512_tile_addend(E[:, :, s_ * 2 * C:], B=B, T=T, lde=Lyr * 2 * C)) for s_ in range(NS)]
+        GAf = torch.empty(B, T, NS * C, device=dev, dtype=torch.float16)   # compact gate rows, as the product's loop at this size (ss_layer512_args.g_compact)
         nbv = torch.randn(C, device=dev)
 
     def launch(l):
@@ -175,9 +177,9 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
             wg_, wr_ = packs[f"w_dil_f.{l}"], packs[f"w_out_f.{l}"]
             if sd:
                 wg_, wr_ = wg_[l % wg_.shape[0]], wr_[l % wr_.shape[0]]
-            L.layer512(Hb[l & 1], wg_, E512[l % NS], GAf[..., (l % NS) * 2 * C:], B=B, T=T, d=d, lens=lens, Hout=Hb[(l & 1) ^ 1], P=Pst,
-                       Wr=wr_, bias_r=packs[f"b_out.{l}"], next_bias=nbv, out_scale=2.0 ** -infer.model.FP16_WSHIFT, ldg=NS * 2 * C,
-                       g_bs=T * NS * 2 * C, n_products=1 if sd else 2)
+            L.layer512(Hb[l & 1], wg_, E512[l % NS], GAf[..., (l % NS) * C:], B=B, T=T, d=d, lens=lens, Hout=Hb[(l & 1) ^ 1], P=Pst,
+                       Wr=wr_, bias_r=packs[f"b_out.{l}"], next_bias=nbv, out_scale=2.0 ** -infer.model.FP16_WSHIFT, ldg=NS * C,
+                       g_bs=T * NS * C, n_products=1 if sd else 2, g_compact=True, e_f16=e16)
             return
         if hbm and q4:   # what run_residual_stack launches in fp16q4 mode when the launch fills the chip (ss_gemm_bf16_gate128q)
             L.gemm_bf16(Xh, packs[f"w_dil_q.{l}"], B=B, T=T, K=C, taps=(-d, 0, d), N=C, Np=2 * C, epi=L.HEPI_GATE, lens=lens,
@@ -370,7 +372,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     dense_block = None
     if dense is not None:
         dense_block = dict(dense, frac=executed / (dense["us_per_launch"] * 1e-6) / peak)
-    abytes = _algorithmic_bytes(B * T, C, hbm, split, f16, fused, wino, wino_m)
+    abytes = _algorithmic_bytes(B * T, C, hbm, split, f16, fused, wino, wino_m, e16=bool(fused and e16))
     out = dict(bound="mfma", kernel=name + " mel dilated conv k=3, 256->512, + gate)", from_committed_profile=in_loop,
                measured=("loop context: replay of 20 x (gate, residual projection) minus replay of the 20 projections, per gate launch" if dense is not None
                          else "20 launches of the kernel back to back in a hipGraph"), dense_replay=dense_block,
@@ -390,13 +392,13 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     return out
 
 
-def _algorithmic_bytes(rows, C, hbm, split, f16, fused, wino, wino_m):
+def _algorithmic_bytes(rows, C, hbm, split, f16, fused, wino, wino_m, e16=False):
     """HBM bytes one launch of the dominant kernel has to move, per precision mode:
     fused fp16x2 layer: conv operand H (fp16, + 16 halo rows per 128) + addend (fp32 x 2C) + stream x (fp32, read + rewritten) + G out (fp16) + H out (fp16);
     fp16x2 / fp16q4 gate: ONE plane of the operand pair is fetched and one written (the second term is never read by the matrix cores);
     bf16x2 gate: both planes in and out; plain bf16: one 2-byte plane; fp32: X, addend, G."""
-    if fused:
-        return rows * (2.0 * C * 144 / 128 + 4.0 * 2 * C + 2 * 4.0 * C + 2.0 * C + 2.0 * C) + 2 * 2.0 * (3 * C * 2 * C + C * C)
+    if fused:   # (e16: the addend as one fp16 set per launch - 2 bytes x 2C)
+        return rows * (2.0 * C * 144 / 128 + (2.0 if e16 else 4.0) * 2 * C + 2 * 4.0 * C + 2.0 * C + 2.0 * C) + 2 * 2.0 * (3 * C * 2 * C + C * C)
     if hbm:
         pin = 1 if (f16 or not split) else 2          # operand planes fetched
         pout = 1 if (f16 or not split) else 2         # output planes written

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 17 /* 17: compact gate rows (ss_layer512_args.g_compact, ss_gemm_bf16_args.a_compact), compact one-term skip weights (ss_gemm_bf16_args.one_product = 2, ss_wavenet.w_skipall_c); 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames, "fp16sd" (ss_wavenet.n_wsets / mfma_products / ws_*, ss_layer512_args.n_products); 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 18 /* 18: fp16 addend sets of ss_layer512 (ss_layer512_args.e_f16, ss_layer512_tile_addend_f16, ss_layer512_addend_halfs, ss_wavenet.n_esets), knob skip_dense; 17: compact gate rows (ss_layer512_args.g_compact, ss_gemm_bf16_args.a_compact), compact one-term skip weights (ss_gemm_bf16_args.one_product = 2, ss_wavenet.w_skipall_c); 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames, "fp16sd" (ss_wavenet.n_wsets / mfma_products / ws_*, ss_layer512_args.n_products); 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -395,7 +395,7 @@ typedef struct ss_layer512_args {
   const float* bias_r;      /* [256] residual half of the output-projection bias, or NULL */
   const float* next_bias;   /* [256] dstep_{l+1}, or NULL */
   int32_t g_compact;        /* 1: G rows are compact (see G) */
-  int32_t reserved_;
+  int32_t e_f16;            /* 1 (n_products = 1 only): E512 is ONE SET of the fp16 form made by ss_layer512_tile_addend_f16 */
   float out_scale;          /* 2^-s of the weight packs */
   float post_scale;         /* 1 / sqrt(2) */
 } ss_layer512_args;
@@ -411,6 +411,14 @@ int64_t ss_layer512_addend_floats(int B, int T);
 /* E [B][T][lde] (the layer's 512 packed addend columns start at E) -> the tiled slab the kernel reads (once per forward and layer); stored as
  * the gate's exp2 arguments: E * -log2(e) in the sigmoid blocks, E * -2 log2(e) in the tanh blocks */
 int ss_layer512_tile_addend(const float* E, int lde, int64_t e_batch_stride, float* out, int B, int T, void* stream);
+/* The same addend as n_sets fp16 SETS for ss_layer512_args.e_f16 (the one-product form, "fp16sd"): set k at out + k * set_stride, each
+ * ss_layer512_addend_halfs(B, T) fp16 elements ([tile][m 4][q 4][wave 8][lane 64] x (4 values of the sigmoid block | 4 of the tanh block): half the bytes
+ * of the fp32 slab, the largest stream of the launch). The addend is the same in every evaluation of a sampling loop, so one fp16 rounding of it would be a
+ * fixed bias (9.5e-5 on the reference's 1000-step golden); the sets are a first-order sigma-delta sequence of roundings of the scaled value (r_0 = 0,
+ * E_k = RNE16(e + r_k), r_(k+1) = r_k + (e - E_k)) and evaluation j of a loop reads set j % n_sets (8 sets: 2.5e-5, exact fp32 slab: 2.2e-5;
+ * oracle/dither_numerics.py --e-sets=N). */
+int64_t ss_layer512_addend_halfs(int B, int T);
+int ss_layer512_tile_addend_f16(const float* E, int lde, int64_t e_batch_stride, uint16_t* out, int n_sets, int64_t set_stride, int B, int T, void* stream);
 /* ss_split_f16 pack [512][3 * 256 * 2] of the gate-interleaved dilated-conv weights -> fragment order (786 432 elements; n_products = 1: the hi
  * terms only, 393 216 elements) */
 int ss_layer512_pack_gate(const uint16_t* w_pairs, uint16_t* out, int n_products, void* stream);
@@ -632,6 +640,11 @@ typedef struct ss_wavenet {
    * XCD's 4 MB L2 across the row tiles of a launch, which the 5.2 MB pair-layout pack does not. NULL: the pair-layout pack is used. */
   const uint16_t* w_skipall_c;
   int64_t ws_w_skipall_c;
+  /* mfma_products = 1, fused-layer form: > 0 -> the conditioner addend slab of ss_layer512 is kept as n_esets fp16 sets (ss_layer512_tile_addend_f16; the
+   * workspace grows by n_esets x L x ss_layer512_addend_halfs x 2 bytes: 29.5 GB for 8 sets at 32 x 5625 rows) and evaluation j reads set j % n_esets;
+   * 0 = the fp32 slab. */
+  int32_t n_esets;
+  int32_t reserved3_;
 } ss_wavenet;
 
 /* bytes of scratch the samplers need for (B, T) */

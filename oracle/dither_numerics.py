@@ -35,7 +35,9 @@ def weight_sets(w, n, sites_scale=2.0 ** SHIFT):
     return sets
 
 
-def make_conv(n_sets, sites, names, order="cyclic"):
+def make_conv(n_sets, sites, names, order="cyclic", e_sets=0):
+    """e_sets > 0: the step-invariant conditioner addend of every layer is ALSO stored in fp16, as e_sets sigma-delta sets cycled over the evaluations
+    (what a 2-byte addend slab of ss_layer512 would hold; 0 = exact fp32, the product's form)"""
     calls, cache = {}, {}
 
     def conv1d_cl(x, w, b, dilation=1, rounded=False):
@@ -45,6 +47,12 @@ def make_conv(n_sets, sites, names, order="cyclic"):
         key = names.get(id(w), "")
         site = ("cond" if "conditioner" in key else "dil" if "dilated" in key else "out" if "residual_layers" in key else
                 "skip" if "skip_projection" in key else None)
+        if site == "cond" and e_sets > 0 and key.startswith("postdiff"):
+            j = calls.get(id(w), 0)
+            calls[id(w)] = j + 1
+            if id(w) not in cache:
+                cache[id(w)] = weight_sets(F.conv1d(xt, w, b, padding=pad, dilation=dilation), e_sets, sites_scale=1.0)
+            return cache[id(w)][j % e_sets].transpose(1, 2)
         if not rounded or site not in sites or not key.startswith("postdiff"):
             return F.conv1d(xt, w, b, padding=pad, dilation=dilation).transpose(1, 2)
         j = calls.get(id(w), 0)
@@ -59,13 +67,13 @@ def make_conv(n_sets, sites, names, order="cyclic"):
     return conv1d_cl
 
 
-def run(name, n_sets, sites=("dil", "out", "skip")):
+def run(name, n_sets, sites=("dil", "out", "skip"), e_sets=0):
     case = harness.load_case(name)
     meta, gold = case["meta"], case["out"]
     hp, sd, batch = harness.case_setup(meta)
     names = {id(v): k for k, v in sd.items()}
     orig = R.conv1d_cl
-    R.conv1d_cl = make_conv(n_sets, sites, names)
+    R.conv1d_cl = make_conv(n_sets, sites, names, e_sets=e_sets)
     try:
         with torch.no_grad():
             ret = R.acoustic_forward(sd, hp, batch, synth.NoiseTape(meta["tape_seed"]), mel2ph=batch.get("mel2ph"))
@@ -81,8 +89,11 @@ if __name__ == "__main__":
     for a in sys.argv[1:]:
         if a.startswith("--golden="):
             golden = a.split("=", 1)[1]
+    es = [int(a.split("=", 1)[1]) for a in sys.argv[1:] if a.startswith("--e-sets=")] or [0]
     ns = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4, 8, 16]
     for n in ns:
-        t0 = time.time()
-        l1, mx, uv = run(golden, n)
-        print(f"one fp16 product, {n:2d} noise-shaped weight set(s) cycled over the evaluations: mel L1 {l1:.3e}  max {mx:.3e}  voicing flips {uv}  ({time.time() - t0:.0f} s)", flush=True)
+        for e in es:
+            t0 = time.time()
+            l1, mx, uv = run(golden, n, e_sets=e)
+            print(f"one fp16 product, {n:2d} noise-shaped weight set(s) cycled over the evaluations" + (f", conditioner addend in fp16 as {e} set(s)" if e else "") +
+                  f": mel L1 {l1:.3e}  max {mx:.3e}  voicing flips {uv}  ({time.time() - t0:.0f} s)", flush=True)

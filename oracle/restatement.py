@@ -85,7 +85,12 @@ FP16_WSHIFT = 8
 # (1.94e-4 on the reference's 1000-step golden) - then averages out over the steps like the activation rounding does: N = 2 / 4 / 8 / 16 / 32 / 64:
 # 1.10e-4 / 5.3e-5 / 3.2e-5 / 2.5e-5 / 2.2e-5 / 2.1e-5 (oracle/dither_numerics.py; fp16x2: 1.9e-5; a never-repeating sequence: 2.0e-5). Half the matrix
 # work and half the weight bytes of fp16x2. Everything else as fp16x2 (conditioner projection exact, stream, f0 denoisers in bf16x2).
+# The step-invariant conditioner ADDEND of every layer (conditioner projection + dilated-conv bias, the largest stream of the HIP path's fused layer
+# launch) is kept the same way at configs[3]'s size: FP16SD_E_SETS fp16 sigma-delta sets of the exactly computed addend, set j mod N_e in evaluation j
+# (ss_layer512_tile_addend_f16; the GPU rounds the addend times the gate's exp2 constant, the restatement the addend itself: same error class, not the same
+# bits). 1 set: 9.5e-5, 4: 3.3e-5, 8: 2.5e-5, 16: 2.3e-5 (oracle/dither_numerics.py --e-sets=N). 0 = exact addend (the HIP path's small-launch form).
 FP16SD_SETS = 32
+FP16SD_E_SETS = 8
 _SD_CALLS = {}
 _SD_CACHE = {}
 
@@ -93,6 +98,24 @@ _SD_CACHE = {}
 def _sd_reset():
     """start of a sampling loop: evaluation counter of every weight back to 0"""
     _SD_CALLS.clear()
+
+
+def _sd_addend(w_key, c):
+    """the exactly computed addend c of the layer whose conditioner weight is w_key -> its fp16 set of this evaluation"""
+    if FP16SD_E_SETS <= 0:
+        return c
+    key = ("addend", id(w_key))
+    j = _SD_CALLS.get(key, 0)
+    _SD_CALLS[key] = j + 1
+    ent = _SD_CACHE.get(key)
+    if ent is None or ent[0] is not w_key or ent[2].shape != c.shape or not torch.equal(ent[2], c):
+        sets, r = [], torch.zeros_like(c)
+        for _ in range(FP16SD_E_SETS):
+            ck = (c + r).half().float()
+            r = r + (c - ck)
+            sets.append(ck)
+        ent = _SD_CACHE[key] = (w_key, sets, c)
+    return ent[1][j % FP16SD_E_SETS]
 
 
 def _sd_weight(w):
@@ -432,6 +455,8 @@ def residual_stack(sd, prefix, x, cond, demb, L, cycle):
         d = 2 ** (l % cycle)
         ds = F.linear(demb, sd[p + ".diffusion_projection.weight"], sd[p + ".diffusion_projection.bias"])[:, None, :]
         c = conv1d_cl(cond, sd[p + ".conditioner_projection.weight"], sd[p + ".conditioner_projection.bias"], rounded="hoisted")
+        if _ROUND == "fp16sd":   # the addend (+ the dilated conv's bias, added below in exact arithmetic here) as fp16 sigma-delta sets over the evaluations
+            c = _sd_addend(sd[p + ".conditioner_projection.weight"], c)
         xin = x + ds
         if _ROUND == "bf16x2":   # the HIP path keeps the residual stream ONLY as the (hi, mid) pair of x + dstep_l (16 significant bits)
             hi, mid = _split2(xin)

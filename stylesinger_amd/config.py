@@ -48,6 +48,7 @@ DEFAULT_HPARAMS = dict(
     mfma_precision="fp32",
     # not a reference key: number of noise-shaped weight sets of mfma_precision "fp16sd" (one fp16 product per GEMM)
     fp16sd_sets=32,
+    fp16sd_e_sets=8,   # fp16sd: the conditioner addend slab of the fused layer launch as this many fp16 sigma-delta sets (0 = fp32 slab)
     # ProDiff decoder (hparams['decoder'] == 'prodiff', egs/stylesinger.yaml:145-155): timesteps = 8 teacher steps there
     timescale=1, pndm_speedup=None,
     # not a reference key: frame bucket of the hipGraph / plan cache (StyleSingerHIP.t_bucket)

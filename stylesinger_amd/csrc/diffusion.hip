@@ -38,6 +38,8 @@ struct WsLayout {
   void* P512;         // ss_layer512_stream_bytes
   float* E512;        // [L][ss_layer512_addend_floats]
   int64_t e512_layer; // floats per layer
+  uint16_t* E512h;    // fp16sd with ss_wavenet.n_esets > 0: [set][L][ss_layer512_addend_halfs] instead of E512
+  int64_t e512h_layer, e512h_set;
   bool g_compact;     // fused form whose skip GEMM runs on the many-round kernel: GAh rows hold the L*C hi terms only (no dead second plane)
   int64_t bytes;
 };
@@ -115,12 +117,20 @@ WsLayout ws_layout(const ss_wavenet* net, int B, int T, void* base) {
   w.P512 = nullptr;
   w.E512 = nullptr;
   w.e512_layer = 0;
+  w.E512h = nullptr;
+  w.e512h_layer = w.e512h_set = 0;
   if (fused512(net, B, T)) {
     w.H512[0] = (uint16_t*)take((ss_layer512_h_elems(B, T) + 1) / 2);
     w.H512[1] = (uint16_t*)take((ss_layer512_h_elems(B, T) + 1) / 2);
     w.P512 = take(ss_layer512_stream_bytes(B, T) / 4);
-    w.e512_layer = ss_layer512_addend_floats(B, T);
-    w.E512 = take(w.e512_layer * net->L);
+    if (net->mfma_products == 1 && net->n_esets > 0) {   // the addend as n_esets fp16 sets (half the bytes per launch; ss_layer512_tile_addend_f16)
+      w.e512h_layer = ss_layer512_addend_halfs(B, T);
+      w.e512h_set = w.e512h_layer * net->L;
+      w.E512h = (uint16_t*)take((w.e512h_set * net->n_esets + 1) / 2);
+    } else {
+      w.e512_layer = ss_layer512_addend_floats(B, T);
+      w.E512 = take(w.e512_layer * net->L);
+    }
   }
   w.bytes = off;
   return w;
@@ -205,6 +215,10 @@ int precompute_cond(const ss_wavenet* net, const float* cond, const int32_t* len
   if (w.E512)   // fused-layer form: every layer's 512 addend columns in ss_layer512's accumulator order
     for (int l = 0; l < net->L; ++l)
       SS_PROPAGATE(ss_layer512_tile_addend(w.E + (int64_t)l * 2 * net->C, NE, (int64_t)T * NE, w.E512 + (int64_t)l * w.e512_layer, B, T, stream));
+  if (w.E512h)  // ... as n_esets fp16 sigma-delta sets (fp16sd)
+    for (int l = 0; l < net->L; ++l)
+      SS_PROPAGATE(ss_layer512_tile_addend_f16(w.E + (int64_t)l * 2 * net->C, NE, (int64_t)T * NE, w.E512h + (int64_t)l * w.e512h_layer, net->n_esets, w.e512h_set, B, T,
+                                               stream));
   for (int l = 0; l < net->L; ++l)
     if (w.E16[l])
       SS_PROPAGATE(ss_gate16_tile_addend(w.E + (int64_t)l * 2 * net->C, NE, (int64_t)T * NE, w.E16[l], B, T, 2 * net->C, 1 << (l % net->dil_cycle),
@@ -223,7 +237,8 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
   const int C = net->C, L = net->L;
   const int NE = L * 2 * C;
   const int sp = smode(net) ? (net->mfma_split == 2 ? 2 : 1) : 0, pl = sp ? 2 : 1;   // split form; planes per 16-bit row
-  for (int l = 0; l < L && w.E512; ++l) {   // fused-layer form: gate + residual projection of layer l in one launch, G kept in LDS
+  const bool fused = w.H512[0] != nullptr;
+  for (int l = 0; l < L && fused; ++l) {   // fused-layer form: gate + residual projection of layer l in one launch, G kept in LDS
     ss_layer512_args f;
     memset(&f, 0, sizeof(f));
     f.Hin = w.H512[l & 1];
@@ -233,7 +248,12 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     f.T = T;
     f.Wg = net->w_dil_f[l] + wset_off(net, net->ws_w_dil_f);
     f.n_products = net->mfma_products == 1 ? 1 : 2;
-    f.E512 = w.E512 + (int64_t)l * w.e512_layer;
+    if (w.E512h) {   // evaluation j reads addend set j % n_esets
+      f.E512 = reinterpret_cast<const float*>(w.E512h + (int64_t)(g_wset_eval % net->n_esets) * w.e512h_set + (int64_t)l * w.e512h_layer);
+      f.e_f16 = 1;
+    } else {
+      f.E512 = w.E512 + (int64_t)l * w.e512_layer;
+    }
     const int gpl = w.g_compact ? 1 : pl;   // planes per G row
     f.G = w.GAh + (int64_t)l * C * gpl;
     f.g_batch_stride = (int64_t)T * L * C * gpl;
@@ -251,7 +271,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
     }
     SS_PROPAGATE(ss_layer512(&f, stream));
   }
-  for (int l = 0; l < L && !w.E512; ++l) {
+  for (int l = 0; l < L && !fused; ++l) {
     const int d = 1 << (l % net->dil_cycle);
     ss_gemm_bf16_args g = base_args_h(net, B, T, lens);
     g.A = w.Yh;
@@ -361,7 +381,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
 
 // Yh = bf16(X + dstep[step][0]) : the first layer's conv operand (bf16-in-HBM mode)
 int stack_entry_h(const ss_wavenet* net, int step, const int32_t* lens, int B, int T, const WsLayout& w, hipStream_t stream) {
-  if (w.E512)
+  if (w.H512[0])
     return ss_layer512_entry(w.X, net->C, (int64_t)T * net->C, net->dstep + (int64_t)step * net->L * net->C, lens, w.H512[0], w.P512, B, T, stream);
   if (net->mfma_split == 2)
     return ss_split_f16(w.X, net->dstep + (int64_t)step * net->L * net->C, 1.0f, w.Yh, B, T, net->C, net->C, 2 * net->C, lens,

@@ -112,7 +112,9 @@ struct L512Item {
   int tile, r0, nm;
 };
 
-template <bool FUSE, int NP>
+// EH: the addend slab holds fp16 values (ss_layer512_args.e_f16; one of the sigma-delta SETS the caller cycles over the evaluations): per lane and
+// (m, q) one 16-byte entry = 4 + 4 values of the two gate operands - half the bytes of the launch's largest stream.
+template <bool FUSE, int NP, bool EH = false>
 __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args a, int tiles_per_item, int n_tiles, int split_tail, unsigned long long* clock_probe) {
 #ifdef SS_L512_TRACE
   const bool probing = false;
@@ -283,19 +285,30 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     // ---- gate epilogue. Addend slab in accumulator order: block (nb, m), quarter q -> one 16-byte load per lane, 1 KB per wave instruction.
     // Request order = order of need (vmcnt retires in order: whatever is waited for drags everything older with it): E(m = 0), E(1) | E(2) |
     // E(3) | the stream P | the next item's DMA pieces last.
+    constexpr int E_BYTES = EH ? E_TILE / 2 : E_TILE;   // bytes of addend per tile
     const __amdgpu_buffer_rsrc_t rsrc_e = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr((const char*)a.E512 + (int64_t)tile * E_TILE + (WAVE_MAJOR ? (int64_t)wave * (E_TILE / 8) : 0)), 0, WAVE_MAJOR ? E_TILE / 8 : E_TILE, 0x00020000);
+        uniform_ptr((const char*)a.E512 + (int64_t)tile * E_BYTES + (WAVE_MAJOR ? (int64_t)wave * (E_BYTES / 8) : 0)), 0, WAVE_MAJOR ? E_BYTES / 8 : E_BYTES, 0x00020000);
     constexpr int BLK = WAVE_MAJOR ? 1024 : 8192;            // bytes between consecutive (nb, m, q) blocks of a wave
     const int wave_off = WAVE_MAJOR ? 0 : wave * 1024;
     // TWO blocks ahead: the slab is 256 KB per tile and CU, and with one block (8 KB per wave) in flight it arrived at ~26 B per cycle and CU -
     // the gate epilogue took 20 k cycles for 5 k of VALU work (profiles/r06_trace_layer512_v3.log)
-    f32x4 ev[3][2][4];
-    auto load_e = [&](f32x4 (&dst)[2][4], int m) {
+    using EvBlock = std::conditional_t<EH, u32x4[4], f32x4[2][4]>;   // EH: [q] = (4 fp16 of nb 0 | 4 fp16 of nb 1)
+    EvBlock ev[3];
+    auto load_e = [&](EvBlock& dst, int m) {
+      if constexpr (EH) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+        for (int q = 0; q < 4; ++q) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((mb0 + m) * 4 + q) * BLK + wave_off, 0);
+      } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + mb0 + m) * 4 + q) * BLK + wave_off, 0));
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            dst[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, w_voff, ((n * 4 + mb0 + m) * 4 + q) * BLK + wave_off, 0));
+      }
+    };
+    auto e_val = [&](const EvBlock& blk, int n, int q, int e) -> float {
+      if constexpr (EH) return ss_t2f_packed<true>(blk[q][2 * n + (e >> 1)], e & 1);
+      else return blk[n][q][e];
     };
     load_e(ev[0], 0);
     load_e(ev[1], 1);
@@ -335,8 +348,8 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int e = 2 * e2 + k, r = 4 * q + e;
-            const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, ev[m % 3][0][q][e]));
-            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, ev[m % 3][1][q][e]), 30.0f));
+            const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, e_val(ev[m % 3], 0, q, e)));
+            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, e_val(ev[m % 3], 1, q, e)), 30.0f));
             float g_ = (1.0f - eb) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));   // sigmoid(v0) * tanh(v1), net.py:72-73
             if (pad) g_ = 0.f;
             v |= (uint32_t)ss_f2t<true>(g_) << (16 * k);
@@ -506,6 +519,46 @@ __global__ void tile_addend_kernel(const float* __restrict__ E, int lde, int64_t
   *reinterpret_cast<float4*>(out + i * 4) = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
 }
 
+// The same addend as N fp16 SETS (ss_layer512_args.e_f16): [set][tile][m 4][q 4][wave 8][lane 64] x (4 fp16 of nb 0 | 4 fp16 of nb 1) - 16 bytes per
+// lane and (m, q), half the slab. The addend is the same in every evaluation of a sampling loop, so ONE fp16 rounding of it would be a fixed bias
+// (9.5e-5 on the reference's 1000-step golden, oracle/dither_numerics.py --e-sets=1); like the fp16sd weights it is therefore stored as a first-order
+// sigma-delta sequence of roundings of the scaled value (r_0 = 0, E_k = RNE16(e + r_k), r_(k+1) = r_k + (e - E_k)) that the caller cycles over the
+// evaluations: 8 sets 2.5e-5, 16 sets 2.3e-5, exact fp32 2.2e-5.
+__global__ void tile_addend_f16_kernel(const float* __restrict__ E, int lde, int64_t e_batch_stride, uint16_t* __restrict__ out, int n_sets, int64_t set_stride,
+                                       int T, int tiles_per_item, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte entry each
+  if (i >= n) return;
+  const int lane = (int)(i & 63), w = (int)(i >> 6) & 7, q = (int)(i >> 9) & 3, m = (int)(i >> 11) & 3;
+  const int64_t tile = i >> 13;
+  const int b = (int)(tile / tiles_per_item), t = (int)(tile % tiles_per_item) * BM + 32 * m + (lane & 31);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (t < T) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float4 x = *reinterpret_cast<const float4*>(E + (int64_t)b * e_batch_stride + (int64_t)t * lde + 64 * w + 32 * nb + 8 * q + 4 * (lane >> 5));
+      const float k = nb ? -2.0f * 1.44269504088896340736f : -1.44269504088896340736f;
+      v[4 * nb] = x.x * k; v[4 * nb + 1] = x.y * k; v[4 * nb + 2] = x.z * k; v[4 * nb + 3] = x.w * k;
+    }
+  }
+  for (int s_ = 0; s_ < n_sets; ++s_) {
+    uint32_t pk[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      uint32_t word = 0;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma clang fp contract(off)
+        const int e = 2 * e2 + kk;
+        const uint16_t h = ss_f2t<true>(v[e] + r[e]);
+        r[e] = r[e] + (v[e] - ss_t2f<true>(h));
+        word |= (uint32_t)h << (16 * kk);
+      }
+      pk[e2] = word;
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)s_ * set_stride + i * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+}
+
 // stack entry: X fp32 [B][T][ldx] -> the stream's two forms: P = x in accumulator order ([tile][m 4][q 4][wave 8][lane 64] x 4 floats; lane
 // (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row 32 m + l31) and H = fp16(x + bias) in slot-major tiles
 // ([tile][slot 32][row 128] x 8 channels). Rows >= lens[b] are zero.
@@ -577,6 +630,20 @@ extern "C" int ss_layer512_pack_res(const uint16_t* w_pairs, uint16_t* out, int 
   return SS_OK;
 }
 
+extern "C" int64_t ss_layer512_addend_halfs(int B, int T) { return (int64_t)B * ss_cdiv(T, BM) * (E_TILE / 4); }   // fp16 elements per set
+
+extern "C" int ss_layer512_tile_addend_f16(const float* E, int lde, int64_t e_batch_stride, uint16_t* out, int n_sets, int64_t set_stride, int B, int T, void* stream) {
+  SS_CHECK_ARG(E && out && B > 0 && T > 0 && (lde % 4) == 0 && lde >= 512 && (e_batch_stride % 4) == 0 && (((uintptr_t)E) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
+               "ss_layer512_tile_addend_f16: E / out 16-byte aligned, lde %% 4 == 0 and >= 512");
+  SS_CHECK_ARG(n_sets >= 1 && n_sets <= 64 && (n_sets == 1 || (set_stride >= ss_layer512_addend_halfs(B, T) && (set_stride % 8) == 0)),
+               "ss_layer512_tile_addend_f16: 1 <= n_sets <= 64, set_stride >= ss_layer512_addend_halfs(B, T) and a multiple of 8");
+  const int tpi = ss_cdiv(T, BM);
+  const int64_t n = (int64_t)B * tpi * (E_TILE / 32);
+  hipLaunchKernelGGL(tile_addend_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, E, lde, e_batch_stride, out, n_sets, set_stride, T, tpi, n);
+  SS_CHECK_LAUNCH("ss_layer512_tile_addend_f16");
+  return SS_OK;
+}
+
 // 1 if the fused layer launch can take this shape and is expected to pay: C = 256 (the kernel's fixed geometry), dilation <= 8, 32-bit offsets,
 // and at least four rounds of 128-row tiles per CU (below that the single-round kernels win)
 extern "C" int ss_layer512_ok(int B, int T, int C, int d_max, int ldg) {
@@ -625,7 +692,9 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
     return SS_OK;
   };
   SS_CHECK_ARG(a.n_products == 0 || a.n_products == 1 || a.n_products == 2, "ss_layer512: n_products = 1 | 2 (0 = 2)");
-  if (a.n_products == 1) SS_PROPAGATE(fuse ? go(&layer512_kernel<true, 1>) : go(&layer512_kernel<false, 1>));
+  SS_CHECK_ARG(!a.e_f16 || a.n_products == 1, "ss_layer512: the fp16 addend sets (e_f16) exist in the one-product form only");
+  if (a.n_products == 1 && a.e_f16) SS_PROPAGATE(fuse ? go(&layer512_kernel<true, 1, true>) : go(&layer512_kernel<false, 1, true>));
+  else if (a.n_products == 1) SS_PROPAGATE(fuse ? go(&layer512_kernel<true, 1>) : go(&layer512_kernel<false, 1>));
   else SS_PROPAGATE(fuse ? go(&layer512_kernel<true, 2>) : go(&layer512_kernel<false, 2>));
   SS_CHECK_LAUNCH("ss_layer512");
   return SS_OK;

@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 17  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 18  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -73,7 +73,7 @@ class WaveNet(C.Structure):
            ("w_skipall_q", _vp), ("gs_w_skipall_q", C.c_int64),
            ("w_dil_f", _vp * SS_MAX_LAYERS), ("w_out_f", _vp * SS_MAX_LAYERS),
            ("n_wsets", C.c_int32), ("mfma_products", C.c_int32)] + [(n, C.c_int64) for n in ("ws_w_dil_h", "ws_w_out_h", "ws_w_skipall_h", "ws_w_dil_f", "ws_w_out_f")] \
-        + [("w_skipall_c", _vp), ("ws_w_skipall_c", C.c_int64)]
+        + [("w_skipall_c", _vp), ("ws_w_skipall_c", C.c_int64), ("n_esets", C.c_int32), ("reserved3_", C.c_int32)]
 
 
 class GemmBf16Args(C.Structure):
@@ -96,7 +96,7 @@ class Layer512Args(C.Structure):
     _fields_ = [
         ("Hin", _vp), ("d", C.c_int32), ("n_products", C.c_int32), ("Hout", _vp), ("P", _vp),
         ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("Wg", _vp), ("Wr", _vp), ("E512", _vp), ("G", _vp), ("g_batch_stride", C.c_int64),
-        ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("next_bias", _vp), ("g_compact", C.c_int32), ("reserved_", C.c_int32), ("out_scale", C.c_float),
+        ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("next_bias", _vp), ("g_compact", C.c_int32), ("e_f16", C.c_int32), ("out_scale", C.c_float),
         ("post_scale", C.c_float),
     ]
 
@@ -675,6 +675,27 @@ def layer512_tile_addend(E, *, B, T, lde=None, e_bs=None, out=None):
     return out
 
 
+def layer512_tile_addend_f16(E, n_sets, *, B, T, lde=None, e_bs=None):
+    """E fp32 [B][T][lde] -> fp16 [n_sets][ss_layer512_addend_halfs]: the addend slab as sigma-delta sets (ss_layer512 with e_f16 reads ONE of them per launch)."""
+    lde = lde if lde is not None else E.shape[-1]
+    n = load().ss_layer512_addend_halfs(B, T)
+    out = torch.empty(n_sets, n, device=E.device, dtype=torch.float16)
+    check(load().ss_layer512_tile_addend_f16(ptr(E), lde, e_bs if e_bs is not None else T * lde, ptr(out), n_sets, n, B, T, stream_ptr()), "ss_layer512_tile_addend_f16")
+    return out
+
+
+def layer512_addend_values(E512, *, B, T, f16=False):
+    """a tiled addend slab (fp32 form, or ONE fp16 set) -> [B][T][512] in the packed column order, as the gate's exp2 arguments (test helper)"""
+    nt = (T + 127) // 128
+    if f16:
+        v = E512.view(B * nt, 4, 4, 8, 2, 32, 2, 4).float()            # tile, m, q, wave, lh, l31, nb, e
+        v = v.permute(0, 1, 5, 3, 6, 2, 4, 7)                          # tile, m, l31, wave, nb, q, lh, e
+    else:
+        v = E512.view(B * nt, 2, 4, 4, 8, 2, 32, 4)                    # tile, nb, m, q, wave, lh, l31, e
+        v = v.permute(0, 2, 6, 4, 1, 3, 5, 7)                          # tile, m, l31, wave, nb, q, lh, e
+    return v.reshape(B, nt * 128, 512)[:, :T]
+
+
 def layer512_entry(X, bias=None, *, B, T, lens=None):
     """ss_layer512_entry: X fp32 [B][T][256] -> (H = fp16(X + bias) in slot-major tiles (fp16 [elems]), P = X in accumulator order (uint8 buffer of fp32))"""
     H = torch.empty(load().ss_layer512_h_elems(B, T), device=X.device, dtype=torch.float16)
@@ -697,10 +718,10 @@ def layer512_stream_values(P, *, B, T):
 
 
 def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None, bias_r=None, next_bias=None, out_scale=1.0 / 256.0,
-             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True, n_products=2, g_compact=False):
+             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True, n_products=2, g_compact=False, e_f16=False):
     """ss_layer512: one launch per residual layer (gate + residual projection) of the fp16x2 mel denoiser; see include/stylesinger_hip.h."""
     a = Layer512Args()
-    a.Hin = ptr(Hin); a.d = d; a.n_products = n_products; a.g_compact = int(g_compact)
+    a.Hin = ptr(Hin); a.d = d; a.n_products = n_products; a.g_compact = int(g_compact); a.e_f16 = int(e_f16)
     a.Hout = ptr(Hout); a.P = ptr(P)
     a.lens = ptr(lens); a.B = B; a.T = T; a.Wg = ptr(Wg); a.Wr = ptr(Wr); a.E512 = ptr(E512)
     a.G = ptr(G); a.ldg = ldg if ldg is not None else G.shape[-1]; a.g_batch_stride = g_bs if g_bs is not None else T * a.ldg

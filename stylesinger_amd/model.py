@@ -197,6 +197,8 @@ class StyleSingerHIP(torch.nn.Module):
         # oracle/dither_numerics.py, oracle contract set_matmul_rounding("fp16sd")). The f0 denoisers keep bf16x2 as in the other fp16 modes.
         self.sd = prec == "fp16sd"
         self.sd_sets = max(1, int(os.environ.get("SS_SD_SETS", hp.get("fp16sd_sets", 32)))) if self.sd else 0
+        # the step-invariant conditioner addend of the fused layer launch as fp16 sigma-delta sets cycled over the evaluations (0 = the fp32 slab)
+        self.sd_e_sets = min(64, max(0, int(os.environ.get("SS_SD_E_SETS", hp.get("fp16sd_e_sets", 8))))) if self.sd else 0
         self.q4 = prec == "fp16q4"
         self.f16 = prec in ("fp16x2", "fp16q4", "fp16sd")
         self.split = prec in ("bf16x2", "fp16x2", "fp16q4", "fp16sd")
@@ -466,6 +468,7 @@ class StyleSingerHIP(torch.nn.Module):
         if self.sd and not f0:   # every w_*_h / w_*_f tensor is [N][...]: pointer = set 0, ws_* = elements between sets
             assert len(packs) == 1
             net.n_wsets, net.mfma_products = self.sd_sets, 1
+            net.n_esets = self.sd_e_sets
             net.ws_w_dil_h, net.ws_w_out_h = packs[0]["w_dil_h.0"][0].numel(), packs[0]["w_out_h.0"][0].numel()
             net.ws_w_skipall_h = packs[0]["w_skipall_h"][0].numel()
             if "w_skipall_c" in packs[0]:

@@ -217,6 +217,57 @@ def test_layer512_one_product_matches_float64_of_the_hi_terms():
         assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), "one product = two products with zero lo terms, bit for bit"
 
 
+def _unpack_e(Ep):
+    """inverse of _pack_e"""
+    E = torch.empty_like(Ep)
+    for p in range(C // 32):
+        E[..., 32 * p:32 * p + 32] = Ep[..., 64 * p:64 * p + 32]
+        E[..., C + 32 * p:C + 32 * p + 32] = Ep[..., 64 * p + 32:64 * p + 64]
+    return E
+
+
+def test_layer512_fp16_addend_sets():
+    """e_f16 ("fp16sd"): the conditioner addend as fp16 SIGMA-DELTA SETS (ss_layer512_tile_addend_f16) - (1) the sets are exactly the first-order
+    sequence r_0 = 0, E_k = RNE16(e + r_k), r_(k+1) = r_k + (e - E_k) of the scaled addend, so any run of k consecutive sets averages to the fp32 value
+    within half an fp16 ulp / k; (2) the launch reading set k equals float64 math on that set's values."""
+    B, T, d, NS = 2, 600, 2, 5
+    c = _case(B, T, [600, 411], d, seed=77)
+    Lyr = c["Lyr"]
+    Esrc = c["Eall"][..., 2 * C:4 * C].contiguous()                      # this layer's packed 512 columns
+    sets = L.layer512_tile_addend_f16(c["Eall"][..., 2 * C:], NS, B=B, T=T, lde=Lyr * 2 * C)
+    slab = L.layer512_tile_addend(c["Eall"][..., 2 * C:], B=B, T=T, lde=Lyr * 2 * C)
+    want = L.layer512_addend_values(slab, B=B, T=T)                     # the scaled fp32 values e
+    kcol = torch.where((torch.arange(2 * C, device=c["dev"]) // 32) % 2 == 0, -1.4426950408889634, -2 * 1.4426950408889634).float()
+    assert torch.equal(want, Esrc * kcol), "the fp32 slab holds E times the gate's exp2 constants"
+    r = torch.zeros_like(want)
+    acc = torch.zeros_like(want, dtype=torch.float64)
+    for k in range(NS):
+        got = L.layer512_addend_values(sets[k], B=B, T=T, f16=True)
+        ek = (want + r).to(torch.float16).float()
+        assert torch.equal(got, ek), f"set {k} is the sigma-delta rounding of the scaled addend"
+        r = r + (want - ek)
+        acc += got.double()
+        ulp = torch.clamp(want.abs(), min=2.0 ** -14) * 2.0 ** -10
+        assert bool(((acc / (k + 1) - want.double()).abs() <= 0.5 * ulp / (k + 1) + 1e-7).all()), f"mean of {k + 1} sets"
+    Wg, Wr = L.layer512_pack_gate(c["Ws"], 1), L.layer512_pack_res(c["Wos"], 1)
+    k = 3
+    ek = L.layer512_addend_values(sets[k], B=B, T=T, f16=True)
+    GA = torch.zeros((B, T, 2 * C), device=c["dev"], dtype=torch.float16)
+    Hout = torch.zeros_like(c["H"])
+    P = c["P"].clone()
+    L.layer512(c["H"], Wg, sets[k], GA, B=B, T=T, d=d, lens=c["lens"], Hout=Hout, P=P, Wr=Wr, bias_r=c["bo"], next_bias=c["nb"], out_scale=c["osc"], n_products=1, e_f16=True)
+    outs = [(GA, Hout, P)]
+    got = L.split_planes(outs[0][0])[0]
+    c2 = dict(c, E=_unpack_e((ek / kcol).double()).float())               # the set's values in the reference's units (fp32 division: error 1 ulp of fp32, far below the bar)
+    eg = (got - _reference(c2, one=True)).abs().max().item()
+    ey = (L.layer512_stream_values(outs[0][2], B=B, T=T) - _stream_ref(c, got, one=True)).abs().max().item()
+    e_exact = (got - _reference(c, one=True)).abs().max().item()
+    print(f"layer512 with fp16 addend set {k} of {NS}: G vs float64 on the set's values {eg:.2e}, stream {ey:.2e}; vs the exact addend {e_exact:.2e} (one set's rounding)")
+    assert eg <= 3e-4 and ey <= 4e-6, (eg, ey)
+    with pytest.raises(L.StyleSingerHipError):   # the fp16 addend exists in the one-product form only
+        L.layer512(c["H"], L.layer512_pack_gate(c["Ws"]), sets[k], outs[0][0], B=B, T=T, d=d, lens=c["lens"], out_scale=c["osc"], n_products=2, e_f16=True)
+
+
 def test_layer512_half_tile_tail_is_bit_identical_to_whole_tiles():
     """300 tiles on 256 workgroups: the 44 tiles of the second round run as 88 HALF tiles (knob layer512_tail, default on) - same arithmetic per
     row, so G, the stream and H must equal the whole-tile schedule bit for bit; and both match float64 of the same terms. Knob 1 (default) lets the even

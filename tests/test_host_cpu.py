@@ -20,7 +20,7 @@ def test_library_loads_and_exports_header_symbols():
     assert len(names) >= 30
     for n in names:
         assert hasattr(l, n), n
-    assert l.ss_abi_version() == lib.ABI_VERSION == 17
+    assert l.ss_abi_version() == lib.ABI_VERSION == 18
     assert l.ss_last_error() is not None
 
 

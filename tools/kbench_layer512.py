@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--lo-bits", type=int, default=0, help="experiment: keep only this many mantissa bits of the weights' lo terms (0 = all 10): does the "
                     "matrix pipe draw less power - and the chip clock higher - when one operand's low mantissa bits are zero?")
     ap.add_argument("--zero-lo", action="store_true", help="experiment: lo terms = 0 (the power a second product of zeros draws)")
+    ap.add_argument("--e16", action="store_true", help="with --one: the addend as fp16 sets (ss_layer512_args.e_f16), one set per launch - the fp16sd loop's form")
     ap.add_argument("--one", action="store_true", help="n_products = 1: ONE fp16 weight term (the fp16sd mode's launch; the pair column still shows fp16x2's two launches)")
     a = ap.parse_args()
     d = torch.device("cuda:0")
@@ -32,7 +33,8 @@ def main():
     H0, P = L.layer512_entry(X0, None, B=B, T=T, lens=lens)
     H = [H0, torch.empty_like(H0)]
     E = torch.randn(B, T, NS * 2 * C, device=d)
-    E512 = [L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C) for s in range(NS)]
+    E512 = [(L.layer512_tile_addend_f16(E[..., s * 2 * C:], 1, B=B, T=T, lde=NS * 2 * C)[0] if a.e16 else L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C))
+            for s in range(NS)]
     GA = torch.empty(B, T, NS * 2 * C, device=d, dtype=torch.float16)
     w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
     Ws = L.split_f16(L.pack_conv_weight(w, interleave_half=C), scale=256.0)
@@ -78,12 +80,12 @@ def main():
         k[0] += 1
         s = k[0] % NS
         L.layer512(H[k[0] & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k[0] & 1) ^ 1], P=P, Wr=Wr, bias_r=bo, next_bias=nb,
-                   ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
+                   ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP, e_f16=a.e16)
 
     def gate_only_new():
         k[0] += 1
         s = k[0] % NS
-        L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
+        L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP, e_f16=a.e16)
 
     for name, fn, fl in (("gate128 + tile256 RESX (the launch pair)", pair, fl_gate + fl_res), ("gate128 alone", gate_only_old, fl_gate),
                          ("layer512 fused (gate + residual projection)" + (", ONE product" if a.one else ""), fused, (fl_gate + fl_res) * fl1),

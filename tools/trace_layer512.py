@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=5625)
     ap.add_argument("--gate-only", action="store_true")
+    ap.add_argument("--e16", action="store_true", help="with --one: the addend as fp16 sets (ss_layer512_args.e_f16), one set per launch - the fp16sd loop's form")
     ap.add_argument("--one", action="store_true", help="n_products = 1 (the fp16sd launch)")
     ap.add_argument("--warm", type=int, default=800, help="launches before the stamped one: the chip ramps its clock up over ~0.1 s of load, and a phase that waits "
                     "for memory costs more CYCLES at a higher clock - a cold trace (1.3 GHz) understates them")
@@ -33,7 +34,8 @@ def main():
     H0, P = L.layer512_entry(X0, None, B=B, T=T, lens=lens)
     H = [H0, torch.empty_like(H0)]
     E = torch.randn(B, T, NS * 2 * C, device=d)
-    E512 = [L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C) for s in range(NS)]
+    E512 = [(L.layer512_tile_addend_f16(E[..., s * 2 * C:], 1, B=B, T=T, lde=NS * 2 * C)[0] if a.e16 else L.layer512_tile_addend(E[..., s * 2 * C:], B=B, T=T, lde=NS * 2 * C))
+            for s in range(NS)]
     GA = torch.empty(B, T, NS * 2 * C, device=d, dtype=torch.float16)
     w = torch.randn(2 * C, C, 3, device=d) / math.sqrt(3 * C)
     NP = 1 if a.one else 2
@@ -49,10 +51,10 @@ def main():
     def run(k):
         s = k % NS
         if a.gate_only:
-            L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
+            L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP, e_f16=a.e16)
         else:
             L.layer512(H[k & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k & 1) ^ 1], P=P, Wr=Wr, bias_r=bo,
-                       next_bias=nb, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP)
+                       next_bias=nb, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP, e_f16=a.e16)
     for k in range(6):
         run(k)
     torch.cuda.synchronize()
