@@ -177,7 +177,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
             wg_, wr_ = packs[f"w_dil_f.{l}"], packs[f"w_out_f.{l}"]
             if sd:
                 wg_, wr_ = wg_[l % wg_.shape[0]], wr_[l % wr_.shape[0]]
-            L.layer512(Hb[l & 1], wg_, E512[l % NS], GAf[..., (l % NS) * C:], B=B, T=T, d=d, lens=lens, Hout=Hb[(l & 1) ^ 1], P=Pst,
+            L.layer512(Hb[l & 1], wg_, E512[l % NS], GAf[..., (l % NS) * C:], B=B, T=T, d=d, lens=lens, Hout=Hb[(l & 1) ^ 1], P=Pst, cur_bias=nbv,
                        Wr=wr_, bias_r=packs[f"b_out.{l}"], next_bias=nbv, out_scale=2.0 ** -infer.model.FP16_WSHIFT, ldg=NS * C,
                        g_bs=T * NS * C, n_products=1 if sd else 2, g_compact=True, e_f16=e16)
             return
@@ -394,11 +394,11 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
 
 def _algorithmic_bytes(rows, C, hbm, split, f16, fused, wino, wino_m, e16=False):
     """HBM bytes one launch of the dominant kernel has to move, per precision mode:
-    fused fp16x2 layer: conv operand H (fp16, + 16 halo rows per 128) + addend (fp32 x 2C) + stream x (fp32, read + rewritten) + G out (fp16) + H out (fp16);
+    fused fp16x2 / fp16sd layer: conv operand H (fp16, + 16 halo rows per 128) + addend (fp32 x 2C; one fp16 set with e16) + the stream's fp16 remainder (read + rewritten) + G out (fp16) + H out (fp16);
     fp16x2 / fp16q4 gate: ONE plane of the operand pair is fetched and one written (the second term is never read by the matrix cores);
     bf16x2 gate: both planes in and out; plain bf16: one 2-byte plane; fp32: X, addend, G."""
     if fused:   # (e16: the addend as one fp16 set per launch - 2 bytes x 2C)
-        return rows * (2.0 * C * 144 / 128 + (2.0 if e16 else 4.0) * 2 * C + 2 * 4.0 * C + 2.0 * C + 2.0 * C) + 2 * 2.0 * (3 * C * 2 * C + C * C)
+        return rows * (2.0 * C * 144 / 128 + (2.0 if e16 else 4.0) * 2 * C + 2 * 2.0 * C + 2.0 * C + 2.0 * C) + 2 * 2.0 * (3 * C * 2 * C + C * C)
     if hbm:
         pin = 1 if (f16 or not split) else 2          # operand planes fetched
         pout = 1 if (f16 or not split) else 2         # output planes written

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 18 /* 18: fp16 addend sets of ss_layer512 (ss_layer512_args.e_f16, ss_layer512_tile_addend_f16, ss_layer512_addend_halfs, ss_wavenet.n_esets), knob skip_dense; 17: compact gate rows (ss_layer512_args.g_compact, ss_gemm_bf16_args.a_compact), compact one-term skip weights (ss_gemm_bf16_args.one_product = 2, ss_wavenet.w_skipall_c); 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames, "fp16sd" (ss_wavenet.n_wsets / mfma_products / ws_*, ss_layer512_args.n_products); 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
+#define SS_ABI_VERSION 19 /* 19: the residual stream of ss_layer512 as (H, fp16 remainder) instead of an fp32 copy (ss_layer512_args.cur_bias; P halves); 18: fp16 addend sets of ss_layer512 (ss_layer512_args.e_f16, ss_layer512_tile_addend_f16, ss_layer512_addend_halfs, ss_wavenet.n_esets), knob skip_dense; 17: compact gate rows (ss_layer512_args.g_compact, ss_gemm_bf16_args.a_compact), compact one-term skip weights (ss_gemm_bf16_args.one_product = 2, ss_wavenet.w_skipall_c); 16: ss_layer512 (one launch per residual layer of the fp16x2 mel denoiser: gate + residual projection with G kept in LDS), ss_layer512_pack_gate / _pack_res / _tile_addend, ss_wavenet.w_dil_f / w_out_f, knob layer512, ss_round_f16_rows takes the items' own lengths, ss_set_q4_guard, ss_mel_denorm reports non-finite frames, "fp16sd" (ss_wavenet.n_wsets / mfma_products / ws_*, ss_layer512_args.n_products); 15: ss_f0track (f0 tracker of the input producers), ss_f0track_params, ss_vad_trim, ss_normalize_volume, ss_round_f16_rows, knob q4_force; removed ss_gemm_bf16_tile128 and the knobs tile128 / skip_deep (measured: no gain); 14: fp16q4 gate (ss_gemm_bf16_args.split = 3 + q_scale, ss_gemm_bf16_gate128q, ss_gate128q_kindex), ss_gemm_bf16_gate128 / _tile128, tuning knobs gate128 / tile128 / skip_deep; 13: fp16x2 mode (ss_gemm_bf16_args.split = 2 + out_scale, ss_split_f16, ss_wavenet.mfma_split = 2 + mfma_out_scale); 12: bf16x2 split-operand mode (ss_gemm_bf16_args.split, ss_split_bf16, ss_wavenet.mfma_split), DDIM eta + double schedule, tuning knob table; 2: grouped launches + Winograd weights; 3: mfma_bf16 fields, samplers, front end, writer; 4: deferred skip; 5: folded skip projection; 6: PLMS step_hi, per-item Philox counters, ss_fill_normal_rows, ProDiff sampler, emotion LSTM; 7: bf16-in-HBM GEMM + bf16 weight copies; 9: input producers (ss_norm_interp_f0, ss_spec_power, ss_reflect_pad), ss_wino43_gate16, ss_gemm16_res; 10: ss_wino43_conv + Winograd packs in ss_hifigan; 11: bf16x3 mode (ss_wino43_gate16x, ss_split3_weights, ss_wavenet.w_dil_x3), ss_wino43_gate16w + ss_pack_gate16_weights */
 #define SS_MAX_TAPS 16
 #define SS_MAX_LAYERS 32
 
@@ -370,10 +370,12 @@ int ss_gemm_bf16_tile256_ok(const ss_gemm_bf16_args* args);
  *   H  = fp16(x + dstep_l), the conv's operand, in slot-major tiles: [tile = b * ceil(T / 128) + t / 128][slot 32][row 128] x 8 channels
  *      (slot s = channels 8 s .. 8 s + 7), ss_layer512_h_elems(B, T) elements. DOUBLE BUFFERED: Hout must differ from Hin (a tile reads halo
  *      rows its neighbours rewrite). Rows >= lens[b] are zero (every producer masks them);
- *   P  x itself in FP32, in accumulator order, ss_layer512_stream_bytes(B, T) bytes, updated in place:
- *      [tile][m 4][q 4][wave 8][lane 64] x 4 floats; lane (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row
- *      32 m + l31 of the tile (the eight waves' blocks of a step lie side by side: the workgroup moves 8 KB contiguous per step). (The two-launch form keeps the stream as an fp16 pair - 22 bits; fp32 costs the same bytes and a third of the
- *      epilogue's instructions.)
+ *   P  = R, the fp16 REMAINDER of the stream: x = (H - dstep_l) + R with H = fp16(x + dstep_l) as above and R = fp16(x - (H - dstep_l)) - 22
+ *      significant bits, as the fp16 pair of the two-launch form - in accumulator order, ss_layer512_stream_bytes(B, T) bytes, updated in place:
+ *      [tile][m 4][q 4][wave 8][lane 64] x 4 fp16; lane (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row 32 m + l31 of
+ *      the tile. The launch takes the H term of its own rows from the activation tile it staged anyway, so the stream costs 2 bytes per element of
+ *      HBM traffic each way (first form of round 6: an fp32 copy, 4 bytes each way - 256 of the 584 KB a tile moved). cur_bias = dstep_l and
+ *      next_bias = dstep_(l+1) are the two biases of that representation.
  * Hout == NULL: gate only (the last layer: its residual stream is never read); P and Wr are then unused. */
 typedef struct ss_layer512_args {
   const uint16_t* Hin;      /* fp16(x + dstep_l), slot-major tiles */
@@ -398,11 +400,12 @@ typedef struct ss_layer512_args {
   int32_t e_f16;            /* 1 (n_products = 1 only): E512 is ONE SET of the fp16 form made by ss_layer512_tile_addend_f16 */
   float out_scale;          /* 2^-s of the weight packs */
   float post_scale;         /* 1 / sqrt(2) */
+  const float* cur_bias;    /* [256] dstep_l (what Hin's values carry on top of x), or NULL */
 } ss_layer512_args;
 int ss_layer512(const ss_layer512_args* args, void* stream);
 /* 1 if the shape fits the kernel's fixed geometry and fills the chip (>= 4 rounds of 128-row tiles per CU; any size with the knob layer512 = 2) */
 int ss_layer512_ok(int B, int T, int C, int d_max, int ldg);
-/* stack entry: X fp32 [B][T][ldx] -> P = x and H = fp16(x + bias) (bias = dstep_0; NULL = none) as above; rows >= lens[b] zero */
+/* stack entry: X fp32 [B][T][ldx] -> H = fp16(x + bias) and P = R = fp16(x - (H - bias)) (bias = dstep_0; NULL = none) as above; rows >= lens[b] zero */
 int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride, const float* bias, const int32_t* lens, uint16_t* H, void* P, int B, int T,
                       void* stream);
 int64_t ss_layer512_stream_bytes(int B, int T);

@@ -268,6 +268,7 @@ int run_residual_stack_h(const ss_wavenet* net, int step, const int32_t* lens, i
       f.Wr = net->w_out_f[l] + wset_off(net, net->ws_w_out_f);
       f.bias_r = net->b_out[l];
       f.next_bias = net->dstep + ((int64_t)step * L + l + 1) * C;
+      f.cur_bias = net->dstep + ((int64_t)step * L + l) * C;
     }
     SS_PROPAGATE(ss_layer512(&f, stream));
   }

@@ -62,7 +62,7 @@ constexpr int wg_wave(int NP) { return KSTEPS * wg_step(NP); }  // 196 608 B per
 constexpr int wr_step(int NP) { return NP * 1024; }
 constexpr int wr_wave(int NP) { return RSTEPS * wr_step(NP); }  // 32 768 B per wave (NP = 2)
 constexpr int E_TILE = BM * 512 * 4;       // 262 144 B of tiled addend per tile
-constexpr int P_TILE = BM * 256 * 4;       // 131 072 B of the pair stream per tile
+constexpr int P_TILE = BM * 256 * 2;       // 65 536 B of the stream's residual term R per tile (fp16; the stream is x = (H - dstep_l) + R)
 // E and P tiles: the eight waves' blocks of one (nb, m, q) step side by side ([..][q][wave 8][lane 64]: the workgroup reads 8 KB contiguous per step).
 // (One 32 KB / 16 KB stream per wave, the first layout of round 6, measures the same: 255.5 / 351.6 against 256.4 / 350.7 us per launch,
 // profiles/r06_kbench_layer512_phase_shift.log - the HBM channel hash copes with either.)
@@ -319,24 +319,36 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     // a SIMD gets the matrix pipe, 25 k against 50 k cycles - works under its partner's MFMAs instead of waiting at the barrier. Its VALU stream
     // then competes with the partner's MFMA issue: conv loop 50 -> 62 k cycles, gate arithmetic 30 k; 403.6 against 397.7 us per launch -
     // profiles/r06_trace_layer512_v5_gate_math_before_b2.log. Work moved between the two waves of a SIMD is zero-sum, as the guide says.)
-    // the stream of this item (fp32, accumulator order: one 16-byte load per (m, q)), requested once half of the conv accumulators are
-    // dead so that the loads fly under the rest of this epilogue, [B3] and the G pass
-    [[maybe_unused]] f32x4 pv[NM][4];
+    // the stream of this item: x = (H - dstep_l) + R with H = fp16(x + dstep_l) - this tile's own rows of the conv operand, still in LDS (a wave's
+    // channels are its own slots, which only its own G writes below will overwrite: read block by block ahead of them) - and R = the fp16 remainder
+    // (accumulator order, 8 bytes per lane and (m, q)), requested once half of the conv accumulators are dead so that the loads fly under the rest
+    // of this epilogue, [B3] and the G pass. 22 significant bits (as the two-launch form's pair), 2 bytes per element of HBM traffic each way
+    // instead of 4: the fp32 copy of the stream was 256 of the 584 KB a tile moved.
+    [[maybe_unused]] u32x2 hown[NM][4];
+    [[maybe_unused]] u32x2 rv[NM][4];
+    constexpr int BLKR = 4096;   // bytes between consecutive (m, q) blocks of R: 8 waves x 512
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE + (WAVE_MAJOR ? (int64_t)wave * (P_TILE / 8) : 0) : (const char*)a.Wg), 0,
-        FUSE ? (WAVE_MAJOR ? P_TILE / 8 : P_TILE) : 0, 0x00020000);
+        uniform_ptr(FUSE ? (const char*)a.P + (int64_t)tile * P_TILE : (const char*)a.Wg), 0, FUSE ? P_TILE : 0, 0x00020000);
     auto load_p = [&]() {
 #pragma unroll
       for (int mm = 0; mm < NM; ++mm)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          pv[mm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, w_voff, ((mb0 + mm) * 4 + q) * BLK + wave_off, 0));
+          rv[mm][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_p, lane * 8, ((mb0 + mm) * 4 + q) * BLKR + wave * 512, 0));
     };
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       if (m + 2 < NM) load_e(ev[(m + 2) % 3], m + 2);
       if constexpr (FUSE) {
         if (m == NM - 2) load_p();
+      }
+      if constexpr (FUSE) {
+        // the H term of row block m, BEFORE this block's G goes over it: G rows 32 m .. 32 m + 31 land on activation rows 32 m - 8 .. 32 m + 23 of the same
+        // slots (other LANES' rows of this block and the tail of block m - 1, read an iteration ago). The dependence runs across lanes, which the
+        // compiler's per-thread alias analysis does not see (it would sink these loads below the stores): hence the wait + memory clobber.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hown[m][q] = *reinterpret_cast<const u32x2*>(Rc + (4 * wave + q) * SLOTB + (HALO + 32 * m + l31) * 16 + 8 * lh);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       const bool pad = t0 + 32 * m + l31 >= row_lim;
 #pragma unroll
@@ -403,12 +415,13 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       for (int s = 0; s < NRING_R - 1; ++s) load_wr(wr[s], s);
       read_g(gf[0], 0);
       // per-channel constants of this lane's 16 channels 32 w + 8 q + 4 lh + e
-      f32x4 bs[4], nb[4];
+      f32x4 bs[4], nb[4], cb[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = 32 * wave + 8 * q + 4 * lh;
         bs[q] = a.bias_r ? *reinterpret_cast<const f32x4*>(a.bias_r + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
         nb[q] = a.next_bias ? *reinterpret_cast<const f32x4*>(a.next_bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        cb[q] = a.cur_bias ? *reinterpret_cast<const f32x4*>(a.cur_bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       auto rstep = [&](auto stag) {
         constexpr int S = decltype(stag)::value;
@@ -423,10 +436,10 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
       unrolled_steps(rstep, std::make_integer_sequence<int, RSTEPS>{});
       L512_STAMP(6);
 
-      // ---- stream update: x' = (x + acc * out_scale + b) * post_scale in fp32, in place in P (16 bytes per lane, 1 KB per instruction);
-      // fp16(x' + next_bias) goes to Hout's slot-major tile: 8 bytes per lane, the two lane halves fill a row's 16-byte slot, 32 rows in a row -
-      // 512 contiguous bytes per instruction. Everything of mine that is in flight has to land first anyway (the stream loads) - and with it
-      // the next item's DMA pieces, which [B1] then needs no memory wait for.
+      // ---- stream update: x = (H - dstep_l) + R ; x' = (x + acc * out_scale + b) * post_scale in fp32; out: H' = fp16(x' + dstep_(l+1)) into Hout's
+      // slot-major tile and R' = fp16(x' - (H' - dstep_(l+1))) in place - 8 bytes per lane each, the two lane halves fill a row's 16-byte slot, 32 rows
+      // in a row: 512 contiguous bytes per instruction. Everything of mine that is in flight has to land first anyway (the stream loads) - and with
+      // it the next item's DMA pieces, which [B1] then needs no memory wait for.
       wait_vmcnt<0>();
       const __amdgpu_buffer_rsrc_t rsrc_ho = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)a.Hout + (int64_t)tile * H_TILE), 0, H_TILE, 0x00020000);
 #pragma unroll
@@ -435,18 +448,19 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
         const int ho = (r0 + 32 * m + l31) * 16 + 8 * lh;   // + slot (4 w + q) * 2048
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 xo;
-          uint32_t hp[2] = {0, 0};
+          uint32_t hp[2] = {0, 0}, rp[2] = {0, 0};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            // no contraction here: H must be fp16 of the STORED x' plus the bias - a multiply-add fused across the two would round differently
-            // from the value the next layer's epilogue reads back from P, and differently between the whole- and the half-tile instantiation
+            // no contraction here: every term is rounded where the next layer's epilogue (and the other tile schedules) round it
 #pragma clang fp contract(off)
-            const float xn = (pv[m][q][e] + fmaf(acc2[m][4 * q + e], a.out_scale, bs[q][e])) * a.post_scale;
-            xo[e] = pad ? 0.f : xn;
-            hp[e >> 1] |= (uint32_t)ss_f2t<true>(pad ? 0.f : xn + nb[q][e]) << (16 * (e & 1));
+            const float xo = (ss_t2f_packed<true>(hown[m][q][e >> 1], e & 1) - cb[q][e]) + ss_t2f_packed<true>(rv[m][q][e >> 1], e & 1);
+            const float xn = (xo + fmaf(acc2[m][4 * q + e], a.out_scale, bs[q][e])) * a.post_scale;
+            const uint16_t hh = ss_f2t<true>(pad ? 0.f : xn + nb[q][e]);
+            const uint16_t rr = ss_f2t<true>(pad ? 0.f : xn - (ss_t2f<true>(hh) - nb[q][e]));
+            hp[e >> 1] |= (uint32_t)hh << (16 * (e & 1));
+            rp[e >> 1] |= (uint32_t)rr << (16 * (e & 1));
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), rsrc_p, w_voff, ((mb0 + m) * 4 + q) * BLK + wave_off, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{rp[0], rp[1]}, rsrc_p, lane * 8, ((mb0 + m) * 4 + q) * BLKR + wave * 512, 0);
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{hp[0], hp[1]}, rsrc_ho, ho, (4 * wave + q) * (BM * 16), 0);
         }
       }
@@ -559,28 +573,33 @@ __global__ void tile_addend_f16_kernel(const float* __restrict__ E, int lde, int
   }
 }
 
-// stack entry: X fp32 [B][T][ldx] -> the stream's two forms: P = x in accumulator order ([tile][m 4][q 4][wave 8][lane 64] x 4 floats; lane
+// stack entry: X fp32 [B][T][ldx] -> the stream's two forms: P = R, the fp16 remainder x - (H - bias), in accumulator order ([tile][m 4][q 4][wave 8][lane 64] x 4 fp16; lane
 // (l31, lh) of (wave, m, q) holds channels 32 wave + 8 q + 4 lh .. + 3 of row 32 m + l31) and H = fp16(x + bias) in slot-major tiles
 // ([tile][slot 32][row 128] x 8 channels). Rows >= lens[b] are zero.
 __global__ void entry_kernel(const float* __restrict__ X, int ldx, int64_t x_batch_stride, const float* __restrict__ bias, const int32_t* __restrict__ lens,
-                             uint16_t* __restrict__ H, float4* __restrict__ P, int T, int tiles_per_item, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte P entry each
+                             uint16_t* __restrict__ H, uint2* __restrict__ P, int T, int tiles_per_item, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-byte R entry each
   if (i >= n) return;
   const int lane = (int)(i & 63), q = (int)(i >> (WAVE_MAJOR ? 6 : 9)) & 3, m = (int)(i >> (WAVE_MAJOR ? 8 : 11)) & 3, w = (int)(i >> (WAVE_MAJOR ? 10 : 6)) & 7;
   const int64_t tile = i >> 13;
   const int b = (int)(tile / tiles_per_item), t = (int)(tile % tiles_per_item) * BM + 32 * m + (lane & 31);
   const int c0 = 32 * w + 8 * q + 4 * (lane >> 5);
   const int len = lens ? min(max(lens[b], 0), T) : T;
-  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t hp[2] = {0, 0};
+  uint32_t hp[2] = {0, 0}, rp[2] = {0, 0};
   if (t < len) {
-    x = *reinterpret_cast<const float4*>(X + (int64_t)b * x_batch_stride + (int64_t)t * ldx + c0);
+    const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)b * x_batch_stride + (int64_t)t * ldx + c0);
     const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float v[4] = {x.x + bb.x, x.y + bb.y, x.z + bb.z, x.w + bb.w};
+    const float xv[4] = {x.x, x.y, x.z, x.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) hp[e >> 1] |= (uint32_t)ss_f2t<true>(v[e]) << (16 * (e & 1));
+    for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)
+      const uint16_t hh = ss_f2t<true>(xv[e] + bv[e]);
+      const uint16_t rr = ss_f2t<true>(xv[e] - (ss_t2f<true>(hh) - bv[e]));
+      hp[e >> 1] |= (uint32_t)hh << (16 * (e & 1));
+      rp[e >> 1] |= (uint32_t)rr << (16 * (e & 1));
+    }
   }
-  P[i] = x;
+  P[i] = make_uint2(rp[0], rp[1]);
   *reinterpret_cast<uint2*>(H + tile * (H_TILE / 2) + ((4 * w + q) * BM + 32 * m + (lane & 31)) * 8 + 4 * (lane >> 5)) = make_uint2(hp[0], hp[1]);
 }
 
@@ -596,8 +615,8 @@ extern "C" int ss_layer512_entry(const float* X, int ldx, int64_t x_batch_stride
   SS_CHECK_ARG((((uintptr_t)X) & 15) == 0 && (((uintptr_t)H) & 15) == 0 && (((uintptr_t)P) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0),
                "ss_layer512_entry: X / H / P / bias must be 16-byte aligned");
   const int tpi = ss_cdiv(T, BM);
-  const int64_t n = (int64_t)B * tpi * (P_TILE / 16);
-  hipLaunchKernelGGL(entry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, x_batch_stride, bias, lens, H, (float4*)P, T, tpi, n);
+  const int64_t n = (int64_t)B * tpi * (P_TILE / 8);
+  hipLaunchKernelGGL(entry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, x_batch_stride, bias, lens, H, (uint2*)P, T, tpi, n);
   SS_CHECK_LAUNCH("ss_layer512_entry");
   return SS_OK;
 }
@@ -668,8 +687,8 @@ extern "C" int ss_layer512(const ss_layer512_args* args, void* stream) {
   if (fuse) {
     SS_CHECK_ARG(a.Wr && a.P && a.Hout != a.Hin && (((uintptr_t)a.Hout) & 15) == 0 && (((uintptr_t)a.Wr) & 15) == 0 && (((uintptr_t)a.P) & 15) == 0,
                  "ss_layer512: the fused form needs Wr, P and an Hout buffer different from Hin (tiles read their neighbours' halo rows)");
-    SS_CHECK_ARG((!a.bias_r || (((uintptr_t)a.bias_r) & 15) == 0) && (!a.next_bias || (((uintptr_t)a.next_bias) & 15) == 0),
-                 "ss_layer512: bias vectors must be 16-byte aligned");
+    SS_CHECK_ARG((!a.bias_r || (((uintptr_t)a.bias_r) & 15) == 0) && (!a.next_bias || (((uintptr_t)a.next_bias) & 15) == 0) &&
+                     (!a.cur_bias || (((uintptr_t)a.cur_bias) & 15) == 0), "ss_layer512: bias vectors must be 16-byte aligned");
   }
   const int tpi = ss_cdiv(a.T, BM);
   const int n_tiles = tpi * a.B;

@@ -19,7 +19,7 @@ SS_MAX_LAYERS = 32
 SS_HG_MAX_UPS = 6
 SS_HG_MAX_KERNELS = 4
 
-ABI_VERSION = 18  # include/stylesinger_hip.h SS_ABI_VERSION
+ABI_VERSION = 19  # include/stylesinger_hip.h SS_ABI_VERSION
 EPI_STORE, EPI_GATE, EPI_RESSKIP, EPI_DDPM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4, 5
 
@@ -97,7 +97,7 @@ class Layer512Args(C.Structure):
         ("Hin", _vp), ("d", C.c_int32), ("n_products", C.c_int32), ("Hout", _vp), ("P", _vp),
         ("lens", _vp), ("B", C.c_int32), ("T", C.c_int32), ("Wg", _vp), ("Wr", _vp), ("E512", _vp), ("G", _vp), ("g_batch_stride", C.c_int64),
         ("ldg", C.c_int32), ("mask_rows", C.c_int32), ("bias_r", _vp), ("next_bias", _vp), ("g_compact", C.c_int32), ("e_f16", C.c_int32), ("out_scale", C.c_float),
-        ("post_scale", C.c_float),
+        ("post_scale", C.c_float), ("cur_bias", _vp),
     ]
 
 
@@ -710,15 +710,21 @@ def layer512_h_values(H, *, B, T):
     return H.view(B * nt, 32, 128, 8).permute(0, 2, 1, 3).reshape(B, nt * 128, 256)[:, :T]
 
 
-def layer512_stream_values(P, *, B, T):
-    """the fp32 stream P (accumulator order) -> [B][T][256] (test helper: the index map of include/stylesinger_hip.h)"""
+def layer512_stream_values(P, H, bias=None, *, B, T, lens=None):
+    """the stream x = (H - bias) + R from its two terms: H (slot-major tiles, = fp16(x + bias)) and P = R, the fp16 remainder in accumulator order
+    -> fp32 [B][T][256], rows >= lens[b] zero (test helper: the index map and the arithmetic of include/stylesinger_hip.h)"""
     nt = (T + 127) // 128
-    v = P.view(torch.float32).view(B * nt, 4, 4, 8, 2, 32, 4)          # tile, m, q, wave, lh, l31, e
-    return v.permute(0, 1, 5, 3, 2, 4, 6).reshape(B, nt * 128, 256)[:, :T]   # tile, (m, l31) = row, (wave, q, lh, e) = channel
+    v = P.view(torch.float16).view(B * nt, 4, 4, 8, 2, 32, 4).float()  # tile, m, q, wave, lh, l31, e
+    r = v.permute(0, 1, 5, 3, 2, 4, 6).reshape(B, nt * 128, 256)[:, :T]   # tile, (m, l31) = row, (wave, q, lh, e) = channel
+    h = layer512_h_values(H, B=B, T=T).float()
+    x = (h - bias) + r if bias is not None else h + r
+    if lens is not None:
+        x = x * (torch.arange(T, device=x.device)[None, :, None] < lens.to(x.device)[:, None, None])
+    return x
 
 
 def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None, bias_r=None, next_bias=None, out_scale=1.0 / 256.0,
-             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True, n_products=2, g_compact=False, e_f16=False):
+             post_scale=0.70710678118654752440, ldg=None, g_bs=None, mask_rows=True, n_products=2, g_compact=False, e_f16=False, cur_bias=None):
     """ss_layer512: one launch per residual layer (gate + residual projection) of the fp16x2 mel denoiser; see include/stylesinger_hip.h."""
     a = Layer512Args()
     a.Hin = ptr(Hin); a.d = d; a.n_products = n_products; a.g_compact = int(g_compact); a.e_f16 = int(e_f16)
@@ -726,7 +732,7 @@ def layer512(Hin, Wg, E512, G, *, B, T, d, lens=None, Hout=None, P=None, Wr=None
     a.lens = ptr(lens); a.B = B; a.T = T; a.Wg = ptr(Wg); a.Wr = ptr(Wr); a.E512 = ptr(E512)
     a.G = ptr(G); a.ldg = ldg if ldg is not None else G.shape[-1]; a.g_batch_stride = g_bs if g_bs is not None else T * a.ldg
     a.mask_rows = int(mask_rows); a.bias_r = ptr(bias_r); a.next_bias = ptr(next_bias)
-    a.out_scale = out_scale; a.post_scale = post_scale
+    a.out_scale = out_scale; a.post_scale = post_scale; a.cur_bias = ptr(cur_bias)
     check(load().ss_layer512(C.byref(a), stream_ptr()), "ss_layer512")
 
 

@@ -20,7 +20,7 @@ def test_library_loads_and_exports_header_symbols():
     assert len(names) >= 30
     for n in names:
         assert hasattr(l, n), n
-    assert l.ss_abi_version() == lib.ABI_VERSION == 18
+    assert l.ss_abi_version() == lib.ABI_VERSION == 19
     assert l.ss_last_error() is not None
 
 
@@ -391,7 +391,7 @@ def test_launch_planning_functions_of_the_library_run_without_a_gpu():
     assert l.ss_set_tuning(b"layer512", 2) == 0 and l.ss_layer512_ok(1, 100, 256, 8, 512) == 1 and l.ss_layer512_ok(1, 100, 192, 8, 512) == 0
     assert l.ss_set_tuning(b"layer512", 1) == 0 and l.ss_set_tuning(b"layer512", 3) != 0
     # buffer sizes: 44 tiles per 30 s item; addend 128 x 512 floats, stream 128 x 256 fp32, H 128 x 256 fp16 per tile
-    assert l.ss_layer512_addend_floats(32, 5625) == 1408 * 128 * 512 and l.ss_layer512_stream_bytes(32, 5625) == 1408 * 128 * 256 * 4
+    assert l.ss_layer512_addend_floats(32, 5625) == 1408 * 128 * 512 and l.ss_layer512_stream_bytes(32, 5625) == 1408 * 128 * 256 * 2
     assert l.ss_layer512_h_elems(32, 5625) == 1408 * 128 * 256 and l.ss_layer512_h_elems(1, 1) == 128 * 256
 
 

@@ -79,7 +79,7 @@ def main():
     def fused():
         k[0] += 1
         s = k[0] % NS
-        L.layer512(H[k[0] & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k[0] & 1) ^ 1], P=P, Wr=Wr, bias_r=bo, next_bias=nb,
+        L.layer512(H[k[0] & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k[0] & 1) ^ 1], P=P, Wr=Wr, bias_r=bo, next_bias=nb, cur_bias=nb,
                    ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP, e_f16=a.e16)
 
     def gate_only_new():

@@ -53,7 +53,7 @@ def main():
         if a.gate_only:
             L.layer512(H[0], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP, e_f16=a.e16)
         else:
-            L.layer512(H[k & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k & 1) ^ 1], P=P, Wr=Wr, bias_r=bo,
+            L.layer512(H[k & 1], Wg, E512[s], GA[..., s * 2 * C:], B=B, T=T, d=2, lens=lens, Hout=H[(k & 1) ^ 1], P=P, Wr=Wr, bias_r=bo, cur_bias=nb,
                        next_bias=nb, ldg=NS * 2 * C, g_bs=T * NS * 2 * C, n_products=NP, e_f16=a.e16)
     for k in range(6):
         run(k)
