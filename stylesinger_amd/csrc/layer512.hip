@@ -293,7 +293,8 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     // TWO blocks ahead: the slab is 256 KB per tile and CU, and with one block (8 KB per wave) in flight it arrived at ~26 B per cycle and CU -
     // the gate epilogue took 20 k cycles for 5 k of VALU work (profiles/r06_trace_layer512_v3.log)
     using EvBlock = std::conditional_t<EH, u32x4[4], f32x4[2][4]>;   // EH: [q] = (4 fp16 of nb 0 | 4 fp16 of nb 1)
-    EvBlock ev[3];
+    constexpr int NEV = 3;   // (all four blocks of the fp16 addend requested up front - 64 registers - measure worse: 231.5 against 225.5 us per launch)
+    EvBlock ev[NEV];
     auto load_e = [&](EvBlock& dst, int m) {
       if constexpr (EH) {
 #pragma unroll
@@ -312,6 +313,10 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     };
     load_e(ev[0], 0);
     load_e(ev[1], 1);
+    // (Measured, no gain: the next item's DMA requested HERE - the other region is free since [B1], and the wave that leaves the conv loop first idles
+    // at [B2] for ~16 k cycles - instead of at the end of the gate epilogue: 216-220 against 220 us; the conv phase grows by what the epilogues lose.
+    // With the fp16 addend and the fp16 stream remainder both epilogues are VALU-bound - 64 gate values x (10 VALU + 2 exp2 + 1 rcp) and 64 stream
+    // values x 15 VALU per lane, two waves per SIMD in the same phase: 11.3 k + 7.7 k cycles - profiles/r06_trace_layer512_final_forms.log)
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my reads of the A tile are done
     __builtin_amdgcn_s_barrier();         // [B2] everyone's are: G may overwrite the A tile; the other region is free since the last item ended
     L512_STAMP(2);
@@ -338,7 +343,9 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
     };
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-      if (m + 2 < NM) load_e(ev[(m + 2) % 3], m + 2);
+      if constexpr (NEV == 3) {
+        if (m + 2 < NM) load_e(ev[(m + 2) % 3], m + 2);
+      }
       if constexpr (FUSE) {
         if (m == NM - 2) load_p();
       }
@@ -360,8 +367,8 @@ __global__ __launch_bounds__(512, 2) void layer512_kernel(const ss_layer512_args
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int e = 2 * e2 + k, r = 4 * q + e;
-            const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, e_val(ev[m % 3], 0, q, e)));
-            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, e_val(ev[m % 3], 1, q, e)), 30.0f));
+            const float ea = __builtin_amdgcn_exp2f(fmaf(acc[0][m][r], ka, e_val(ev[m % NEV], 0, q, e)));
+            const float eb = __builtin_amdgcn_exp2f(fminf(fmaf(acc[1][m][r], kbx, e_val(ev[m % NEV], 1, q, e)), 30.0f));
             float g_ = (1.0f - eb) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));   // sigmoid(v0) * tanh(v1), net.py:72-73
             if (pad) g_ = 0.f;
             v |= (uint32_t)ss_f2t<true>(g_) << (16 * k);
