@@ -348,7 +348,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
         try:
             import csv
             for row in csv.DictReader(open(csv_l512)):
-                if f"layer512_kernel<true, {1 if sd else 2}>" in row["Name"]:
+                if f"layer512_kernel<true, {1 if sd else 2}," in row["Name"]:
                     us = float(row["AverageNs"]) * 1e-3
                     in_loop = {"us_per_launch": us, "calls": int(row["Calls"]), "executed_mfma_frac": executed / (us * 1e-6) / peak, "source": "profiles/" + l512_name}
                     break
@@ -955,9 +955,9 @@ def main():
                 one = args.config in ("c4", "c4sd")
                 npr = 1 if one else 2
                 tk = top_kernels("r06_bench_c4_fp16sd_20steps_kernel_stats.csv" if one else "r06_bench_c4x2_20steps_kernel_stats.csv", {
-                    f"layer512_kernel<true, {npr}>": (npr * (2.0 * 180000 * 768 * 512 + 2.0 * 180000 * 256 * 256), H16),
-                    f"layer512_kernel<false, {npr}>": (npr * 2.0 * 180000 * 768 * 512, H16),
-                    "tile256s_kernel<0, true, true>" if one else "tile256s_kernel<0, true, false>": (npr * 2.0 * 180000 * 5120 * 256, H16)}, n=10)
+                    f"layer512_kernel<true, {npr},": (npr * (2.0 * 180000 * 768 * 512 + 2.0 * 180000 * 256 * 256), H16),
+                    f"layer512_kernel<false, {npr},": (npr * 2.0 * 180000 * 768 * 512, H16),
+                    "tile256s_kernel<0, true, true," if one else "tile256s_kernel<0, true, false,": (npr * 2.0 * 180000 * 5120 * 256, H16)}, n=12)
                 if tk:
                     tk["note"] = (f"profiled command: bench.py --config {'c4' if one else 'c4x2'} --diff-steps 20 (20 mel steps AND 20 f0 steps: the f0 loops' and the vocoder's "
                                   "shares are ~10x what they are in the 1000-step config; the per-launch averages are what carries over; the 19 000-20 000 launches of 11-16 us are "
