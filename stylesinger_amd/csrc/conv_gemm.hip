@@ -32,6 +32,10 @@ extern "C" int ss_conv_gemm(const ss_conv_gemm_args* args, void* stream_) {
   if (tile == 0) {
     if (n_cols <= 32) tile = SS_TILE_128x32;
     else if (n_cols <= 64) tile = (gate || blocks(128, 64) >= 512) ? SS_TILE_128x64 : SS_TILE_64x64;
+    // 65 .. 96 columns over many rounds with a short K (the mel denoiser's output projection at BASELINE configs[3]: 180 000 rows, K = 256, N = 80, fused
+    // with the DDPM update): three 32-column tiles waste nothing of a 128-column tile's matrix work and epilogue, and the A tile's three readers run side by
+    // side out of L2 - 138 us against 327 us (tools/kbench_final.py, profiles/r06_kbench_final_projection.log)
+    else if (!gate && n_cols <= 96 && a.Cin * a.ntaps <= 256 && blocks(128, 32) >= 3072) tile = SS_TILE_128x32;
     else if (blocks(128, 128) >= 768) tile = SS_TILE_128x128;
     else if (gate || blocks(64, 128) >= 384) tile = SS_TILE_64x128;
     else tile = SS_TILE_64x64;
