@@ -201,3 +201,4 @@ __device__ __forceinline__ void ss_boxmuller(uint32_t a, uint32_t b, float& z0, 
 #define SS_CLK(var) do { } while (0)
 #define SS_CLK_VM(var) do { } while (0)
 #endif
+
