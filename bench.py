@@ -314,7 +314,7 @@ def kernel_roofline(infer, B, T, bf16, iters=20):
     traffic = None
     pmc_src = None
     form = "layer512sd" if (fused and sd) else "layer512" if fused else (f"wino43_16_mt{mt}" if wino_m == 4 and mt else "wino43" if wino_m == 4 else "wino" if wino else ("fp16q4" if q4 else "fp16x2" if f16 else "bf16x2" if split else "bf16" if bf16 else "direct"))
-    for fn in ("r06_pmc_layer512.json", "r05_pmc_gate128.json", "r05_pmc_gate.json", "r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
+    for fn in ("r06_pmc_layer512sd.json", "r06_pmc_layer512.json", "r05_pmc_gate128.json", "r05_pmc_gate.json", "r04_pmc_gate.json", "r04_pmc_gate_c4_bf16x2.json", "r03_pmc_gate.json", "r03_pmc_gate_c4_bf16.json", "r02_pmc_gate.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj):
             continue

@@ -20,7 +20,7 @@
 #   ablate-res16     the same for the residual-projection kernel (tools/ablate_r16.sh build, in the container)
 #   kbench-layer512  round 6: ss_layer512 (one launch per residual layer of the fp16x2 mel stack) against the launch pair it replaces, C4 shape
 #   trace-layer512   per-phase shader-clock timing of layer512_kernel (builds the -DSS_L512_TRACE library first; hipcc works on the box)
-#   pmc-layer512     PMC passes on layer512_kernel (profiles/r06_pmc_layer512.json)
+#   pmc-layer512 [--one --e16]  PMC passes on layer512_kernel (profiles/r06_pmc_layer512.json; with --one --e16 the fp16sd form: r06_pmc_layer512sd.json)
 #   profile-c4 [cfg] rocprofv3 kernel stats of the C4 loop at 20 diffusion steps (cfg = c4 (fp16sd, default) | c4x2: profiles/r06_bench_c4_fp16sd_20steps_kernel_stats.csv,
 #                    r06_bench_c4x2_20steps_kernel_stats.csv)
 #   phases-layer512  the layer launch with its half tiles first / last and as whole tiles (knob layer512_tail; profiles/r06_kbench_layer512_phase_shift.log)
