@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+from conftest import record_measurement  # noqa: E402
 from stylesinger_amd import config, synth  # noqa: E402
 from stylesinger_amd import lib as L  # noqa: E402
 from stylesinger_amd.model import StyleSingerHIP  # noqa: E402
@@ -221,3 +222,37 @@ def test_skip_gemm_compact_operand_equals_the_pair_layout(one):
     with pytest.raises(L.StyleSingerHipError):
         L.gemm_bf16(Ah[:1, :300].contiguous(), Ws, B=1, T=300, K=K, taps=(0,), N=C, Np=Ws.shape[0], epi=L.HEPI_STORE, out=torch.empty(1, 300, C, device=dev),
                     bias=L.pack_bias(bias), split=2, out_scale=1.0 / 256.0, a_compact=True)
+
+
+def test_fp16sd_fused_path_under_the_ddim_sampler():
+    """The weight sets and the fp16 addend sets of "fp16sd" are indexed by the evaluation number of the sampling loop, which every sampler has to hand
+    to the stack (`g_wset_eval`): here the strided sampler. (1) eta = 1 over all 100 steps IS the reference's ancestral chain (tests/test_gpu_round4.py):
+    the fused one-product path (knob layer512 = 2 forces the one item onto it) against the REAL reference's 100-step golden; (2) eta = 0 over 10 of the
+    steps - only 10 of the 32 sets take part, the least favourable case for the noise shaping - against the fp32 path's own 10-step result."""
+    from oracle import harness
+    case = harness.load_case("acoustic_t64_s100")
+    meta, gold = case["meta"], case["out"]
+    hp, sd, batch = harness.case_setup(meta)
+    K = hp["K_step"]
+    noise = synth.draw_acoustic_noise(synth.NoiseTape(meta["tape_seed"]), meta["B"], meta["T"], meta["steps_f0"], meta["steps_mel"])
+    b = {k: v.cuda() for k, v in batch.items()}
+    exact = _model(hp, sd)
+    ref10 = _fwd(exact, b, noise=noise, sampler="ddim", ddim_steps=10)["mel_out"]
+    L.check(L.load().ss_set_tuning(b"layer512", 2), "layer512")
+    try:
+        m = _model(dict(hp, mfma_precision="fp16sd"), sd)
+        assert m.sd and m.sd_e_sets == 8
+        got = _fwd(m, b, noise=noise, sampler="ddim", ddim_steps=K, eta=1.0)
+        got10 = _fwd(m, b, noise=noise, sampler="ddim", ddim_steps=10)["mel_out"]
+        torch.cuda.synchronize()
+    finally:
+        L.check(L.load().ss_set_tuning(b"layer512", 1), "layer512")
+    d = (got["mel_out"].cpu() - gold["mel_out"]).abs()
+    uv = int(((got["pitch_pred"][..., 1].cpu() > 0) != (gold["pitch_pred"][..., 1] > 0)).sum())
+    d10 = (got10 - ref10).abs()
+    print(f"fp16sd on ss_layer512 under the strided sampler: eta = 1, 100 steps vs the real reference {d.mean().item():.3e} (max {d.max().item():.3e}), voicing flips {uv}; "
+          f"eta = 0, 10 steps vs the fp32 path {d10.mean().item():.3e} (max {d10.max().item():.3e})")
+    record_measurement("fp16sd_ddim_eta1_100steps_vs_reference_golden_t64", mel_l1=d.mean().item(), mel_max=d.max().item(), voicing_flips=uv,
+                       ddim10_vs_fp32_l1=d10.mean().item())
+    assert uv == 0 and d.mean().item() <= 6e-5, d.mean().item()
+    assert d10.mean().item() <= 3e-4, d10.mean().item()
