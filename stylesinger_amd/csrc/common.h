@@ -180,6 +180,17 @@ __device__ __forceinline__ void ss_boxmuller(uint32_t a, uint32_t b, float& z0, 
   z1 = r * s;
 }
 
+// The mel sampler's Gaussian draw (SS_EPI_DDPM epilogue of ss_conv_gemm, mel_tail_kernel): element (frame t, bin n) of item b at step `step` is output t & 3
+// of the Philox block with counter ((t >> 2) * N + n, b) - a block's four words become four normals (two Box-Muller pairs), and a lane of the MFMA
+// epilogue holds four consecutive frames of a bin: one block per four elements (round 6; before, every element ran its own block and used one of its
+// four words: 7 of the 23 us of the C2 launch). The draw depends on (item, frame, bin, step) only - not on T padding, batching or tiling.
+__device__ __forceinline__ void ss_mel_draw4(const SsPhilox& rng, uint32_t t4, uint32_t N, uint32_t n, uint32_t b, uint32_t step, float (&z)[4]) {
+  uint32_t o[4];
+  rng.gen(t4 * N + n, b, step, 0x4d454c44u, o);
+  ss_boxmuller(o[0], o[1], z[0], z[1]);
+  ss_boxmuller(o[2], o[3], z[2], z[3]);
+}
+
 // SS_TRACE (debug builds only, tools/wave_trace.py): phase stamps on the shader clock. SS_CLK waits for the LDS/scalar queue (lgkmcnt 0),
 // SS_CLK_VM for the vector-memory queue (vmcnt 0) before reading s_memtime; both pin the schedule around them.
 #ifdef SS_TRACE

@@ -574,6 +574,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
           xv[r] = ok ? Cb[(int64_t)row * a.ldc + col] : 0.f;
           zv[r] = (ok && a.noise && a.ddpm_sigma != 0.f) ? a.noise[((int64_t)b * a.T + row) * a.N + col] : 0.f;
         }
+        if (a.ddpm_sigma != 0.f && !a.noise && col_ok) {   // in-kernel noise: one Philox block per four consecutive frames of this lane (ss_mel_draw4)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row4 = row_of(m, 4 * j);     // a multiple of 4: tile origin, 32 m, 8 j, 4 lh
+            if (row4 < a.T) {
+              float z4[4];
+              ss_mel_draw4(rng, (uint32_t)(row4 >> 2), (uint32_t)a.N, (uint32_t)col, (uint32_t)b, a.step, z4);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) zv[4 * j + i] = z4[i];
+            }
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row_of(m, r);
@@ -584,14 +596,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
           x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
           if (a.ddpm_x0_pred) x0 = eps;  // the network output IS x0 (ProDiffusion.p_sample, prodiff.py:150-153), no clamp
           const float mean = a.ddpm_c1 * x0 + a.ddpm_c2 * x;
-          float z = zv[r];
-          if (a.ddpm_sigma != 0.f && !a.noise) {
-            uint32_t o[4];  // counter = (element of the item, item): the draw does not depend on how far T is padded
-            rng.gen((uint32_t)(row * a.N + col), (uint32_t)b, a.step, 0x4d454c44u, o);
-            float z1;
-            ss_boxmuller(o[0], o[1], z, z1);
-          }
-          float xn = mean + a.ddpm_sigma * z;
+          float xn = mean + a.ddpm_sigma * zv[r];
           if (a.mask_rows && row >= len) xn = 0.f;
           Cb[(int64_t)row * a.ldc + col] = xn;
         }

@@ -918,10 +918,9 @@ __global__ __launch_bounds__(256) void mel_tail_kernel(const SkipSrc src, const 
     if (sigma != 0.f) {
       if (noise) z = noise[i * M + n];
       else {
-        uint32_t o[4];  // counter = (element of the item, item): exactly the SS_EPI_DDPM epilogue's draw
-        rng.gen((uint32_t)(t * M + n), (uint32_t)b, step, 0x4d454c44u, o);
-        float z1;
-        ss_boxmuller(o[0], o[1], z, z1);
+        float z4[4];   // exactly the SS_EPI_DDPM epilogue's draw: output t & 3 of the block of frames 4 (t >> 2) .. + 3 of this bin
+        ss_mel_draw4(rng, (uint32_t)(t >> 2), (uint32_t)M, (uint32_t)n, (uint32_t)b, step, z4);
+        z = z4[t & 3];
       }
     }
     float xn = mean + sigma * z;
