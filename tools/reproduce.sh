@@ -24,6 +24,10 @@
 #   profile-c4 [cfg] rocprofv3 kernel stats of the C4 loop at 20 diffusion steps (cfg = c4 (fp16sd, default) | c4x2: profiles/r06_bench_c4_fp16sd_20steps_kernel_stats.csv,
 #                    r06_bench_c4x2_20steps_kernel_stats.csv)
 #   phases-layer512  the layer launch with its half tiles first / last and as whole tiles (knob layer512_tail; profiles/r06_kbench_layer512_phase_shift.log)
+#   kbench-final     the mel output projection + DDPM update per tile choice, with / without the in-kernel noise (profiles/r06_kbench_final_projection.log)
+#   kbench-skip      the K = L C skip GEMM: pair layout, compact A, compact A + W (64-channel steps; SS_SKIP_DENSE=0: 32) (profiles/r06_kbench_skip_gemm_dense.log)
+#   groups-layer512  EXPERIMENT (own shared object): the fp16sd layer launch as two wave groups half a period apart (profiles/r06_kbench_layer512_groups.log)
+#   numerics-sd      CPU: the fp16sd numerics study (weight sets; --e-sets=N: the conditioner addend as N fp16 sets)
 #   power            rocm-smi power / sclk sampled under 12 s of back-to-back layer launches (1400 W = the cap)
 #   launch-floor     null-kernel hipGraph with the C2 mel loop's launch topology (tools/launch_floor.py)
 #   c5-full          the full per-GPU share of BASELINE configs[4]: 32 references x 256 targets (profiles/r06_bench_c5_full_share.json)
@@ -92,6 +96,18 @@ case "$sec" in
     SS_LIB_PATH=stylesinger_amd/_abl/libss_l512trace.so python tools/trace_layer512.py "$@" ;;
   pmc-layer512)
     bash tools/pmc_layer512.sh "$@" ;;
+  kbench-final)
+    python tools/kbench_final.py "$@" ;;
+  kbench-skip)
+    python tools/kbench_h.py --f16 --which skip --iters 200
+    python tools/kbench_h.py --f16 --which skip --compact 1 --iters 200
+    python tools/kbench_h.py --f16 --which skip --compact 2 --iters 200
+    SS_SKIP_DENSE=0 python tools/kbench_h.py --f16 --which skip --compact 2 --iters 200 ;;
+  groups-layer512)
+    python tools/kbench_layer512_groups.py "$@" ;;
+  numerics-sd)
+    python -m oracle.dither_numerics 1 2 4 8 16 32
+    python -m oracle.dither_numerics 32 --e-sets=1 --e-sets=4 --e-sets=8 --e-sets=16 ;;
   phases-layer512)
     for k in 1 2 0; do echo "--- layer512_tail = $k"; SS_LAYER512_TAIL=$k python tools/kbench_layer512.py --one --iters 400 --which fused; SS_LAYER512_TAIL=$k python tools/kbench_layer512.py --iters 400 --which fused; done ;;
   profile-c4)
